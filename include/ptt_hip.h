@@ -1,0 +1,191 @@
+/*
+ * ptt_hip.h — C ABI of libptt_hip.so, the MI355X (gfx950) implementation of PTT's
+ * per-frame point-feature hot path.
+ *
+ * Every entry point replaces one call the reference makes into the third-party CUDA
+ * extension `pointnet2_ops._ext` (reference: ptt/models/backbones_3d/pointnet2/
+ * pointnet2_utils.py:24) or one pure-PyTorch module forward on the hot path; the
+ * reference call site each one stands in for is cited beside it.
+ *
+ * Conventions
+ *   - plain C: raw DEVICE pointers, sizes, a hipStream_t passed as void*.
+ *   - every function returns 0 (PTT_OK) or a negative PTT_E* code; nothing throws,
+ *     nothing allocates, nothing synchronises the host. Kernels are enqueued on
+ *     `stream` and the call returns immediately.
+ *   - caller owns all buffers (outputs and workspaces); layouts are row-major and
+ *     contiguous unless a stride argument says otherwise.
+ *   - thread-safe and re-entrant: no global state beyond a thread-local last-error
+ *     string.
+ *   - clouds are (B, N, 3) fp32 "xyz"; indices are int32 as in the reference
+ *     (pointnet2_utils.py:58-85, 265-294).
+ */
+#ifndef PTT_HIP_H
+#define PTT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PTT_ABI_VERSION 1
+
+enum {
+    PTT_OK = 0,
+    PTT_EINVAL = -1,        /* bad size / null pointer / inconsistent descriptor   */
+    PTT_EUNSUPPORTED = -2,  /* shape outside what the kernels are instantiated for */
+    PTT_ELAUNCH = -3,       /* hipLaunch / runtime error, see ptt_last_error_string */
+    PTT_EWORKSPACE = -4     /* workspace too small                                  */
+};
+
+typedef void* ptt_stream_t; /* hipStream_t */
+
+int ptt_version(void);
+const char* ptt_error_name(int code);
+const char* ptt_last_error_string(void);
+
+/* ---------------------------------------------------------------------------------
+ * F1  furthest point sampling
+ * replaces _ext.furthest_point_sampling(xyz, npoint)        pointnet2_utils.py:78
+ *   xyz  (B,N,3) f32   ->  idx_out (B,npoint) i32
+ * idx[0]=0; running min-dist starts at 1e10; points with x*x+y*y+z*z <= 1e-3 are
+ * neither updated nor selectable; d=(dx*dx+dy*dy)+dz*dz in fp32 without FMA
+ * contraction; arg-max ties -> lowest index; no candidate -> 0.
+ * ------------------------------------------------------------------------------- */
+int ptt_fps_f32(const float* xyz, int B, int N, int npoint, int32_t* idx_out,
+                ptt_stream_t stream);
+
+/* ---------------------------------------------------------------------------------
+ * F2  gather centres
+ * replaces _ext.gather_points(features, idx)                pointnet2_utils.py:112
+ *          _ext.gather_points_grad(grad_out, idx, N)        pointnet2_utils.py:118
+ *   feat (B,C,N) f32, idx (B,M) i32 -> out (B,C,M);   out[b,c,j] = feat[b,c,idx[b,j]]
+ *   grad: grad_feat (B,C,N) is zero-filled by the call, then += over all j.
+ * ------------------------------------------------------------------------------- */
+int ptt_gather_f32(const float* feat, const int32_t* idx, int B, int C, int N, int M,
+                   float* out, ptt_stream_t stream);
+int ptt_gather_grad_f32(const float* grad_out, const int32_t* idx, int B, int C, int N,
+                        int M, float* grad_feat, ptt_stream_t stream);
+
+/* ---------------------------------------------------------------------------------
+ * F3  ball query  (centres first, as the reference calls it)
+ * replaces _ext.ball_query(new_xyz, xyz, radius, nsample)   pointnet2_utils.py:287
+ *   new_xyz (B,M,3), xyz (B,N,3) -> idx_out (B,M,nsample) i32
+ * first `nsample` indices k in ascending order with (dx*dx+dy*dy)+dz*dz < r*r
+ * (fp32, strict); unfilled slots repeat the first hit; no hit -> zeros.
+ * ------------------------------------------------------------------------------- */
+int ptt_ball_query_f32(const float* new_xyz, const float* xyz, int B, int M, int N,
+                       float radius, int nsample, int32_t* idx_out, ptt_stream_t stream);
+
+/* ---------------------------------------------------------------------------------
+ * F4  grouping
+ * replaces _ext.group_points(features, idx)                 pointnet2_utils.py:237
+ *          _ext.group_points_grad(grad_out, idx, N)         pointnet2_utils.py:257
+ *   feat (B,C,N), idx (B,M,ns) -> out (B,C,M,ns);  out[b,c,j,k] = feat[b,c,idx[b,j,k]]
+ * ------------------------------------------------------------------------------- */
+int ptt_group_f32(const float* feat, const int32_t* idx, int B, int C, int N, int M,
+                  int ns, float* out, ptt_stream_t stream);
+int ptt_group_grad_f32(const float* grad_out, const int32_t* idx, int B, int C, int N,
+                       int M, int ns, float* grad_feat, ptt_stream_t stream);
+
+/* ---------------------------------------------------------------------------------
+ * T1  k nearest neighbours inside one cloud
+ * replaces square_distance(xyz, xyz).argsort()[:, :, :k]    transformer_block/variants.py:150-151
+ *   xyz (B,N,3) -> idx_out (B,N,k) i32, ascending by (squared distance, index);
+ *   d = (dx*dx+dy*dy)+dz*dz in fp32 (model_utils/layer_utils.py:26). Requires k <= N.
+ * ------------------------------------------------------------------------------- */
+int ptt_knn_f32(const float* xyz, int B, int N, int k, int32_t* idx_out,
+                ptt_stream_t stream);
+
+/* ---------------------------------------------------------------------------------
+ * Weight packing for the fp32-MFMA kernels.
+ *   W (Cout,K) row-major (an nn.Linear / 1x1-conv weight)  ->  packed fragment order
+ *   [K8][Cout32][64 lanes][4]  with K padded to a multiple of 8 and Cout to 32 (zeros).
+ *   `k_front` leading input channels may be rotated behind the others (0 = keep order).
+ * ------------------------------------------------------------------------------- */
+size_t ptt_packed_weight_elems(int Cout, int K);
+int ptt_pack_weight_f32(const float* W, int Cout, int K, float* packed,
+                        ptt_stream_t stream);
+
+/* ---------------------------------------------------------------------------------
+ * Row-wise linear layer on fp32 MFMA:  out = act(X @ W^T * scale + shift) (+ residual)
+ * replaces nn.Linear / Conv1d(k=1) forwards on the hot path:
+ *   TransformerBlock.fc1 / w_qs / w_ks / w_vs / fc2          variants.py:154-156,164
+ *   PointNet2BackboneLight.cov_final                         pointnet2_backbone.py:46
+ *   X (rows, K) with row stride ldx; out (rows, Cout) with row stride ldo;
+ *   scale/shift per output channel (NULL = 1 / 0); residual (rows, Cout) stride ldr or NULL.
+ * ------------------------------------------------------------------------------- */
+int ptt_linear_f32(const float* X, int rows, int K, int ldx, const float* Wpacked, int Cout,
+                   const float* scale, const float* shift, int relu, const float* residual,
+                   int ldr, float* out, int ldo, ptt_stream_t stream);
+
+/* ---------------------------------------------------------------------------------
+ * F4+F5+F6+F7 fused: group -> (xyz - centre)/radius -> concat -> SharedMLP(eval BN
+ * folded to scale/shift, ReLU) -> max over nsample.
+ * replaces QueryAndGroup.forward                           pointnet2_utils.py:320-380
+ *          SharedMLP forward (eval)                        pytorch_utils.py:12-36
+ *          F.max_pool2d over nsample                       pointnet2_modules.py:85-88
+ * Grouped tensors never reach HBM.
+ * ------------------------------------------------------------------------------- */
+#define PTT_SA_MAX_LAYERS 4
+
+typedef struct ptt_sa_layer {
+    const float* Wpacked; /* ptt_pack_weight_f32 of the (Cout,Cin) conv weight        */
+    const float* scale;   /* (Cout) gamma/sqrt(var+eps), or NULL = 1                   */
+    const float* shift;   /* (Cout) beta - mean*scale (or conv bias), or NULL = 0      */
+    int Cin;              /* input channels of this layer (first layer: 3*use_xyz + C) */
+    int Cout;             /* multiple of 32                                            */
+    int relu;
+} ptt_sa_layer;
+
+typedef struct ptt_sa_desc {
+    const float* xyz;     /* (B,N,3)                                                   */
+    const float* new_xyz; /* (B,M,3) centres                                           */
+    const int32_t* idx;   /* (B,M,nsample) from ptt_ball_query_f32                     */
+    const float* feat;    /* point features or NULL when C == 0                        */
+    int64_t feat_sb, feat_sc, feat_sn; /* element strides of feat[b][c][n]             */
+    float* out;           /* pooled features                                           */
+    int64_t out_sb, out_sc, out_sm;    /* element strides of out[b][c][m]              */
+    int B, N, M, nsample, C;
+    float radius;
+    int use_xyz;          /* prepend the 3 relative coordinates (reference default)    */
+    int normalize_xyz;    /* divide them by radius (pointnet2_utils.py:353-354)        */
+    int n_layers;
+    ptt_sa_layer layers[PTT_SA_MAX_LAYERS];
+} ptt_sa_desc;
+
+int ptt_sa_fused_fwd_f32(const ptt_sa_desc* d, ptt_stream_t stream);
+
+/* ---------------------------------------------------------------------------------
+ * T2..T6 fused per-(point,neighbour) part of the Point-Transformer block:
+ *   delta = fc_delta(xyz_i - xyz_j);  a = fc_gamma(q_i - k_j + delta);
+ *   attn = softmax_j(a / sqrt(D));    res_i = sum_j attn * (v_j + delta)
+ * replaces TransformerBlock.forward lines                  variants.py:158-163
+ *   qkv (B,N,3*D) = [q | k | v] rows (from ptt_linear_f32 with the stacked weight),
+ *   knn (B,N,k) i32. D = 512 and k = 16 are the instantiated configuration.
+ *   res (B,N,D); attn (B,N,k,D) or NULL (the heads discard it: centroids_voting_head.py:76).
+ * ------------------------------------------------------------------------------- */
+typedef struct ptt_attn_desc {
+    const float* xyz;      /* (B,N,3) */
+    const int32_t* knn;    /* (B,N,k) */
+    const float* qkv;      /* (B,N,3*D) */
+    const float* Wd1;      /* fc_delta[0].weight (D,3) row-major, unpacked */
+    const float* bd1;      /* (D) */
+    const float* Wd2p;     /* packed fc_delta[2].weight */
+    const float* bd2;
+    const float* Wg1p;     /* packed fc_gamma[0].weight */
+    const float* bg1;
+    const float* Wg2p;     /* packed fc_gamma[2].weight */
+    const float* bg2;
+    float* res;            /* (B,N,D) */
+    float* attn;           /* (B,N,k,D) or NULL */
+    int B, N, k, D;
+} ptt_attn_desc;
+
+int ptt_pt_attn_pair_f32(const ptt_attn_desc* d, ptt_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTT_HIP_H */

@@ -1,0 +1,159 @@
+/*
+ * ptt_oracle.c — CPU ORACLE for the index ops of PTT's hot path. TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+ * library, and only as the checker / the timed CPU baseline. The product path
+ * (ptt_amd/, libptt_hip.so) never links, imports or calls it.
+ *
+ * What it restates. The reference calls a third-party CUDA extension for these ops:
+ *   pointnet2_ops._ext  (erikwijmans/Pointnet2_PyTorch, pointnet2_ops_lib; pulled in by
+ *   /root/reference/requirements.txt:3 as a bare git URL with NO pinned revision; its
+ *   source is absent from /root/reference and from this container)
+ * at the call sites ptt/models/backbones_3d/pointnet2/pointnet2_utils.py:78 (FPS),
+ * :112/:118 (gather, gather grad), :237/:257 (group, group grad), :287 (ball query), and
+ * does kNN as square_distance(...).argsort()[:, :, :k] (transformer_block/variants.py:150-151,
+ * model_utils/layer_utils.py:12-26). The reference has no tests, golden vectors or CPU
+ * implementation for the four extension ops, so for those ops:  PARITY UNPINNED  — this
+ * file restates the upstream package's published algorithm as specified in SURVEY.md §8c
+ * and is the contract both the HIP kernels and the tests follow. kNN, gather and group
+ * semantics ARE pinned: tests/golden/make_golden.py checks them against the imported
+ * reference (torch argsort / the reference's own QueryAndGroup glue run on these ops).
+ *
+ * Arithmetic: fp32 throughout, squared distance = (dx*dx + dy*dy) + dz*dz with no fused
+ * multiply-add (build with -ffp-contract=off; see ptt_amd/build.py:build_oracle).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+static inline float sqdist3(const float* a, const float* b) {
+    const float dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
+    const float s = dx * dx + dy * dy;
+    return s + dz * dz;
+}
+
+/* FPS — restates upstream furthest_point_sampling as called at pointnet2_utils.py:78.
+ * tmp[:] = 1e10; idx[0] = 0; each round: for every k with |p_k|^2 > 1e-3 update
+ * tmp[k] = min(tmp[k], d(k, last)) and track the arg-max (strictly greater => lowest k on
+ * ties); no candidate => 0. */
+void oracle_fps(const float* xyz, int B, int N, int npoint, int32_t* idx) {
+#pragma omp parallel for schedule(dynamic)
+    for (int b = 0; b < B; ++b) {
+        const float* p = xyz + (size_t)b * N * 3;
+        int32_t* out = idx + (size_t)b * npoint;
+        float* tmp = (float*)malloc(sizeof(float) * (size_t)N);
+        unsigned char* skip = (unsigned char*)malloc((size_t)N);
+        for (int k = 0; k < N; ++k) {
+            tmp[k] = 1e10f;
+            const float mag = (p[3 * k] * p[3 * k] + p[3 * k + 1] * p[3 * k + 1]) + p[3 * k + 2] * p[3 * k + 2];
+            skip[k] = !(mag > 1e-3f);
+        }
+        int last = 0;
+        if (npoint > 0) out[0] = 0;
+        for (int j = 1; j < npoint; ++j) {
+            float best = -1.0f;
+            int besti = 0;
+            for (int k = 0; k < N; ++k) {
+                if (skip[k]) continue;
+                const float d = sqdist3(p + 3 * k, p + 3 * last);
+                const float m = d < tmp[k] ? d : tmp[k];
+                tmp[k] = m;
+                if (m > best) { best = m; besti = k; }
+            }
+            last = besti;
+            out[j] = besti;
+        }
+        free(tmp);
+        free(skip);
+    }
+}
+
+/* ball query — restates upstream ball_query(new_xyz, xyz, radius, nsample) as called at
+ * pointnet2_utils.py:287: scan k ascending, hit iff d2 < r*r (strict, fp32); the first hit
+ * fills every slot, later hits overwrite slots 1.. in order; stop at nsample; no hit => 0. */
+void oracle_ball_query(const float* new_xyz, const float* xyz, int B, int M, int N, float radius, int nsample,
+                       int32_t* idx) {
+    const float r2 = radius * radius;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < B; ++b)
+        for (int j = 0; j < M; ++j) {
+            const float* c = new_xyz + ((size_t)b * M + j) * 3;
+            const float* p = xyz + (size_t)b * N * 3;
+            int32_t* out = idx + ((size_t)b * M + j) * nsample;
+            for (int l = 0; l < nsample; ++l) out[l] = 0;
+            int cnt = 0;
+            for (int k = 0; k < N && cnt < nsample; ++k) {
+                const float d2 = sqdist3(c, p + 3 * k);
+                if (d2 < r2) {
+                    if (cnt == 0)
+                        for (int l = 0; l < nsample; ++l) out[l] = k;
+                    out[cnt] = k;
+                    ++cnt;
+                }
+            }
+        }
+}
+
+/* gather: out[b,c,j] = feat[b,c,idx[b,j]]   (pointnet2_utils.py:88-122) */
+void oracle_gather(const float* feat, const int32_t* idx, int B, int C, int N, int M, float* out) {
+    for (int b = 0; b < B; ++b)
+        for (int c = 0; c < C; ++c)
+            for (int j = 0; j < M; ++j)
+                out[((size_t)b * C + c) * M + j] = feat[((size_t)b * C + c) * N + idx[(size_t)b * M + j]];
+}
+
+void oracle_gather_grad(const float* go, const int32_t* idx, int B, int C, int N, int M, float* gf) {
+    memset(gf, 0, sizeof(float) * (size_t)B * C * N);
+    for (int b = 0; b < B; ++b)
+        for (int c = 0; c < C; ++c)
+            for (int j = 0; j < M; ++j)
+                gf[((size_t)b * C + c) * N + idx[(size_t)b * M + j]] += go[((size_t)b * C + c) * M + j];
+}
+
+/* group: out[b,c,j,k] = feat[b,c,idx[b,j,k]]   (pointnet2_utils.py:214-262) */
+void oracle_group(const float* feat, const int32_t* idx, int B, int C, int N, int M, int ns, float* out) {
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < B; ++b)
+        for (int c = 0; c < C; ++c) {
+            const float* f = feat + ((size_t)b * C + c) * N;
+            float* o = out + ((size_t)b * C + c) * M * ns;
+            const int32_t* id = idx + (size_t)b * M * ns;
+            for (size_t e = 0; e < (size_t)M * ns; ++e) o[e] = f[id[e]];
+        }
+}
+
+void oracle_group_grad(const float* go, const int32_t* idx, int B, int C, int N, int M, int ns, float* gf) {
+    memset(gf, 0, sizeof(float) * (size_t)B * C * N);
+    for (int b = 0; b < B; ++b)
+        for (int c = 0; c < C; ++c) {
+            float* g = gf + ((size_t)b * C + c) * N;
+            const float* o = go + ((size_t)b * C + c) * M * ns;
+            const int32_t* id = idx + (size_t)b * M * ns;
+            for (size_t e = 0; e < (size_t)M * ns; ++e) g[id[e]] += o[e];
+        }
+}
+
+/* kNN — restates dists = square_distance(xyz, xyz); dists.argsort()[:, :, :k]
+ * (variants.py:150-151) as the k smallest by (distance, index): a stable refinement of the
+ * reference's argsort. */
+void oracle_knn(const float* xyz, int B, int N, int k, int32_t* idx) {
+#pragma omp parallel for schedule(static)
+    for (int b = 0; b < B; ++b) {
+        const float* p = xyz + (size_t)b * N * 3;
+        float* d = (float*)malloc(sizeof(float) * (size_t)N);
+        unsigned char* used = (unsigned char*)malloc((size_t)N);
+        for (int i = 0; i < N; ++i) {
+            for (int c = 0; c < N; ++c) { d[c] = sqdist3(p + 3 * i, p + 3 * c); used[c] = 0; }
+            for (int r = 0; r < k; ++r) {
+                int best = -1;
+                for (int c = 0; c < N; ++c)
+                    if (!used[c] && (best < 0 || d[c] < d[best])) best = c;
+                used[best] = 1;
+                idx[((size_t)b * N + i) * k + r] = best;
+            }
+        }
+        free(d);
+        free(used);
+    }
+}

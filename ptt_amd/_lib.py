@@ -1,0 +1,97 @@
+"""ctypes binding of libptt_hip.so (the C ABI declared in include/ptt_hip.h).
+
+There is no fallback: if the shared library is missing or fails to load, every op raises.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libptt_hip.so")
+
+PTT_SA_MAX_LAYERS = 4
+
+# every symbol include/ptt_hip.h declares (tests check the library exports all of them)
+EXPORTS = [
+    "ptt_version", "ptt_error_name", "ptt_last_error_string",
+    "ptt_fps_f32", "ptt_gather_f32", "ptt_gather_grad_f32", "ptt_ball_query_f32",
+    "ptt_group_f32", "ptt_group_grad_f32", "ptt_knn_f32",
+    "ptt_packed_weight_elems", "ptt_pack_weight_f32", "ptt_linear_f32",
+    "ptt_sa_fused_fwd_f32", "ptt_pt_attn_pair_f32",
+]
+
+
+class SaLayer(Structure):
+    _fields_ = [("Wpacked", c_void_p), ("scale", c_void_p), ("shift", c_void_p),
+                ("Cin", c_int), ("Cout", c_int), ("relu", c_int)]
+
+
+class SaDesc(Structure):
+    _fields_ = [("xyz", c_void_p), ("new_xyz", c_void_p), ("idx", c_void_p), ("feat", c_void_p),
+                ("feat_sb", c_int64), ("feat_sc", c_int64), ("feat_sn", c_int64),
+                ("out", c_void_p), ("out_sb", c_int64), ("out_sc", c_int64), ("out_sm", c_int64),
+                ("B", c_int), ("N", c_int), ("M", c_int), ("nsample", c_int), ("C", c_int),
+                ("radius", c_float), ("use_xyz", c_int), ("normalize_xyz", c_int), ("n_layers", c_int),
+                ("layers", SaLayer * PTT_SA_MAX_LAYERS)]
+
+
+class AttnDesc(Structure):
+    _fields_ = [("xyz", c_void_p), ("knn", c_void_p), ("qkv", c_void_p),
+                ("Wd1", c_void_p), ("bd1", c_void_p), ("Wd2p", c_void_p), ("bd2", c_void_p),
+                ("Wg1p", c_void_p), ("bg1", c_void_p), ("Wg2p", c_void_p), ("bg2", c_void_p),
+                ("res", c_void_p), ("attn", c_void_p),
+                ("B", c_int), ("N", c_int), ("k", c_int), ("D", c_int)]
+
+
+_lib = None
+
+
+def _declare(lib):
+    vp, i, f = c_void_p, c_int, c_float
+    lib.ptt_version.restype = c_int
+    lib.ptt_error_name.restype = c_char_p
+    lib.ptt_error_name.argtypes = [i]
+    lib.ptt_last_error_string.restype = c_char_p
+    sigs = {
+        "ptt_fps_f32": [vp, i, i, i, vp, vp],
+        "ptt_gather_f32": [vp, vp, i, i, i, i, vp, vp],
+        "ptt_gather_grad_f32": [vp, vp, i, i, i, i, vp, vp],
+        "ptt_ball_query_f32": [vp, vp, i, i, i, f, i, vp, vp],
+        "ptt_group_f32": [vp, vp, i, i, i, i, i, vp, vp],
+        "ptt_group_grad_f32": [vp, vp, i, i, i, i, i, vp, vp],
+        "ptt_knn_f32": [vp, i, i, i, vp, vp],
+        "ptt_pack_weight_f32": [vp, i, i, vp, vp],
+        "ptt_linear_f32": [vp, i, i, i, vp, i, vp, vp, i, vp, i, vp, i, vp],
+        "ptt_sa_fused_fwd_f32": [POINTER(SaDesc), vp],
+        "ptt_pt_attn_pair_f32": [POINTER(AttnDesc), vp],
+    }
+    for name, args in sigs.items():
+        fn = getattr(lib, name)
+        fn.restype = c_int
+        fn.argtypes = args
+    lib.ptt_packed_weight_elems.restype = c_size_t
+    lib.ptt_packed_weight_elems.argtypes = [i, i]
+
+
+def lib():
+    """Load libptt_hip.so once. Raises RuntimeError (never falls back) when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "ptt_amd: %s is missing — build it with `python -m ptt_amd.build` "
+                "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+        try:
+            loaded = ctypes.CDLL(LIB_PATH)
+        except OSError as e:  # e.g. no ROCm runtime on this host
+            raise RuntimeError("ptt_amd: cannot load %s: %s" % (LIB_PATH, e))
+        _declare(loaded)
+        _lib = loaded
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        l = lib()
+        raise RuntimeError("%s failed: %s (%s)" % (what, l.ptt_error_name(rc).decode(),
+                                                   l.ptt_last_error_string().decode()))

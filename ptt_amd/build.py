@@ -1,0 +1,74 @@
+"""In-tree build of libptt_hip.so (gfx950) and of the CPU oracle used by the tests.
+
+`hipcc` cross-compiles for gfx950 without a GPU, so this runs in the build container;
+the resulting .so files are git-ignored but travel to the GPU box with the tree.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "ptt_amd", "csrc")
+LIBDIR = os.path.join(ROOT, "ptt_amd", "lib")
+LIB = os.path.join(LIBDIR, "libptt_hip.so")
+
+HIP_SOURCES = ["errors.hip", "point_ops.hip", "mfma_ops.hip"]
+# FPS / ball query / kNN index parity needs un-fused fp32 arithmetic (see point_ops.hip header)
+EXTRA_FLAGS = {"point_ops.hip": ["-ffp-contract=off"]}
+
+
+def _hipcc():
+    return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_hip(force=False, verbose=False):
+    os.makedirs(LIBDIR, exist_ok=True)
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers.append(os.path.join(ROOT, "include", "ptt_hip.h"))
+    objs = []
+    for src in HIP_SOURCES:
+        s = os.path.join(CSRC, src)
+        if not os.path.exists(s):
+            continue
+        o = os.path.join(LIBDIR, src.replace(".hip", ".o"))
+        objs.append(o)
+        if force or _stale(o, [s] + headers):
+            cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", s, "-o", o]
+            cmd += EXTRA_FLAGS.get(src, [])
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+    if force or _stale(LIB, objs):
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+def build_oracle(force=False, verbose=False):
+    odir = os.path.join(ROOT, "oracle")
+    src = os.path.join(odir, "ptt_oracle.c")
+    out = os.path.join(odir, "build", "libptt_oracle.so")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    if force or _stale(out, [src]):
+        cmd = ["gcc", "-O2", "-ffp-contract=off", "-fno-fast-math", "-shared", "-fPIC", "-fopenmp", src, "-o", out, "-lm"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return out
+
+
+if __name__ == "__main__":
+    force = "--force" in sys.argv
+    print(build_hip(force=force, verbose=True))
+    if os.path.exists(os.path.join(ROOT, "oracle", "ptt_oracle.c")):
+        print(build_oracle(force=force, verbose=True))

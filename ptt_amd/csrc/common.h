@@ -1,0 +1,57 @@
+// Shared host/device helpers for libptt_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/ptt_hip.h"
+
+namespace ptt {
+
+// thread-local last-error text, returned by ptt_last_error_string()
+char* last_error_buf();
+int fail(int code, const char* fmt, ...);
+int check_launch(const char* what);
+
+static inline hipStream_t as_stream(ptt_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+// ---- wave64 cross-lane reductions on DPP (no LDS traffic) -------------------------
+// After 4 row-local butterfly steps every lane of a 16-lane row holds the row result;
+// row_bcast:15 / row_bcast:31 then fold the four rows into lane 63.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_i32(int v) {
+    return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xF, false);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __builtin_bit_cast(float, dpp_i32<CTRL, ROW_MASK>(__builtin_bit_cast(int, v)));
+}
+
+__device__ __forceinline__ float wave_max_f32(float v) {
+    v = fmaxf(v, dpp_f32<0xB1, 0xF>(v));   // quad_perm [1,0,3,2]
+    v = fmaxf(v, dpp_f32<0x4E, 0xF>(v));   // quad_perm [2,3,0,1]
+    v = fmaxf(v, dpp_f32<0x141, 0xF>(v));  // row_half_mirror
+    v = fmaxf(v, dpp_f32<0x140, 0xF>(v));  // row_mirror
+    v = fmaxf(v, dpp_f32<0x142, 0xA>(v));  // row_bcast:15 into rows 1,3
+    v = fmaxf(v, dpp_f32<0x143, 0xC>(v));  // row_bcast:31 into rows 2,3
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ float wave_min_f32(float v) {
+    v = fminf(v, dpp_f32<0xB1, 0xF>(v));
+    v = fminf(v, dpp_f32<0x4E, 0xF>(v));
+    v = fminf(v, dpp_f32<0x141, 0xF>(v));
+    v = fminf(v, dpp_f32<0x140, 0xF>(v));
+    v = fminf(v, dpp_f32<0x142, 0xA>(v));
+    v = fminf(v, dpp_f32<0x143, 0xC>(v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ int wave_min_i32(int v) {
+    v = min(v, dpp_i32<0xB1, 0xF>(v));
+    v = min(v, dpp_i32<0x4E, 0xF>(v));
+    v = min(v, dpp_i32<0x141, 0xF>(v));
+    v = min(v, dpp_i32<0x140, 0xF>(v));
+    v = min(v, dpp_i32<0x142, 0xA>(v));
+    v = min(v, dpp_i32<0x143, 0xC>(v));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+}  // namespace ptt

@@ -1,0 +1,543 @@
+// fp32-MFMA kernels of the hot path (gfx950): weight packing, row-wise linear layers, the
+// fused set-abstraction level (group -> normalise -> SharedMLP -> max-pool) and the fused
+// per-(point,neighbour) part of the Point-Transformer block.
+//
+// Common structure
+//   * one workgroup = 4 waves (256 threads), two workgroups per CU (<= 80 KB LDS each), so
+//     the MFMA pipe of a SIMD always has a second wave to run while the first one gathers,
+//     writes an epilogue or waits at a barrier;
+//   * the activation tile X[rows][K] lives in LDS (row stride ldk == 4 mod 8 floats, which
+//     makes the ds_read_b128 A-fragment reads bank-conflict free) and is overwritten in
+//     place by each layer's output — grouped / per-pair tensors never reach HBM;
+//   * weights are pre-packed once into MFMA B-fragment order [K/8][Cout/32][lane][4], so a
+//     wave fetches a fragment with ONE coalesced 1 KiB global_load_dwordx4 straight from
+//     L2 (weights are <= 1 MiB per layer and shared by every workgroup);
+//   * v_mfma_f32_32x32x2_f32: exact fp32 (bitwise an fmaf chain), 64 cycles per issue.
+//     A K-block of 8 input channels is 4 MFMAs; lane half h (lane>>5) feeds channels
+//     8*kb + 4*h + j to MFMA j, so each lane's 4 operands are one 16-byte load.
+//   * C/D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+//     a tile's 32 rows are the neighbours of one centre (or of two, 16 each), so max-pool
+//     and the softmax over neighbours are register-local plus one lane^32 exchange.
+#include <math.h>
+#include "common.h"
+
+namespace ptt {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int tile_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
+
+__device__ __forceinline__ float xor32(float v) { return __shfl_xor(v, 32, 64); }
+
+// ------------------------------------------------------------------------------------------
+// weight packing
+// ------------------------------------------------------------------------------------------
+__global__ void pack_weight_kernel(const float* __restrict__ W, int Cout, int K, int NT, size_t total,
+                                   float* __restrict__ P) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int j = (int)(e & 3);
+        const int lane = (int)((e >> 2) & 63);
+        const size_t tile = e >> 8;
+        const int ct = (int)(tile % NT);
+        const int kb = (int)(tile / NT);
+        const int col = ct * 32 + (lane & 31);
+        const int k = kb * 8 + 4 * (lane >> 5) + j;
+        P[e] = (col < Cout && k < K) ? W[(size_t)col * K + k] : 0.0f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// The shared GEMM core: acc[rt][u] += X[rt-th 32 rows][0:8*nkb] * W[:, col tile ct0 + 4*u]
+// A from LDS (one ds_read_b128 per row tile per K-block), B from packed global weights with
+// a one-block register prefetch. `nvalid` = number of this wave's column tiles that exist.
+// ------------------------------------------------------------------------------------------
+template <int RT, int CT>
+__device__ __forceinline__ void gemm_core(const float* Xs, int ldk, int nkb, const f32x4* __restrict__ Wp, int NT,
+                                          int ct0, int nvalid, int lane, f32x16 (&acc)[RT][CT]) {
+    const int row = lane & 31, half = lane >> 5;
+    const float* arow = Xs + row * ldk + 4 * half;
+    const f32x4* bp = Wp + (size_t)ct0 * 64 + lane;
+    const size_t bstep = (size_t)NT * 64;
+
+    f32x4 bcur[CT], bnxt[CT];
+#pragma unroll
+    for (int u = 0; u < CT; ++u) bcur[u] = (u < nvalid) ? bp[(size_t)u * 4 * 64] : f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int kb = 0; kb < nkb; ++kb) {
+        const f32x4* bn = bp + (size_t)(kb + 1) * bstep;
+        if (kb + 1 < nkb) {
+#pragma unroll
+            for (int u = 0; u < CT; ++u)
+                if (u < nvalid) bnxt[u] = bn[(size_t)u * 4 * 64];
+        }
+        f32x4 a[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) a[rt] = *reinterpret_cast<const f32x4*>(arow + rt * 32 * ldk + kb * 8);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int u = 0; u < CT; ++u)
+                if (u < nvalid) {
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt)
+                        acc[rt][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rt][j], bcur[u][j], acc[rt][u], 0, 0, 0);
+                }
+#pragma unroll
+        for (int u = 0; u < CT; ++u) bcur[u] = bnxt[u];
+    }
+}
+
+template <int RT, int CT>
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[RT][CT]) {
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int u = 0; u < CT; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[rt][u][r] = 0.f;
+}
+
+// ------------------------------------------------------------------------------------------
+// Linear: out[rows, Cout] = act(X[rows, K] @ W^T * scale + shift) (+ residual)
+// grid = (ceil(rows/32), ceil(Cout/256)); a workgroup owns 32 rows x 256 columns.
+// ------------------------------------------------------------------------------------------
+struct LinearParams {
+    const float* X; const float* Wp; const float* scale; const float* shift; const float* residual; float* out;
+    int rows, K, ldx, Cout, relu, ldr, ldo, ldk, nkb, NT;
+};
+
+__global__ __launch_bounds__(256, 2) void linear_kernel(LinearParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Xs = smem;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int row0 = blockIdx.x * 32;
+    const int Kpad = p.nkb * 8;
+
+    // stage the 32-row activation tile (zero-padded rows / columns)
+    for (int e = t; e < 32 * Kpad; e += 256) {
+        const int r = e / Kpad, c = e - r * Kpad;
+        const int gr = row0 + r;
+        Xs[r * p.ldk + c] = (gr < p.rows && c < p.K) ? p.X[(size_t)gr * p.ldx + c] : 0.f;
+    }
+    __syncthreads();
+
+    const int ctbase = blockIdx.y * 8 + w;  // this wave's first column tile, the second is +4
+    int nvalid = 0;
+    if (ctbase < p.NT) nvalid = (ctbase + 4 < p.NT) ? 2 : 1;
+    if (nvalid == 0) return;
+
+    f32x16 acc[1][2];
+    zero_acc(acc);
+    gemm_core<1, 2>(Xs, p.ldk, p.nkb, reinterpret_cast<const f32x4*>(p.Wp), p.NT, ctbase, nvalid, lane, acc);
+
+    const int half = lane >> 5;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        if (u >= nvalid) break;
+        const int col = (ctbase + 4 * u) * 32 + (lane & 31);
+        if (col >= p.Cout) continue;
+        const float sc = p.scale ? p.scale[col] : 1.f;
+        const float sh = p.shift ? p.shift[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int gr = row0 + tile_row(r, half);
+            if (gr >= p.rows) continue;
+            float y = acc[0][u][r] * sc + sh;
+            if (p.relu) y = fmaxf(y, 0.f);
+            if (p.residual) y += p.residual[(size_t)gr * p.ldr + col];
+            p.out[(size_t)gr * p.ldo + col] = y;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Fused set-abstraction level. A workgroup owns 64 grouped rows = 64/NS centres.
+// ------------------------------------------------------------------------------------------
+struct SaLayerDev { const float* Wp; const float* scale; const float* shift; int Cin, Cout, relu, nkb, NT; };
+struct SaParams {
+    const float* xyz; const float* new_xyz; const int32_t* idx; const float* feat; float* out;
+    long long fsb, fsc, fsn, osb, osc, osm;
+    int B, N, M, C, use_xyz, normalize, n_layers, ldk, K0;
+    float radius;
+    SaLayerDev L[PTT_SA_MAX_LAYERS];
+};
+
+template <int NS, int CT>
+__device__ __forceinline__ void sa_layer(const SaParams& p, const SaLayerDev& L, bool last, float* Xs, int lane, int w,
+                                         int centre0, int ncentres) {
+    f32x16 acc[2][CT];
+    zero_acc(acc);
+    int nvalid = 0;
+#pragma unroll
+    for (int u = 0; u < CT; ++u)
+        if (w + 4 * u < L.NT) nvalid = u + 1;
+    if (nvalid > 0)
+        gemm_core<2, CT>(Xs, p.ldk, L.nkb, reinterpret_cast<const f32x4*>(L.Wp), L.NT, w, nvalid, lane, acc);
+    __syncthreads();  // every wave has finished reading this layer's input tile
+
+    const int half = lane >> 5;
+#pragma unroll
+    for (int u = 0; u < CT; ++u) {
+        if (u >= nvalid) break;
+        const int col = (w + 4 * u) * 32 + (lane & 31);
+        const bool colok = col < L.Cout;
+        const float sc = (L.scale && colok) ? L.scale[col] : 1.f;
+        const float sh = (L.shift && colok) ? L.shift[col] : 0.f;
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            float y[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[rt][u][r] * sc + sh;
+                if (L.relu) v = fmaxf(v, 0.f);
+                y[r] = colok ? v : 0.f;
+            }
+            if (!last) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) Xs[(rt * 32 + tile_row(r, half)) * p.ldk + col] = y[r];
+            } else if (NS == 32) {
+                float m = y[0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) m = fmaxf(m, y[r]);
+                m = fmaxf(m, xor32(m));
+                const int c = centre0 + rt;
+                if (half == 0 && colok && rt < ncentres) {
+                    const int b = c / p.M, mm = c - b * p.M;
+                    p.out[b * p.osb + col * p.osc + mm * p.osm] = m;
+                }
+            } else {  // NS == 16: rows 0..15 (regs 0..7) and rows 16..31 (regs 8..15) are two centres
+                float m0 = y[0], m1 = y[8];
+#pragma unroll
+                for (int r = 1; r < 8; ++r) { m0 = fmaxf(m0, y[r]); m1 = fmaxf(m1, y[8 + r]); }
+                m0 = fmaxf(m0, xor32(m0));
+                m1 = fmaxf(m1, xor32(m1));
+                if (half == 0 && colok) {
+                    const int ca = rt * 2, cb = rt * 2 + 1;
+                    if (ca < ncentres) {
+                        const int c = centre0 + ca; const int b = c / p.M, mm = c - b * p.M;
+                        p.out[b * p.osb + col * p.osc + mm * p.osm] = m0;
+                    }
+                    if (cb < ncentres) {
+                        const int c = centre0 + cb; const int b = c / p.M, mm = c - b * p.M;
+                        p.out[b * p.osb + col * p.osc + mm * p.osm] = m1;
+                    }
+                }
+            }
+        }
+    }
+    if (!last) __syncthreads();
+}
+
+template <int NS>
+__global__ __launch_bounds__(256, 2) void sa_fused_kernel(SaParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Xs = smem;                                      // [64][ldk]
+    int* nbr = reinterpret_cast<int*>(smem + 64 * p.ldk);  // [64] flat row index b*N + n of each grouped row
+    constexpr int CPW = 64 / NS;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int total_centres = p.B * p.M;
+    const int centre0 = blockIdx.x * CPW;
+    const int ncentres = min(CPW, total_centres - centre0);
+
+    // ---- group: relative (normalised) coordinates + neighbour features -> X ----
+    const int xoff = p.use_xyz ? 3 : 0;
+    if (t < 64) {
+        const int r = t;
+        int c = centre0 + r / NS;
+        if (c >= total_centres) c = total_centres - 1;
+        const int b = c / p.M;
+        const int n = p.idx[(size_t)c * NS + (r % NS)];
+        const int flat = b * p.N + n;
+        nbr[r] = flat;
+        if (p.use_xyz) {
+            float dx = p.xyz[(size_t)flat * 3 + 0] - p.new_xyz[(size_t)c * 3 + 0];
+            float dy = p.xyz[(size_t)flat * 3 + 1] - p.new_xyz[(size_t)c * 3 + 1];
+            float dz = p.xyz[(size_t)flat * 3 + 2] - p.new_xyz[(size_t)c * 3 + 2];
+            if (p.normalize) { dx /= p.radius; dy /= p.radius; dz /= p.radius; }
+            Xs[r * p.ldk + 0] = dx; Xs[r * p.ldk + 1] = dy; Xs[r * p.ldk + 2] = dz;
+        }
+    }
+    __syncthreads();
+    const int Kpad0 = p.L[0].nkb * 8;
+    for (int r = w; r < 64; r += 4) {
+        const int flat = nbr[r];
+        const int b = flat / p.N, n = flat - b * p.N;
+        const float* f = p.feat + b * p.fsb + n * p.fsn;
+        float* xr = Xs + r * p.ldk + xoff;
+        for (int c = lane; c < p.C; c += 64) xr[c] = f[c * p.fsc];
+        for (int c = p.K0 + lane; c < Kpad0; c += 64) Xs[r * p.ldk + c] = 0.f;
+    }
+    __syncthreads();
+
+    for (int l = 0; l < p.n_layers; ++l) {
+        const SaLayerDev& L = p.L[l];
+        const bool last = (l == p.n_layers - 1);
+        const int ctw = (L.NT + 3) >> 2;
+        if (ctw <= 1) sa_layer<NS, 1>(p, L, last, Xs, lane, w, centre0, ncentres);
+        else if (ctw == 2) sa_layer<NS, 2>(p, L, last, Xs, lane, w, centre0, ncentres);
+        else sa_layer<NS, 4>(p, L, last, Xs, lane, w, centre0, ncentres);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Point-Transformer pair kernel. A workgroup owns 2 points x 16 neighbours = 32 pair rows
+// and all D = 512 channels; wave w owns column tiles w, w+4, w+8, w+12.
+// ------------------------------------------------------------------------------------------
+struct AttnParams {
+    const float* xyz; const int32_t* knn; const float* qkv; const float* Wd1; const float* bd1;
+    const float* Wd2p; const float* bd2; const float* Wg1p; const float* bg1; const float* Wg2p; const float* bg2;
+    float* res; float* attn;
+    int BN, N;
+};
+
+template <int D>
+__global__ __launch_bounds__(256, 2) void pt_attn_pair_kernel(AttnParams p) {
+    constexpr int KNN = 16, NT = D / 32, CT = NT / 4, LDK = D + 4, NKB = D / 8;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Xs = smem;                                       // [32][LDK]
+    int* nb = reinterpret_cast<int*>(smem + 32 * LDK);      // [32] flat neighbour row (b*N + n)
+    float* dxyz = smem + 32 * LDK + 32;                     // [32][3]
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, half = lane >> 5;
+    const int pt0 = blockIdx.x * 2;                          // flat point index of tile row 0
+    const int npts = min(2, p.BN - pt0);
+
+    if (t < 32) {
+        int pt = pt0 + (t >> 4);
+        if (pt >= p.BN) pt = p.BN - 1;
+        const int b = pt / p.N;
+        const int n = p.knn[(size_t)pt * KNN + (t & 15)];
+        const int flat = b * p.N + n;
+        nb[t] = flat;
+        dxyz[t * 3 + 0] = p.xyz[(size_t)pt * 3 + 0] - p.xyz[(size_t)flat * 3 + 0];
+        dxyz[t * 3 + 1] = p.xyz[(size_t)pt * 3 + 1] - p.xyz[(size_t)flat * 3 + 1];
+        dxyz[t * 3 + 2] = p.xyz[(size_t)pt * 3 + 2] - p.xyz[(size_t)flat * 3 + 2];
+    }
+    __syncthreads();
+
+    // fc_delta[0] + ReLU (K = 3) on the vector ALU, straight into the LDS tile
+#pragma unroll
+    for (int cc = 0; cc < D / 256; ++cc) {
+        const int c = t + cc * 256;
+        const float w0 = p.Wd1[c * 3 + 0], w1 = p.Wd1[c * 3 + 1], w2 = p.Wd1[c * 3 + 2], bb = p.bd1[c];
+#pragma unroll 8
+        for (int r = 0; r < 32; ++r) {
+            const float h = ((dxyz[r * 3 + 0] * w0 + dxyz[r * 3 + 1] * w1) + dxyz[r * 3 + 2] * w2) + bb;
+            Xs[r * LDK + c] = fmaxf(h, 0.f);
+        }
+    }
+    __syncthreads();
+
+    int cols[CT];
+#pragma unroll
+    for (int u = 0; u < CT; ++u) cols[u] = (w + 4 * u) * 32 + (lane & 31);
+
+    // ---- delta = fc_delta[2](h) ----
+    f32x16 delta[1][CT];
+    zero_acc(delta);
+    gemm_core<1, CT>(Xs, LDK, NKB, reinterpret_cast<const f32x4*>(p.Wd2p), NT, w, CT, lane, delta);
+#pragma unroll
+    for (int u = 0; u < CT; ++u) {
+        const float bb = p.bd2[cols[u]];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) delta[0][u][r] += bb;
+    }
+    int nrow[16];  // flat neighbour row of each of this lane's 16 tile rows
+#pragma unroll
+    for (int r = 0; r < 16; ++r) nrow[r] = nb[tile_row(r, half)];
+
+    __syncthreads();  // all waves done with h
+    // t = (q_i - k_j) + delta  -> X
+    {
+        const int pa = pt0, pb = (npts > 1) ? pt0 + 1 : pt0;
+#pragma unroll
+        for (int u = 0; u < CT; ++u) {
+            const float qa = p.qkv[(size_t)pa * 3 * D + cols[u]];
+            const float qb = p.qkv[(size_t)pb * 3 * D + cols[u]];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float kv = p.qkv[(size_t)nrow[r] * 3 * D + D + cols[u]];
+                const float q = (r < 8) ? qa : qb;
+                Xs[tile_row(r, half) * LDK + cols[u]] = (q - kv) + delta[0][u][r];
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- g = relu(fc_gamma[0](t)) -> X ----
+    {
+        f32x16 acc[1][CT];
+        zero_acc(acc);
+        gemm_core<1, CT>(Xs, LDK, NKB, reinterpret_cast<const f32x4*>(p.Wg1p), NT, w, CT, lane, acc);
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < CT; ++u) {
+            const float bb = p.bg1[cols[u]];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Xs[tile_row(r, half) * LDK + cols[u]] = fmaxf(acc[0][u][r] + bb, 0.f);
+        }
+        __syncthreads();
+    }
+
+    // ---- a = fc_gamma[2](g); softmax over the 16 neighbours; res = sum attn * (v + delta) ----
+    f32x16 acc[1][CT];
+    zero_acc(acc);
+    gemm_core<1, CT>(Xs, LDK, NKB, reinterpret_cast<const f32x4*>(p.Wg2p), NT, w, CT, lane, acc);
+    const float inv_scale_div = sqrtf((float)D);
+#pragma unroll
+    for (int u = 0; u < CT; ++u) {
+        const float bb = p.bg2[cols[u]];
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {
+            float s[8];
+            float m = -__builtin_inff();
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                s[r] = (acc[0][u][pp * 8 + r] + bb) / inv_scale_div;
+                m = fmaxf(m, s[r]);
+            }
+            m = fmaxf(m, xor32(m));
+            float sum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { s[r] = expf(s[r] - m); sum += s[r]; }
+            sum += xor32(sum);
+            float o = 0.f;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int rr = pp * 8 + r;
+                const float a = s[r] / sum;
+                const float vv = p.qkv[(size_t)nrow[rr] * 3 * D + 2 * D + cols[u]];
+                o += a * (vv + delta[0][u][rr]);
+                if (p.attn && pp < npts) {
+                    const int row = tile_row(rr, half);  // = pp*16 + j
+                    p.attn[((size_t)(pt0 + pp) * KNN + (row & 15)) * D + cols[u]] = a;
+                }
+            }
+            o += xor32(o);
+            if (half == 0 && pp < npts) p.res[(size_t)(pt0 + pp) * D + cols[u]] = o;
+        }
+    }
+}
+
+static int set_lds_limit(const void* fn, int bytes) {
+    if (bytes <= 48 * 1024) return PTT_OK;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess)
+        return check_launch("hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+    return PTT_OK;
+}
+
+}  // namespace ptt
+
+using namespace ptt;
+
+extern "C" size_t ptt_packed_weight_elems(int Cout, int K) {
+    if (Cout <= 0 || K <= 0) return 0;
+    const size_t NT = (size_t)(Cout + 31) / 32, NKB = (size_t)(K + 7) / 8;
+    return NT * NKB * 256;
+}
+
+extern "C" int ptt_pack_weight_f32(const float* W, int Cout, int K, float* packed, ptt_stream_t stream) {
+    if (Cout <= 0 || K <= 0) return fail(PTT_EINVAL, "ptt_pack_weight_f32: Cout=%d K=%d", Cout, K);
+    if (!W || !packed) return fail(PTT_EINVAL, "ptt_pack_weight_f32: null pointer");
+    const size_t total = ptt_packed_weight_elems(Cout, K);
+    const int NT = (Cout + 31) / 32;
+    size_t g = (total + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)g), dim3(256), 0, as_stream(stream), W, Cout, K, NT, total,
+                       packed);
+    return check_launch("pack_weight_kernel");
+}
+
+extern "C" int ptt_linear_f32(const float* X, int rows, int K, int ldx, const float* Wpacked, int Cout,
+                              const float* scale, const float* shift, int relu, const float* residual, int ldr,
+                              float* out, int ldo, ptt_stream_t stream) {
+    if (rows < 0 || K <= 0 || Cout <= 0 || ldx < K || ldo < Cout || (residual && ldr < Cout))
+        return fail(PTT_EINVAL, "ptt_linear_f32: rows=%d K=%d Cout=%d ldx=%d ldo=%d ldr=%d", rows, K, Cout, ldx, ldo,
+                    ldr);
+    if (rows == 0) return PTT_OK;
+    if (!X || !Wpacked || !out) return fail(PTT_EINVAL, "ptt_linear_f32: null pointer");
+    LinearParams p;
+    p.X = X; p.Wp = Wpacked; p.scale = scale; p.shift = shift; p.residual = residual; p.out = out;
+    p.rows = rows; p.K = K; p.ldx = ldx; p.Cout = Cout; p.relu = relu; p.ldr = ldr; p.ldo = ldo;
+    p.nkb = (K + 7) / 8; p.NT = (Cout + 31) / 32; p.ldk = p.nkb * 8 + 4;
+    const int lds = 32 * p.ldk * (int)sizeof(float);
+    if (lds > 80 * 1024) return fail(PTT_EUNSUPPORTED, "ptt_linear_f32: K=%d needs %d B of LDS per tile", K, lds);
+    int rc = set_lds_limit(reinterpret_cast<const void*>(linear_kernel), lds);
+    if (rc) return rc;
+    const dim3 grid((rows + 31) / 32, (p.NT + 7) / 8);
+    hipLaunchKernelGGL(linear_kernel, grid, dim3(256), lds, as_stream(stream), p);
+    return check_launch("linear_kernel");
+}
+
+extern "C" int ptt_sa_fused_fwd_f32(const ptt_sa_desc* d, ptt_stream_t stream) {
+    if (!d) return fail(PTT_EINVAL, "ptt_sa_fused_fwd_f32: null descriptor");
+    if (d->B < 0 || d->N <= 0 || d->M < 0 || d->C < 0 || d->n_layers < 1 || d->n_layers > PTT_SA_MAX_LAYERS)
+        return fail(PTT_EINVAL, "ptt_sa_fused_fwd_f32: B=%d N=%d M=%d C=%d layers=%d", d->B, d->N, d->M, d->C,
+                    d->n_layers);
+    if (d->nsample != 16 && d->nsample != 32)
+        return fail(PTT_EUNSUPPORTED, "ptt_sa_fused_fwd_f32: nsample=%d (16 and 32 are instantiated)", d->nsample);
+    if (d->B == 0 || d->M == 0) return PTT_OK;
+    if (!d->xyz || !d->new_xyz || !d->idx || !d->out || (d->C > 0 && !d->feat))
+        return fail(PTT_EINVAL, "ptt_sa_fused_fwd_f32: null pointer");
+    if (!d->use_xyz && d->C == 0) return fail(PTT_EINVAL, "ptt_sa_fused_fwd_f32: no xyz and no features");
+
+    SaParams p;
+    p.xyz = d->xyz; p.new_xyz = d->new_xyz; p.idx = d->idx; p.feat = d->feat; p.out = d->out;
+    p.fsb = d->feat_sb; p.fsc = d->feat_sc; p.fsn = d->feat_sn;
+    p.osb = d->out_sb; p.osc = d->out_sc; p.osm = d->out_sm;
+    p.B = d->B; p.N = d->N; p.M = d->M; p.C = d->C; p.use_xyz = d->use_xyz ? 1 : 0;
+    p.normalize = d->normalize_xyz ? 1 : 0; p.n_layers = d->n_layers; p.radius = d->radius;
+    p.K0 = (d->use_xyz ? 3 : 0) + d->C;
+    int maxk = 0, cin = p.K0;
+    for (int l = 0; l < d->n_layers; ++l) {
+        const ptt_sa_layer& s = d->layers[l];
+        if (s.Cin != cin) return fail(PTT_EINVAL, "ptt_sa_fused_fwd_f32: layer %d Cin=%d, expected %d", l, s.Cin, cin);
+        if (s.Cout <= 0 || (s.Cout % 32) != 0 || s.Cout > 512)
+            return fail(PTT_EUNSUPPORTED, "ptt_sa_fused_fwd_f32: layer %d Cout=%d must be a multiple of 32 <= 512", l,
+                        s.Cout);
+        if (!s.Wpacked) return fail(PTT_EINVAL, "ptt_sa_fused_fwd_f32: layer %d has no weights", l);
+        SaLayerDev& L = p.L[l];
+        L.Wp = s.Wpacked; L.scale = s.scale; L.shift = s.shift; L.Cin = s.Cin; L.Cout = s.Cout; L.relu = s.relu;
+        L.nkb = (s.Cin + 7) / 8; L.NT = s.Cout / 32;
+        if (L.nkb * 8 > maxk) maxk = L.nkb * 8;
+        if (l + 1 < d->n_layers && s.Cout > maxk) maxk = s.Cout;
+        cin = s.Cout;
+    }
+    p.ldk = maxk + 4;
+    const int lds = (64 * p.ldk + 64) * (int)sizeof(float);
+    if (lds > 160 * 1024) return fail(PTT_EUNSUPPORTED, "ptt_sa_fused_fwd_f32: %d B of LDS per workgroup", lds);
+    const int total_centres = d->B * d->M;
+    hipStream_t s = as_stream(stream);
+    int rc;
+    if (d->nsample == 32) {
+        if ((rc = set_lds_limit(reinterpret_cast<const void*>(sa_fused_kernel<32>), lds))) return rc;
+        hipLaunchKernelGGL((sa_fused_kernel<32>), dim3((total_centres + 1) / 2), dim3(256), lds, s, p);
+    } else {
+        if ((rc = set_lds_limit(reinterpret_cast<const void*>(sa_fused_kernel<16>), lds))) return rc;
+        hipLaunchKernelGGL((sa_fused_kernel<16>), dim3((total_centres + 3) / 4), dim3(256), lds, s, p);
+    }
+    return check_launch("sa_fused_kernel");
+}
+
+extern "C" int ptt_pt_attn_pair_f32(const ptt_attn_desc* d, ptt_stream_t stream) {
+    if (!d) return fail(PTT_EINVAL, "ptt_pt_attn_pair_f32: null descriptor");
+    if (d->B < 0 || d->N <= 0) return fail(PTT_EINVAL, "ptt_pt_attn_pair_f32: B=%d N=%d", d->B, d->N);
+    if (d->D != 512 || d->k != 16)
+        return fail(PTT_EUNSUPPORTED, "ptt_pt_attn_pair_f32: D=%d k=%d (D=512, k=16 is instantiated)", d->D, d->k);
+    if (d->B == 0) return PTT_OK;
+    if (!d->xyz || !d->knn || !d->qkv || !d->Wd1 || !d->bd1 || !d->Wd2p || !d->bd2 || !d->Wg1p || !d->bg1 ||
+        !d->Wg2p || !d->bg2 || !d->res)
+        return fail(PTT_EINVAL, "ptt_pt_attn_pair_f32: null pointer");
+    AttnParams p;
+    p.xyz = d->xyz; p.knn = d->knn; p.qkv = d->qkv; p.Wd1 = d->Wd1; p.bd1 = d->bd1; p.Wd2p = d->Wd2p; p.bd2 = d->bd2;
+    p.Wg1p = d->Wg1p; p.bg1 = d->bg1; p.Wg2p = d->Wg2p; p.bg2 = d->bg2; p.res = d->res; p.attn = d->attn;
+    p.BN = d->B * d->N; p.N = d->N;
+    if ((d->N & 1) != 0)
+        return fail(PTT_EUNSUPPORTED, "ptt_pt_attn_pair_f32: N=%d must be even (a tile holds two points of one cloud)",
+                    d->N);
+    const int lds = (32 * (512 + 4) + 32 + 96) * (int)sizeof(float);
+    int rc = set_lds_limit(reinterpret_cast<const void*>(pt_attn_pair_kernel<512>), lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((pt_attn_pair_kernel<512>), dim3((p.BN + 1) / 2), dim3(256), lds, as_stream(stream), p);
+    return check_launch("pt_attn_pair_kernel");
+}

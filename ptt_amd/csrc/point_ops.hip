@@ -1,0 +1,348 @@
+// Point-cloud index ops for gfx950: furthest point sampling, ball query, gather, group,
+// kNN. These replace the CUDA-only third-party `pointnet2_ops._ext` the reference calls
+// (ptt/models/backbones_3d/pointnet2/pointnet2_utils.py:24,78,112,118,237,257,287) and the
+// square_distance+argsort kNN of the transformer (transformer_block/variants.py:150-151).
+//
+// Arithmetic contract (restated in oracle/ptt_oracle.c): squared distances
+// are (dx*dx + dy*dy) + dz*dz in fp32 with NO fused multiply-add, so that indices are
+// bit-reproducible against the CPU oracle. This whole file is compiled with
+// -ffp-contract=off and carries the pragma below.
+#pragma clang fp contract(off)
+
+#include <limits.h>
+#include "common.h"
+
+namespace ptt {
+
+__device__ __forceinline__ float sqdist3(float ax, float ay, float az, float bx, float by, float bz) {
+    const float dx = ax - bx, dy = ay - by, dz = az - bz;
+    return (dx * dx + dy * dy) + dz * dz;
+}
+
+// ------------------------------------------------------------------------------------------
+// FPS. One workgroup per cloud, T threads, P points per thread held in registers together
+// with their running min-distance; nothing but the chosen index leaves the CU per iteration.
+// Iteration = register update -> DPP wave arg-max -> (T>64) one LDS slot per wave + one
+// barrier -> every thread folds the <=16 slots redundantly. Skipped points (|p|^2 <= 1e-3)
+// and padding carry min-dist -1 so they can never win and never change.
+// ------------------------------------------------------------------------------------------
+template <int T, int P>
+__global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, int N, int npoint,
+                                               int32_t* __restrict__ idx_out) {
+    constexpr int W = T / 64;
+    const int b = blockIdx.x;
+    const float* __restrict__ pts = xyz + (size_t)b * N * 3;
+    int32_t* __restrict__ out = idx_out + (size_t)b * npoint;
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wv = t >> 6;
+
+    float px[P], py[P], pz[P], md[P];
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        const int k = t + i * T;
+        float x = 0.f, y = 0.f, z = 0.f, m = -1.0f;
+        if (k < N) {
+            x = pts[3 * k + 0];
+            y = pts[3 * k + 1];
+            z = pts[3 * k + 2];
+            const float mag = (x * x + y * y) + z * z;
+            m = (mag > 1e-3f) ? 1e10f : -1.0f;
+        }
+        px[i] = x; py[i] = y; pz[i] = z; md[i] = m;
+    }
+
+    // slots[parity][wave] = {dist, idx(bits), x, y, z}
+    __shared__ float slots[2][W > 1 ? W : 1][8];
+
+    float lx = pts[0], ly = pts[1], lz = pts[2];
+    if (t == 0) out[0] = 0;
+
+    for (int j = 1; j < npoint; ++j) {
+        float best = -1.0f, bx = 0.f, by = 0.f, bz = 0.f;
+        int besti = INT_MAX;
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            const float d = sqdist3(px[i], py[i], pz[i], lx, ly, lz);
+            const float m = fminf(md[i], d);
+            md[i] = m;
+            if (m > best) { best = m; besti = t + i * T; bx = px[i]; by = py[i]; bz = pz[i]; }
+        }
+        const float wmax = wave_max_f32(best);
+        const int widx = wave_min_i32(best == wmax ? besti : INT_MAX);
+
+        if constexpr (W == 1) {
+            int sel = widx;
+            if (sel == INT_MAX) {
+                sel = 0; lx = pts[0]; ly = pts[1]; lz = pts[2];
+            } else {
+                const int src = sel & 63;  // owner lane: k = lane + i*64
+                lx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bx), src));
+                ly = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, by), src));
+                lz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bz), src));
+            }
+            if (lane == 0) out[j] = sel;
+        } else {
+            const int par = j & 1;
+            if (widx == INT_MAX) {
+                if (lane == 0) { slots[par][wv][0] = -1.0f; slots[par][wv][1] = __builtin_bit_cast(float, INT_MAX); }
+            } else if (besti == widx) {
+                float* s = slots[par][wv];
+                s[0] = wmax; s[1] = __builtin_bit_cast(float, widx); s[2] = bx; s[3] = by; s[4] = bz;
+            }
+            __syncthreads();
+            float gd = -1.0f, gx = 0.f, gy = 0.f, gz = 0.f;
+            int gi = INT_MAX;
+#pragma unroll
+            for (int w = 0; w < W; ++w) {
+                const float* s = slots[par][w];
+                const float d = s[0];
+                const int i = __builtin_bit_cast(int, s[1]);
+                if (d > gd || (d == gd && i < gi)) { gd = d; gi = i; gx = s[2]; gy = s[3]; gz = s[4]; }
+            }
+            if (gi == INT_MAX) { gi = 0; gx = pts[0]; gy = pts[1]; gz = pts[2]; }
+            lx = gx; ly = gy; lz = gz;
+            if (t == 0) out[j] = gi;
+        }
+    }
+}
+
+template <int T, int P>
+static int launch_fps(const float* xyz, int B, int N, int npoint, int32_t* idx, hipStream_t s) {
+    hipLaunchKernelGGL((fps_kernel<T, P>), dim3(B), dim3(T), 0, s, xyz, N, npoint, idx);
+    return check_launch("fps_kernel");
+}
+
+// ------------------------------------------------------------------------------------------
+// Ball query. One wave per centre sweeps the cloud 64 points at a time (coalesced), a
+// ballot + prefix popcount keeps hits in index order, and the wave stops as soon as
+// nsample hits are stored.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ball_query_kernel(const float* __restrict__ new_xyz,
+                                                         const float* __restrict__ xyz, int BM, int M, int N,
+                                                         float r2, int ns, int32_t* __restrict__ idx_out) {
+    const int centre = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (centre >= BM) return;
+    const int lane = threadIdx.x & 63;
+    const int b = centre / M;
+    const float* __restrict__ pts = xyz + (size_t)b * N * 3;
+    int32_t* __restrict__ out = idx_out + (size_t)centre * ns;
+    const float cx = new_xyz[(size_t)centre * 3 + 0];
+    const float cy = new_xyz[(size_t)centre * 3 + 1];
+    const float cz = new_xyz[(size_t)centre * 3 + 2];
+
+    int cnt = 0, first = 0;
+    for (int base = 0; base < N; base += 64) {
+        const int k = base + lane;
+        bool hit = false;
+        if (k < N) {
+            const float d = sqdist3(cx, cy, cz, pts[3 * k + 0], pts[3 * k + 1], pts[3 * k + 2]);
+            hit = d < r2;
+        }
+        const unsigned long long mask = __ballot(hit);
+        if (mask != 0ull) {
+            if (cnt == 0) first = base + (__ffsll((long long)mask) - 1);
+            const int pos = cnt + __popcll(mask & ((1ull << lane) - 1ull));
+            if (hit && pos < ns) out[pos] = k;
+            cnt += __popcll(mask);
+            if (cnt >= ns) break;
+        }
+    }
+    const int fill = (cnt > 0) ? first : 0;
+    for (int s = cnt + lane; s < ns; s += 64) out[s] = fill;
+}
+
+// ------------------------------------------------------------------------------------------
+// gather / group and their scatter-add backward passes (channel-major features, as the
+// reference hands them over).
+// ------------------------------------------------------------------------------------------
+__global__ void gather_kernel(const float* __restrict__ feat, const int32_t* __restrict__ idx, int C, int N, int M,
+                              float* __restrict__ out, size_t total) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int j = (int)(e % M);
+        const size_t bc = e / M;
+        const int b = (int)(bc / C);
+        out[e] = feat[bc * N + idx[(size_t)b * M + j]];
+    }
+}
+__global__ void gather_grad_kernel(const float* __restrict__ go, const int32_t* __restrict__ idx, int C, int N, int M,
+                                   float* __restrict__ gf, size_t total) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int j = (int)(e % M);
+        const size_t bc = e / M;
+        const int b = (int)(bc / C);
+        atomicAdd(&gf[bc * N + idx[(size_t)b * M + j]], go[e]);
+    }
+}
+__global__ void group_kernel(const float* __restrict__ feat, const int32_t* __restrict__ idx, int C, int N, int M,
+                             int ns, float* __restrict__ out, size_t total) {
+    const size_t mk = (size_t)M * ns;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t jk = e % mk;
+        const size_t bc = e / mk;
+        const int b = (int)(bc / C);
+        out[e] = feat[bc * N + idx[(size_t)b * mk + jk]];
+    }
+}
+__global__ void group_grad_kernel(const float* __restrict__ go, const int32_t* __restrict__ idx, int C, int N, int M,
+                                  int ns, float* __restrict__ gf, size_t total) {
+    const size_t mk = (size_t)M * ns;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t jk = e % mk;
+        const size_t bc = e / mk;
+        const int b = (int)(bc / C);
+        atomicAdd(&gf[bc * N + idx[(size_t)b * mk + jk]], go[e]);
+    }
+}
+
+static inline int grid_for(size_t total, int block) {
+    size_t g = (total + block - 1) / block;
+    if (g > 2048u * 8u) g = 2048u * 8u;
+    if (g == 0) g = 1;
+    return (int)g;
+}
+
+// ------------------------------------------------------------------------------------------
+// kNN inside one cloud: one wave per query point, P candidates per lane in registers,
+// k rounds of (lane-local min, DPP wave min on distance, DPP wave min on index among ties).
+// ------------------------------------------------------------------------------------------
+template <int P>
+__global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ xyz, int BN, int N, int k,
+                                                  int32_t* __restrict__ idx_out) {
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= BN) return;
+    const int lane = threadIdx.x & 63;
+    const int b = q / N;
+    const float* __restrict__ pts = xyz + (size_t)b * N * 3;
+    const float qx = xyz[(size_t)q * 3 + 0], qy = xyz[(size_t)q * 3 + 1], qz = xyz[(size_t)q * 3 + 2];
+    int32_t* __restrict__ out = idx_out + (size_t)q * k;
+
+    float d[P];
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        const int c = lane + i * 64;
+        d[i] = (c < N) ? sqdist3(qx, qy, qz, pts[3 * c + 0], pts[3 * c + 1], pts[3 * c + 2]) : __builtin_inff();
+    }
+    for (int r = 0; r < k; ++r) {
+        float best = __builtin_inff();
+        int besti = INT_MAX;
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            const int c = lane + i * 64;
+            if (c < N && d[i] < best) { best = d[i]; besti = c; }
+        }
+        const float wmin = wave_min_f32(best);
+        const int sel = wave_min_i32((best == wmin) ? besti : INT_MAX);
+        if (lane == 0) out[r] = sel;
+        // retire the winner: it can never be the minimum again
+#pragma unroll
+        for (int i = 0; i < P; ++i)
+            if (lane + i * 64 == sel) d[i] = __builtin_nanf("");
+    }
+}
+
+}  // namespace ptt
+
+using namespace ptt;
+
+extern "C" int ptt_fps_f32(const float* xyz, int B, int N, int npoint, int32_t* idx_out, ptt_stream_t stream) {
+    if (B < 0 || N <= 0 || npoint < 0) return fail(PTT_EINVAL, "ptt_fps_f32: B=%d N=%d npoint=%d", B, N, npoint);
+    if (B == 0 || npoint == 0) return PTT_OK;
+    if (!xyz || !idx_out) return fail(PTT_EINVAL, "ptt_fps_f32: null pointer");
+    hipStream_t s = as_stream(stream);
+    if (N <= 64) return launch_fps<64, 1>(xyz, B, N, npoint, idx_out, s);
+    if (N <= 128) return launch_fps<64, 2>(xyz, B, N, npoint, idx_out, s);
+    if (N <= 256) return launch_fps<64, 4>(xyz, B, N, npoint, idx_out, s);
+    if (N <= 512) return launch_fps<256, 2>(xyz, B, N, npoint, idx_out, s);
+    if (N <= 1024) return launch_fps<256, 4>(xyz, B, N, npoint, idx_out, s);
+    if (N <= 2048) return launch_fps<256, 8>(xyz, B, N, npoint, idx_out, s);
+    if (N <= 4096) return launch_fps<512, 8>(xyz, B, N, npoint, idx_out, s);
+    if (N <= 8192) return launch_fps<1024, 8>(xyz, B, N, npoint, idx_out, s);
+    if (N <= 16384) return launch_fps<1024, 16>(xyz, B, N, npoint, idx_out, s);
+    if (N <= 32768) return launch_fps<1024, 32>(xyz, B, N, npoint, idx_out, s);
+    return fail(PTT_EUNSUPPORTED, "ptt_fps_f32: N=%d exceeds the register-resident limit 32768", N);
+}
+
+extern "C" int ptt_ball_query_f32(const float* new_xyz, const float* xyz, int B, int M, int N, float radius,
+                                  int nsample, int32_t* idx_out, ptt_stream_t stream) {
+    if (B < 0 || M < 0 || N <= 0 || nsample <= 0)
+        return fail(PTT_EINVAL, "ptt_ball_query_f32: B=%d M=%d N=%d nsample=%d", B, M, N, nsample);
+    if (B == 0 || M == 0) return PTT_OK;
+    if (!new_xyz || !xyz || !idx_out) return fail(PTT_EINVAL, "ptt_ball_query_f32: null pointer");
+    const float r2 = radius * radius;
+    const int BM = B * M;
+    hipLaunchKernelGGL(ball_query_kernel, dim3((BM + 3) / 4), dim3(256), 0, as_stream(stream), new_xyz, xyz, BM, M,
+                       N, r2, nsample, idx_out);
+    return check_launch("ball_query_kernel");
+}
+
+extern "C" int ptt_gather_f32(const float* feat, const int32_t* idx, int B, int C, int N, int M, float* out,
+                              ptt_stream_t stream) {
+    if (B < 0 || C < 0 || N <= 0 || M < 0) return fail(PTT_EINVAL, "ptt_gather_f32: bad sizes");
+    const size_t total = (size_t)B * C * M;
+    if (total == 0) return PTT_OK;
+    if (!feat || !idx || !out) return fail(PTT_EINVAL, "ptt_gather_f32: null pointer");
+    hipLaunchKernelGGL(gather_kernel, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), feat, idx, C, N, M,
+                       out, total);
+    return check_launch("gather_kernel");
+}
+
+extern "C" int ptt_gather_grad_f32(const float* grad_out, const int32_t* idx, int B, int C, int N, int M,
+                                   float* grad_feat, ptt_stream_t stream) {
+    if (B < 0 || C < 0 || N <= 0 || M < 0) return fail(PTT_EINVAL, "ptt_gather_grad_f32: bad sizes");
+    const size_t nout = (size_t)B * C * N;
+    if (nout == 0) return PTT_OK;
+    if (!grad_feat) return fail(PTT_EINVAL, "ptt_gather_grad_f32: null pointer");
+    if (hipMemsetAsync(grad_feat, 0, nout * sizeof(float), as_stream(stream)) != hipSuccess)
+        return check_launch("gather_grad memset");
+    const size_t total = (size_t)B * C * M;
+    if (total == 0) return PTT_OK;
+    if (!grad_out || !idx) return fail(PTT_EINVAL, "ptt_gather_grad_f32: null pointer");
+    hipLaunchKernelGGL(gather_grad_kernel, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), grad_out, idx,
+                       C, N, M, grad_feat, total);
+    return check_launch("gather_grad_kernel");
+}
+
+extern "C" int ptt_group_f32(const float* feat, const int32_t* idx, int B, int C, int N, int M, int ns, float* out,
+                             ptt_stream_t stream) {
+    if (B < 0 || C < 0 || N <= 0 || M < 0 || ns < 0) return fail(PTT_EINVAL, "ptt_group_f32: bad sizes");
+    const size_t total = (size_t)B * C * M * ns;
+    if (total == 0) return PTT_OK;
+    if (!feat || !idx || !out) return fail(PTT_EINVAL, "ptt_group_f32: null pointer");
+    hipLaunchKernelGGL(group_kernel, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), feat, idx, C, N, M,
+                       ns, out, total);
+    return check_launch("group_kernel");
+}
+
+extern "C" int ptt_group_grad_f32(const float* grad_out, const int32_t* idx, int B, int C, int N, int M, int ns,
+                                  float* grad_feat, ptt_stream_t stream) {
+    if (B < 0 || C < 0 || N <= 0 || M < 0 || ns < 0) return fail(PTT_EINVAL, "ptt_group_grad_f32: bad sizes");
+    const size_t nout = (size_t)B * C * N;
+    if (nout == 0) return PTT_OK;
+    if (!grad_feat) return fail(PTT_EINVAL, "ptt_group_grad_f32: null pointer");
+    if (hipMemsetAsync(grad_feat, 0, nout * sizeof(float), as_stream(stream)) != hipSuccess)
+        return check_launch("group_grad memset");
+    const size_t total = (size_t)B * C * M * ns;
+    if (total == 0) return PTT_OK;
+    if (!grad_out || !idx) return fail(PTT_EINVAL, "ptt_group_grad_f32: null pointer");
+    hipLaunchKernelGGL(group_grad_kernel, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), grad_out, idx,
+                       C, N, M, ns, grad_feat, total);
+    return check_launch("group_grad_kernel");
+}
+
+extern "C" int ptt_knn_f32(const float* xyz, int B, int N, int k, int32_t* idx_out, ptt_stream_t stream) {
+    if (B < 0 || N <= 0 || k <= 0 || k > N) return fail(PTT_EINVAL, "ptt_knn_f32: B=%d N=%d k=%d", B, N, k);
+    if (B == 0) return PTT_OK;
+    if (!xyz || !idx_out) return fail(PTT_EINVAL, "ptt_knn_f32: null pointer");
+    const int BN = B * N;
+    const dim3 grid((BN + 3) / 4), block(256);
+    hipStream_t s = as_stream(stream);
+#define PTT_KNN_CASE(P)                                                                          \
+    if (N <= 64 * P) {                                                                           \
+        hipLaunchKernelGGL((knn_kernel<P>), grid, block, 0, s, xyz, BN, N, k, idx_out);          \
+        return check_launch("knn_kernel");                                                       \
+    }
+    PTT_KNN_CASE(1) PTT_KNN_CASE(2) PTT_KNN_CASE(4) PTT_KNN_CASE(8) PTT_KNN_CASE(16) PTT_KNN_CASE(32) PTT_KNN_CASE(64)
+#undef PTT_KNN_CASE
+    return fail(PTT_EUNSUPPORTED, "ptt_knn_f32: N=%d exceeds 4096", N);
+}

@@ -1,0 +1,243 @@
+"""Operator boundary: torch-tensor front-ends of the C ABI (include/ptt_hip.h).
+
+The first group has the names, argument order and error behaviour of the third-party
+`pointnet2_ops._ext` functions the reference calls (pointnet2_utils.py:78,112,118,237,
+257,287): device tensors only (a CPU tensor raises RuntimeError, as upstream does),
+fp32 / int32, contiguous. Kernels are enqueued on the current torch stream; nothing
+synchronises. The second group exposes the fused fp32-MFMA kernels.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import AttnDesc, SaDesc, SaLayer
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(t, name, dtype, ndim=None):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("%s must be a torch.Tensor" % name)
+    if not t.is_cuda:
+        raise RuntimeError("%s must be a device (HIP) tensor — CPU tensors are not supported" % name)
+    if t.dtype != dtype:
+        raise RuntimeError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise RuntimeError("%s must be contiguous" % name)
+    if ndim is not None and t.dim() != ndim:
+        raise RuntimeError("%s must have %d dimensions, got %s" % (name, ndim, tuple(t.shape)))
+    return t
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+# --------------------------------------------------------------------------- _ext-compatible ops
+def furthest_point_sampling(xyz, npoint):
+    """(B,N,3) f32 -> (B,npoint) i32.  Replaces _ext.furthest_point_sampling (pointnet2_utils.py:78)."""
+    _chk(xyz, "xyz", torch.float32, 3)
+    B, N, _ = xyz.shape
+    out = torch.empty((B, int(npoint)), dtype=torch.int32, device=xyz.device)
+    with torch.cuda.device(xyz.device):
+        _lib.check(_lib.lib().ptt_fps_f32(_ptr(xyz), B, N, int(npoint), _ptr(out), _stream()), "ptt_fps_f32")
+    return out
+
+
+def gather_points(features, idx):
+    """(B,C,N) f32, (B,M) i32 -> (B,C,M).  Replaces _ext.gather_points (pointnet2_utils.py:112)."""
+    _chk(features, "features", torch.float32, 3)
+    _chk(idx, "idx", torch.int32, 2)
+    B, C, N = features.shape
+    M = idx.shape[1]
+    out = torch.empty((B, C, M), dtype=torch.float32, device=features.device)
+    with torch.cuda.device(features.device):
+        _lib.check(_lib.lib().ptt_gather_f32(_ptr(features), _ptr(idx), B, C, N, M, _ptr(out), _stream()),
+                   "ptt_gather_f32")
+    return out
+
+
+def gather_points_grad(grad_out, idx, N):
+    """(B,C,M) f32, (B,M) i32 -> (B,C,N).  Replaces _ext.gather_points_grad (pointnet2_utils.py:118)."""
+    _chk(grad_out, "grad_out", torch.float32, 3)
+    _chk(idx, "idx", torch.int32, 2)
+    B, C, M = grad_out.shape
+    out = torch.empty((B, C, int(N)), dtype=torch.float32, device=grad_out.device)
+    with torch.cuda.device(grad_out.device):
+        _lib.check(_lib.lib().ptt_gather_grad_f32(_ptr(grad_out), _ptr(idx), B, C, int(N), M, _ptr(out), _stream()),
+                   "ptt_gather_grad_f32")
+    return out
+
+
+def ball_query(new_xyz, xyz, radius, nsample):
+    """centres first: (B,M,3), (B,N,3) -> (B,M,nsample) i32.  Replaces _ext.ball_query (pointnet2_utils.py:287)."""
+    _chk(new_xyz, "new_xyz", torch.float32, 3)
+    _chk(xyz, "xyz", torch.float32, 3)
+    B, M, _ = new_xyz.shape
+    N = xyz.shape[1]
+    out = torch.empty((B, M, int(nsample)), dtype=torch.int32, device=xyz.device)
+    with torch.cuda.device(xyz.device):
+        _lib.check(_lib.lib().ptt_ball_query_f32(_ptr(new_xyz), _ptr(xyz), B, M, N, float(radius), int(nsample),
+                                                 _ptr(out), _stream()), "ptt_ball_query_f32")
+    return out
+
+
+def group_points(features, idx):
+    """(B,C,N) f32, (B,M,ns) i32 -> (B,C,M,ns).  Replaces _ext.group_points (pointnet2_utils.py:237)."""
+    _chk(features, "features", torch.float32, 3)
+    _chk(idx, "idx", torch.int32, 3)
+    B, C, N = features.shape
+    _, M, ns = idx.shape
+    out = torch.empty((B, C, M, ns), dtype=torch.float32, device=features.device)
+    with torch.cuda.device(features.device):
+        _lib.check(_lib.lib().ptt_group_f32(_ptr(features), _ptr(idx), B, C, N, M, ns, _ptr(out), _stream()),
+                   "ptt_group_f32")
+    return out
+
+
+def group_points_grad(grad_out, idx, N):
+    """(B,C,M,ns) f32 -> (B,C,N).  Replaces _ext.group_points_grad (pointnet2_utils.py:257)."""
+    _chk(grad_out, "grad_out", torch.float32, 4)
+    _chk(idx, "idx", torch.int32, 3)
+    B, C, M, ns = grad_out.shape
+    out = torch.empty((B, C, int(N)), dtype=torch.float32, device=grad_out.device)
+    with torch.cuda.device(grad_out.device):
+        _lib.check(_lib.lib().ptt_group_grad_f32(_ptr(grad_out), _ptr(idx), B, C, int(N), M, ns, _ptr(out),
+                                                 _stream()), "ptt_group_grad_f32")
+    return out
+
+
+def _unreached(name):
+    def fn(*a, **k):
+        raise NotImplementedError("%s is never reached by PTT (SURVEY.md §2.1) and is not provided" % name)
+    fn.__name__ = name
+    return fn
+
+
+three_nn = _unreached("three_nn")
+three_interpolate = _unreached("three_interpolate")
+three_interpolate_grad = _unreached("three_interpolate_grad")
+furthest_point_sampling_with_dist = _unreached("furthest_point_sampling_with_dist")
+
+
+# --------------------------------------------------------------------------- fused / MFMA ops
+def knn(xyz, k):
+    """(B,N,3) f32 -> (B,N,k) i32 ascending by (squared distance, index).
+    Replaces square_distance(xyz, xyz).argsort()[:, :, :k] (transformer_block/variants.py:150-151)."""
+    _chk(xyz, "xyz", torch.float32, 3)
+    B, N, _ = xyz.shape
+    out = torch.empty((B, N, int(k)), dtype=torch.int32, device=xyz.device)
+    with torch.cuda.device(xyz.device):
+        _lib.check(_lib.lib().ptt_knn_f32(_ptr(xyz), B, N, int(k), _ptr(out), _stream()), "ptt_knn_f32")
+    return out
+
+
+def pack_weight(weight):
+    """(Cout,K[,1[,1]]) f32 -> packed MFMA B-fragment buffer (1-D f32 tensor)."""
+    w = weight.detach()
+    w = w.reshape(w.shape[0], -1).contiguous().float()
+    _chk(w, "weight", torch.float32, 2)
+    Cout, K = w.shape
+    n = _lib.lib().ptt_packed_weight_elems(Cout, K)
+    out = torch.empty((n,), dtype=torch.float32, device=w.device)
+    with torch.cuda.device(w.device):
+        _lib.check(_lib.lib().ptt_pack_weight_f32(_ptr(w), Cout, K, _ptr(out), _stream()), "ptt_pack_weight_f32")
+    return out
+
+
+def linear(x, wpacked, cout, scale=None, shift=None, relu=False, residual=None, out=None):
+    """Row-wise y = act(x @ W^T * scale + shift) (+ residual) on fp32 MFMA.
+    x: (..., K) with contiguous last dim and uniform row stride; returns (..., cout)."""
+    if not x.is_cuda or x.dtype != torch.float32:
+        raise RuntimeError("x must be a float32 device tensor")
+    K = x.shape[-1]
+    x2 = x.reshape(-1, K)
+    if x2.stride(1) != 1:
+        x2 = x2.contiguous()
+    rows = x2.shape[0]
+    if out is None:
+        out = torch.empty(tuple(x.shape[:-1]) + (int(cout),), dtype=torch.float32, device=x.device)
+    o2 = out.view(-1, int(cout))
+    r2 = None
+    if residual is not None:
+        r2 = residual.reshape(-1, int(cout))
+        if r2.stride(1) != 1:
+            r2 = r2.contiguous()
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().ptt_linear_f32(
+            _ptr(x2), rows, K, x2.stride(0) if rows > 1 else K, _ptr(wpacked), int(cout), _ptr(scale), _ptr(shift),
+            1 if relu else 0, _ptr(r2), (r2.stride(0) if (r2 is not None and rows > 1) else int(cout)),
+            _ptr(o2), o2.stride(0) if rows > 1 else int(cout), _stream()), "ptt_linear_f32")
+    return out
+
+
+def sa_fused_forward(xyz, new_xyz, idx, features, layers, radius, use_xyz=True, normalize_xyz=False,
+                     point_major_out=True):
+    """Fused group -> normalise -> SharedMLP(eval) -> max-pool (QueryAndGroup + SharedMLP + max_pool2d,
+    pointnet2_utils.py:320-380, pytorch_utils.py:12-36, pointnet2_modules.py:84-88).
+
+    xyz (B,N,3), new_xyz (B,M,3), idx (B,M,ns) i32, features (B,C,N) in ANY strides (a transposed
+    view of point-major storage gathers coalesced) or None.
+    layers: list of (wpacked, scale|None, shift|None, cin, cout, relu).
+    Returns (B,Cout,M); with point_major_out it is a transposed view of (B,M,Cout) storage."""
+    _chk(xyz, "xyz", torch.float32, 3)
+    _chk(new_xyz, "new_xyz", torch.float32, 3)
+    _chk(idx, "idx", torch.int32, 3)
+    B, N, _ = xyz.shape
+    _, M, ns = idx.shape
+    d = SaDesc()
+    d.xyz, d.new_xyz, d.idx = xyz.data_ptr(), new_xyz.data_ptr(), idx.data_ptr()
+    if features is not None:
+        if not features.is_cuda or features.dtype != torch.float32 or features.dim() != 3:
+            raise RuntimeError("features must be a (B,C,N) float32 device tensor")
+        d.feat = features.data_ptr()
+        d.feat_sb, d.feat_sc, d.feat_sn = features.stride()
+        d.C = features.shape[1]
+    else:
+        d.feat, d.C = None, 0
+    cout = layers[-1][4]
+    if point_major_out:
+        store = torch.empty((B, M, cout), dtype=torch.float32, device=xyz.device)
+        out = store.transpose(1, 2)
+    else:
+        out = torch.empty((B, cout, M), dtype=torch.float32, device=xyz.device)
+    d.out = out.data_ptr()
+    d.out_sb, d.out_sc, d.out_sm = out.stride()
+    d.B, d.N, d.M, d.nsample = B, N, M, ns
+    d.radius, d.use_xyz, d.normalize_xyz = float(radius), int(bool(use_xyz)), int(bool(normalize_xyz))
+    d.n_layers = len(layers)
+    for i, (wp, sc, sh, cin, co, relu) in enumerate(layers):
+        L = d.layers[i]
+        L.Wpacked = wp.data_ptr()
+        L.scale = sc.data_ptr() if sc is not None else None
+        L.shift = sh.data_ptr() if sh is not None else None
+        L.Cin, L.Cout, L.relu = int(cin), int(co), int(bool(relu))
+    with torch.cuda.device(xyz.device):
+        _lib.check(_lib.lib().ptt_sa_fused_fwd_f32(ctypes.byref(d), _stream()), "ptt_sa_fused_fwd_f32")
+    return out
+
+
+def pt_attn_pair(xyz, knn_idx, qkv, wd1, bd1, wd2p, bd2, wg1p, bg1, wg2p, bg2, d_model, want_attn=True):
+    """Fused per-(point,neighbour) part of TransformerBlock.forward (variants.py:158-163).
+    Returns (res (B,N,D), attn (B,N,k,D) | None)."""
+    _chk(xyz, "xyz", torch.float32, 3)
+    _chk(knn_idx, "knn_idx", torch.int32, 3)
+    _chk(qkv, "qkv", torch.float32, 3)
+    B, N, _ = xyz.shape
+    k = knn_idx.shape[2]
+    D = int(d_model)
+    res = torch.empty((B, N, D), dtype=torch.float32, device=xyz.device)
+    attn = torch.empty((B, N, k, D), dtype=torch.float32, device=xyz.device) if want_attn else None
+    d = AttnDesc()
+    d.xyz, d.knn, d.qkv = xyz.data_ptr(), knn_idx.data_ptr(), qkv.data_ptr()
+    d.Wd1, d.bd1, d.Wd2p, d.bd2 = wd1.data_ptr(), bd1.data_ptr(), wd2p.data_ptr(), bd2.data_ptr()
+    d.Wg1p, d.bg1, d.Wg2p, d.bg2 = wg1p.data_ptr(), bg1.data_ptr(), wg2p.data_ptr(), bg2.data_ptr()
+    d.res = res.data_ptr()
+    d.attn = attn.data_ptr() if attn is not None else None
+    d.B, d.N, d.k, d.D = B, N, k, D
+    with torch.cuda.device(xyz.device):
+        _lib.check(_lib.lib().ptt_pt_attn_pair_f32(ctypes.byref(d), _stream()), "ptt_pt_attn_pair_f32")
+    return res, attn

@@ -1,0 +1,114 @@
+"""GPU parity of the fp32-MFMA kernels against the torch-CPU oracle (oracle/dense_ref.py).
+
+Tolerance: fp32 features within 1e-4 (BASELINE.json north_star), written as
+atol=1e-4, rtol=1e-4 on O(1) activations.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import dense_ref as R
+from oracle import index_ops as O
+from ptt_amd import ops, synth
+from tests.util import fold_layers, mlp_layers, transformer_params
+
+pytestmark = pytest.mark.gpu
+TOL = dict(atol=1e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize("rows,K,Cout,relu,res", [(77, 256, 512, False, False), (256, 512, 1536, False, False),
+                                                  (130, 512, 256, False, True), (64, 3, 64, True, False),
+                                                  (33, 131, 96, True, True)])
+def test_linear(dev, rows, K, Cout, relu, res):
+    rs = np.random.RandomState(rows + K)
+    x = torch.from_numpy(rs.standard_normal((rows, K)).astype(np.float32))
+    w = torch.from_numpy((rs.standard_normal((Cout, K)) / np.sqrt(K)).astype(np.float32))
+    b = torch.from_numpy(rs.standard_normal(Cout).astype(np.float32))
+    r = torch.from_numpy(rs.standard_normal((rows, Cout)).astype(np.float32)) if res else None
+    ref = F.linear(x, w, b)
+    if relu:
+        ref = F.relu(ref)
+    if res:
+        ref = ref + r
+    wp = ops.pack_weight(w.to(dev))
+    got = ops.linear(x.to(dev), wp, Cout, None, b.to(dev), relu, r.to(dev) if res else None)
+    np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), **TOL)
+
+
+def test_pack_weight_is_transpose_detecting(dev):
+    """A = I against an asymmetric W: the GEMM must return W^T rows exactly."""
+    K, Cout = 40, 64
+    w = torch.arange(Cout * K, dtype=torch.float32).reshape(Cout, K) / 7.0
+    x = torch.eye(K)
+    got = ops.linear(x.to(dev), ops.pack_weight(w.to(dev)), Cout)
+    np.testing.assert_array_equal(got.cpu().numpy(), w.t().numpy())
+
+
+SA_CASES = [
+    # N, M, C, spec, radius, ns        (the four SA shapes of tools/cfgs/kitti_models/ptt.yaml)
+    (1024, 512, 0, [3, 64, 64, 128], 0.3, 32),
+    (512, 256, 128, [131, 128, 128, 256], 0.5, 32),
+    (256, 128, 256, [259, 128, 128, 256], 0.7, 32),
+    (128, 64, 257, [260, 256, 256, 256], 0.3, 16),
+    (200, 50, 5, [8, 32, 96], 0.4, 16),
+]
+
+
+@pytest.mark.parametrize("N,M,C,spec,radius,ns", SA_CASES)
+@pytest.mark.parametrize("point_major", [False, True])
+def test_sa_fused(dev, N, M, C, spec, radius, ns, point_major):
+    B = 3
+    rs = np.random.RandomState(N + C)
+    s, _ = synth.frames(N, B, N, 64, K_s=max(16, N // 2))
+    s[2] = 0.0
+    xyz = torch.from_numpy(s)
+    inds = torch.from_numpy(O.fps(s, M))
+    new_xyz = torch.gather(xyz, 1, inds.long()[..., None].expand(-1, -1, 3)).contiguous()
+    feats = torch.from_numpy(rs.standard_normal((B, C, N)).astype(np.float32)) if C else None
+    layers = mlp_layers(N, spec)
+    grouped, _, idx = R.query_and_group(xyz, new_xyz, feats, radius, ns, True, True)
+    ref = F.max_pool2d(R.shared_mlp_eval(grouped, layers), kernel_size=[1, ns]).squeeze(-1)
+
+    f_dev = None
+    if feats is not None:
+        f_dev = feats.to(dev)
+        if point_major:   # (B,C,N) view of (B,N,C) storage: the coalesced gather path
+            f_dev = f_dev.transpose(1, 2).contiguous().transpose(1, 2)
+    idx_dev = ops.ball_query(new_xyz.to(dev), xyz.to(dev), radius, ns)
+    np.testing.assert_array_equal(idx_dev.cpu().numpy(), idx.numpy())
+    got = ops.sa_fused_forward(xyz.to(dev), new_xyz.to(dev), idx_dev, f_dev, fold_layers(layers, dev, ops), radius,
+                               True, True, point_major_out=point_major)
+    assert tuple(got.shape) == (B, spec[-1], M)
+    np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), **TOL)
+
+
+@pytest.mark.parametrize("N", [128, 64])
+def test_transformer_pair_kernel(dev, N):
+    B, D, k = 2, 512, 16
+    rs = np.random.RandomState(N)
+    P = transformer_params(N)
+    s, _ = synth.frames(N, B, N, 64, K_s=N)
+    xyz = torch.from_numpy(s)
+    feats = torch.from_numpy(rs.standard_normal((B, N, 256)).astype(np.float32))
+    ref_res, ref_attn = R.transformer_block(xyz, feats, P, k)
+
+    d = lambda n: P[n].to(dev).contiguous()
+    knn = ops.knn(xyz.to(dev), k)
+    x = ops.linear(feats.to(dev), ops.pack_weight(d("fc1.weight")), D, None, d("fc1.bias"))
+    wqkv = torch.cat([P["w_qs.weight"], P["w_ks.weight"], P["w_vs.weight"]], 0).to(dev)
+    qkv = ops.linear(x, ops.pack_weight(wqkv), 3 * D)
+    res, attn = ops.pt_attn_pair(xyz.to(dev), knn, qkv, d("fc_delta.0.weight"), d("fc_delta.0.bias"),
+                                 ops.pack_weight(d("fc_delta.2.weight")), d("fc_delta.2.bias"),
+                                 ops.pack_weight(d("fc_gamma.0.weight")), d("fc_gamma.0.bias"),
+                                 ops.pack_weight(d("fc_gamma.2.weight")), d("fc_gamma.2.bias"), D, True)
+    out = ops.linear(res, ops.pack_weight(d("fc2.weight")), 256, None, d("fc2.bias"), False, feats.to(dev))
+    np.testing.assert_allclose(attn.cpu().numpy(), ref_attn.numpy(), **TOL)
+    np.testing.assert_allclose(out.cpu().numpy(), ref_res.numpy(), **TOL)
+    # attn=None path gives the same res
+    res2, none = ops.pt_attn_pair(xyz.to(dev), knn, qkv, d("fc_delta.0.weight"), d("fc_delta.0.bias"),
+                                  ops.pack_weight(d("fc_delta.2.weight")), d("fc_delta.2.bias"),
+                                  ops.pack_weight(d("fc_gamma.0.weight")), d("fc_gamma.0.bias"),
+                                  ops.pack_weight(d("fc_gamma.2.weight")), d("fc_gamma.2.bias"), D, False)
+    assert none is None
+    np.testing.assert_array_equal(res2.cpu().numpy(), res.cpu().numpy())

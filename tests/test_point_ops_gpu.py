@@ -1,0 +1,115 @@
+"""GPU parity of the index ops against the CPU oracle: bit-exact (int32 indices, fp32 copies).
+
+Covers the reference's call sites pointnet2_utils.py:78 (FPS), :112/:118 (gather), :237/:257
+(group), :287 (ball query) and variants.py:150-151 (kNN), on the input distribution the
+reference produces (duplicates from resampling, all-zero clouds, points in the 1e-3 origin
+ball, under-filled balls).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import index_ops as O
+from ptt_amd import ops, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _clouds(seed, B, N, kind="car", K=None, zero=0):
+    s, _ = synth.frames(seed, B, N, 64, K_s=K if K is not None else max(8, int(N * 0.6)), K_t=32, kind=kind,
+                        zero_clouds=zero)
+    return s
+
+
+@pytest.mark.parametrize("N,npoint", [(64, 32), (128, 64), (200, 77), (256, 256), (512, 256), (1024, 512),
+                                      (2048, 512), (4096, 1024), (8192, 512), (16384, 64)])
+def test_fps_matches_oracle(dev, N, npoint):
+    xyz = _clouds(N, 3, N)
+    got = ops.furthest_point_sampling(_dev(xyz, dev), npoint).cpu().numpy()
+    ref = O.fps(xyz, npoint)
+    assert got.dtype == np.int32
+    np.testing.assert_array_equal(got, ref)
+
+
+def test_fps_edge_cases(dev):
+    rs = np.random.RandomState(7)
+    B, N = 6, 1024
+    xyz = _clouds(11, B, N, kind="ped", K=40)          # heavy duplication: FPS exhausts unique points
+    xyz[1] = 0.0                                         # all-zero cloud (regularize_pc:359-362)
+    xyz[2, :300] = rs.uniform(-0.015, 0.015, (300, 3))   # many points inside the 1e-3 origin ball
+    xyz[3, 0] = 0.0                                      # start point itself is skipped
+    xyz[4] = rs.uniform(-1, 1, (N, 3)).round(1)          # coarse grid => many exact distance ties
+    got = ops.furthest_point_sampling(_dev(xyz, dev), 512).cpu().numpy()
+    np.testing.assert_array_equal(got, O.fps(xyz, 512))
+    assert (got[1] == 0).all()
+
+
+@pytest.mark.parametrize("N,M,r,ns", [(1024, 512, 0.3, 32), (512, 256, 0.5, 32), (256, 128, 0.7, 32),
+                                      (128, 64, 0.3, 16), (2048, 512, 0.3, 32), (100, 37, 0.4, 8),
+                                      (16384, 256, 0.3, 32), (300, 64, 5.0, 64)])
+def test_ball_query_matches_oracle(dev, N, M, r, ns):
+    xyz = _clouds(N + M, 4, N)
+    xyz[3] = 0.0
+    centres = xyz[:, :M].copy()
+    centres[0] += 100.0                                  # no hits at all => zeros
+    got = ops.ball_query(_dev(centres, dev), _dev(xyz, dev), r, ns).cpu().numpy()
+    ref = O.ball_query(centres, xyz, r, ns)
+    np.testing.assert_array_equal(got, ref)
+    assert (got[0] == 0).all()
+
+
+def test_gather_group_and_grads(dev):
+    rs = np.random.RandomState(3)
+    B, C, N, M, ns = 3, 19, 257, 64, 16
+    feat = rs.standard_normal((B, C, N)).astype(np.float32)
+    idx1 = rs.randint(0, N, (B, M)).astype(np.int32)
+    idx2 = rs.randint(0, N, (B, M, ns)).astype(np.int32)
+    np.testing.assert_array_equal(ops.gather_points(_dev(feat, dev), _dev(idx1, dev)).cpu().numpy(),
+                                  O.gather(feat, idx1))
+    np.testing.assert_array_equal(ops.group_points(_dev(feat, dev), _dev(idx2, dev)).cpu().numpy(),
+                                  O.group(feat, idx2))
+    go1 = rs.standard_normal((B, C, M)).astype(np.float32)
+    go2 = rs.standard_normal((B, C, M, ns)).astype(np.float32)
+    # scatter-add order differs (atomics) => fp32 tolerance, not bit-exactness
+    np.testing.assert_allclose(ops.gather_points_grad(_dev(go1, dev), _dev(idx1, dev), N).cpu().numpy(),
+                               O.gather_grad(go1, idx1, N), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(ops.group_points_grad(_dev(go2, dev), _dev(idx2, dev), N).cpu().numpy(),
+                               O.group_grad(go2, idx2, N), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("N,k", [(64, 16), (128, 16), (100, 7), (512, 16), (2048, 16)])
+def test_knn_matches_oracle(dev, N, k):
+    xyz = _clouds(5 * N, 3, N, kind="ped", K=max(k, N // 3))   # duplicates => exact ties, broken by index
+    xyz[2] = 0.0
+    got = ops.knn(_dev(xyz, dev), k).cpu().numpy()
+    np.testing.assert_array_equal(got, O.knn(xyz, k))
+
+
+def test_cpu_tensors_are_rejected():
+    with pytest.raises(RuntimeError):
+        ops.furthest_point_sampling(torch.zeros(1, 8, 3), 4)
+    with pytest.raises(RuntimeError):
+        ops.ball_query(torch.zeros(1, 2, 3), torch.zeros(1, 8, 3), 0.3, 4)
+
+
+def test_full_size_properties(dev):
+    """Config-2 sizes (B=48, 2048 pts): properties that need no oracle."""
+    s, _ = synth.frames(0, 48, 2048, 1024)
+    xyz = _dev(s, dev)
+    idx = ops.furthest_point_sampling(xyz, 512)
+    assert int(idx.min()) >= 0 and int(idx.max()) < 2048 and (idx[:, 0] == 0).all()
+    # K_s=600 unique points < 512? no: 600 >= 512, so FPS never repeats a coordinate
+    sel = torch.gather(xyz, 1, idx.long()[..., None].expand(-1, -1, 3)).cpu().numpy()
+    for b in range(0, 48, 7):
+        assert len(np.unique(sel[b], axis=0)) == 512
+    new_xyz = torch.gather(xyz, 1, idx.long()[..., None].expand(-1, -1, 3)).contiguous()
+    bq = ops.ball_query(new_xyz, xyz, 0.3, 32).long()
+    nb = torch.gather(xyz, 1, bq.reshape(48, -1)[..., None].expand(-1, -1, 3)).reshape(48, 512, 32, 3)
+    d2 = ((nb - new_xyz[:, :, None]) ** 2).sum(-1)
+    assert float(d2.max()) < 0.3 * 0.3 + 1e-6          # every returned neighbour is inside the ball
+    first = bq[..., :1]
+    assert (bq >= first).all()                          # first slot is the lowest-index hit
