@@ -30,6 +30,11 @@ def lib():
     return _lib
 
 
+def set_threads(n):
+    """OpenMP threads of the C oracle (its libgomp is separate from torch's)."""
+    lib().oracle_set_threads(int(n))
+
+
 def _f32(a):
     return np.ascontiguousarray(a, dtype=np.float32)
 

@@ -27,6 +27,13 @@
 #include <stdlib.h>
 #include <string.h>
 
+#ifdef _OPENMP
+#include <omp.h>
+void oracle_set_threads(int n) { if (n > 0) omp_set_num_threads(n); }
+#else
+void oracle_set_threads(int n) { (void)n; }
+#endif
+
 static inline float sqdist3(const float* a, const float* b) {
     const float dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
     const float s = dx * dx + dy * dy;

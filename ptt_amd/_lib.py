@@ -81,6 +81,9 @@ def lib():
             raise RuntimeError(
                 "ptt_amd: %s is missing — build it with `python -m ptt_amd.build` "
                 "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+        # torch must initialise ITS bundled HIP runtime first: libptt_hip.so then binds to the
+        # libamdhip64 already in the process instead of pulling a second copy from /opt/rocm.
+        import torch  # noqa: F401
         try:
             loaded = ctypes.CDLL(LIB_PATH)
         except OSError as e:  # e.g. no ROCm runtime on this host

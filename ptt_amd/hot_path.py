@@ -1,0 +1,104 @@
+"""The per-frame hot path as one module: what bench.py times and smoke() checks.
+
+One *frame* = one (search, template) cloud pair through
+    PointNet2BackboneLight.forward   (3 SA levels x 2 branches + cov_final, pointnet2_backbone.py:52-67)
+ -> TransformerBlock on the 128 search seeds          (centroids_voting_head.py:71-76)
+ -> vote_aggregation SA level 128 -> 64, r=.3, ns=16  (box_voting_head.py:75-79)
+ -> TransformerBlock on the 64 proposals              (box_voting_head.py:81-86)
+with the constants of tools/cfgs/kitti_models/ptt.yaml:41-51,72-79,96-112.
+The small Conv1d heads and CosineSimAug that sit between these stages in the full tracker are
+outside the hot path; `bridge()` stands in for them with the same tensor shapes and layouts
+(votes = seeds, votes_feats = cat(score, feats) channel-major as centroids_voting_head.py:94).
+"""
+import torch
+import torch.nn as nn
+
+from .models.backbones_3d.pointnet2.pointnet2_modules import PointnetSAModuleVotes
+from .models.backbones_3d.pointnet2_backbone import PointNet2BackboneLight
+from .models.transformer_block import build_transformer
+
+
+class AttrDict(dict):
+    """dict with attribute access — the slice of EasyDict behaviour the model code uses."""
+
+    def __getattr__(self, k):
+        try:
+            v = self[k]
+        except KeyError:
+            raise AttributeError(k)
+        return v
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+    @staticmethod
+    def wrap(obj):
+        if isinstance(obj, dict):
+            return AttrDict({k: AttrDict.wrap(v) for k, v in obj.items()})
+        return obj
+
+
+def kitti_model_cfg():
+    """MODEL section constants of tools/cfgs/kitti_models/ptt.yaml (nuScenes is identical)."""
+    tb = dict(ENABLE=True, NAME='TransformerBlock', DIM_INPUT=256, DIM_MODEL=512, KNN=16, N_HEADS=1, N_LAYERS=1)
+    return AttrDict.wrap(dict(
+        BACKBONE_3D=dict(NAME='PointNet2BackboneLight', DEBUG=False, SA_CONFIG=dict(
+            SAMPLE_METHOD=['fps', 'sequence', 'sequence'], USE_XYZ=True, NORMALIZE_XYZ=True,
+            NPOINTS_SEARCH=[512, 256, 128], NPOINTS_TEMPLATE=[256, 128, 64], RADIUS=[0.3, 0.5, 0.7],
+            NSAMPLE=[32, 32, 32], MLPS=[[0, 64, 64, 128], [128, 128, 128, 256], [256, 128, 128, 256]])),
+        CENTROID_HEAD=dict(TRANSFORMER_BLOCK=dict(tb)),
+        BOX_HEAD=dict(SA_CONFIG=dict(NPOINTS=64, RADIUS=0.3, NSAMPLE=16, MLPS=[257, 256, 256, 256], USE_XYZ=True,
+                                     NORMALIZE_XYZ=True, SAMPLE_METHOD='fps'),
+                      TRANSFORMER_BLOCK=dict(tb)),
+    ))
+
+
+class FrameHotPath(nn.Module):
+    def __init__(self, model_cfg=None):
+        super().__init__()
+        cfg = model_cfg if model_cfg is not None else kitti_model_cfg()
+        self.cfg = cfg
+        self.backbone_3d = PointNet2BackboneLight(cfg.BACKBONE_3D, input_channels=3)
+        self.centroid_transformer = build_transformer(cfg.CENTROID_HEAD.TRANSFORMER_BLOCK)
+        sa = cfg.BOX_HEAD.SA_CONFIG
+        self.vote_aggregation = PointnetSAModuleVotes(
+            radius=sa.RADIUS, nsample=sa.NSAMPLE, mlp=list(sa.MLPS), use_xyz=sa.get('USE_XYZ', True),
+            normalize_xyz=sa.get('NORMALIZE_XYZ', True), sample_method=sa.SAMPLE_METHOD)
+        self.box_transformer = build_transformer(cfg.BOX_HEAD.TRANSFORMER_BLOCK)
+        self.npoints_box = sa.NPOINTS
+
+    @staticmethod
+    def bridge(seeds, feats_bnc):
+        """Stand-in for the heads between the two transformers: votes (B,128,3), votes_feats (B,257,128)."""
+        score = torch.sigmoid(feats_bnc[:, :, :1])
+        return seeds, torch.cat((score, feats_bnc), dim=2).transpose(1, 2).contiguous()
+
+    def forward(self, search_points, template_points):
+        d = self.backbone_3d({'search_points': search_points, 'template_points': template_points})
+        seeds = d['search_seeds']
+        fused = self.centroid_transformer(xyz=seeds, features=d['search_feats'].transpose(1, 2).contiguous())[0]
+        votes, votes_feats = self.bridge(seeds, fused)
+        centres, prop_feats, _ = self.vote_aggregation(xyz=votes, features=votes_feats, npoint=self.npoints_box)
+        box_feats = self.box_transformer(xyz=centres, features=prop_feats.transpose(1, 2).contiguous())[0]
+        d['centroid_feats'] = fused
+        d['pred_box_center'] = centres
+        d['box_feats'] = box_feats
+        return d
+
+
+def randomize_(module, seed=0):
+    """Random-init weights incl. non-trivial BatchNorm running statistics (no checkpoints offline)."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for m in module.modules():
+            if isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d)):
+                m.weight.copy_(torch.empty_like(m.weight, device='cpu').uniform_(0.5, 1.5, generator=g))
+                m.bias.copy_(torch.empty_like(m.bias, device='cpu').normal_(0, 0.1, generator=g))
+                m.running_mean.copy_(torch.empty_like(m.running_mean, device='cpu').normal_(0, 0.2, generator=g))
+                m.running_var.copy_(torch.empty_like(m.running_var, device='cpu').uniform_(0.5, 1.5, generator=g))
+            elif isinstance(m, (nn.Conv1d, nn.Conv2d, nn.Linear)):
+                fan_in = m.weight[0].numel()
+                m.weight.copy_(torch.empty_like(m.weight, device='cpu').normal_(0, (2.0 / fan_in) ** 0.5, generator=g))
+                if m.bias is not None:
+                    m.bias.copy_(torch.empty_like(m.bias, device='cpu').uniform_(-0.1, 0.1, generator=g))
+    return module

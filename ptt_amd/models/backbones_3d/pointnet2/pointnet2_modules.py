@@ -1,0 +1,129 @@
+"""Mirror of ptt/models/backbones_3d/pointnet2/pointnet2_modules.py: PointnetSAModuleVotes (:22-90).
+
+Same constructor, attributes (`grouper`, `mlp_module`, `sample_method`), state_dict keys and
+`forward(xyz, features, npoint, inds=None) -> (new_xyz, new_features, inds_int64)` contract.
+
+Two execution paths, chosen per call:
+  * eval mode on a HIP device (inference / tracking): sample -> ball query -> ONE fused kernel
+    (ptt_sa_fused_fwd_f32: group, centre-subtract, /radius, concat, 3x[1x1 conv + folded BN +
+    ReLU] on fp32 MFMA, max over nsample). The grouped (B,C,M,ns) tensors the reference
+    materialises (pointnet2_utils.py:351-361) never exist. Output features are stored
+    point-major (B,M,C) and returned as the (B,C,M) transposed view, which is also the layout
+    the next level gathers from with coalesced loads.
+  * training mode (BatchNorm needs batch statistics): the reference's op sequence on the HIP
+    ops + stock torch conv/BN, with autograd through gather/group.
+"""
+from typing import List
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .... import ops
+from . import pointnet2_utils
+from . import pytorch_utils as pt_utils
+
+
+class PointnetSAModuleVotes(nn.Module):
+    def __init__(self, *, mlp: List[int], radius: float = None, nsample: int = None, bn: bool = True,
+                 use_xyz: bool = True, normalize_xyz: bool = False, sample_uniformly: bool = False,
+                 sample_method='fps'):
+        super().__init__()
+        self.radius = radius
+        self.nsample = nsample
+        self.mlp_module = None
+        self.use_xyz = use_xyz
+        self.normalize_xyz = normalize_xyz
+        self.sample_uniformly = sample_uniformly
+        self.grouper = pointnet2_utils.QueryAndGroup(radius, nsample, use_xyz=use_xyz, ret_grouped_xyz=True,
+                                                     normalize_xyz=normalize_xyz, sample_uniformly=sample_uniformly,
+                                                     ret_unique_cnt=False)
+        mlp_spec = mlp
+        if use_xyz and len(mlp_spec) > 0:
+            mlp_spec[0] += 3        # in place on the caller's list, exactly as the reference does (:51-53)
+        self.mlp_module = pt_utils.SharedMLP(mlp_spec, bn=bn)
+        self.sample_method = sample_method
+        self._fused_cache = None    # (key, [(wpacked, scale, shift, cin, cout, relu), ...])
+
+    # ------------------------------------------------------------------ sampling (reference :63-77)
+    def _sample(self, xyz, features, npoint):
+        if self.sample_method == 'fps':
+            return pointnet2_utils.furthest_point_sample(xyz, npoint)
+        if self.sample_method in ('rs', 'sequence'):
+            return torch.arange(npoint, dtype=torch.int32, device=xyz.device).repeat(xyz.size(0), 1)
+        if self.sample_method == 'ffps':
+            raise NotImplementedError("sample_method 'ffps' needs furthest_point_sampling_with_dist, which the "
+                                      "reference's extension never provided (tools/cfgs/kitti_models/ptt.yaml:42)")
+        raise NotImplementedError(self.sample_method)
+
+    # ------------------------------------------------------------------ fused-path parameters
+    def _fusable(self, xyz, features):
+        if self.training or not xyz.is_cuda or self.sample_uniformly or self.nsample not in (16, 32):
+            return False
+        if features is not None and features.dtype != torch.float32:
+            return False
+        for unit in self.mlp_module:
+            conv = getattr(unit, 'conv', None)
+            if conv is None or conv.kernel_size != (1, 1) or conv.weight.shape[0] % 32 != 0 or conv.weight.shape[0] > 512:
+                return False
+            if list(unit._modules.keys())[0] != 'conv':     # pre-activation units are not folded
+                return False
+        return len(self.mlp_module) <= 4
+
+    def _fused_params(self, device):
+        tensors = []
+        for unit in self.mlp_module:
+            tensors.append(unit.conv.weight)
+            if unit.conv.bias is not None:
+                tensors.append(unit.conv.bias)
+            if hasattr(unit, 'normlayer'):
+                bn = unit.normlayer.bn
+                tensors += [bn.weight, bn.bias, bn.running_mean, bn.running_var]
+        key = (str(device),) + tuple((t.data_ptr(), t._version) for t in tensors)
+        if self._fused_cache is not None and self._fused_cache[0] == key:
+            return self._fused_cache[1]
+        layers = []
+        with torch.no_grad():
+            for unit in self.mlp_module:
+                w = unit.conv.weight
+                cout, cin = w.shape[0], w.shape[1]
+                scale = shift = None
+                if hasattr(unit, 'normlayer'):
+                    bn = unit.normlayer.bn
+                    scale = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).float().contiguous()
+                    shift = (bn.bias - bn.running_mean * scale).float().contiguous()
+                    if unit.conv.bias is not None:
+                        shift = (shift + unit.conv.bias * scale).contiguous()
+                elif unit.conv.bias is not None:
+                    shift = unit.conv.bias.detach().float().contiguous()
+                layers.append((ops.pack_weight(w), scale, shift, cin, cout, hasattr(unit, 'activation')))
+        self._fused_cache = (key, layers)
+        return layers
+
+    # ------------------------------------------------------------------ forward (reference :57-90)
+    def forward(self, xyz: torch.Tensor, features: torch.Tensor, npoint: int, inds: torch.Tensor = None):
+        prefix = False      # True when the centres are simply the first npoint points
+        if inds is None:
+            inds = self._sample(xyz, features, npoint)
+            prefix = self.sample_method in ('rs', 'sequence')
+        else:
+            assert inds.shape[1] == npoint
+            inds = inds.to(torch.int32)
+
+        if self._fusable(xyz, features):
+            xyz = xyz.contiguous()
+            if prefix:
+                new_xyz = xyz[:, :npoint].contiguous()
+            else:
+                new_xyz = torch.gather(xyz, 1, inds.long().unsqueeze(-1).expand(-1, -1, 3))
+            idx = ops.ball_query(new_xyz, xyz, self.radius, self.nsample)
+            new_features = ops.sa_fused_forward(xyz, new_xyz, idx, features, self._fused_params(xyz.device),
+                                                self.radius, self.use_xyz, self.normalize_xyz, point_major_out=True)
+            return new_xyz, new_features, inds.to(torch.int64)
+
+        xyz_flipped = xyz.transpose(1, 2).contiguous()
+        new_xyz = pointnet2_utils.gather_operation(xyz_flipped, inds).transpose(1, 2).contiguous()
+        grouped_features, grouped_xyz = self.grouper(xyz, new_xyz, features)      # (B,C,M,ns)
+        y = self.mlp_module(grouped_features)
+        y = F.max_pool2d(y, kernel_size=[1, y.size(3)]).squeeze(-1)               # (B,Cout,M)
+        return new_xyz, y, inds.to(torch.int64)

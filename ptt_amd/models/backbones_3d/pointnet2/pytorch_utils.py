@@ -1,0 +1,155 @@
+"""Mirror of the layer builders of ptt/models/backbones_3d/pointnet2/pytorch_utils.py that the
+hot path uses: SharedMLP (:12-36) made of Conv2d(1x1) + BatchNorm2d + ReLU units (:39-189),
+plus the Conv1d/FC/Seq builders the heads assemble their small stacks from (:124-155, :263-427).
+
+Child-module NAMES are part of the checkpoint contract (tracker3d_template.py:96-124 matches
+state_dict entries by key and shape): a unit is an nn.Sequential with children `conv`,
+`normlayer` (itself a Sequential holding `bn`) and `activation`; SharedMLP names its units
+`layer0`, `layer1`, ... Parameters are initialised as the reference does (kaiming-normal conv
+weights, BN weight 1 / bias 0, no conv bias when BN follows).
+"""
+import torch.nn as nn
+
+
+class _Norm(nn.Sequential):
+    def __init__(self, channels, norm_cls, name=""):
+        super().__init__()
+        self.add_module(name + "bn", norm_cls(channels))
+        nn.init.constant_(self[0].weight, 1.0)
+        nn.init.constant_(self[0].bias, 0.0)
+
+
+class BatchNorm1d(_Norm):
+    def __init__(self, in_size, name=""):
+        super().__init__(in_size, nn.BatchNorm1d, name)
+
+
+class BatchNorm2d(_Norm):
+    def __init__(self, in_size, name=""):
+        super().__init__(in_size, nn.BatchNorm2d, name)
+
+
+class BatchNorm3d(_Norm):
+    def __init__(self, in_size, name=""):
+        super().__init__(in_size, nn.BatchNorm3d, name)
+
+
+class _ConvUnit(nn.Sequential):
+    """[norm ->][act ->] conv [-> norm][-> act]; preact puts norm/act first (reference :39-91)."""
+
+    def __init__(self, conv_cls, norm_wrapper, in_size, out_size, kernel_size, stride, padding, dilation,
+                 activation, bn, init, bias, preact, name):
+        super().__init__()
+        use_bias = bias and not bn
+        conv = conv_cls(in_size, out_size, kernel_size=kernel_size, stride=stride, padding=padding,
+                        dilation=dilation, bias=use_bias)
+        init(conv.weight)
+        if use_bias:
+            nn.init.constant_(conv.bias, 0)
+
+        def add_norm_act():
+            if bn:
+                self.add_module(name + "normlayer", norm_wrapper(in_size if preact else out_size))
+            if activation is not None:
+                self.add_module(name + "activation", activation)
+
+        if preact:
+            add_norm_act()
+        self.add_module(name + "conv", conv)
+        if not preact:
+            add_norm_act()
+
+
+class Conv1d(_ConvUnit):
+    def __init__(self, in_size, out_size, kernel_size=1, stride=1, padding=0, dilation=1,
+                 activation=nn.ReLU(inplace=True), bn=False, init=nn.init.kaiming_normal_, bias=True,
+                 preact=False, name="", norm_layer=BatchNorm1d):
+        super().__init__(nn.Conv1d, norm_layer, in_size, out_size, kernel_size, stride, padding, dilation,
+                         activation, bn, init, bias, preact, name)
+
+
+class Conv2d(_ConvUnit):
+    def __init__(self, in_size, out_size, kernel_size=(1, 1), stride=(1, 1), padding=(0, 0), dilation=(1, 1),
+                 activation=nn.ReLU(inplace=True), bn=False, init=nn.init.kaiming_normal_, bias=True,
+                 preact=False, name="", norm_layer=BatchNorm2d):
+        super().__init__(nn.Conv2d, norm_layer, in_size, out_size, kernel_size, stride, padding, dilation,
+                         activation, bn, init, bias, preact, name)
+
+
+class Conv3d(_ConvUnit):
+    def __init__(self, in_size, out_size, kernel_size=(1, 1, 1), stride=(1, 1, 1), padding=(0, 0, 0),
+                 dilation=(1, 1, 1), activation=nn.ReLU(inplace=True), bn=False, init=nn.init.kaiming_normal_,
+                 bias=True, preact=False, name="", norm_layer=BatchNorm3d):
+        super().__init__(nn.Conv3d, norm_layer, in_size, out_size, kernel_size, stride, padding, dilation,
+                         activation, bn, init, bias, preact, name)
+
+
+class FC(nn.Sequential):
+    def __init__(self, in_size, out_size, *, activation=nn.ReLU(inplace=True), bn=False, init=None, preact=False,
+                 name=""):
+        super().__init__()
+        fc = nn.Linear(in_size, out_size, bias=not bn)
+        if init is not None:
+            init(fc.weight)
+        if not bn:
+            nn.init.constant_(fc.bias, 0)
+        if preact:
+            if bn:
+                self.add_module(name + "bn", BatchNorm1d(in_size))
+            if activation is not None:
+                self.add_module(name + "activation", activation)
+        self.add_module(name + "fc", fc)
+        if not preact:
+            if bn:
+                self.add_module(name + "bn", BatchNorm1d(out_size))
+            if activation is not None:
+                self.add_module(name + "activation", activation)
+
+
+class SharedMLP(nn.Sequential):
+    """Stack of 1x1 Conv2d units over a (B,C,M,nsample) grouped tensor (reference :12-36)."""
+
+    def __init__(self, args, *, bn=False, activation=nn.ReLU(inplace=True), preact=False, first=False, name=""):
+        super().__init__()
+        for i in range(len(args) - 1):
+            plain = first and preact and i == 0      # the very first pre-activated unit gets no norm/act
+            self.add_module(
+                name + "layer{}".format(i),
+                Conv2d(args[i], args[i + 1], bn=(not plain) and bn, activation=None if plain else activation,
+                       preact=preact))
+
+
+class Seq(nn.Sequential):
+    """Fluent builder the heads use: Seq(c).conv1d(c1, bn=True).conv1d(c2, activation=None) (reference :263-427).
+    Children are named by their position, which is what the reference's checkpoints contain."""
+
+    def __init__(self, input_channels):
+        super().__init__()
+        self.count = 0
+        self.current_channels = input_channels
+
+    def _push(self, module, out_size):
+        self.add_module(str(self.count), module)
+        self.count += 1
+        self.current_channels = out_size
+        return self
+
+    def conv1d(self, out_size, kernel_size=1, stride=1, padding=0, dilation=1, activation=nn.ReLU(inplace=True),
+               bn=False, init=nn.init.kaiming_normal_, bias=True, preact=False, name="", norm_layer=BatchNorm1d):
+        return self._push(Conv1d(self.current_channels, out_size, kernel_size, stride, padding, dilation, activation,
+                                 bn, init, bias, preact, name, norm_layer), out_size)
+
+    def conv2d(self, out_size, kernel_size=(1, 1), stride=(1, 1), padding=(0, 0), dilation=(1, 1),
+               activation=nn.ReLU(inplace=True), bn=False, init=nn.init.kaiming_normal_, bias=True, preact=False,
+               name="", norm_layer=BatchNorm2d):
+        return self._push(Conv2d(self.current_channels, out_size, kernel_size, stride, padding, dilation, activation,
+                                 bn, init, bias, preact, name, norm_layer), out_size)
+
+    def fc(self, out_size, activation=nn.ReLU(inplace=True), bn=False, init=None, preact=False, name=""):
+        return self._push(FC(self.current_channels, out_size, activation=activation, bn=bn, init=init, preact=preact,
+                             name=name), out_size)
+
+    def dropout(self, p=0.5):
+        self.add_module(str(self.count), nn.Dropout(p=p))
+        self.count += 1
+        return self

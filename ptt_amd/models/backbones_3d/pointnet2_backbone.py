@@ -1,0 +1,75 @@
+"""Mirror of ptt/models/backbones_3d/pointnet2_backbone.py: PointNet2BackboneLight (:8-67).
+
+Three set-abstraction levels applied to the search and the template cloud with shared
+weights, a final 1x1 Conv1d (`cov_final`), and the composition of the per-level sample
+indices back to the raw cloud. Attribute names (`SA_modules`, `cov_final`,
+`num_point_features`) and the batch_dict key contract are the reference's. In eval mode on a
+HIP device `cov_final` runs on the fp32-MFMA linear kernel straight from the point-major
+features the last SA level produced.
+"""
+from typing import List
+
+import torch
+import torch.nn as nn
+
+from ... import ops
+from .pointnet2 import pointnet2_modules
+
+
+class PointNet2BackboneLight(nn.Module):
+    def __init__(self, model_cfg, input_channels, **kwargs):
+        super().__init__()
+        self.model_cfg = model_cfg
+        input_channels -= 3
+        self.num_points_each_layer = []
+        self.SA_modules = nn.ModuleList()
+        sa = self.model_cfg.SA_CONFIG
+        for k in range(len(sa.RADIUS)):
+            mlps = list(sa.MLPS[k])
+            if k == 0:
+                mlps[0] = input_channels
+            self.SA_modules.append(pointnet2_modules.PointnetSAModuleVotes(
+                radius=sa.RADIUS[k], nsample=sa.NSAMPLE[k], mlp=mlps,
+                use_xyz=sa.get('USE_XYZ', True), normalize_xyz=sa.get('NORMALIZE_XYZ', True),
+                sample_method=sa.SAMPLE_METHOD[k]))
+        self.cov_final = nn.Conv1d(256, 256, kernel_size=1)
+        self.num_point_features = sa.MLPS[-1][-1]
+        self._cov_cache = None
+
+    @staticmethod
+    def _break_up_pc(pc):
+        xyz = pc[..., 0:3].contiguous()
+        features = pc[..., 3:].contiguous() if pc.size(-1) > 3 else None   # as the reference (:38)
+        return xyz, features
+
+    def _cov_final(self, features):
+        """features (B,256,M). Eval + HIP + point-major storage: MFMA linear; else stock Conv1d."""
+        if self.training or not features.is_cuda:
+            return self.cov_final(features)
+        w, b = self.cov_final.weight, self.cov_final.bias
+        key = (w.data_ptr(), w._version, b.data_ptr(), b._version)
+        if self._cov_cache is None or self._cov_cache[0] != key:
+            self._cov_cache = (key, ops.pack_weight(w), b.detach().float().contiguous())
+        rows = features.transpose(1, 2)                        # (B,M,C); contiguous when point-major
+        out = ops.linear(rows, self._cov_cache[1], w.shape[0], None, self._cov_cache[2])
+        return out.transpose(1, 2)                              # (B,C,M) view
+
+    def branch_forward(self, pts, npoints: List):
+        xyz, features = self._break_up_pc(pts)
+        xyz, features, inds0 = self.SA_modules[0](xyz=xyz, features=features, npoint=npoints[0])
+        xyz, features, inds1 = self.SA_modules[1](xyz=xyz, features=features, npoint=npoints[1])
+        xyz, features, inds2 = self.SA_modules[2](xyz=xyz, features=features, npoint=npoints[2])
+        point_features = self._cov_final(features)
+        assert inds1.dtype == inds2.dtype == torch.int64, 'index type must be int64, not {}'.format(inds2.dtype)
+        inds = inds0.gather(1, inds1).gather(1, inds2)
+        return xyz, point_features, inds
+
+    def forward(self, batch_dict):
+        sa = self.model_cfg.SA_CONFIG
+        batch_dict['search_seeds'], batch_dict['search_feats'], batch_dict['search_inds'] = \
+            self.branch_forward(batch_dict['search_points'], sa.NPOINTS_SEARCH)
+        batch_dict['template_seeds'], batch_dict['template_feats'], batch_dict['template_inds'] = \
+            self.branch_forward(batch_dict['template_points'], sa.NPOINTS_TEMPLATE)
+        batch_dict.pop('search_points')
+        batch_dict.pop('template_points')
+        return batch_dict

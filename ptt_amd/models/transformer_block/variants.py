@@ -1,0 +1,120 @@
+"""Mirror of ptt/models/transformer_block/variants.py: TransformerBlock (:127-165, the variant every
+shipped config selects) and TransformerBlockSTD (:12-40).
+
+TransformerBlock is Point-Transformer *vector* attention over the k nearest neighbours:
+    delta_ij = fc_delta(xyz_i - xyz_j)
+    attn_ij  = softmax_j( fc_gamma(q_i - k_j + delta_ij) / sqrt(d_model) )      (per channel)
+    res_i    = fc2( sum_j attn_ij * (v_j + delta_ij) ) + features_i
+Parameter names (fc1, fc2, fc_delta.{0,2}, fc_gamma.{0,2}, w_qs, w_ks, w_vs) are the reference's,
+so its checkpoints load unchanged.
+
+Eval mode on a HIP device runs five kernels: kNN, fc1, stacked q|k|v projection, the fused pair
+kernel (fc_delta[2], fc_gamma[0], fc_gamma[2] on fp32 MFMA + softmax + weighted sum, with every
+(B,N,k,d_model) intermediate kept in LDS/registers) and fc2+residual. The reference returns
+`(res, attn)`; both heads keep only `[0]` (centroids_voting_head.py:76, box_voting_head.py:86), so
+the (B,N,k,d_model) attention tensor is written to HBM only when `materialize_attn` is True —
+otherwise the second return value is None.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ... import ops
+from ..model_utils import index_points, square_distance
+
+
+class TransformerBlock(nn.Module):
+    def __init__(self, d_points, d_model, k, **kwargs) -> None:
+        super().__init__()
+        self.fc1 = nn.Linear(d_points, d_model)
+        self.fc2 = nn.Linear(d_model, d_points)
+        self.fc_delta = nn.Sequential(nn.Linear(3, d_model), nn.ReLU(), nn.Linear(d_model, d_model))
+        self.fc_gamma = nn.Sequential(nn.Linear(d_model, d_model), nn.ReLU(), nn.Linear(d_model, d_model))
+        self.w_qs = nn.Linear(d_model, d_model, bias=False)
+        self.w_ks = nn.Linear(d_model, d_model, bias=False)
+        self.w_vs = nn.Linear(d_model, d_model, bias=False)
+        self.k = k
+        self.d_model = d_model
+        self.d_points = d_points
+        self.materialize_attn = False
+        self._cache = None
+
+    # ---------------------------------------------------------------- fused-path parameters
+    def _fusable(self, xyz, features):
+        return (not self.training and xyz.is_cuda and self.d_model == 512 and self.k == 16
+                and xyz.shape[1] % 2 == 0 and xyz.shape[1] >= self.k and features.dtype == torch.float32)
+
+    def _params(self):
+        ts = [self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, self.w_qs.weight, self.w_ks.weight,
+              self.w_vs.weight, self.fc_delta[0].weight, self.fc_delta[0].bias, self.fc_delta[2].weight,
+              self.fc_delta[2].bias, self.fc_gamma[0].weight, self.fc_gamma[0].bias, self.fc_gamma[2].weight,
+              self.fc_gamma[2].bias]
+        key = tuple((t.data_ptr(), t._version) for t in ts)
+        if self._cache is not None and self._cache[0] == key:
+            return self._cache[1]
+        with torch.no_grad():
+            f = lambda t: t.detach().float().contiguous()
+            P = dict(
+                fc1=ops.pack_weight(self.fc1.weight), fc1_b=f(self.fc1.bias),
+                qkv=ops.pack_weight(torch.cat([self.w_qs.weight, self.w_ks.weight, self.w_vs.weight], 0)),
+                wd1=f(self.fc_delta[0].weight), bd1=f(self.fc_delta[0].bias),
+                wd2=ops.pack_weight(self.fc_delta[2].weight), bd2=f(self.fc_delta[2].bias),
+                wg1=ops.pack_weight(self.fc_gamma[0].weight), bg1=f(self.fc_gamma[0].bias),
+                wg2=ops.pack_weight(self.fc_gamma[2].weight), bg2=f(self.fc_gamma[2].bias),
+                fc2=ops.pack_weight(self.fc2.weight), fc2_b=f(self.fc2.bias))
+        self._cache = (key, P)
+        return P
+
+    # xyz: b x n x 3, features: b x n x f
+    def forward(self, xyz, features):
+        if self._fusable(xyz, features):
+            P = self._params()
+            D = self.d_model
+            xyz = xyz.contiguous()
+            knn_idx = ops.knn(xyz, self.k)
+            x = ops.linear(features, P['fc1'], D, None, P['fc1_b'])
+            qkv = ops.linear(x, P['qkv'], 3 * D)
+            res, attn = ops.pt_attn_pair(xyz, knn_idx, qkv, P['wd1'], P['bd1'], P['wd2'], P['bd2'], P['wg1'],
+                                         P['bg1'], P['wg2'], P['bg2'], D, self.materialize_attn)
+            res = ops.linear(res, P['fc2'], self.d_points, None, P['fc2_b'], False, features)
+            return res, attn
+
+        # training / CPU: the reference's op sequence in stock torch (variants.py:149-165)
+        dists = square_distance(xyz, xyz)
+        knn_idx = dists.argsort()[:, :, :self.k]
+        knn_xyz = index_points(xyz, knn_idx)
+        pre = features
+        x = self.fc1(features)
+        q, k, v = self.w_qs(x), index_points(self.w_ks(x), knn_idx), index_points(self.w_vs(x), knn_idx)
+        pos_enc = self.fc_delta(xyz[:, :, None] - knn_xyz)
+        attn = self.fc_gamma(q[:, :, None] - k + pos_enc)
+        attn = F.softmax(attn / np.sqrt(k.size(-1)), dim=-2)
+        res = torch.einsum('bmnf,bmnf->bmf', attn, v + pos_enc)
+        res = self.fc2(res) + pre
+        return res, attn
+
+
+class TransformerBlockSTD(nn.Module):
+    """Dense scaled-dot-product variant (variants.py:12-40): softmax(q k^T / sqrt(d)) @ (v + fc_delta(xyz)).
+    Not selected by any shipped config; kept for API completeness on stock torch ops (the N x N
+    score matrix is at most 128 x 128 here, so rocBLAS GEMMs are the right tool)."""
+
+    def __init__(self, d_points, d_model, k, **kwargs) -> None:
+        super().__init__()
+        self.fc1 = nn.Linear(d_points, d_model)
+        self.fc2 = nn.Linear(d_model, d_points)
+        self.fc_delta = nn.Sequential(nn.Linear(3, d_model), nn.ReLU(), nn.Linear(d_model, d_model))
+        self.w_qs = nn.Linear(d_model, d_model, bias=False)
+        self.w_ks = nn.Linear(d_model, d_model, bias=False)
+        self.w_vs = nn.Linear(d_model, d_model, bias=False)
+        self.k = k
+
+    def forward(self, xyz, features):
+        pre = features
+        x = self.fc1(features)
+        q, k, v = self.w_qs(x), self.w_ks(x), self.w_vs(x)
+        attn = F.softmax(q @ k.transpose(1, 2) / np.sqrt(k.size(-1)), dim=-1)
+        res = attn @ (v + self.fc_delta(xyz))
+        res = self.fc2(res) + pre
+        return res, attn

@@ -18,6 +18,42 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+# Optional per-kernel timing with HIP events recorded on the SAME stream the kernels are
+# enqueued on (the current torch stream). Off by default; bench.py switches it on for the
+# kernels whose roofline it reports.
+_timing = None
+
+
+def start_kernel_timing(names):
+    global _timing
+    _timing = {n: [] for n in names}
+
+
+def stop_kernel_timing():
+    """-> {name: [milliseconds per launch]} (synchronises)."""
+    global _timing
+    t, _timing = _timing, None
+    torch.cuda.synchronize()
+    return {n: [a.elapsed_time(b) for a, b in ev] for n, ev in (t or {}).items()}
+
+
+class _timed(object):
+    def __init__(self, name):
+        self.ev = None
+        if _timing is not None and name in _timing:
+            self.ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            self.name = name
+
+    def __enter__(self):
+        if self.ev:
+            self.ev[0].record()
+
+    def __exit__(self, *a):
+        if self.ev:
+            self.ev[1].record()
+            _timing[self.name].append(self.ev)
+
+
 def _chk(t, name, dtype, ndim=None):
     if not isinstance(t, torch.Tensor):
         raise TypeError("%s must be a torch.Tensor" % name)
@@ -42,7 +78,7 @@ def furthest_point_sampling(xyz, npoint):
     _chk(xyz, "xyz", torch.float32, 3)
     B, N, _ = xyz.shape
     out = torch.empty((B, int(npoint)), dtype=torch.int32, device=xyz.device)
-    with torch.cuda.device(xyz.device):
+    with torch.cuda.device(xyz.device), _timed('ptt_fps_f32'):
         _lib.check(_lib.lib().ptt_fps_f32(_ptr(xyz), B, N, int(npoint), _ptr(out), _stream()), "ptt_fps_f32")
     return out
 
@@ -79,7 +115,7 @@ def ball_query(new_xyz, xyz, radius, nsample):
     B, M, _ = new_xyz.shape
     N = xyz.shape[1]
     out = torch.empty((B, M, int(nsample)), dtype=torch.int32, device=xyz.device)
-    with torch.cuda.device(xyz.device):
+    with torch.cuda.device(xyz.device), _timed('ptt_ball_query_f32'):
         _lib.check(_lib.lib().ptt_ball_query_f32(_ptr(new_xyz), _ptr(xyz), B, M, N, float(radius), int(nsample),
                                                  _ptr(out), _stream()), "ptt_ball_query_f32")
     return out
@@ -130,7 +166,7 @@ def knn(xyz, k):
     _chk(xyz, "xyz", torch.float32, 3)
     B, N, _ = xyz.shape
     out = torch.empty((B, N, int(k)), dtype=torch.int32, device=xyz.device)
-    with torch.cuda.device(xyz.device):
+    with torch.cuda.device(xyz.device), _timed('ptt_knn_f32'):
         _lib.check(_lib.lib().ptt_knn_f32(_ptr(xyz), B, N, int(k), _ptr(out), _stream()), "ptt_knn_f32")
     return out
 
@@ -166,7 +202,7 @@ def linear(x, wpacked, cout, scale=None, shift=None, relu=False, residual=None, 
         r2 = residual.reshape(-1, int(cout))
         if r2.stride(1) != 1:
             r2 = r2.contiguous()
-    with torch.cuda.device(x.device):
+    with torch.cuda.device(x.device), _timed('ptt_linear_f32'):
         _lib.check(_lib.lib().ptt_linear_f32(
             _ptr(x2), rows, K, x2.stride(0) if rows > 1 else K, _ptr(wpacked), int(cout), _ptr(scale), _ptr(shift),
             1 if relu else 0, _ptr(r2), (r2.stride(0) if (r2 is not None and rows > 1) else int(cout)),
@@ -215,7 +251,7 @@ def sa_fused_forward(xyz, new_xyz, idx, features, layers, radius, use_xyz=True, 
         L.scale = sc.data_ptr() if sc is not None else None
         L.shift = sh.data_ptr() if sh is not None else None
         L.Cin, L.Cout, L.relu = int(cin), int(co), int(bool(relu))
-    with torch.cuda.device(xyz.device):
+    with torch.cuda.device(xyz.device), _timed('ptt_sa_fused_fwd_f32'):
         _lib.check(_lib.lib().ptt_sa_fused_fwd_f32(ctypes.byref(d), _stream()), "ptt_sa_fused_fwd_f32")
     return out
 
@@ -238,6 +274,6 @@ def pt_attn_pair(xyz, knn_idx, qkv, wd1, bd1, wd2p, bd2, wg1p, bg1, wg2p, bg2, d
     d.res = res.data_ptr()
     d.attn = attn.data_ptr() if attn is not None else None
     d.B, d.N, d.k, d.D = B, N, k, D
-    with torch.cuda.device(xyz.device):
+    with torch.cuda.device(xyz.device), _timed('ptt_pt_attn_pair_f32'):
         _lib.check(_lib.lib().ptt_pt_attn_pair_f32(ctypes.byref(d), _stream()), "ptt_pt_attn_pair_f32")
     return res, attn
