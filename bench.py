@@ -146,7 +146,8 @@ def main():
     # ---- CPU baseline: rank 0, N=1 only, bounded sample ----
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import frame_ref, index_ops
+        from oracle import frame_ref
+        from oracle import index_ops as oracle_index_ops
         try:
             ncpu = len(os.sched_getaffinity(0))
         except AttributeError:
@@ -157,7 +158,7 @@ def main():
 
         def run_cpu(threads, frames):
             torch.set_num_threads(threads)
-            index_ops.set_threads(threads)
+            oracle_index_ops.set_threads(threads)
             t1 = time.perf_counter()
             with torch.no_grad():
                 frame_ref.frame(sd, cfg, sc[:frames], tc[:frames])

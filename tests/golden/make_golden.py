@@ -1,0 +1,242 @@
+#!/usr/bin/env python
+"""Generate the golden fixtures under tests/golden/ by running the REFERENCE's own pure-PyTorch
+modules (imported from /root/reference, in the build container only) on seeded inputs.
+
+What travels to the GPU box is data only: inputs, expected outputs and the numpy seeds the weights
+are regenerated from (tests/util.py). Nothing of the reference's source is copied.
+
+The reference cannot run without its third-party CUDA extension `pointnet2_ops._ext`
+(pointnet2_utils.py:24), `thop` (variants.py:7) and `easydict` (config.py); this script injects
+in-process stand-ins for exactly those three imports: `_ext` is backed by the repo's CPU oracle
+(oracle/index_ops.py), so every fixture pins  reference glue + torch layers  ON TOP OF  the oracle's
+index ops; the index ops themselves have no reference implementation to compare with ("parity
+unpinned", see oracle/ptt_oracle.c) — their golden vectors (G7) are authored by this build.
+
+Fixtures:
+  G1 query_and_group.npz   QueryAndGroup layout / centre subtraction / normalisation
+  G2 shared_mlp.npz        SharedMLP eval with non-trivial BN running stats
+  G3 sa_module.npz         PointnetSAModuleVotes: fps / sequence / caller-supplied inds, int64 cast, order
+  G4 backbone_branch.npz   PointNet2BackboneLight.branch_forward incl. index composition
+  G5 transformer.npz       TransformerBlock res + attn samples, N=128 and N=64, duplicated points
+  G7 index_ops.npz         op-level edge cases (duplicates, zero cloud, origin ball, under-filled balls)
+  G8 knn_argsort.npz       kNN vs the reference's square_distance + argsort on tie-free inputs
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+
+from oracle import dense_ref as R           # noqa: E402
+from oracle import index_ops as O           # noqa: E402
+from ptt_amd import synth                   # noqa: E402
+from tests.util import mlp_layers, transformer_params   # noqa: E402
+
+
+def _install_stubs():
+    ext = types.ModuleType("pointnet2_ops._ext")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    ext.furthest_point_sampling = lambda xyz, n: t(O.fps(xyz.numpy(), n))
+    ext.gather_points = lambda f, i: t(O.gather(f.numpy(), i.numpy()))
+    ext.gather_points_grad = lambda g, i, n: t(O.gather_grad(g.numpy(), i.numpy(), n))
+    ext.ball_query = lambda new_xyz, xyz, r, ns: t(O.ball_query(new_xyz.numpy(), xyz.numpy(), r, ns))
+    ext.group_points = lambda f, i: t(O.group(f.numpy(), i.numpy()))
+    ext.group_points_grad = lambda g, i, n: t(O.group_grad(g.numpy(), i.numpy(), n))
+    pkg = types.ModuleType("pointnet2_ops")
+    pkg._ext = ext
+    sys.modules["pointnet2_ops"] = pkg
+    sys.modules["pointnet2_ops._ext"] = ext
+    thop = types.ModuleType("thop")
+    thop.profile = lambda *a, **k: (0, 0)
+    thop.clever_format = lambda *a, **k: ("0", "0")
+    sys.modules["thop"] = thop
+
+    class EasyDict(dict):
+        def __init__(self, d=None, **kw):
+            super().__init__()
+            for k, v in dict(d or {}, **kw).items():
+                self[k] = v
+
+        def __setitem__(self, k, v):
+            if isinstance(v, dict) and not isinstance(v, EasyDict):
+                v = EasyDict(v)
+            super().__setitem__(k, v)
+
+        __setattr__ = __setitem__
+
+        def __getattr__(self, k):
+            try:
+                return self[k]
+            except KeyError:
+                raise AttributeError(k)
+
+    ed = types.ModuleType("easydict")
+    ed.EasyDict = EasyDict
+    sys.modules["easydict"] = ed
+    # the reference hard-codes .cuda() in hot-path code (pointnet2_modules.py:69,71): identity on CPU
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+    return EasyDict
+
+
+def _load_mlp(ref_mlp, layers):
+    with torch.no_grad():
+        for unit, L in zip(ref_mlp, layers):
+            unit.conv.weight.copy_(L["conv_weight"])
+            bn = unit.normlayer.bn
+            bn.weight.copy_(L["bn_weight"]); bn.bias.copy_(L["bn_bias"])
+            bn.running_mean.copy_(L["bn_mean"]); bn.running_var.copy_(L["bn_var"])
+
+
+def main():
+    EasyDict = _install_stubs()
+    sys.path.insert(0, REF)
+    from ptt.models.backbones_3d.pointnet2 import pointnet2_modules as ref_mod
+    from ptt.models.backbones_3d.pointnet2 import pointnet2_utils as ref_utils
+    from ptt.models.backbones_3d.pointnet2 import pytorch_utils as ref_pt
+    from ptt.models.backbones_3d.pointnet2_backbone import PointNet2BackboneLight as RefBackbone
+    from ptt.models.model_utils import square_distance as ref_sqdist
+    from ptt.models.transformer_block.variants import TransformerBlock as RefTB
+
+    torch.manual_seed(0)
+    save = lambda name, **kw: np.savez_compressed(os.path.join(HERE, name), **kw)
+    report = []
+
+    # ---------------- G1 QueryAndGroup ----------------
+    rs = np.random.RandomState(101)
+    s, _ = synth.frames(101, 2, 256, 64, K_s=120)
+    xyz = torch.from_numpy(s)
+    inds = torch.from_numpy(O.fps(s, 64))
+    new_xyz = torch.gather(xyz, 1, inds.long()[..., None].expand(-1, -1, 3)).contiguous()
+    feats = torch.from_numpy(rs.standard_normal((2, 5, 256)).astype(np.float32))
+    g = ref_utils.QueryAndGroup(0.5, 16, use_xyz=True, ret_grouped_xyz=True, normalize_xyz=True)
+    nf, gx, idx = g(xyz, new_xyz, feats, return_idx=True)
+    mine_nf, mine_gx, mine_idx = R.query_and_group(xyz, new_xyz, feats, 0.5, 16, True, True)
+    assert torch.equal(nf, mine_nf) and torch.equal(gx, mine_gx) and torch.equal(idx, mine_idx)
+    save("G1_query_and_group.npz", xyz=s, new_xyz=new_xyz.numpy(), feats=feats.numpy(), radius=0.5, nsample=16,
+         new_features=nf.numpy(), grouped_xyz=gx.numpy(), idx=idx.numpy())
+    report.append("G1 QueryAndGroup: oracle == reference bitwise")
+
+    # ---------------- G2 SharedMLP eval ----------------
+    spec = [8, 32, 32, 64]
+    layers = mlp_layers(202, spec)
+    m = ref_pt.SharedMLP(list(spec), bn=True).eval()
+    _load_mlp(m, layers)
+    x = torch.from_numpy(np.random.RandomState(202).standard_normal((2, 8, 24, 16)).astype(np.float32))
+    with torch.no_grad():
+        y = m(x)
+    mine = R.shared_mlp_eval(x, layers)
+    assert torch.allclose(y, mine, atol=1e-6, rtol=1e-6), float((y - mine).abs().max())
+    save("G2_shared_mlp.npz", x=x.numpy(), y=y.numpy(), spec=np.array(spec), seed=202)
+    report.append("G2 SharedMLP eval: max |oracle - reference| = %.2e" % float((y - mine).abs().max()))
+
+    # ---------------- G3 PointnetSAModuleVotes ----------------
+    out = {}
+    for tag, method, use_inds in (("fps", "fps", False), ("seq", "sequence", False), ("inds", "fps", True)):
+        spec3 = [5, 32, 32, 64]
+        layers3 = mlp_layers(303, [8, 32, 32, 64])
+        sa = ref_mod.PointnetSAModuleVotes(mlp=list(spec3), radius=0.5, nsample=16, normalize_xyz=True,
+                                           sample_method=method).eval()
+        _load_mlp(sa.mlp_module, layers3)
+        given = torch.from_numpy(np.random.RandomState(7).randint(0, 256, (2, 64)).astype(np.int32)) if use_inds else None
+        with torch.no_grad():
+            nx, nfe, ii = sa(xyz, feats, 64, inds=given)
+        mx, mf, mi = R.sa_module(xyz, feats, 64, layers3, 0.5, 16, method, True, True, inds=given)
+        assert torch.equal(nx, mx) and torch.equal(ii, mi) and ii.dtype == torch.int64
+        assert torch.allclose(nfe, mf, atol=1e-6, rtol=1e-6)
+        out.update({tag + "_new_xyz": nx.numpy(), tag + "_feats": nfe.numpy(), tag + "_inds": ii.numpy()})
+        if use_inds:
+            out["given_inds"] = given.numpy()
+    save("G3_sa_module.npz", xyz=s, feats=feats.numpy(), radius=0.5, nsample=16, npoint=64, seed=303, **out)
+    report.append("G3 PointnetSAModuleVotes (fps / sequence / given inds): oracle == reference (1e-6)")
+
+    # ---------------- G4 backbone branch ----------------
+    cfg = EasyDict(dict(DEBUG=False, SA_CONFIG=dict(
+        SAMPLE_METHOD=['fps', 'sequence', 'sequence'], USE_XYZ=True, NORMALIZE_XYZ=True,
+        NPOINTS_SEARCH=[512, 256, 128], NPOINTS_TEMPLATE=[256, 128, 64], RADIUS=[0.3, 0.5, 0.7],
+        NSAMPLE=[32, 32, 32], MLPS=[[0, 64, 64, 128], [128, 128, 128, 256], [256, 128, 128, 256]])))
+    bb = RefBackbone(cfg, input_channels=3).eval()
+    specs = [[3, 64, 64, 128], [131, 128, 128, 256], [259, 128, 128, 256]]
+    all_layers = [mlp_layers(400 + i, sp) for i, sp in enumerate(specs)]
+    for sa, L in zip(bb.SA_modules, all_layers):
+        _load_mlp(sa.mlp_module, L)
+    rs4 = np.random.RandomState(404)
+    cw = torch.from_numpy((rs4.standard_normal((256, 256, 1)) / 16).astype(np.float32))
+    cb = torch.from_numpy((rs4.standard_normal(256) * 0.1).astype(np.float32))
+    with torch.no_grad():
+        bb.cov_final.weight.copy_(cw); bb.cov_final.bias.copy_(cb)
+    s4, t4 = synth.frames(404, 2, 1024, 512)
+    with torch.no_grad():
+        sx, sf, si = bb.branch_forward(torch.from_numpy(s4), [512, 256, 128])
+    sa_cfgs = [dict(layers=all_layers[i], radius=[0.3, 0.5, 0.7][i], nsample=32,
+                    sample_method=['fps', 'sequence', 'sequence'][i], normalize_xyz=True) for i in range(3)]
+    mx, mf, mi = R.backbone_branch(torch.from_numpy(s4), [512, 256, 128], sa_cfgs, cw, cb)
+    assert torch.equal(sx, mx) and torch.equal(si, mi)
+    assert torch.allclose(sf, mf, atol=1e-5, rtol=1e-5), float((sf - mf).abs().max())
+    save("G4_backbone_branch.npz", pts=s4, seeds=sx.numpy(), feats=sf.numpy(), inds=si.numpy(),
+         cov_w=cw.numpy(), cov_b=cb.numpy())
+    report.append("G4 backbone branch_forward: oracle vs reference max diff %.2e" % float((sf - mf).abs().max()))
+
+    # ---------------- G5 TransformerBlock ----------------
+    g5 = {}
+    for N in (128, 64):
+        P = transformer_params(500 + N)
+        tb = RefTB(256, 512, 16).eval()
+        tb.load_state_dict(P)
+        s5, _ = synth.frames(500 + N, 2, N, 64, K_s=N)
+        # duplicated points carry duplicated features (what the tracker produces: same xyz -> same ball -> same feats)
+        s5[1, N // 2:] = s5[1, :N // 2]
+        f5 = np.random.RandomState(N).standard_normal((2, N, 256)).astype(np.float32)
+        f5[1, N // 2:] = f5[1, :N // 2]
+        with torch.no_grad():
+            res, attn = tb(torch.from_numpy(s5), torch.from_numpy(f5))
+        mres, mattn = R.transformer_block(torch.from_numpy(s5), torch.from_numpy(f5), P, 16)
+        d_res = float((res - mres).abs().max())
+        assert d_res < 2e-5, d_res
+        g5.update({"xyz%d" % N: s5, "feat%d" % N: f5, "res%d" % N: res.numpy(),
+                   "attn_sample%d" % N: attn[:, ::16, :, ::32].contiguous().numpy()})
+        report.append("G5 TransformerBlock N=%d: oracle vs reference max |res diff| = %.2e (incl. duplicated points)"
+                      % (N, d_res))
+    save("G5_transformer.npz", **g5)
+
+    # ---------------- G8 kNN vs reference square_distance + argsort (tie-free) ----------------
+    rs8 = np.random.RandomState(808)
+    x8 = rs8.uniform(-3, 3, (3, 128, 3)).astype(np.float32)
+    ref_idx = ref_sqdist(torch.from_numpy(x8), torch.from_numpy(x8)).argsort()[:, :, :16]
+    mine_idx = O.knn(x8, 16)
+    assert np.array_equal(ref_idx.numpy(), mine_idx.astype(np.int64))
+    save("G8_knn_argsort.npz", xyz=x8, knn=ref_idx.numpy().astype(np.int32))
+    report.append("G8 kNN: oracle == reference square_distance+argsort on tie-free clouds")
+
+    # ---------------- G7 op-level edge cases (authored here; no reference implementation exists) ----------------
+    rs7 = np.random.RandomState(707)
+    c = np.empty((5, 1024, 3), np.float32)
+    c[0] = synth.cloud(rs7, 1024, 40, synth.SEARCH_BOX, synth.PED_SIGMA, 0.2)      # 40 unique points resampled
+    c[1] = 0.0                                                                      # all-zero cloud
+    c[2] = synth.cloud(rs7, 1024, 600, synth.SEARCH_BOX, synth.CAR_SIGMA)
+    c[2, :200] = rs7.uniform(-0.015, 0.015, (200, 3))                               # inside the 1e-3 origin ball
+    c[3] = synth.cloud(rs7, 1024, 1024, synth.SEARCH_BOX, synth.CAR_SIGMA, 1.0)
+    c[4] = rs7.uniform(-1, 1, (1024, 3)).round(1)                                   # exact distance ties
+    f = O.fps(c, 512)
+    f_full = O.fps(c[:, :128], 128)                                                 # npoint == N
+    centres = np.take_along_axis(c, f[..., None].astype(np.int64).repeat(3, -1), 1)[:, :128]
+    bq = O.ball_query(centres, c, 0.3, 32)
+    bq_far = O.ball_query(centres + 50.0, c, 0.3, 32)                               # no hits -> zeros
+    kn = O.knn(c[:, :128], 16)
+    save("G7_index_ops.npz", clouds=c, fps512=f, fps_full128=f_full, centres=centres, bq=bq, bq_far=bq_far, knn=kn)
+    report.append("G7 index-op edge cases written (build-authored contract)")
+
+    with open(os.path.join(HERE, "GOLDEN_REPORT.txt"), "w") as fh:
+        fh.write("generated by tests/golden/make_golden.py against /root/reference (torch %s)\n" % torch.__version__)
+        fh.write("\n".join(report) + "\n")
+    print("\n".join(report))
+
+
+if __name__ == "__main__":
+    main()

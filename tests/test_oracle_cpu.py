@@ -1,0 +1,162 @@
+"""CPU suite (-m "not gpu"): the oracle against the committed golden fixtures (generated from the imported
+reference by tests/golden/make_golden.py), the C-ABI library's symbol table, checkpoint key names and the
+host-side sharding logic. No kernel is launched here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import dense_ref as R
+from oracle import index_ops as O
+from tests.util import mlp_layers, transformer_params
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _g(name):
+    return np.load(os.path.join(GOLD, name))
+
+
+def test_G1_query_and_group():
+    g = _g("G1_query_and_group.npz")
+    nf, gx, idx = R.query_and_group(torch.from_numpy(g["xyz"]), torch.from_numpy(g["new_xyz"]),
+                                    torch.from_numpy(g["feats"]), float(g["radius"]), int(g["nsample"]), True, True)
+    np.testing.assert_array_equal(idx.numpy(), g["idx"])
+    np.testing.assert_array_equal(gx.numpy(), g["grouped_xyz"])
+    np.testing.assert_array_equal(nf.numpy(), g["new_features"])
+    assert nf.shape[1] == 3 + g["feats"].shape[1]                  # xyz channels first, then features
+
+
+def test_G2_shared_mlp_eval():
+    g = _g("G2_shared_mlp.npz")
+    y = R.shared_mlp_eval(torch.from_numpy(g["x"]), mlp_layers(int(g["seed"]), list(g["spec"])))
+    np.testing.assert_allclose(y.numpy(), g["y"], atol=1e-6, rtol=1e-6)
+
+
+@pytest.mark.parametrize("tag,method", [("fps", "fps"), ("seq", "sequence"), ("inds", "fps")])
+def test_G3_sa_module(tag, method):
+    g = _g("G3_sa_module.npz")
+    inds = torch.from_numpy(g["given_inds"]) if tag == "inds" else None
+    nx, nf, ii = R.sa_module(torch.from_numpy(g["xyz"]), torch.from_numpy(g["feats"]), int(g["npoint"]),
+                             mlp_layers(int(g["seed"]), [8, 32, 32, 64]), float(g["radius"]), int(g["nsample"]),
+                             method, True, True, inds=inds)
+    assert ii.dtype == torch.int64
+    np.testing.assert_array_equal(ii.numpy(), g[tag + "_inds"])
+    np.testing.assert_array_equal(nx.numpy(), g[tag + "_new_xyz"])
+    np.testing.assert_allclose(nf.numpy(), g[tag + "_feats"], atol=1e-6, rtol=1e-6)
+
+
+def test_G4_backbone_branch():
+    g = _g("G4_backbone_branch.npz")
+    specs = [[3, 64, 64, 128], [131, 128, 128, 256], [259, 128, 128, 256]]
+    sa_cfgs = [dict(layers=mlp_layers(400 + i, sp), radius=[0.3, 0.5, 0.7][i], nsample=32,
+                    sample_method=['fps', 'sequence', 'sequence'][i], normalize_xyz=True) for i, sp in enumerate(specs)]
+    x, f, i = R.backbone_branch(torch.from_numpy(g["pts"]), [512, 256, 128], sa_cfgs, torch.from_numpy(g["cov_w"]),
+                                torch.from_numpy(g["cov_b"]))
+    np.testing.assert_array_equal(i.numpy(), g["inds"])
+    np.testing.assert_array_equal(x.numpy(), g["seeds"])
+    np.testing.assert_allclose(f.numpy(), g["feats"], atol=1e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("N", [128, 64])
+def test_G5_transformer_block(N):
+    g = _g("G5_transformer.npz")
+    res, attn = R.transformer_block(torch.from_numpy(g["xyz%d" % N]), torch.from_numpy(g["feat%d" % N]),
+                                    transformer_params(500 + N), 16)
+    np.testing.assert_allclose(res.numpy(), g["res%d" % N], atol=2e-5, rtol=2e-5)
+    np.testing.assert_allclose(attn[:, ::16, :, ::32].numpy(), g["attn_sample%d" % N], atol=1e-6, rtol=1e-5)
+    np.testing.assert_allclose(attn.sum(-2).numpy(), 1.0, atol=1e-5)     # softmax over the neighbour axis
+
+
+def test_G7_index_op_edge_cases():
+    g = _g("G7_index_ops.npz")
+    c = g["clouds"]
+    np.testing.assert_array_equal(O.fps(c, 512), g["fps512"])
+    np.testing.assert_array_equal(O.fps(c[:, :128], 128), g["fps_full128"])
+    np.testing.assert_array_equal(O.ball_query(g["centres"], c, 0.3, 32), g["bq"])
+    np.testing.assert_array_equal(O.ball_query(g["centres"] + 50.0, c, 0.3, 32), g["bq_far"])
+    np.testing.assert_array_equal(O.knn(c[:, :128], 16), g["knn"])
+    assert (g["fps512"][1] == 0).all() and (g["bq_far"] == 0).all()       # zero cloud / empty balls
+    assert sorted(g["fps_full128"][3].tolist()) == list(range(128))       # npoint == N on distinct points: a permutation
+    # origin-ball points are never selected (except the forced start index 0)
+    mag = (c[2] ** 2).sum(-1)
+    assert (mag[g["fps512"][2][1:]] > 1e-3).all()
+
+
+def test_G8_knn_equals_reference_argsort():
+    g = _g("G8_knn_argsort.npz")
+    np.testing.assert_array_equal(O.knn(g["xyz"], 16), g["knn"])
+
+
+def test_oracle_semantics_small():
+    """Hand-checkable cases of the spec in SURVEY.md §8c."""
+    pts = np.array([[[0, 0, 0], [1, 0, 0], [0, 2, 0], [3, 0, 0], [1, 0, 0]]], np.float32)
+    # start 0 (skipped point: inside the origin ball), farthest from it is 3 (d=9), then 2, then 1 (tie 1/4 -> lowest)
+    np.testing.assert_array_equal(O.fps(pts, 4), [[0, 3, 2, 1]])
+    bq = O.ball_query(np.array([[[1, 0, 0]]], np.float32), pts, 1.01, 4)
+    np.testing.assert_array_equal(bq, [[[0, 1, 4, 0]]])                    # hits 0,1,4 in index order, pad = first hit
+    np.testing.assert_array_equal(O.ball_query(np.array([[[9, 9, 9]]], np.float32), pts, 0.5, 3), [[[0, 0, 0]]])
+    np.testing.assert_array_equal(O.knn(pts, 3)[0, 1], [1, 4, 0])          # duplicate at distance 0, index order
+
+
+def test_gather_group_grads_are_adjoint():
+    rs = np.random.RandomState(0)
+    f = rs.standard_normal((2, 3, 17)).astype(np.float32)
+    idx = rs.randint(0, 17, (2, 5, 4)).astype(np.int32)
+    go = rs.standard_normal((2, 3, 5, 4)).astype(np.float32)
+    lhs = float((O.group(f, idx) * go).sum())
+    rhs = float((f * O.group_grad(go, idx, 17)).sum())
+    assert abs(lhs - rhs) < 1e-3
+
+
+def test_library_exports_every_declared_symbol():
+    """include/ptt_hip.h <-> libptt_hip.so: every declared entry point is exported (no compute call)."""
+    header = open(os.path.join(ROOT, "include", "ptt_hip.h")).read()
+    declared = set(re.findall(r"\b(ptt_[a-z0-9_]+)\s*\(", header))
+    from ptt_amd import _lib
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    assert os.path.exists(_lib.LIB_PATH), "run `python -m ptt_amd.build` first"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    lib.ptt_version.restype = ctypes.c_int
+    assert lib.ptt_version() == 1
+
+
+def test_product_path_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "ptt_amd")):
+        for fn in files:
+            if fn.endswith(".py"):
+                src = open(os.path.join(dirpath, fn)).read()
+                path = os.path.join(dirpath, fn)
+                assert not re.search(r"^\s*(from|import)\s+\.*oracle", src, re.M), path      # no import of oracle/
+                assert "libptt_oracle" not in src or fn == "build.py", path               # only build.py names the checker's .so
+
+
+def test_ops_reject_cpu_tensors_loudly():
+    from ptt_amd import ops
+    with pytest.raises(RuntimeError):
+        ops.furthest_point_sampling(torch.zeros(1, 8, 3), 4)
+    with pytest.raises(RuntimeError):
+        ops.knn(torch.zeros(1, 8, 3), 4)
+
+
+def test_state_dict_keys_match_reference_contract():
+    from ptt_amd.hot_path import FrameHotPath
+    sd = FrameHotPath().state_dict()
+    for k in ["backbone_3d.SA_modules.0.mlp_module.layer0.conv.weight",
+              "backbone_3d.SA_modules.2.mlp_module.layer2.normlayer.bn.running_var",
+              "backbone_3d.SA_modules.1.mlp_module.layer1.normlayer.bn.num_batches_tracked",
+              "backbone_3d.cov_final.weight", "backbone_3d.cov_final.bias",
+              "vote_aggregation.mlp_module.layer0.conv.weight",
+              "centroid_transformer.fc_delta.2.bias", "box_transformer.fc_gamma.0.weight",
+              "box_transformer.w_qs.weight"]:
+        assert k in sd, k
+    assert tuple(sd["vote_aggregation.mlp_module.layer0.conv.weight"].shape) == (256, 260, 1, 1)
+    assert tuple(sd["backbone_3d.SA_modules.0.mlp_module.layer0.conv.weight"].shape) == (64, 3, 1, 1)
+    tb = sum(v.numel() for k, v in sd.items() if k.startswith("box_transformer."))
+    assert tb == 1839360                                                    # SURVEY.md §8a T3 [probe]
