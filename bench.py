@@ -29,7 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from ptt_amd import ops, synth                      # noqa: E402
-from ptt_amd.hot_path import FrameHotPath, kitti_model_cfg, randomize_   # noqa: E402
+from ptt_amd.hot_path import FrameHotPath, GraphedHotPath, kitti_model_cfg, randomize_   # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: dense f32-input MFMA peak
 PEAK_HBM_GBS = 8000.0               # spec; ~6300 achievable
@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--ns", type=int, default=2048, help="search points per frame")
     ap.add_argument("--nt", type=int, default=1024, help="template points per frame")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--cpu-frames", type=int, default=8)
     args = ap.parse_args()
 
@@ -85,9 +86,12 @@ def main():
     search = torch.from_numpy(s_np).to(dev)
     template = torch.from_numpy(t_np).to(dev)
 
-    def step():
+    def eager_step():
         with torch.no_grad():
             return model(search, template)
+
+    graphed = None if args.no_graph else GraphedHotPath(model, search, template)
+    step = eager_step if graphed is None else (lambda: graphed())
 
     def sync_all():
         torch.cuda.synchronize()
@@ -100,13 +104,24 @@ def main():
     sync_all()
     timed = ["ptt_pt_attn_pair_f32", "ptt_fps_f32", "ptt_ball_query_f32", "ptt_sa_fused_fwd_f32", "ptt_linear_f32",
              "ptt_knn_f32"]
-    ops.start_kernel_timing(timed)
+    if graphed is None:
+        ops.start_kernel_timing(timed)          # HIP events around each launch, inside the timed region
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     sync_all()
     elapsed = time.perf_counter() - t0
-    ktimes = ops.stop_kernel_timing()
+    if graphed is None:
+        ktimes = ops.stop_kernel_timing()
+    else:
+        # events cannot be recorded inside a replayed graph: the per-kernel durations come from the same
+        # kernels, same inputs, launched eagerly (single stream) right after the timed region
+        model.overlap_branches = False
+        ops.start_kernel_timing(timed)
+        for _ in range(args.steps):
+            eager_step()
+        ktimes = ops.stop_kernel_timing()
+        model.overlap_branches = True
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -126,6 +141,8 @@ def main():
     roofline = {"kernel": "pt_attn_pair_kernel<512>", "bound": "mfma", "achieved": round(achieved, 2),
                 "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
                 "traffic": None, "avg_launch_ms": round(pair_avg_ms, 4), "launches": n_launch,
+                "timing": "HIP events on the launch stream" + ("" if graphed is None else
+                                                               ", eager pass of the same kernels after the graphed timed region"),
                 "alg_flops_per_launch": flops_per_launch}
 
     # secondary: FPS + ball-query algorithmic HBM GB/s vs peak (BASELINE.json metric, second half)
@@ -192,7 +209,8 @@ def main():
                                    "TransformerBlocks (d_model 512, k 16), random-init weights, eval mode"
                                    % (B, args.ns, args.nt),
                        "frames_per_gpu_per_step": B, "search_points": args.ns, "template_points": args.nt,
-                       "sharding": "frames across ranks, no data-path collective"},
+                       "sharding": "frames across ranks, no data-path collective",
+                       "launch": "eager" if graphed is None else "hipGraph replay, template branch on a second stream"},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "index_ops": index_ops,

@@ -102,7 +102,6 @@ int ptt_knn_f32(const float* xyz, int B, int N, int k, int32_t* idx_out,
  * Weight packing for the fp32-MFMA kernels.
  *   W (Cout,K) row-major (an nn.Linear / 1x1-conv weight)  ->  packed fragment order
  *   [K8][Cout32][64 lanes][4]  with K padded to a multiple of 8 and Cout to 32 (zeros).
- *   `k_front` leading input channels may be rotated behind the others (0 = keep order).
  * ------------------------------------------------------------------------------- */
 size_t ptt_packed_weight_elems(int Cout, int K);
 int ptt_pack_weight_f32(const float* W, int Cout, int K, float* packed,

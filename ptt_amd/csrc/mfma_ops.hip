@@ -19,6 +19,7 @@
 //     a tile's 32 rows are the neighbours of one centre (or of two, 16 each), so max-pool
 //     and the softmax over neighbours are register-local plus one lane^32 exchange.
 #include <math.h>
+#include <stdlib.h>
 #include "common.h"
 
 namespace ptt {
@@ -29,6 +30,20 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ int tile_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
 
 __device__ __forceinline__ float xor32(float v) { return __shfl_xor(v, 32, 64); }
+
+// Two workgroups share each CU (and each SIMD's MFMA pipe). Launched together with identical work
+// they run in lockstep, so their non-MFMA phases (gather, epilogue, softmax) coincide and the matrix
+// pipe idles. The workgroup that got the SECOND LDS allocation of its CU (HW_REG_LDS_ALLOC.LDS_BASE
+// != 0) in the FIRST wave of workgroups therefore starts `quanta` x ~8k cycles late; later workgroups
+// inherit the offset from the slot they replace. Placement only changes speed, never results.
+__device__ __forceinline__ void stagger_second_slot(int first_wave_blocks, int quanta) {
+    if ((int)blockIdx.x < first_wave_blocks) {
+        const unsigned lds_base = __builtin_amdgcn_s_getreg((7 << 11) | (0 << 6) | 6) & 0xffu;  // HW_REG_LDS_ALLOC[7:0]
+        if (lds_base != 0) {
+            for (int i = 0; i < quanta; ++i) __builtin_amdgcn_s_sleep(127);
+        }
+    }
+}
 
 // ------------------------------------------------------------------------------------------
 // weight packing
@@ -47,14 +62,31 @@ __global__ void pack_weight_kernel(const float* __restrict__ W, int Cout, int K,
     }
 }
 
+// One K-block: 4 * RT * CT MFMAs on the first CT column tiles of acc (ACT >= CT columns wide).
+template <int RT, int CT, int ACT>
+__device__ __forceinline__ void gemm_mfma_block(const f32x4 (&a)[RT], const f32x4 (&b)[CT], f32x16 (&acc)[RT][ACT]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int u = 0; u < CT; ++u)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+                acc[rt][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rt][j], b[u][j], acc[rt][u], 0, 0, 0);
+}
+
 // ------------------------------------------------------------------------------------------
-// The shared GEMM core: acc[rt][u] += X[rt-th 32 rows][0:8*nkb] * W[:, col tile ct0 + 4*u]
-// A from LDS (one ds_read_b128 per row tile per K-block), B from packed global weights with
-// a one-block register prefetch. `nvalid` = number of this wave's column tiles that exist.
-// ------------------------------------------------------------------------------------------
-template <int RT, int CT>
+// The shared GEMM core: acc[rt][u] += X[rt-th 32 rows][0:8*nkb] * W[:, column tile ct0 + 4*u], u < CT.
+// A from LDS (one ds_read_b128 per row tile per K-block), B from the packed global weights with a
+// one-block register prefetch that hipcc unrolls and interleaves with counted vmcnt waits.
+// CT is a COMPILE-TIME tile count on purpose: a run-time "how many of my column tiles exist" test
+// puts the loads under control flow, and the waitcnt pass then falls back to vmcnt(0) before every
+// MFMA group, which drains the prefetch (measured 2-4x slower K-loops).
+// (A hand-pinned two-register-set pipeline with sched_barrier(0) was measured 4-6 % SLOWER than this
+//  form: the loop is bound by the L2->CU fetch path, not by load placement — see DESIGN.md.)
+template <int RT, int CT, int ACT>
 __device__ __forceinline__ void gemm_core(const float* Xs, int ldk, int nkb, const f32x4* __restrict__ Wp, int NT,
-                                          int ct0, int nvalid, int lane, f32x16 (&acc)[RT][CT]) {
+                                          int ct0, int lane, f32x16 (&acc)[RT][ACT]) {
+    static_assert(CT <= ACT, "accumulator array too narrow");
     const int row = lane & 31, half = lane >> 5;
     const float* arow = Xs + row * ldk + 4 * half;
     const f32x4* bp = Wp + (size_t)ct0 * 64 + lane;
@@ -62,29 +94,34 @@ __device__ __forceinline__ void gemm_core(const float* Xs, int ldk, int nkb, con
 
     f32x4 bcur[CT], bnxt[CT];
 #pragma unroll
-    for (int u = 0; u < CT; ++u) bcur[u] = (u < nvalid) ? bp[(size_t)u * 4 * 64] : f32x4{0.f, 0.f, 0.f, 0.f};
-
+    for (int u = 0; u < CT; ++u) { bcur[u] = bp[(size_t)u * 4 * 64]; bnxt[u] = bcur[u]; }
     for (int kb = 0; kb < nkb; ++kb) {
-        const f32x4* bn = bp + (size_t)(kb + 1) * bstep;
         if (kb + 1 < nkb) {
+            const f32x4* bn = bp + (size_t)(kb + 1) * bstep;
 #pragma unroll
-            for (int u = 0; u < CT; ++u)
-                if (u < nvalid) bnxt[u] = bn[(size_t)u * 4 * 64];
+            for (int u = 0; u < CT; ++u) bnxt[u] = bn[(size_t)u * 4 * 64];
         }
         f32x4 a[RT];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) a[rt] = *reinterpret_cast<const f32x4*>(arow + rt * 32 * ldk + kb * 8);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int u = 0; u < CT; ++u)
-                if (u < nvalid) {
-#pragma unroll
-                    for (int rt = 0; rt < RT; ++rt)
-                        acc[rt][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rt][j], bcur[u][j], acc[rt][u], 0, 0, 0);
-                }
+        gemm_mfma_block<RT, CT, ACT>(a, bcur, acc);
 #pragma unroll
         for (int u = 0; u < CT; ++u) bcur[u] = bnxt[u];
+    }
+}
+
+// Run the core on however many of this wave's (up to CT) column tiles exist: a wave-uniform
+// dispatch to compile-time tile counts.
+template <int RT, int CT>
+__device__ __forceinline__ void gemm_tiles(const float* Xs, int ldk, int nkb, const f32x4* __restrict__ Wp, int NT,
+                                           int ct0, int nvalid, int lane, f32x16 (&acc)[RT][CT]) {
+    if (nvalid >= CT) gemm_core<RT, CT, CT>(Xs, ldk, nkb, Wp, NT, ct0, lane, acc);
+    else if constexpr (CT > 1) {
+        if (nvalid == 1) gemm_core<RT, 1, CT>(Xs, ldk, nkb, Wp, NT, ct0, lane, acc);
+        else if constexpr (CT > 2) {
+            if (nvalid == 2) gemm_core<RT, 2, CT>(Xs, ldk, nkb, Wp, NT, ct0, lane, acc);
+            else if (nvalid == 3) gemm_core<RT, 3, CT>(Xs, ldk, nkb, Wp, NT, ct0, lane, acc);
+        }
     }
 }
 
@@ -100,36 +137,80 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[RT][CT]) {
 
 // ------------------------------------------------------------------------------------------
 // Linear: out[rows, Cout] = act(X[rows, K] @ W^T * scale + shift) (+ residual)
-// grid = (ceil(rows/32), ceil(Cout/256)); a workgroup owns 32 rows x 256 columns.
+// A workgroup owns RT*32 rows x 256 columns (wave w: column tiles w and w+4 of its group, all
+// row tiles, so every weight fragment feeds RT MFMAs). X is staged through two LDS buffers in
+// K-chunks of 128 channels with float4 loads; the next chunk is fetched into registers while the
+// current one is being multiplied and written to the other buffer afterwards (one barrier per chunk). grid = (ceil(rows/(32*RT)), ceil(Cout/256)).
 // ------------------------------------------------------------------------------------------
 struct LinearParams {
     const float* X; const float* Wp; const float* scale; const float* shift; const float* residual; float* out;
-    int rows, K, ldx, Cout, relu, ldr, ldo, ldk, nkb, NT;
+    int rows, K, ldx, Cout, relu, ldr, ldo, nkb, NT, vec_ok;
 };
 
+constexpr int LIN_KC = 128;          // channels per staged chunk
+constexpr int LIN_LDK = LIN_KC + 4;  // LDS row stride (== 4 mod 8)
+
+// VEC: K % 4 == 0, ldx % 4 == 0 and X 16-byte aligned -> one float4 per slot, bounds by slot.
+template <int RT, bool VEC>
+__device__ __forceinline__ void lin_fetch(const LinearParams& p, int row0, int k0, int t, f32x4 (&st)[RT * 4]) {
+#pragma unroll
+    for (int i = 0; i < RT * 4; ++i) {
+        const int e = t + i * 256;               // float4 slot inside the [RT*32][32] chunk
+        const int r = e >> 5, c = k0 + ((e & 31) << 2);
+        const int gr = row0 + r;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (VEC) {
+            if (gr < p.rows && c < p.K) v = *reinterpret_cast<const f32x4*>(p.X + (size_t)gr * p.ldx + c);
+        } else if (gr < p.rows) {
+            const float* src = p.X + (size_t)gr * p.ldx + c;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (c + q < p.K) v[q] = src[q];
+        }
+        st[i] = v;
+    }
+}
+
+template <int RT>
+__device__ __forceinline__ void lin_stage(float* Xs, int t, const f32x4 (&st)[RT * 4]) {
+#pragma unroll
+    for (int i = 0; i < RT * 4; ++i) {
+        const int e = t + i * 256;
+        *reinterpret_cast<f32x4*>(Xs + (e >> 5) * LIN_LDK + ((e & 31) << 2)) = st[i];
+    }
+}
+
+template <int RT, bool VEC>
 __global__ __launch_bounds__(256, 2) void linear_kernel(LinearParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Xs = smem;
+    float* Xs = smem;                                    // 2 x [RT*32][LIN_LDK]
+    constexpr int BUF = RT * 32 * LIN_LDK;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    const int row0 = blockIdx.x * 32;
-    const int Kpad = p.nkb * 8;
-
-    // stage the 32-row activation tile (zero-padded rows / columns)
-    for (int e = t; e < 32 * Kpad; e += 256) {
-        const int r = e / Kpad, c = e - r * Kpad;
-        const int gr = row0 + r;
-        Xs[r * p.ldk + c] = (gr < p.rows && c < p.K) ? p.X[(size_t)gr * p.ldx + c] : 0.f;
-    }
-    __syncthreads();
-
-    const int ctbase = blockIdx.y * 8 + w;  // this wave's first column tile, the second is +4
+    const int row0 = blockIdx.x * 32 * RT;
+    const int ctbase = blockIdx.y * 8 + w;               // this wave's first column tile, the second is +4
     int nvalid = 0;
     if (ctbase < p.NT) nvalid = (ctbase + 4 < p.NT) ? 2 : 1;
-    if (nvalid == 0) return;
+    const int nchunks = (p.nkb * 8 + LIN_KC - 1) / LIN_KC;
+    const size_t bstep = (size_t)p.NT * 64;
 
-    f32x16 acc[1][2];
+    f32x4 st[RT * 4];
+    f32x16 acc[RT][2];
     zero_acc(acc);
-    gemm_core<1, 2>(Xs, p.ldk, p.nkb, reinterpret_cast<const f32x4*>(p.Wp), p.NT, ctbase, nvalid, lane, acc);
+    lin_fetch<RT, VEC>(p, row0, 0, t, st);
+    lin_stage<RT>(Xs, t, st);
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        float* cur = Xs + (c & 1) * BUF;
+        if (c + 1 < nchunks) lin_fetch<RT, VEC>(p, row0, (c + 1) * LIN_KC, t, st);
+        const int nkb_c = min(LIN_KC / 8, p.nkb - c * (LIN_KC / 8));
+        gemm_tiles<RT, 2>(cur, LIN_LDK, nkb_c, reinterpret_cast<const f32x4*>(p.Wp) + (size_t)c * (LIN_KC / 8) * bstep,
+                          p.NT, ctbase, nvalid, lane, acc);
+        if (c + 1 < nchunks) {
+            lin_stage<RT>(Xs + ((c + 1) & 1) * BUF, t, st);   // the other buffer: last read in chunk c-1
+            __syncthreads();
+        }
+    }
+    if (nvalid == 0) return;
 
     const int half = lane >> 5;
 #pragma unroll
@@ -140,14 +221,16 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(LinearParams p) {
         const float sc = p.scale ? p.scale[col] : 1.f;
         const float sh = p.shift ? p.shift[col] : 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int gr = row0 + tile_row(r, half);
-            if (gr >= p.rows) continue;
-            float y = acc[0][u][r] * sc + sh;
-            if (p.relu) y = fmaxf(y, 0.f);
-            if (p.residual) y += p.residual[(size_t)gr * p.ldr + col];
-            p.out[(size_t)gr * p.ldo + col] = y;
-        }
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int gr = row0 + rt * 32 + tile_row(r, half);
+                if (gr >= p.rows) continue;
+                float y = acc[rt][u][r] * sc + sh;
+                if (p.relu) y = fmaxf(y, 0.f);
+                if (p.residual) y += p.residual[(size_t)gr * p.ldr + col];
+                p.out[(size_t)gr * p.ldo + col] = y;
+            }
     }
 }
 
@@ -172,8 +255,7 @@ __device__ __forceinline__ void sa_layer(const SaParams& p, const SaLayerDev& L,
 #pragma unroll
     for (int u = 0; u < CT; ++u)
         if (w + 4 * u < L.NT) nvalid = u + 1;
-    if (nvalid > 0)
-        gemm_core<2, CT>(Xs, p.ldk, L.nkb, reinterpret_cast<const f32x4*>(L.Wp), L.NT, w, nvalid, lane, acc);
+    gemm_tiles<2, CT>(Xs, p.ldk, L.nkb, reinterpret_cast<const f32x4*>(L.Wp), L.NT, w, nvalid, lane, acc);
     __syncthreads();  // every wave has finished reading this layer's input tile
 
     const int half = lane >> 5;
@@ -275,8 +357,7 @@ __global__ __launch_bounds__(256, 2) void sa_fused_kernel(SaParams p) {
         const bool last = (l == p.n_layers - 1);
         const int ctw = (L.NT + 3) >> 2;
         if (ctw <= 1) sa_layer<NS, 1>(p, L, last, Xs, lane, w, centre0, ncentres);
-        else if (ctw == 2) sa_layer<NS, 2>(p, L, last, Xs, lane, w, centre0, ncentres);
-        else sa_layer<NS, 4>(p, L, last, Xs, lane, w, centre0, ncentres);
+        else sa_layer<NS, 2>(p, L, last, Xs, lane, w, centre0, ncentres);
     }
 }
 
@@ -288,7 +369,8 @@ struct AttnParams {
     const float* xyz; const int32_t* knn; const float* qkv; const float* Wd1; const float* bd1;
     const float* Wd2p; const float* bd2; const float* Wg1p; const float* bg1; const float* Wg2p; const float* bg2;
     float* res; float* attn;
-    int BN, N;
+    int BN, N, first_wave, stagger;
+    long long* dbg;   // dev only: per-phase s_memtime stamps (PTT_DEBUG_STAMPS), NULL in production
 };
 
 template <int D>
@@ -301,6 +383,9 @@ __global__ __launch_bounds__(256, 2) void pt_attn_pair_kernel(AttnParams p) {
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, half = lane >> 5;
     const int pt0 = blockIdx.x * 2;                          // flat point index of tile row 0
     const int npts = min(2, p.BN - pt0);
+#define PTT_STAMP(i) do { if (p.dbg && t == 0 && blockIdx.x < 4096) p.dbg[blockIdx.x * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+    stagger_second_slot(p.first_wave, p.stagger);
+    PTT_STAMP(0);
 
     if (t < 32) {
         int pt = pt0 + (t >> 4);
@@ -328,6 +413,7 @@ __global__ __launch_bounds__(256, 2) void pt_attn_pair_kernel(AttnParams p) {
     }
     __syncthreads();
 
+    PTT_STAMP(1);
     int cols[CT];
 #pragma unroll
     for (int u = 0; u < CT; ++u) cols[u] = (w + 4 * u) * 32 + (lane & 31);
@@ -335,13 +421,14 @@ __global__ __launch_bounds__(256, 2) void pt_attn_pair_kernel(AttnParams p) {
     // ---- delta = fc_delta[2](h) ----
     f32x16 delta[1][CT];
     zero_acc(delta);
-    gemm_core<1, CT>(Xs, LDK, NKB, reinterpret_cast<const f32x4*>(p.Wd2p), NT, w, CT, lane, delta);
+    gemm_core<1, CT, CT>(Xs, LDK, NKB, reinterpret_cast<const f32x4*>(p.Wd2p), NT, w, lane, delta);
 #pragma unroll
     for (int u = 0; u < CT; ++u) {
         const float bb = p.bd2[cols[u]];
 #pragma unroll
         for (int r = 0; r < 16; ++r) delta[0][u][r] += bb;
     }
+    PTT_STAMP(2);
     int nrow[16];  // flat neighbour row of each of this lane's 16 tile rows
 #pragma unroll
     for (int r = 0; r < 16; ++r) nrow[r] = nb[tile_row(r, half)];
@@ -364,11 +451,13 @@ __global__ __launch_bounds__(256, 2) void pt_attn_pair_kernel(AttnParams p) {
     }
     __syncthreads();
 
+    PTT_STAMP(3);
     // ---- g = relu(fc_gamma[0](t)) -> X ----
     {
         f32x16 acc[1][CT];
         zero_acc(acc);
-        gemm_core<1, CT>(Xs, LDK, NKB, reinterpret_cast<const f32x4*>(p.Wg1p), NT, w, CT, lane, acc);
+        gemm_core<1, CT, CT>(Xs, LDK, NKB, reinterpret_cast<const f32x4*>(p.Wg1p), NT, w, lane, acc);
+        PTT_STAMP(4);
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < CT; ++u) {
@@ -382,8 +471,10 @@ __global__ __launch_bounds__(256, 2) void pt_attn_pair_kernel(AttnParams p) {
     // ---- a = fc_gamma[2](g); softmax over the 16 neighbours; res = sum attn * (v + delta) ----
     f32x16 acc[1][CT];
     zero_acc(acc);
-    gemm_core<1, CT>(Xs, LDK, NKB, reinterpret_cast<const f32x4*>(p.Wg2p), NT, w, CT, lane, acc);
-    const float inv_scale_div = sqrtf((float)D);
+    PTT_STAMP(5);
+    gemm_core<1, CT, CT>(Xs, LDK, NKB, reinterpret_cast<const f32x4*>(p.Wg2p), NT, w, lane, acc);
+    PTT_STAMP(6);
+    const float inv_sqrt_d = 1.0f / sqrtf((float)D);
 #pragma unroll
     for (int u = 0; u < CT; ++u) {
         const float bb = p.bg2[cols[u]];
@@ -393,19 +484,20 @@ __global__ __launch_bounds__(256, 2) void pt_attn_pair_kernel(AttnParams p) {
             float m = -__builtin_inff();
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
-                s[r] = (acc[0][u][pp * 8 + r] + bb) / inv_scale_div;
+                s[r] = (acc[0][u][pp * 8 + r] + bb) * inv_sqrt_d;
                 m = fmaxf(m, s[r]);
             }
             m = fmaxf(m, xor32(m));
             float sum = 0.f;
 #pragma unroll
-            for (int r = 0; r < 8; ++r) { s[r] = expf(s[r] - m); sum += s[r]; }
+            for (int r = 0; r < 8; ++r) { s[r] = __expf(s[r] - m); sum += s[r]; }
             sum += xor32(sum);
+            const float rsum = __builtin_amdgcn_rcpf(sum);
             float o = 0.f;
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
                 const int rr = pp * 8 + r;
-                const float a = s[r] / sum;
+                const float a = s[r] * rsum;
                 const float vv = p.qkv[(size_t)nrow[rr] * 3 * D + 2 * D + cols[u]];
                 o += a * (vv + delta[0][u][rr]);
                 if (p.attn && pp < npts) {
@@ -417,6 +509,8 @@ __global__ __launch_bounds__(256, 2) void pt_attn_pair_kernel(AttnParams p) {
             if (half == 0 && pp < npts) p.res[(size_t)(pt0 + pp) * D + cols[u]] = o;
         }
     }
+    PTT_STAMP(7);
+#undef PTT_STAMP
 }
 
 static int set_lds_limit(const void* fn, int bytes) {
@@ -459,13 +553,24 @@ extern "C" int ptt_linear_f32(const float* X, int rows, int K, int ldx, const fl
     LinearParams p;
     p.X = X; p.Wp = Wpacked; p.scale = scale; p.shift = shift; p.residual = residual; p.out = out;
     p.rows = rows; p.K = K; p.ldx = ldx; p.Cout = Cout; p.relu = relu; p.ldr = ldr; p.ldo = ldo;
-    p.nkb = (K + 7) / 8; p.NT = (Cout + 31) / 32; p.ldk = p.nkb * 8 + 4;
-    const int lds = 32 * p.ldk * (int)sizeof(float);
-    if (lds > 80 * 1024) return fail(PTT_EUNSUPPORTED, "ptt_linear_f32: K=%d needs %d B of LDS per tile", K, lds);
-    int rc = set_lds_limit(reinterpret_cast<const void*>(linear_kernel), lds);
+    p.nkb = (K + 7) / 8; p.NT = (Cout + 31) / 32;
+    p.vec_ok = ((ldx & 3) == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0) ? 1 : 0;
+    const int colgroups = (p.NT + 7) / 8;
+    // 64-row tiles halve the weight traffic per FLOP; keep 32-row tiles when that would leave CUs idle
+    const bool big = (long long)((rows + 63) / 64) * colgroups >= 512;
+    hipStream_t s = as_stream(stream);
+    const bool vec = p.vec_ok && (K & 3) == 0;
+    const int lds = 2 * (big ? 64 : 32) * LIN_LDK * (int)sizeof(float);
+    const void* fn;
+    if (big) fn = vec ? reinterpret_cast<const void*>(linear_kernel<2, true>) : reinterpret_cast<const void*>(linear_kernel<2, false>);
+    else fn = vec ? reinterpret_cast<const void*>(linear_kernel<1, true>) : reinterpret_cast<const void*>(linear_kernel<1, false>);
+    int rc = set_lds_limit(fn, lds);
     if (rc) return rc;
-    const dim3 grid((rows + 31) / 32, (p.NT + 7) / 8);
-    hipLaunchKernelGGL(linear_kernel, grid, dim3(256), lds, as_stream(stream), p);
+    const dim3 grid(big ? (rows + 63) / 64 : (rows + 31) / 32, colgroups);
+    if (big && vec) hipLaunchKernelGGL((linear_kernel<2, true>), grid, dim3(256), lds, s, p);
+    else if (big) hipLaunchKernelGGL((linear_kernel<2, false>), grid, dim3(256), lds, s, p);
+    else if (vec) hipLaunchKernelGGL((linear_kernel<1, true>), grid, dim3(256), lds, s, p);
+    else hipLaunchKernelGGL((linear_kernel<1, false>), grid, dim3(256), lds, s, p);
     return check_launch("linear_kernel");
 }
 
@@ -492,8 +597,8 @@ extern "C" int ptt_sa_fused_fwd_f32(const ptt_sa_desc* d, ptt_stream_t stream) {
     for (int l = 0; l < d->n_layers; ++l) {
         const ptt_sa_layer& s = d->layers[l];
         if (s.Cin != cin) return fail(PTT_EINVAL, "ptt_sa_fused_fwd_f32: layer %d Cin=%d, expected %d", l, s.Cin, cin);
-        if (s.Cout <= 0 || (s.Cout % 32) != 0 || s.Cout > 512)
-            return fail(PTT_EUNSUPPORTED, "ptt_sa_fused_fwd_f32: layer %d Cout=%d must be a multiple of 32 <= 512", l,
+        if (s.Cout <= 0 || (s.Cout % 32) != 0 || s.Cout > 256)
+            return fail(PTT_EUNSUPPORTED, "ptt_sa_fused_fwd_f32: layer %d Cout=%d must be a multiple of 32 <= 256", l,
                         s.Cout);
         if (!s.Wpacked) return fail(PTT_EINVAL, "ptt_sa_fused_fwd_f32: layer %d has no weights", l);
         SaLayerDev& L = p.L[l];
@@ -532,10 +637,15 @@ extern "C" int ptt_pt_attn_pair_f32(const ptt_attn_desc* d, ptt_stream_t stream)
     p.xyz = d->xyz; p.knn = d->knn; p.qkv = d->qkv; p.Wd1 = d->Wd1; p.bd1 = d->bd1; p.Wd2p = d->Wd2p; p.bd2 = d->bd2;
     p.Wg1p = d->Wg1p; p.bg1 = d->bg1; p.Wg2p = d->Wg2p; p.bg2 = d->bg2; p.res = d->res; p.attn = d->attn;
     p.BN = d->B * d->N; p.N = d->N;
+    p.first_wave = 512; p.stagger = 11;
+    if (const char* e = getenv("PTT_PAIR_STAGGER")) p.stagger = atoi(e);
+    p.dbg = nullptr;
+    if (const char* e = getenv("PTT_DEBUG_STAMPS")) p.dbg = reinterpret_cast<long long*>(strtoull(e, nullptr, 16));
     if ((d->N & 1) != 0)
         return fail(PTT_EUNSUPPORTED, "ptt_pt_attn_pair_f32: N=%d must be even (a tile holds two points of one cloud)",
                     d->N);
-    const int lds = (32 * (512 + 4) + 32 + 96) * (int)sizeof(float);
+    int lds = (32 * (512 + 4) + 32 + 96) * (int)sizeof(float);
+    if (const char* e = getenv("PTT_PAIR_LDS_PAD")) lds += atoi(e);   // dev: force 1 workgroup per CU
     int rc = set_lds_limit(reinterpret_cast<const void*>(pt_attn_pair_kernel<512>), lds);
     if (rc) return rc;
     hipLaunchKernelGGL((pt_attn_pair_kernel<512>), dim3((p.BN + 1) / 2), dim3(256), lds, as_stream(stream), p);

@@ -66,6 +66,10 @@ class FrameHotPath(nn.Module):
             normalize_xyz=sa.get('NORMALIZE_XYZ', True), sample_method=sa.SAMPLE_METHOD)
         self.box_transformer = build_transformer(cfg.BOX_HEAD.TRANSFORMER_BLOCK)
         self.npoints_box = sa.NPOINTS
+        # FPS is a latency-bound chain on B workgroups; running the template branch on a second HIP
+        # stream lets its kernels fill the CUs the search branch's FPS leaves idle (and vice versa).
+        self.overlap_branches = True
+        self._side_stream = None
 
     @staticmethod
     def bridge(seeds, feats_bnc):
@@ -73,8 +77,26 @@ class FrameHotPath(nn.Module):
         score = torch.sigmoid(feats_bnc[:, :, :1])
         return seeds, torch.cat((score, feats_bnc), dim=2).transpose(1, 2).contiguous()
 
+    def _backbone(self, search_points, template_points):
+        bb = self.backbone_3d
+        if not (self.overlap_branches and search_points.is_cuda and not self.training):
+            return bb({'search_points': search_points, 'template_points': template_points})
+        sa = bb.model_cfg.SA_CONFIG
+        if self._side_stream is None or self._side_stream.device != search_points.device:
+            self._side_stream = torch.cuda.Stream(device=search_points.device)
+        main, side = torch.cuda.current_stream(search_points.device), self._side_stream
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            t_seeds, t_feats, t_inds = bb.branch_forward(template_points, sa.NPOINTS_TEMPLATE)
+        s_seeds, s_feats, s_inds = bb.branch_forward(search_points, sa.NPOINTS_SEARCH)
+        main.wait_stream(side)
+        for t in (t_seeds, t_feats, t_inds, template_points):
+            t.record_stream(main)
+        return {'search_seeds': s_seeds, 'search_feats': s_feats, 'search_inds': s_inds,
+                'template_seeds': t_seeds, 'template_feats': t_feats, 'template_inds': t_inds}
+
     def forward(self, search_points, template_points):
-        d = self.backbone_3d({'search_points': search_points, 'template_points': template_points})
+        d = self._backbone(search_points, template_points)
         seeds = d['search_seeds']
         fused = self.centroid_transformer(xyz=seeds, features=d['search_feats'].transpose(1, 2).contiguous())[0]
         votes, votes_feats = self.bridge(seeds, fused)
@@ -84,6 +106,36 @@ class FrameHotPath(nn.Module):
         d['pred_box_center'] = centres
         d['box_feats'] = box_feats
         return d
+
+
+class GraphedHotPath(object):
+    """hipGraph replay of one hot-path step for fixed shapes (tracking and benchmarking run the same
+    shapes every step): removes the per-kernel host launch cost and the gaps between ~60 dependent
+    launches. Inputs are copied into static buffers; outputs are the captured tensors."""
+
+    def __init__(self, model, search_points, template_points, warmup=3):
+        self.model = model
+        self.search = search_points.clone()
+        self.template = template_points.clone()
+        with torch.no_grad():
+            s = torch.cuda.Stream(device=search_points.device)
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                for _ in range(warmup):                  # weight packing / LDS attributes happen here, not in capture
+                    model(self.search, self.template)
+            torch.cuda.current_stream().wait_stream(s)
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.out = model(self.search, self.template)
+
+    def __call__(self, search_points=None, template_points=None):
+        if search_points is not None:
+            self.search.copy_(search_points, non_blocking=True)
+        if template_points is not None:
+            self.template.copy_(template_points, non_blocking=True)
+        self.graph.replay()
+        return self.out
 
 
 def randomize_(module, seed=0):

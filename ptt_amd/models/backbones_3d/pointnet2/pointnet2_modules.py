@@ -64,7 +64,7 @@ class PointnetSAModuleVotes(nn.Module):
             return False
         for unit in self.mlp_module:
             conv = getattr(unit, 'conv', None)
-            if conv is None or conv.kernel_size != (1, 1) or conv.weight.shape[0] % 32 != 0 or conv.weight.shape[0] > 512:
+            if conv is None or conv.kernel_size != (1, 1) or conv.weight.shape[0] % 32 != 0 or conv.weight.shape[0] > 256:
                 return False
             if list(unit._modules.keys())[0] != 'conv':     # pre-activation units are not folded
                 return False

@@ -1,0 +1,101 @@
+#!/usr/bin/env python
+"""Micro-benchmarks of the individual hot-path kernels at bench.py's shapes (B=48, KITTI-Car config).
+Used for A/B work and as the small target of `rocprofv3 --pmc` passes. Prints one line per case:
+name, mean ms over --iters launches (HIP events on the launch stream), algorithmic TFLOP/s."""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ptt_amd import ops, synth                                   # noqa: E402
+from tests.util import fold_layers, mlp_layers, transformer_params   # noqa: E402
+
+
+def timeit(fn, iters, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="")
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=48)
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    B = a.batch
+    want = lambda n: (not a.only) or any(n.startswith(o) for o in a.only.split(","))
+    rs = np.random.RandomState(0)
+
+    # ---- pair kernel ----
+    for N in (128, 64):
+        name = "pair_N%d" % N
+        if not want(name):
+            continue
+        P = {k: v.to(dev).contiguous() for k, v in transformer_params(1).items()}
+        s, _ = synth.frames(1, B, N, 64, K_s=N)
+        xyz = torch.from_numpy(s).to(dev)
+        knn = ops.knn(xyz, 16)
+        qkv = torch.randn(B, N, 1536, device=dev)
+        packs = [ops.pack_weight(P[k]) for k in ("fc_delta.2.weight", "fc_gamma.0.weight", "fc_gamma.2.weight")]
+        fn = lambda: ops.pt_attn_pair(xyz, knn, qkv, P["fc_delta.0.weight"], P["fc_delta.0.bias"], packs[0],
+                                      P["fc_delta.2.bias"], packs[1], P["fc_gamma.0.bias"], packs[2],
+                                      P["fc_gamma.2.bias"], 512, False)
+        ms = timeit(fn, a.iters)
+        fl = 2.0 * B * N * 16 * (3 * 512 + 3 * 512 * 512)
+        print("%-14s %8.4f ms  %7.2f TFLOP/s" % (name, ms, fl / ms / 1e9))
+
+    # ---- SA levels ----
+    sa_cases = [("sa0_s", 2048, 512, 0, [3, 64, 64, 128], 0.3, 32), ("sa1_s", 512, 256, 128, [131, 128, 128, 256], 0.5, 32),
+                ("sa2_s", 256, 128, 256, [259, 128, 128, 256], 0.7, 32), ("sa_box", 128, 64, 257, [260, 256, 256, 256], 0.3, 16)]
+    for name, N, M, C, spec, r, ns in sa_cases:
+        if not want(name):
+            continue
+        s, _ = synth.frames(2, B, N, 64, K_s=max(64, int(N * 0.3)))
+        xyz = torch.from_numpy(s).to(dev)
+        new_xyz = xyz[:, :M].contiguous()
+        idx = ops.ball_query(new_xyz, xyz, r, ns)
+        feats = torch.randn(B, N, C, device=dev).transpose(1, 2) if C else None
+        if name == "sa_box":
+            feats = feats.contiguous()                     # channel-major, as the box head hands it over
+        layers = fold_layers(mlp_layers(3, spec), dev, ops)
+        fn = lambda: ops.sa_fused_forward(xyz, new_xyz, idx, feats, layers, r, True, True)
+        ms = timeit(fn, a.iters)
+        fl = 2.0 * B * M * ns * sum(ci * co for ci, co in zip(spec[:-1], spec[1:]))
+        print("%-14s %8.4f ms  %7.2f TFLOP/s" % (name, ms, fl / ms / 1e9))
+
+    # ---- linear ----
+    for name, rows, K, Cout in (("lin_fc1", B * 128, 256, 512), ("lin_qkv", B * 128, 512, 1536), ("lin_fc2", B * 128, 512, 256),
+                                ("lin_cov", B * 128, 256, 256)):
+        if not want(name):
+            continue
+        x = torch.randn(rows, K, device=dev)
+        w = ops.pack_weight(torch.randn(Cout, K, device=dev) / K ** 0.5)
+        b = torch.randn(Cout, device=dev)
+        fn = lambda: ops.linear(x, w, Cout, None, b)
+        ms = timeit(fn, a.iters)
+        print("%-14s %8.4f ms  %7.2f TFLOP/s" % (name, ms, 2.0 * rows * K * Cout / ms / 1e9))
+
+    # ---- FPS ----
+    for name, N, m in (("fps_2048", 2048, 512), ("fps_1024", 1024, 256), ("fps_128", 128, 64)):
+        if not want(name):
+            continue
+        s, _ = synth.frames(4, B, N, 64, K_s=max(64, int(N * 0.3)))
+        xyz = torch.from_numpy(s).to(dev)
+        ms = timeit(lambda: ops.furthest_point_sampling(xyz, m), a.iters)
+        print("%-14s %8.4f ms  %7.3f us/iteration" % (name, ms, ms * 1e3 / (m - 1)))
+
+
+if __name__ == "__main__":
+    main()
