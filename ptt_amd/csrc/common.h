@@ -35,6 +35,22 @@ __device__ __forceinline__ float wave_max_f32(float v) {
     v = fmaxf(v, dpp_f32<0x143, 0xC>(v));  // row_bcast:31 into rows 2,3
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
+// Same reduction with the DPP modifier fused into v_max_f32 (one VALU op per step instead of
+// copy + v_mov_dpp + canonicalise + max). Inputs must not be NaN. "s_nop 1" covers the
+// VALU-write -> DPP-read hazard of the in-place chain.
+__device__ __forceinline__ float wave_max_f32_fused(float v) {
+    asm volatile(
+        "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
 __device__ __forceinline__ float wave_min_f32(float v) {
     v = fminf(v, dpp_f32<0xB1, 0xF>(v));
     v = fminf(v, dpp_f32<0x4E, 0xF>(v));

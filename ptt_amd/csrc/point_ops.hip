@@ -10,6 +10,7 @@
 #pragma clang fp contract(off)
 
 #include <limits.h>
+#include <stdlib.h>
 #include "common.h"
 
 namespace ptt {
@@ -22,10 +23,19 @@ __device__ __forceinline__ float sqdist3(float ax, float ay, float az, float bx,
 // ------------------------------------------------------------------------------------------
 // FPS. One workgroup per cloud, T threads, P points per thread held in registers together
 // with their running min-distance; nothing but the chosen index leaves the CU per iteration.
-// Iteration = register update -> DPP wave arg-max -> (T>64) one LDS slot per wave + one
-// barrier -> every thread folds the <=16 slots redundantly. Skipped points (|p|^2 <= 1e-3)
-// and padding carry min-dist -1 so they can never win and never change.
+// Thread t owns the CONTIGUOUS points [t*P, t*P+P): a lower lane (and a lower wave) always
+// holds lower indices, so the arg-max tie-break "lowest index" is simply the lowest lane whose
+// local best equals the wave maximum — one ballot + find-first-set instead of a second
+// cross-lane reduction.
+// Iteration = register update (branch-free selects) -> fused-DPP wave max -> ballot/ffs ->
+// (T > 64) one LDS slot per wave + ONE barrier (slots are double-buffered by iteration parity)
+// -> every thread folds the <= 16 slots redundantly. Skipped points (|p|^2 <= 1e-3) and
+// padding carry min-dist -1 so they can never win and never change.
 // ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float lane_bcast(float v, int src_lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src_lane));
+}
+
 template <int T, int P>
 __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, int N, int npoint,
                                                int32_t* __restrict__ idx_out) {
@@ -40,7 +50,7 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
     float px[P], py[P], pz[P], md[P];
 #pragma unroll
     for (int i = 0; i < P; ++i) {
-        const int k = t + i * T;
+        const int k = t * P + i;
         float x = 0.f, y = 0.f, z = 0.f, m = -1.0f;
         if (k < N) {
             x = pts[3 * k + 0];
@@ -52,64 +62,87 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
         px[i] = x; py[i] = y; pz[i] = z; md[i] = m;
     }
 
-    // slots[parity][wave] = {dist, idx(bits), x, y, z}
-    __shared__ float slots[2][W > 1 ? W : 1][8];
+    // slots[parity][wave] = {dist, idx(bits), x, y | z}
+    __shared__ __attribute__((aligned(16))) float slots[2][W > 1 ? W : 1][8];
+    // The chosen indices are collected in LDS and written out once at the end: a global store inside
+    // the loop puts its write-acknowledge latency (vmcnt counts stores; the barrier waits vmcnt(0))
+    // on the critical path of every iteration.
+    extern __shared__ int sel_lds[];
 
     float lx = pts[0], ly = pts[1], lz = pts[2];
-    if (t == 0) out[0] = 0;
+    if (t == 0 && npoint > 0) sel_lds[0] = 0;
 
     for (int j = 1; j < npoint; ++j) {
         float best = -1.0f, bx = 0.f, by = 0.f, bz = 0.f;
-        int besti = INT_MAX;
+        int besti = 0;
 #pragma unroll
         for (int i = 0; i < P; ++i) {
             const float d = sqdist3(px[i], py[i], pz[i], lx, ly, lz);
             const float m = fminf(md[i], d);
             md[i] = m;
-            if (m > best) { best = m; besti = t + i * T; bx = px[i]; by = py[i]; bz = pz[i]; }
+            const bool take = m > best;          // strict: the lowest index wins ties inside a thread
+            best = take ? m : best;
+            besti = take ? t * P + i : besti;
+            bx = take ? px[i] : bx;
+            by = take ? py[i] : by;
+            bz = take ? pz[i] : bz;
         }
-        const float wmax = wave_max_f32(best);
-        const int widx = wave_min_i32(best == wmax ? besti : INT_MAX);
-
+        const float wmax = wave_max_f32_fused(best);
+        const unsigned long long winners = __ballot(best == wmax);
+        const int src = __ffsll((long long)winners) - 1;          // lowest lane among the maxima
         if constexpr (W == 1) {
-            int sel = widx;
-            if (sel == INT_MAX) {
-                sel = 0; lx = pts[0]; ly = pts[1]; lz = pts[2];
+            const int widx = __builtin_amdgcn_readlane(besti, src);
+            if (wmax < 0.f) {                    // no selectable point left: index 0 (upstream's besti init)
+                lx = pts[0]; ly = pts[1]; lz = pts[2];
+                if (lane == 0) sel_lds[j] = 0;
             } else {
-                const int src = sel & 63;  // owner lane: k = lane + i*64
-                lx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bx), src));
-                ly = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, by), src));
-                lz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bz), src));
+                lx = lane_bcast(bx, src); ly = lane_bcast(by, src); lz = lane_bcast(bz, src);
+                if (lane == 0) sel_lds[j] = widx;
             }
-            if (lane == 0) out[j] = sel;
         } else {
             const int par = j & 1;
-            if (widx == INT_MAX) {
-                if (lane == 0) { slots[par][wv][0] = -1.0f; slots[par][wv][1] = __builtin_bit_cast(float, INT_MAX); }
-            } else if (besti == widx) {
-                float* s = slots[par][wv];
-                s[0] = wmax; s[1] = __builtin_bit_cast(float, widx); s[2] = bx; s[3] = by; s[4] = bz;
+            if (lane == src) {                   // the winning lane publishes its own candidate
+                float4* s4 = reinterpret_cast<float4*>(slots[par][wv]);
+                s4[0] = make_float4(best, __builtin_bit_cast(float, besti), bx, by);
+                slots[par][wv][4] = bz;
             }
             __syncthreads();
-            float gd = -1.0f, gx = 0.f, gy = 0.f, gz = 0.f;
-            int gi = INT_MAX;
+            float gd, gx, gy, gz;
+            int gi;
+            if constexpr (W <= 4) {
+                gd = -1.0f; gx = 0.f; gy = 0.f; gz = 0.f; gi = 0;
 #pragma unroll
-            for (int w = 0; w < W; ++w) {
-                const float* s = slots[par][w];
-                const float d = s[0];
-                const int i = __builtin_bit_cast(int, s[1]);
-                if (d > gd || (d == gd && i < gi)) { gd = d; gi = i; gx = s[2]; gy = s[3]; gz = s[4]; }
+                for (int w = 0; w < W; ++w) {      // ascending waves hold ascending indices: strict > keeps the lowest
+                    const float4 s4 = *reinterpret_cast<const float4*>(slots[par][w]);
+                    const float sz = slots[par][w][4];
+                    const bool take = s4.x > gd;
+                    gd = take ? s4.x : gd;
+                    gi = take ? __builtin_bit_cast(int, s4.y) : gi;
+                    gx = take ? s4.z : gx;
+                    gy = take ? s4.w : gy;
+                    gz = take ? sz : gz;
+                }
+            } else {                                // many waves: fold the slots with one more wave reduction
+                float4 s4 = make_float4(-1.0f, 0.f, 0.f, 0.f);
+                float sz = 0.f;
+                if (lane < W) { s4 = *reinterpret_cast<const float4*>(slots[par][lane]); sz = slots[par][lane][4]; }
+                gd = wave_max_f32_fused(s4.x);
+                const int sl = __ffsll((long long)__ballot(s4.x == gd)) - 1;
+                gi = __builtin_amdgcn_readlane(__builtin_bit_cast(int, s4.y), sl);
+                gx = lane_bcast(s4.z, sl); gy = lane_bcast(s4.w, sl); gz = lane_bcast(sz, sl);
             }
-            if (gi == INT_MAX) { gi = 0; gx = pts[0]; gy = pts[1]; gz = pts[2]; }
+            if (gd < 0.f) { gi = 0; gx = pts[0]; gy = pts[1]; gz = pts[2]; }
             lx = gx; ly = gy; lz = gz;
-            if (t == 0) out[j] = gi;
+            if (t == 0) sel_lds[j] = gi;
         }
     }
+    __syncthreads();
+    for (int j = t; j < npoint; j += T) out[j] = sel_lds[j];
 }
 
 template <int T, int P>
 static int launch_fps(const float* xyz, int B, int N, int npoint, int32_t* idx, hipStream_t s) {
-    hipLaunchKernelGGL((fps_kernel<T, P>), dim3(B), dim3(T), 0, s, xyz, N, npoint, idx);
+    hipLaunchKernelGGL((fps_kernel<T, P>), dim3(B), dim3(T), (size_t)npoint * sizeof(int), s, xyz, N, npoint, idx);
     return check_launch("fps_kernel");
 }
 
@@ -249,13 +282,22 @@ extern "C" int ptt_fps_f32(const float* xyz, int B, int N, int npoint, int32_t* 
     if (B < 0 || N <= 0 || npoint < 0) return fail(PTT_EINVAL, "ptt_fps_f32: B=%d N=%d npoint=%d", B, N, npoint);
     if (B == 0 || npoint == 0) return PTT_OK;
     if (!xyz || !idx_out) return fail(PTT_EINVAL, "ptt_fps_f32: null pointer");
+    if (npoint > 15360) return fail(PTT_EUNSUPPORTED, "ptt_fps_f32: npoint=%d exceeds the LDS index buffer (15360)", npoint);
     hipStream_t s = as_stream(stream);
     if (N <= 64) return launch_fps<64, 1>(xyz, B, N, npoint, idx_out, s);
     if (N <= 128) return launch_fps<64, 2>(xyz, B, N, npoint, idx_out, s);
     if (N <= 256) return launch_fps<64, 4>(xyz, B, N, npoint, idx_out, s);
     if (N <= 512) return launch_fps<256, 2>(xyz, B, N, npoint, idx_out, s);
     if (N <= 1024) return launch_fps<256, 4>(xyz, B, N, npoint, idx_out, s);
-    if (N <= 2048) return launch_fps<256, 8>(xyz, B, N, npoint, idx_out, s);
+    if (N <= 2048) {
+        if (const char* e = getenv("PTT_FPS_T")) {      // dev: workgroup-size sweep
+            const int T = atoi(e);
+            if (T == 256) return launch_fps<256, 8>(xyz, B, N, npoint, idx_out, s);
+            if (T == 1024) return launch_fps<1024, 2>(xyz, B, N, npoint, idx_out, s);
+            if (T == 128) return launch_fps<128, 16>(xyz, B, N, npoint, idx_out, s);
+        }
+        return launch_fps<512, 4>(xyz, B, N, npoint, idx_out, s);   // measured fastest of 128/256/512/1024 at N = 2048
+    }
     if (N <= 4096) return launch_fps<512, 8>(xyz, B, N, npoint, idx_out, s);
     if (N <= 8192) return launch_fps<1024, 8>(xyz, B, N, npoint, idx_out, s);
     if (N <= 16384) return launch_fps<1024, 16>(xyz, B, N, npoint, idx_out, s);

@@ -44,6 +44,7 @@ class PointnetSAModuleVotes(nn.Module):
         self.mlp_module = pt_utils.SharedMLP(mlp_spec, bn=bn)
         self.sample_method = sample_method
         self._fused_cache = None    # (key, [(wpacked, scale, shift, cin, cout, relu), ...])
+        self._arange_cache = None
 
     # ------------------------------------------------------------------ sampling (reference :63-77)
     def _sample(self, xyz, features, npoint):
@@ -102,24 +103,32 @@ class PointnetSAModuleVotes(nn.Module):
 
     # ------------------------------------------------------------------ forward (reference :57-90)
     def forward(self, xyz: torch.Tensor, features: torch.Tensor, npoint: int, inds: torch.Tensor = None):
-        prefix = False      # True when the centres are simply the first npoint points
-        if inds is None:
+        fused = self._fusable(xyz, features)
+        prefix = inds is None and self.sample_method in ('rs', 'sequence')   # centres = the first npoint points
+        if fused and prefix:
+            # 'sequence' indices are constants of (B, npoint): build them once, not four tiny kernels per call
+            key = (xyz.size(0), npoint, str(xyz.device))
+            if self._arange_cache is None or self._arange_cache[0] != key:
+                self._arange_cache = (key, torch.arange(npoint, dtype=torch.int64, device=xyz.device)
+                                      .repeat(xyz.size(0), 1))
+            inds64 = self._arange_cache[1]
+        elif inds is None:
             inds = self._sample(xyz, features, npoint)
-            prefix = self.sample_method in ('rs', 'sequence')
         else:
             assert inds.shape[1] == npoint
             inds = inds.to(torch.int32)
 
-        if self._fusable(xyz, features):
+        if fused:
             xyz = xyz.contiguous()
             if prefix:
                 new_xyz = xyz[:, :npoint].contiguous()
             else:
-                new_xyz = torch.gather(xyz, 1, inds.long().unsqueeze(-1).expand(-1, -1, 3))
+                inds64 = inds.to(torch.int64)
+                new_xyz = torch.gather(xyz, 1, inds64.unsqueeze(-1).expand(-1, -1, 3))
             idx = ops.ball_query(new_xyz, xyz, self.radius, self.nsample)
             new_features = ops.sa_fused_forward(xyz, new_xyz, idx, features, self._fused_params(xyz.device),
                                                 self.radius, self.use_xyz, self.normalize_xyz, point_major_out=True)
-            return new_xyz, new_features, inds.to(torch.int64)
+            return new_xyz, new_features, inds64
 
         xyz_flipped = xyz.transpose(1, 2).contiguous()
         new_xyz = pointnet2_utils.gather_operation(xyz_flipped, inds).transpose(1, 2).contiguous()

@@ -95,6 +95,12 @@ def main():
         xyz = torch.from_numpy(s).to(dev)
         ms = timeit(lambda: ops.furthest_point_sampling(xyz, m), a.iters)
         print("%-14s %8.4f ms  %7.3f us/iteration" % (name, ms, ms * 1e3 / (m - 1)))
+        if N == 2048:
+            for T in (128, 512, 1024):
+                os.environ["PTT_FPS_T"] = str(T)
+                ms = timeit(lambda: ops.furthest_point_sampling(xyz, m), a.iters)
+                print("%-14s %8.4f ms  %7.3f us/iteration" % (name + "_T%d" % T, ms, ms * 1e3 / (m - 1)))
+            os.environ.pop("PTT_FPS_T")
 
 
 if __name__ == "__main__":
