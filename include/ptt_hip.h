@@ -106,6 +106,12 @@ int ptt_knn_f32(const float* xyz, int B, int N, int k, int32_t* idx_out,
 size_t ptt_packed_weight_elems(int Cout, int K);
 int ptt_pack_weight_f32(const float* W, int Cout, int K, float* packed,
                         ptt_stream_t stream);
+/* Same, with the input channels rotated: packed position k holds original channel (k+rot) mod K.
+ * The fused SA kernel keeps each grouped row as [features | xyz] (16-byte aligned feature rows),
+ * while the reference concatenates [xyz | features] (pointnet2_utils.py:359-361): pack the FIRST
+ * SharedMLP layer of ptt_sa_fused_fwd_f32 with rot = 3 when use_xyz, rot = 0 otherwise. */
+int ptt_pack_weight_rot_f32(const float* W, int Cout, int K, int rot, float* packed,
+                            ptt_stream_t stream);
 
 /* ---------------------------------------------------------------------------------
  * Row-wise linear layer on fp32 MFMA:  out = act(X @ W^T * scale + shift) (+ residual)
@@ -130,7 +136,7 @@ int ptt_linear_f32(const float* X, int rows, int K, int ldx, const float* Wpacke
 #define PTT_SA_MAX_LAYERS 4
 
 typedef struct ptt_sa_layer {
-    const float* Wpacked; /* ptt_pack_weight_f32 of the (Cout,Cin) conv weight        */
+    const float* Wpacked; /* packed (Cout,Cin) conv weight; layer 0: rot = 3 if use_xyz      */
     const float* scale;   /* (Cout) gamma/sqrt(var+eps), or NULL = 1                   */
     const float* shift;   /* (Cout) beta - mean*scale (or conv bias), or NULL = 0      */
     int Cin;              /* input channels of this layer (first layer: 3*use_xyz + C) */

@@ -16,7 +16,7 @@ EXPORTS = [
     "ptt_version", "ptt_error_name", "ptt_last_error_string",
     "ptt_fps_f32", "ptt_gather_f32", "ptt_gather_grad_f32", "ptt_ball_query_f32",
     "ptt_group_f32", "ptt_group_grad_f32", "ptt_knn_f32",
-    "ptt_packed_weight_elems", "ptt_pack_weight_f32", "ptt_linear_f32",
+    "ptt_packed_weight_elems", "ptt_pack_weight_f32", "ptt_pack_weight_rot_f32", "ptt_linear_f32",
     "ptt_sa_fused_fwd_f32", "ptt_pt_attn_pair_f32",
 ]
 
@@ -61,6 +61,7 @@ def _declare(lib):
         "ptt_group_grad_f32": [vp, vp, i, i, i, i, i, vp, vp],
         "ptt_knn_f32": [vp, i, i, i, vp, vp],
         "ptt_pack_weight_f32": [vp, i, i, vp, vp],
+        "ptt_pack_weight_rot_f32": [vp, i, i, i, vp, vp],
         "ptt_linear_f32": [vp, i, i, i, vp, i, vp, vp, i, vp, i, vp, i, vp],
         "ptt_sa_fused_fwd_f32": [POINTER(SaDesc), vp],
         "ptt_pt_attn_pair_f32": [POINTER(AttnDesc), vp],

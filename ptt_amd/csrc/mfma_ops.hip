@@ -37,18 +37,18 @@ __device__ __forceinline__ float xor32(float v) { return __shfl_xor(v, 32, 64); 
 // != 0) in the FIRST wave of workgroups therefore starts `quanta` x ~8k cycles late; later workgroups
 // inherit the offset from the slot they replace. Placement only changes speed, never results.
 __device__ __forceinline__ void stagger_second_slot(int first_wave_blocks, int quanta) {
-    if ((int)blockIdx.x < first_wave_blocks) {
-        const unsigned lds_base = __builtin_amdgcn_s_getreg((7 << 11) | (0 << 6) | 6) & 0xffu;  // HW_REG_LDS_ALLOC[7:0]
-        if (lds_base != 0) {
-            for (int i = 0; i < quanta; ++i) __builtin_amdgcn_s_sleep(127);
-        }
+    if ((int)blockIdx.x < first_wave_blocks && quanta > 0) {
+        const unsigned alloc = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 6);   // HW_REG_LDS_ALLOC
+        const unsigned lds_base = alloc & 0xffu, lds_size = (alloc >> 12) & 0x1ffu;
+        const int slot = lds_size ? (int)(lds_base / lds_size) : (lds_base != 0);          // 0,1,2,.. on this CU
+        for (int i = 0; i < slot * quanta; ++i) __builtin_amdgcn_s_sleep(127);
     }
 }
 
 // ------------------------------------------------------------------------------------------
 // weight packing
 // ------------------------------------------------------------------------------------------
-__global__ void pack_weight_kernel(const float* __restrict__ W, int Cout, int K, int NT, size_t total,
+__global__ void pack_weight_kernel(const float* __restrict__ W, int Cout, int K, int NT, int rot, size_t total,
                                    float* __restrict__ P) {
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
         const int j = (int)(e & 3);
@@ -58,7 +58,8 @@ __global__ void pack_weight_kernel(const float* __restrict__ W, int Cout, int K,
         const int kb = (int)(tile / NT);
         const int col = ct * 32 + (lane & 31);
         const int k = kb * 8 + 4 * (lane >> 5) + j;
-        P[e] = (col < Cout && k < K) ? W[(size_t)col * K + k] : 0.0f;
+        // packed position k holds original input channel (k + rot) mod K
+        P[e] = (col < Cout && k < K) ? W[(size_t)col * K + (k + rot) % K] : 0.0f;
     }
 }
 
@@ -83,7 +84,7 @@ __device__ __forceinline__ void gemm_mfma_block(const f32x4 (&a)[RT], const f32x
 // MFMA group, which drains the prefetch (measured 2-4x slower K-loops).
 // (A hand-pinned two-register-set pipeline with sched_barrier(0) was measured 4-6 % SLOWER than this
 //  form: the loop is bound by the L2->CU fetch path, not by load placement — see DESIGN.md.)
-template <int RT, int CT, int ACT>
+template <int RT, int CT, int ACT, int CTS = 4>   // CTS: distance (in column tiles) between this wave's tiles
 __device__ __forceinline__ void gemm_core(const float* Xs, int ldk, int nkb, const f32x4* __restrict__ Wp, int NT,
                                           int ct0, int lane, f32x16 (&acc)[RT][ACT]) {
     static_assert(CT <= ACT, "accumulator array too narrow");
@@ -94,12 +95,12 @@ __device__ __forceinline__ void gemm_core(const float* Xs, int ldk, int nkb, con
 
     f32x4 bcur[CT], bnxt[CT];
 #pragma unroll
-    for (int u = 0; u < CT; ++u) { bcur[u] = bp[(size_t)u * 4 * 64]; bnxt[u] = bcur[u]; }
+    for (int u = 0; u < CT; ++u) { bcur[u] = bp[(size_t)u * CTS * 64]; bnxt[u] = bcur[u]; }
     for (int kb = 0; kb < nkb; ++kb) {
         if (kb + 1 < nkb) {
             const f32x4* bn = bp + (size_t)(kb + 1) * bstep;
 #pragma unroll
-            for (int u = 0; u < CT; ++u) bnxt[u] = bn[(size_t)u * 4 * 64];
+            for (int u = 0; u < CT; ++u) bnxt[u] = bn[(size_t)u * CTS * 64];
         }
         f32x4 a[RT];
 #pragma unroll
@@ -241,10 +242,76 @@ struct SaLayerDev { const float* Wp; const float* scale; const float* shift; int
 struct SaParams {
     const float* xyz; const float* new_xyz; const int32_t* idx; const float* feat; float* out;
     long long fsb, fsc, fsn, osb, osc, osm;
-    int B, N, M, C, use_xyz, normalize, n_layers, ldk, K0;
+    int B, N, M, C, use_xyz, normalize, n_layers, ldk, K0, first_wave, stagger, vec_gather;
     float radius;
+    long long* dbg;   // dev only (PTT_DEBUG_STAMPS)
     SaLayerDev L[PTT_SA_MAX_LAYERS];
 };
+
+// ------------------------------------------------------------------------------------------
+// Grouping for the SA kernels: the calling wave fills ROWS consecutive rows of an LDS tile with
+// [ neighbour features (C) | (xyz_nbr - centre)(/radius) (3) | zeros up to Kpad0 ]
+// (features FIRST so that point-major rows land 16-byte aligned; layer 0's weight is packed with
+// the matching rotation, see ptt_pack_weight_rot_f32). Memory-level parallelism is the point:
+// all index loads, then all feature loads of the wave's rows are in flight together — a
+// row-at-a-time loop serialises ~16 L2 round trips and was HALF of the kernel's time.
+// ------------------------------------------------------------------------------------------
+template <int NS, int ROWS>
+__device__ __forceinline__ void sa_gather_rows(const SaParams& p, float* Xt, int row0, int centre0, int lane) {
+    static_assert(ROWS == 16 || ROWS == 32, "rows per wave");
+    const int total_centres = p.B * p.M;
+    const int Kpad0 = p.L[0].nkb * 8;
+    int b_l = 0, n_l = 0;
+    if (lane < ROWS) {
+        const int r = row0 + lane;
+        int c = centre0 + r / NS;
+        if (c >= total_centres) c = total_centres - 1;
+        b_l = c / p.M;
+        n_l = p.idx[(size_t)c * NS + (r % NS)];
+        if (p.use_xyz) {
+            const size_t flat = (size_t)b_l * p.N + n_l;
+            float dx = p.xyz[flat * 3 + 0] - p.new_xyz[(size_t)c * 3 + 0];
+            float dy = p.xyz[flat * 3 + 1] - p.new_xyz[(size_t)c * 3 + 1];
+            float dz = p.xyz[flat * 3 + 2] - p.new_xyz[(size_t)c * 3 + 2];
+            if (p.normalize) { dx /= p.radius; dy /= p.radius; dz /= p.radius; }
+            float* x = Xt + r * p.ldk + p.C;
+            x[0] = dx; x[1] = dy; x[2] = dz;
+        }
+        for (int c2 = p.K0; c2 < Kpad0; ++c2) Xt[r * p.ldk + c2] = 0.f;
+    }
+    if (p.C == 0) return;
+    if (p.vec_gather) {                                  // point-major rows: one float4 per lane per row
+        const int nq = p.C >> 2;
+#pragma unroll
+        for (int base = 0; base < ROWS; base += 16) {
+            f32x4 v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int bb = __builtin_amdgcn_readlane(b_l, base + i), nn = __builtin_amdgcn_readlane(n_l, base + i);
+                const float* src = p.feat + (long long)bb * p.fsb + (long long)nn * p.fsn;
+                if (lane < nq) v[i] = *reinterpret_cast<const f32x4*>(src + lane * 4);
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if (lane < nq) *reinterpret_cast<f32x4*>(Xt + (row0 + base + i) * p.ldk + lane * 4) = v[i];
+        }
+    } else {                                             // any strides: 64/ROWS lane groups stride over the channels
+        constexpr int G = 64 / ROWS;
+        const int r = lane % ROWS, g = lane / ROWS;
+        const int bb = __shfl(b_l, r, 64), nn = __shfl(n_l, r, 64);
+        const float* src = p.feat + (long long)bb * p.fsb + (long long)nn * p.fsn;
+        float* dst = Xt + (row0 + r) * p.ldk;
+        int c = g;
+        for (; c + 15 * G < p.C; c += 16 * G) {
+            float v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = src[(long long)(c + i * G) * p.fsc];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) dst[c + i * G] = v[i];
+        }
+        for (; c < p.C; c += G) dst[c] = src[(long long)c * p.fsc];
+    }
+}
 
 template <int NS, int CT>
 __device__ __forceinline__ void sa_layer(const SaParams& p, const SaLayerDev& L, bool last, float* Xs, int lane, int w,
@@ -315,49 +382,111 @@ template <int NS>
 __global__ __launch_bounds__(256, 2) void sa_fused_kernel(SaParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Xs = smem;                                      // [64][ldk]
-    int* nbr = reinterpret_cast<int*>(smem + 64 * p.ldk);  // [64] flat row index b*N + n of each grouped row
     constexpr int CPW = 64 / NS;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int total_centres = p.B * p.M;
     const int centre0 = blockIdx.x * CPW;
     const int ncentres = min(CPW, total_centres - centre0);
+    stagger_second_slot(p.first_wave, p.stagger);
+#define PTT_STAMP(i) do { if (p.dbg && t == 0 && blockIdx.x < 4096) p.dbg[blockIdx.x * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+    PTT_STAMP(0);
 
-    // ---- group: relative (normalised) coordinates + neighbour features -> X ----
-    const int xoff = p.use_xyz ? 3 : 0;
-    if (t < 64) {
-        const int r = t;
-        int c = centre0 + r / NS;
-        if (c >= total_centres) c = total_centres - 1;
-        const int b = c / p.M;
-        const int n = p.idx[(size_t)c * NS + (r % NS)];
-        const int flat = b * p.N + n;
-        nbr[r] = flat;
-        if (p.use_xyz) {
-            float dx = p.xyz[(size_t)flat * 3 + 0] - p.new_xyz[(size_t)c * 3 + 0];
-            float dy = p.xyz[(size_t)flat * 3 + 1] - p.new_xyz[(size_t)c * 3 + 1];
-            float dz = p.xyz[(size_t)flat * 3 + 2] - p.new_xyz[(size_t)c * 3 + 2];
-            if (p.normalize) { dx /= p.radius; dy /= p.radius; dz /= p.radius; }
-            Xs[r * p.ldk + 0] = dx; Xs[r * p.ldk + 1] = dy; Xs[r * p.ldk + 2] = dz;
-        }
-    }
-    __syncthreads();
-    const int Kpad0 = p.L[0].nkb * 8;
-    for (int r = w; r < 64; r += 4) {
-        const int flat = nbr[r];
-        const int b = flat / p.N, n = flat - b * p.N;
-        const float* f = p.feat + b * p.fsb + n * p.fsn;
-        float* xr = Xs + r * p.ldk + xoff;
-        for (int c = lane; c < p.C; c += 64) xr[c] = f[c * p.fsc];
-        for (int c = p.K0 + lane; c < Kpad0; c += 64) Xs[r * p.ldk + c] = 0.f;
-    }
+    // ---- group: neighbour features + relative (normalised) coordinates -> X; wave w fills rows 16w..16w+15 ----
+    sa_gather_rows<NS, 16>(p, Xs, w * 16, centre0, lane);
     __syncthreads();
 
+    PTT_STAMP(1);
     for (int l = 0; l < p.n_layers; ++l) {
         const SaLayerDev& L = p.L[l];
         const bool last = (l == p.n_layers - 1);
         const int ctw = (L.NT + 3) >> 2;
         if (ctw <= 1) sa_layer<NS, 1>(p, L, last, Xs, lane, w, centre0, ncentres);
         else sa_layer<NS, 2>(p, L, last, Xs, lane, w, centre0, ncentres);
+        PTT_STAMP(2 + l);
+    }
+#undef PTT_STAMP
+}
+
+// ------------------------------------------------------------------------------------------
+// Wave-private variant of the fused set-abstraction level, for levels whose whole weight set is
+// small enough to live in L1/L2 (SA0: 3->64->64->128 = 50 KB): every wave owns 32 grouped rows
+// (32/NS centres) and ALL output columns, its activation tile is private in LDS, so the layer
+// chain runs without a single workgroup barrier and all four waves do the same amount of work
+// (the column-split kernel leaves half the waves idle when a layer has only two column tiles).
+// ------------------------------------------------------------------------------------------
+template <int NS, int CT>
+__device__ __forceinline__ void sa_wave_layer(const SaParams& p, const SaLayerDev& L, bool last, float* Xw, int lane,
+                                              int centre0, int ncentres) {
+    f32x16 acc[1][CT];
+    zero_acc(acc);
+    gemm_core<1, CT, CT, 1>(Xw, p.ldk, L.nkb, reinterpret_cast<const f32x4*>(L.Wp), L.NT, 0, lane, acc);
+    __builtin_amdgcn_wave_barrier();
+    const int half = lane >> 5;
+#pragma unroll
+    for (int u = 0; u < CT; ++u) {
+        const int col = u * 32 + (lane & 31);
+        const float sc = L.scale ? L.scale[col] : 1.f;
+        const float sh = L.shift ? L.shift[col] : 0.f;
+        float y[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = acc[0][u][r] * sc + sh;
+            if (L.relu) v = fmaxf(v, 0.f);
+            y[r] = v;
+        }
+        if (!last) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Xw[tile_row(r, half) * p.ldk + col] = y[r];
+        } else if (NS == 32) {
+            float m = y[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) m = fmaxf(m, y[r]);
+            m = fmaxf(m, xor32(m));
+            if (half == 0 && ncentres > 0) {
+                const int b = centre0 / p.M, mm = centre0 - b * p.M;
+                p.out[b * p.osb + col * p.osc + mm * p.osm] = m;
+            }
+        } else {
+            float m0 = y[0], m1 = y[8];
+#pragma unroll
+            for (int r = 1; r < 8; ++r) { m0 = fmaxf(m0, y[r]); m1 = fmaxf(m1, y[8 + r]); }
+            m0 = fmaxf(m0, xor32(m0));
+            m1 = fmaxf(m1, xor32(m1));
+            if (half == 0) {
+                if (ncentres > 0) {
+                    const int b = centre0 / p.M, mm = centre0 - b * p.M;
+                    p.out[b * p.osb + col * p.osc + mm * p.osm] = m0;
+                }
+                if (ncentres > 1) {
+                    const int c = centre0 + 1; const int b = c / p.M, mm = c - b * p.M;
+                    p.out[b * p.osb + col * p.osc + mm * p.osm] = m1;
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int NS>
+__global__ __launch_bounds__(256, 3) void sa_wave_kernel(SaParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int CPW = 32 / NS;                             // centres per wave
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    float* Xw = smem + w * 32 * p.ldk;                       // this wave's private [32][ldk] tile
+    const int total_centres = p.B * p.M;
+    const int centre0 = (blockIdx.x * 4 + w) * CPW;
+    if (centre0 >= total_centres) return;
+    const int ncentres = min(CPW, total_centres - centre0);
+
+    sa_gather_rows<NS, 32>(p, Xw, 0, centre0, lane);
+    __builtin_amdgcn_wave_barrier();
+
+    for (int l = 0; l < p.n_layers; ++l) {
+        const SaLayerDev& L = p.L[l];
+        const bool last = (l == p.n_layers - 1);
+        if (L.NT == 1) sa_wave_layer<NS, 1>(p, L, last, Xw, lane, centre0, ncentres);
+        else if (L.NT == 2) sa_wave_layer<NS, 2>(p, L, last, Xw, lane, centre0, ncentres);
+        else sa_wave_layer<NS, 4>(p, L, last, Xw, lane, centre0, ncentres);
     }
 }
 
@@ -530,16 +659,21 @@ extern "C" size_t ptt_packed_weight_elems(int Cout, int K) {
     return NT * NKB * 256;
 }
 
-extern "C" int ptt_pack_weight_f32(const float* W, int Cout, int K, float* packed, ptt_stream_t stream) {
-    if (Cout <= 0 || K <= 0) return fail(PTT_EINVAL, "ptt_pack_weight_f32: Cout=%d K=%d", Cout, K);
-    if (!W || !packed) return fail(PTT_EINVAL, "ptt_pack_weight_f32: null pointer");
+extern "C" int ptt_pack_weight_rot_f32(const float* W, int Cout, int K, int rot, float* packed, ptt_stream_t stream) {
+    if (Cout <= 0 || K <= 0 || rot < 0 || rot >= K)
+        return fail(PTT_EINVAL, "ptt_pack_weight_rot_f32: Cout=%d K=%d rot=%d", Cout, K, rot);
+    if (!W || !packed) return fail(PTT_EINVAL, "ptt_pack_weight_rot_f32: null pointer");
     const size_t total = ptt_packed_weight_elems(Cout, K);
     const int NT = (Cout + 31) / 32;
     size_t g = (total + 255) / 256;
     if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)g), dim3(256), 0, as_stream(stream), W, Cout, K, NT, total,
+    hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)g), dim3(256), 0, as_stream(stream), W, Cout, K, NT, rot, total,
                        packed);
     return check_launch("pack_weight_kernel");
+}
+
+extern "C" int ptt_pack_weight_f32(const float* W, int Cout, int K, float* packed, ptt_stream_t stream) {
+    return ptt_pack_weight_rot_f32(W, Cout, K, 0, packed, stream);
 }
 
 extern "C" int ptt_linear_f32(const float* X, int rows, int K, int ldx, const float* Wpacked, int Cout,
@@ -609,11 +743,39 @@ extern "C" int ptt_sa_fused_fwd_f32(const ptt_sa_desc* d, ptt_stream_t stream) {
         cin = s.Cout;
     }
     p.ldk = maxk + 4;
-    const int lds = (64 * p.ldk + 64) * (int)sizeof(float);
-    if (lds > 160 * 1024) return fail(PTT_EUNSUPPORTED, "ptt_sa_fused_fwd_f32: %d B of LDS per workgroup", lds);
+    p.vec_gather = (d->C > 0 && d->feat_sc == 1 && (d->C & 3) == 0 && d->C <= 256 && (d->feat_sn & 3) == 0 &&
+                    (d->feat_sb & 3) == 0 && (reinterpret_cast<uintptr_t>(d->feat) & 15) == 0) ? 1 : 0;
+    p.first_wave = 1024; p.stagger = 2;
+    if (const char* e = getenv("PTT_SA_STAGGER")) p.stagger = atoi(e);
+    p.dbg = nullptr;
+    if (const char* e = getenv("PTT_DEBUG_STAMPS")) p.dbg = reinterpret_cast<long long*>(strtoull(e, nullptr, 16));
     const int total_centres = d->B * d->M;
     hipStream_t s = as_stream(stream);
     int rc;
+    // small weight set (fits L1/L2 comfortably) and <= 4 column tiles everywhere: barrier-free wave-private kernel
+    size_t wbytes = 0;
+    bool wave_ok = true;
+    for (int l = 0; l < d->n_layers; ++l) {
+        wbytes += (size_t)d->layers[l].Cin * d->layers[l].Cout * sizeof(float);
+        const int nt = d->layers[l].Cout / 32;
+        if (!(nt == 1 || nt == 2 || nt == 4)) wave_ok = false;
+    }
+    if (const char* e = getenv("PTT_SA_WAVE")) wave_ok = wave_ok && atoi(e) != 0;   // dev: A/B switch
+    if (wave_ok && wbytes <= 64 * 1024) {
+        const int lds = 4 * 32 * p.ldk * (int)sizeof(float);
+        const int cpw = 32 / d->nsample, per_wg = 4 * cpw;
+        const dim3 grid((total_centres + per_wg - 1) / per_wg);
+        if (d->nsample == 32) {
+            if ((rc = set_lds_limit(reinterpret_cast<const void*>(sa_wave_kernel<32>), lds))) return rc;
+            hipLaunchKernelGGL((sa_wave_kernel<32>), grid, dim3(256), lds, s, p);
+        } else {
+            if ((rc = set_lds_limit(reinterpret_cast<const void*>(sa_wave_kernel<16>), lds))) return rc;
+            hipLaunchKernelGGL((sa_wave_kernel<16>), grid, dim3(256), lds, s, p);
+        }
+        return check_launch("sa_wave_kernel");
+    }
+    const int lds = 64 * p.ldk * (int)sizeof(float);
+    if (lds > 160 * 1024) return fail(PTT_EUNSUPPORTED, "ptt_sa_fused_fwd_f32: %d B of LDS per workgroup", lds);
     if (d->nsample == 32) {
         if ((rc = set_lds_limit(reinterpret_cast<const void*>(sa_fused_kernel<32>), lds))) return rc;
         hipLaunchKernelGGL((sa_fused_kernel<32>), dim3((total_centres + 1) / 2), dim3(256), lds, s, p);

@@ -85,9 +85,10 @@ class PointnetSAModuleVotes(nn.Module):
             return self._fused_cache[1]
         layers = []
         with torch.no_grad():
-            for unit in self.mlp_module:
+            for li, unit in enumerate(self.mlp_module):
                 w = unit.conv.weight
                 cout, cin = w.shape[0], w.shape[1]
+                rot = 3 if (li == 0 and self.use_xyz and cin > 3) else 0     # kernel row layout is [features | xyz]
                 scale = shift = None
                 if hasattr(unit, 'normlayer'):
                     bn = unit.normlayer.bn
@@ -97,7 +98,7 @@ class PointnetSAModuleVotes(nn.Module):
                         shift = (shift + unit.conv.bias * scale).contiguous()
                 elif unit.conv.bias is not None:
                     shift = unit.conv.bias.detach().float().contiguous()
-                layers.append((ops.pack_weight(w), scale, shift, cin, cout, hasattr(unit, 'activation')))
+                layers.append((ops.pack_weight(w, rot), scale, shift, cin, cout, hasattr(unit, 'activation')))
         self._fused_cache = (key, layers)
         return layers
 

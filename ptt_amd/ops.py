@@ -171,8 +171,10 @@ def knn(xyz, k):
     return out
 
 
-def pack_weight(weight):
-    """(Cout,K[,1[,1]]) f32 -> packed MFMA B-fragment buffer (1-D f32 tensor)."""
+def pack_weight(weight, rot=0):
+    """(Cout,K[,1[,1]]) f32 -> packed MFMA B-fragment buffer (1-D f32 tensor).
+    rot: rotate the input channels left (the first SharedMLP layer of sa_fused_forward needs rot=3 when
+    use_xyz: the kernel keeps grouped rows as [features | xyz])."""
     w = weight.detach()
     w = w.reshape(w.shape[0], -1).contiguous().float()
     _chk(w, "weight", torch.float32, 2)
@@ -180,7 +182,8 @@ def pack_weight(weight):
     n = _lib.lib().ptt_packed_weight_elems(Cout, K)
     out = torch.empty((n,), dtype=torch.float32, device=w.device)
     with torch.cuda.device(w.device):
-        _lib.check(_lib.lib().ptt_pack_weight_f32(_ptr(w), Cout, K, _ptr(out), _stream()), "ptt_pack_weight_f32")
+        _lib.check(_lib.lib().ptt_pack_weight_rot_f32(_ptr(w), Cout, K, int(rot), _ptr(out), _stream()),
+                   "ptt_pack_weight_rot_f32")
     return out
 
 
@@ -217,7 +220,7 @@ def sa_fused_forward(xyz, new_xyz, idx, features, layers, radius, use_xyz=True, 
 
     xyz (B,N,3), new_xyz (B,M,3), idx (B,M,ns) i32, features (B,C,N) in ANY strides (a transposed
     view of point-major storage gathers coalesced) or None.
-    layers: list of (wpacked, scale|None, shift|None, cin, cout, relu).
+    layers: list of (wpacked, scale|None, shift|None, cin, cout, relu); layers[0] packed with rot=3 if use_xyz.
     Returns (B,Cout,M); with point_major_out it is a transposed view of (B,M,Cout) storage."""
     _chk(xyz, "xyz", torch.float32, 3)
     _chk(new_xyz, "new_xyz", torch.float32, 3)

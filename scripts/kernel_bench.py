@@ -74,6 +74,12 @@ def main():
         ms = timeit(fn, a.iters)
         fl = 2.0 * B * M * ns * sum(ci * co for ci, co in zip(spec[:-1], spec[1:]))
         print("%-14s %8.4f ms  %7.2f TFLOP/s" % (name, ms, fl / ms / 1e9))
+        if os.environ.get("SWEEP_SA_STAGGER"):
+            for sg in (1, 2, 3, 4, 6):
+                os.environ["PTT_SA_STAGGER"] = str(sg)
+                ms = timeit(fn, a.iters)
+                print("%-14s %8.4f ms  %7.2f TFLOP/s" % (name + "_sg%d" % sg, ms, fl / ms / 1e9))
+            os.environ.pop("PTT_SA_STAGGER")
 
     # ---- linear ----
     for name, rows, K, Cout in (("lin_fc1", B * 128, 256, 512), ("lin_qkv", B * 128, 512, 1536), ("lin_fc2", B * 128, 512, 256),

@@ -48,10 +48,11 @@ def transformer_params(seed, d_points=256, d_model=512):
 def fold_layers(layers, dev, ops):
     """oracle layer dicts -> the (wpacked, scale, shift, cin, cout, relu) tuples of ops.sa_fused_forward."""
     out = []
-    for L in layers:
+    for li, L in enumerate(layers):
         w = L["conv_weight"].to(dev)
+        rot = 3 if (li == 0 and w.shape[1] > 3) else 0      # the fused kernel's row layout is [features | xyz]
         scale = (L["bn_weight"] / torch.sqrt(L["bn_var"] + L["eps"]))
         shift = L["bn_bias"] - L["bn_mean"] * scale
-        out.append((ops.pack_weight(w), scale.to(dev).contiguous(), shift.to(dev).contiguous(),
+        out.append((ops.pack_weight(w, rot), scale.to(dev).contiguous(), shift.to(dev).contiguous(),
                     w.shape[1], w.shape[0], True))
     return out
