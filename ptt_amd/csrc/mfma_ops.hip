@@ -31,6 +31,19 @@ __device__ __forceinline__ int tile_row(int reg, int half) { return (reg & 3) + 
 
 __device__ __forceinline__ float xor32(float v) { return __shfl_xor(v, 32, 64); }
 
+// lane <-> lane^32 combine on v_permlane32_swap (one VALU op, no LDS round trip): after the swap `lo`
+// holds the lower half-wave's values in both halves and `hi` the upper half-wave's.
+// Inline asm on purpose: with both operands holding the SAME value hipcc (ROCm 7.2) folds
+// __builtin_amdgcn_permlane32_swap's two results into one and the exchange silently disappears
+// (scripts/permlane_probe.hip). s_nop 1 = the VALU-write -> v_permlane read hazard, inside the string.
+__device__ __forceinline__ void swap_halves(float v, float& lo, float& hi) {
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    lo = a; hi = b;
+}
+__device__ __forceinline__ float max_halves(float v) { float lo, hi; swap_halves(v, lo, hi); return fmaxf(lo, hi); }
+__device__ __forceinline__ float add_halves(float v) { float lo, hi; swap_halves(v, lo, hi); return lo + hi; }
+
 // Two workgroups share each CU (and each SIMD's MFMA pipe). Launched together with identical work
 // they run in lockstep, so their non-MFMA phases (gather, epilogue, softmax) coincide and the matrix
 // pipe idles. The workgroup that got the SECOND LDS allocation of its CU (HW_REG_LDS_ALLOC.LDS_BASE
@@ -40,7 +53,8 @@ __device__ __forceinline__ void stagger_second_slot(int first_wave_blocks, int q
     if ((int)blockIdx.x < first_wave_blocks && quanta > 0) {
         const unsigned alloc = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 6);   // HW_REG_LDS_ALLOC
         const unsigned lds_base = alloc & 0xffu, lds_size = (alloc >> 12) & 0x1ffu;
-        const int slot = lds_size ? (int)(lds_base / lds_size) : (lds_base != 0);          // 0,1,2,.. on this CU
+        int slot = lds_size ? (int)(lds_base / lds_size) : 0;                                // 0,1,2,.. on this CU
+        if (lds_base != 0 && slot == 0) slot = 1;                                            // field granularities differ
         for (int i = 0; i < slot * quanta; ++i) __builtin_amdgcn_s_sleep(127);
     }
 }
@@ -349,7 +363,7 @@ __device__ __forceinline__ void sa_layer(const SaParams& p, const SaLayerDev& L,
                 float m = y[0];
 #pragma unroll
                 for (int r = 1; r < 16; ++r) m = fmaxf(m, y[r]);
-                m = fmaxf(m, xor32(m));
+                m = max_halves(m);
                 const int c = centre0 + rt;
                 if (half == 0 && colok && rt < ncentres) {
                     const int b = c / p.M, mm = c - b * p.M;
@@ -359,8 +373,8 @@ __device__ __forceinline__ void sa_layer(const SaParams& p, const SaLayerDev& L,
                 float m0 = y[0], m1 = y[8];
 #pragma unroll
                 for (int r = 1; r < 8; ++r) { m0 = fmaxf(m0, y[r]); m1 = fmaxf(m1, y[8 + r]); }
-                m0 = fmaxf(m0, xor32(m0));
-                m1 = fmaxf(m1, xor32(m1));
+                m0 = max_halves(m0);
+                m1 = max_halves(m1);
                 if (half == 0 && colok) {
                     const int ca = rt * 2, cb = rt * 2 + 1;
                     if (ca < ncentres) {
@@ -441,7 +455,7 @@ __device__ __forceinline__ void sa_wave_layer(const SaParams& p, const SaLayerDe
             float m = y[0];
 #pragma unroll
             for (int r = 1; r < 16; ++r) m = fmaxf(m, y[r]);
-            m = fmaxf(m, xor32(m));
+            m = max_halves(m);
             if (half == 0 && ncentres > 0) {
                 const int b = centre0 / p.M, mm = centre0 - b * p.M;
                 p.out[b * p.osb + col * p.osc + mm * p.osm] = m;
@@ -450,8 +464,8 @@ __device__ __forceinline__ void sa_wave_layer(const SaParams& p, const SaLayerDe
             float m0 = y[0], m1 = y[8];
 #pragma unroll
             for (int r = 1; r < 8; ++r) { m0 = fmaxf(m0, y[r]); m1 = fmaxf(m1, y[8 + r]); }
-            m0 = fmaxf(m0, xor32(m0));
-            m1 = fmaxf(m1, xor32(m1));
+            m0 = max_halves(m0);
+            m1 = max_halves(m1);
             if (half == 0) {
                 if (ncentres > 0) {
                     const int b = centre0 / p.M, mm = centre0 - b * p.M;
@@ -513,6 +527,14 @@ __global__ __launch_bounds__(256, 2) void pt_attn_pair_kernel(AttnParams p) {
     const int pt0 = blockIdx.x * 2;                          // flat point index of tile row 0
     const int npts = min(2, p.BN - pt0);
 #define PTT_STAMP(i) do { if (p.dbg && t == 0 && blockIdx.x < 4096) p.dbg[blockIdx.x * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+    // fc_delta[0] rows of this thread's two channels: requested before anything depends on them
+    float wd1[D / 256][4];
+#pragma unroll
+    for (int cc = 0; cc < D / 256; ++cc) {
+        const int c = t + cc * 256;
+        wd1[cc][0] = p.Wd1[c * 3 + 0]; wd1[cc][1] = p.Wd1[c * 3 + 1]; wd1[cc][2] = p.Wd1[c * 3 + 2];
+        wd1[cc][3] = p.bd1[c];
+    }
     stagger_second_slot(p.first_wave, p.stagger);
     PTT_STAMP(0);
 
@@ -533,7 +555,7 @@ __global__ __launch_bounds__(256, 2) void pt_attn_pair_kernel(AttnParams p) {
 #pragma unroll
     for (int cc = 0; cc < D / 256; ++cc) {
         const int c = t + cc * 256;
-        const float w0 = p.Wd1[c * 3 + 0], w1 = p.Wd1[c * 3 + 1], w2 = p.Wd1[c * 3 + 2], bb = p.bd1[c];
+        const float w0 = wd1[cc][0], w1 = wd1[cc][1], w2 = wd1[cc][2], bb = wd1[cc][3];
 #pragma unroll 8
         for (int r = 0; r < 32; ++r) {
             const float h = ((dxyz[r * 3 + 0] * w0 + dxyz[r * 3 + 1] * w1) + dxyz[r * 3 + 2] * w2) + bb;
@@ -609,6 +631,9 @@ __global__ __launch_bounds__(256, 2) void pt_attn_pair_kernel(AttnParams p) {
         const float bb = p.bg2[cols[u]];
 #pragma unroll
         for (int pp = 0; pp < 2; ++pp) {
+            float vv[8];                                   // neighbour values: in flight while the softmax is computed
+#pragma unroll
+            for (int r = 0; r < 8; ++r) vv[r] = p.qkv[(size_t)nrow[pp * 8 + r] * 3 * D + 2 * D + cols[u]];
             float s[8];
             float m = -__builtin_inff();
 #pragma unroll
@@ -616,25 +641,24 @@ __global__ __launch_bounds__(256, 2) void pt_attn_pair_kernel(AttnParams p) {
                 s[r] = (acc[0][u][pp * 8 + r] + bb) * inv_sqrt_d;
                 m = fmaxf(m, s[r]);
             }
-            m = fmaxf(m, xor32(m));
+            m = max_halves(m);
             float sum = 0.f;
 #pragma unroll
             for (int r = 0; r < 8; ++r) { s[r] = __expf(s[r] - m); sum += s[r]; }
-            sum += xor32(sum);
+            sum = add_halves(sum);
             const float rsum = __builtin_amdgcn_rcpf(sum);
             float o = 0.f;
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
                 const int rr = pp * 8 + r;
                 const float a = s[r] * rsum;
-                const float vv = p.qkv[(size_t)nrow[rr] * 3 * D + 2 * D + cols[u]];
-                o += a * (vv + delta[0][u][rr]);
+                o += a * (vv[r] + delta[0][u][rr]);
                 if (p.attn && pp < npts) {
                     const int row = tile_row(rr, half);  // = pp*16 + j
                     p.attn[((size_t)(pt0 + pp) * KNN + (row & 15)) * D + cols[u]] = a;
                 }
             }
-            o += xor32(o);
+            o = add_halves(o);
             if (half == 0 && pp < npts) p.res[(size_t)(pt0 + pp) * D + cols[u]] = o;
         }
     }
@@ -799,7 +823,7 @@ extern "C" int ptt_pt_attn_pair_f32(const ptt_attn_desc* d, ptt_stream_t stream)
     p.xyz = d->xyz; p.knn = d->knn; p.qkv = d->qkv; p.Wd1 = d->Wd1; p.bd1 = d->bd1; p.Wd2p = d->Wd2p; p.bd2 = d->bd2;
     p.Wg1p = d->Wg1p; p.bg1 = d->bg1; p.Wg2p = d->Wg2p; p.bg2 = d->bg2; p.res = d->res; p.attn = d->attn;
     p.BN = d->B * d->N; p.N = d->N;
-    p.first_wave = 512; p.stagger = 11;
+    p.first_wave = 512; p.stagger = 8;
     if (const char* e = getenv("PTT_PAIR_STAGGER")) p.stagger = atoi(e);
     p.dbg = nullptr;
     if (const char* e = getenv("PTT_DEBUG_STAMPS")) p.dbg = reinterpret_cast<long long*>(strtoull(e, nullptr, 16));
