@@ -29,7 +29,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from ptt_amd import ops, synth                      # noqa: E402
-from ptt_amd.hot_path import FrameHotPath, GraphedHotPath, kitti_model_cfg, randomize_   # noqa: E402
+from ptt_amd.hot_path import (FrameHotPath, GraphedHotPath, PipelinedHotPath, kitti_model_cfg,   # noqa: E402
+                              randomize_)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: dense f32-input MFMA peak
 PEAK_HBM_GBS = 8000.0               # spec; ~6300 achievable
@@ -60,6 +61,8 @@ def main():
     ap.add_argument("--nt", type=int, default=1024, help="template points per frame")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="do not overlap the FPS of batch n+1 with the dense kernels of batch n")
     ap.add_argument("--cpu-frames", type=int, default=8)
     args = ap.parse_args()
 
@@ -90,7 +93,11 @@ def main():
         with torch.no_grad():
             return model(search, template)
 
-    graphed = None if args.no_graph else GraphedHotPath(model, search, template)
+    graphed = None
+    if not args.no_graph:
+        graphed = (GraphedHotPath if args.no_pipeline else PipelinedHotPath)(model, search, template)
+    # pipelined: replay k runs the dense stage of batch k and the sampling stage of batch k+1; K replays
+    # therefore execute K full batches' worth of every kernel (the warm-up replays prime the pipeline)
     step = eager_step if graphed is None else (lambda: graphed())
 
     def sync_all():
@@ -210,7 +217,11 @@ def main():
                                    % (B, args.ns, args.nt),
                        "frames_per_gpu_per_step": B, "search_points": args.ns, "template_points": args.nt,
                        "sharding": "frames across ranks, no data-path collective",
-                       "launch": "eager" if graphed is None else "hipGraph replay, template branch on a second stream"},
+                       "launch": ("eager" if graphed is None else
+                                  "hipGraph replay, template branch on a second stream" +
+                                  ("" if args.no_pipeline else "; software-pipelined across batches: FPS of batch n+1 "
+                                   "runs on a side stream during the dense kernels of batch n (every batch still "
+                                   "executes every kernel)"))},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "index_ops": index_ops,

@@ -68,6 +68,12 @@ int ptt_gather_f32(const float* feat, const int32_t* idx, int B, int C, int N, i
 int ptt_gather_grad_f32(const float* grad_out, const int32_t* idx, int B, int C, int N,
                         int M, float* grad_feat, ptt_stream_t stream);
 
+/* Centres of one SA level in one launch (the xyz gather + transposes of pointnet2_modules.py:79-81 and
+ * the int64 cast of :90): new_xyz[b,m,:] = xyz[b, idx[b,m], :]; idx == NULL selects the first M points
+ * ('sequence' sampling, :70-71); idx64_out (B,M) receives the indices as int64, or NULL. */
+int ptt_select_centres_f32(const float* xyz, const int32_t* idx, int B, int N, int M, float* new_xyz,
+                           int64_t* idx64_out, ptt_stream_t stream);
+
 /* ---------------------------------------------------------------------------------
  * F3  ball query  (centres first, as the reference calls it)
  * replaces _ext.ball_query(new_xyz, xyz, radius, nsample)   pointnet2_utils.py:287

@@ -14,7 +14,7 @@ PTT_SA_MAX_LAYERS = 4
 # every symbol include/ptt_hip.h declares (tests check the library exports all of them)
 EXPORTS = [
     "ptt_version", "ptt_error_name", "ptt_last_error_string",
-    "ptt_fps_f32", "ptt_gather_f32", "ptt_gather_grad_f32", "ptt_ball_query_f32",
+    "ptt_fps_f32", "ptt_gather_f32", "ptt_gather_grad_f32", "ptt_select_centres_f32", "ptt_ball_query_f32",
     "ptt_group_f32", "ptt_group_grad_f32", "ptt_knn_f32",
     "ptt_packed_weight_elems", "ptt_pack_weight_f32", "ptt_pack_weight_rot_f32", "ptt_linear_f32",
     "ptt_sa_fused_fwd_f32", "ptt_pt_attn_pair_f32",
@@ -56,6 +56,7 @@ def _declare(lib):
         "ptt_fps_f32": [vp, i, i, i, vp, vp],
         "ptt_gather_f32": [vp, vp, i, i, i, i, vp, vp],
         "ptt_gather_grad_f32": [vp, vp, i, i, i, i, vp, vp],
+        "ptt_select_centres_f32": [vp, vp, i, i, i, vp, vp, vp],
         "ptt_ball_query_f32": [vp, vp, i, i, i, f, i, vp, vp],
         "ptt_group_f32": [vp, vp, i, i, i, i, i, vp, vp],
         "ptt_group_grad_f32": [vp, vp, i, i, i, i, i, vp, vp],

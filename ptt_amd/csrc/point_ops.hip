@@ -228,6 +228,22 @@ __global__ void group_grad_kernel(const float* __restrict__ go, const int32_t* _
     }
 }
 
+// centres of one SA level in a single launch: new_xyz[b,m,:] = xyz[b, idx[b,m], :] (idx NULL = the first M
+// points, the 'sequence' sampling of pointnet2_modules.py:70-71) and the int64 copy of the indices the
+// module returns (pointnet2_modules.py:90).
+__global__ void select_centres_kernel(const float* __restrict__ xyz, const int32_t* __restrict__ idx, int N, int M,
+                                      float* __restrict__ new_xyz, long long* __restrict__ idx64, size_t total) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int m = (int)(e % M);
+        const size_t b = e / M;
+        const int n = idx ? idx[e] : m;
+        const float* src = xyz + (b * N + n) * 3;
+        float* dst = new_xyz + e * 3;
+        dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
+        if (idx64) idx64[e] = n;
+    }
+}
+
 static inline int grid_for(size_t total, int block) {
     size_t g = (total + block - 1) / block;
     if (g > 2048u * 8u) g = 2048u * 8u;
@@ -327,6 +343,17 @@ extern "C" int ptt_gather_f32(const float* feat, const int32_t* idx, int B, int 
     hipLaunchKernelGGL(gather_kernel, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), feat, idx, C, N, M,
                        out, total);
     return check_launch("gather_kernel");
+}
+
+extern "C" int ptt_select_centres_f32(const float* xyz, const int32_t* idx, int B, int N, int M, float* new_xyz,
+                                      int64_t* idx64_out, ptt_stream_t stream) {
+    if (B < 0 || N <= 0 || M < 0 || (!idx && M > N)) return fail(PTT_EINVAL, "ptt_select_centres_f32: B=%d N=%d M=%d", B, N, M);
+    const size_t total = (size_t)B * M;
+    if (total == 0) return PTT_OK;
+    if (!xyz || !new_xyz) return fail(PTT_EINVAL, "ptt_select_centres_f32: null pointer");
+    hipLaunchKernelGGL(select_centres_kernel, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), xyz, idx, N, M,
+                       new_xyz, reinterpret_cast<long long*>(idx64_out), total);
+    return check_launch("select_centres_kernel");
 }
 
 extern "C" int ptt_gather_grad_f32(const float* grad_out, const int32_t* idx, int B, int C, int N, int M,

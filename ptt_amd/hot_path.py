@@ -77,26 +77,41 @@ class FrameHotPath(nn.Module):
         score = torch.sigmoid(feats_bnc[:, :, :1])
         return seeds, torch.cat((score, feats_bnc), dim=2).transpose(1, 2).contiguous()
 
-    def _backbone(self, search_points, template_points):
+    def sample(self, search_points, template_points):
+        """Level-0 furthest point sampling of both clouds -> (inds_search, inds_template) int32. Split out so
+        that a driver can run it for the NEXT batch on a side stream (PipelinedHotPath)."""
+        from .models.backbones_3d.pointnet2 import pointnet2_utils
+        sa = self.backbone_3d.model_cfg.SA_CONFIG
+        assert sa.SAMPLE_METHOD[0] == 'fps'
+        return (pointnet2_utils.furthest_point_sample(search_points[..., 0:3].contiguous(), sa.NPOINTS_SEARCH[0]),
+                pointnet2_utils.furthest_point_sample(template_points[..., 0:3].contiguous(), sa.NPOINTS_TEMPLATE[0]))
+
+    def _backbone(self, search_points, template_points, inds=None):
         bb = self.backbone_3d
-        if not (self.overlap_branches and search_points.is_cuda and not self.training):
-            return bb({'search_points': search_points, 'template_points': template_points})
         sa = bb.model_cfg.SA_CONFIG
+        i_s, i_t = inds if inds is not None else (None, None)
+        if not (self.overlap_branches and search_points.is_cuda and not self.training):
+            if inds is None:
+                return bb({'search_points': search_points, 'template_points': template_points})
+            s_seeds, s_feats, s_inds = bb.branch_forward(search_points, sa.NPOINTS_SEARCH, i_s)
+            t_seeds, t_feats, t_inds = bb.branch_forward(template_points, sa.NPOINTS_TEMPLATE, i_t)
+            return {'search_seeds': s_seeds, 'search_feats': s_feats, 'search_inds': s_inds,
+                    'template_seeds': t_seeds, 'template_feats': t_feats, 'template_inds': t_inds}
         if self._side_stream is None or self._side_stream.device != search_points.device:
             self._side_stream = torch.cuda.Stream(device=search_points.device)
         main, side = torch.cuda.current_stream(search_points.device), self._side_stream
         side.wait_stream(main)
         with torch.cuda.stream(side):
-            t_seeds, t_feats, t_inds = bb.branch_forward(template_points, sa.NPOINTS_TEMPLATE)
-        s_seeds, s_feats, s_inds = bb.branch_forward(search_points, sa.NPOINTS_SEARCH)
+            t_seeds, t_feats, t_inds = bb.branch_forward(template_points, sa.NPOINTS_TEMPLATE, i_t)
+        s_seeds, s_feats, s_inds = bb.branch_forward(search_points, sa.NPOINTS_SEARCH, i_s)
         main.wait_stream(side)
         for t in (t_seeds, t_feats, t_inds, template_points):
             t.record_stream(main)
         return {'search_seeds': s_seeds, 'search_feats': s_feats, 'search_inds': s_inds,
                 'template_seeds': t_seeds, 'template_feats': t_feats, 'template_inds': t_inds}
 
-    def forward(self, search_points, template_points):
-        d = self._backbone(search_points, template_points)
+    def forward(self, search_points, template_points, inds=None):
+        d = self._backbone(search_points, template_points, inds)
         seeds = d['search_seeds']
         fused = self.centroid_transformer(xyz=seeds, features=d['search_feats'].transpose(1, 2).contiguous())[0]
         votes, votes_feats = self.bridge(seeds, fused)
@@ -136,6 +151,59 @@ class GraphedHotPath(object):
             self.template.copy_(template_points, non_blocking=True)
         self.graph.replay()
         return self.out
+
+
+class PipelinedHotPath(object):
+    """Throughput mode: hipGraph replay in which the FPS of batch n+1 (a latency-bound chain that occupies
+    only B of the 256 CUs) runs on a side stream while batch n is in the MFMA kernels. Batches are
+    independent, all work of every batch is still executed — it is software pipelining across batches, so a
+    call returns the outputs of the PREVIOUS call's inputs (`flush()` drains the last one).
+
+        pipe = PipelinedHotPath(model, search0, template0)      # primes the pipeline with batch 0
+        out0 = pipe(search1, template1)                         # results of batch 0, FPS of batch 1 in flight
+        out1 = pipe(search2, template2) ...
+    """
+
+    def __init__(self, model, search_points, template_points, warmup=3):
+        self.model = model
+        dev = search_points.device
+        self.cur = [search_points.clone(), template_points.clone()]       # batch n (dense stage input)
+        self.nxt = [search_points.clone(), template_points.clone()]       # batch n+1 (sampling stage input)
+        self.side = torch.cuda.Stream(device=dev)
+        with torch.no_grad():
+            s = torch.cuda.Stream(device=dev)
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                for _ in range(warmup):
+                    inds = model.sample(*self.cur)
+                    model(self.cur[0], self.cur[1], inds)
+                self.inds_cur = [t.clone() for t in model.sample(*self.cur)]
+            torch.cuda.current_stream().wait_stream(s)
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                main = torch.cuda.current_stream()
+                self.side.wait_stream(main)
+                with torch.cuda.stream(self.side):
+                    inds_nxt = model.sample(*self.nxt)                     # stage A of batch n+1
+                self.out = model(self.cur[0], self.cur[1], self.inds_cur)  # stage B of batch n
+                main.wait_stream(self.side)
+                # rotate: what was "next" becomes "current" for the following replay
+                for dst, src in zip(self.inds_cur, inds_nxt):
+                    dst.copy_(src)
+                for dst, src in zip(self.cur, self.nxt):
+                    dst.copy_(src)
+
+    def __call__(self, next_search=None, next_template=None):
+        if next_search is not None:
+            self.nxt[0].copy_(next_search, non_blocking=True)
+        if next_template is not None:
+            self.nxt[1].copy_(next_template, non_blocking=True)
+        self.graph.replay()
+        return self.out
+
+    def flush(self):
+        return self.__call__()
 
 
 def randomize_(module, seed=0):

@@ -109,10 +109,12 @@ class PointnetSAModuleVotes(nn.Module):
         if fused and prefix:
             # 'sequence' indices are constants of (B, npoint): build them once, not four tiny kernels per call
             key = (xyz.size(0), npoint, str(xyz.device))
-            if self._arange_cache is None or self._arange_cache[0] != key:
-                self._arange_cache = (key, torch.arange(npoint, dtype=torch.int64, device=xyz.device)
-                                      .repeat(xyz.size(0), 1))
-            inds64 = self._arange_cache[1]
+            if self._arange_cache is None:
+                self._arange_cache = {}
+            if key not in self._arange_cache:          # search and template branches alternate (B, npoint)
+                self._arange_cache[key] = torch.arange(npoint, dtype=torch.int64, device=xyz.device).repeat(
+                    xyz.size(0), 1)
+            inds64 = self._arange_cache[key]
         elif inds is None:
             inds = self._sample(xyz, features, npoint)
         else:
@@ -122,10 +124,9 @@ class PointnetSAModuleVotes(nn.Module):
         if fused:
             xyz = xyz.contiguous()
             if prefix:
-                new_xyz = xyz[:, :npoint].contiguous()
+                new_xyz, _ = ops.select_centres(xyz, None, npoint)
             else:
-                inds64 = inds.to(torch.int64)
-                new_xyz = torch.gather(xyz, 1, inds64.unsqueeze(-1).expand(-1, -1, 3))
+                new_xyz, inds64 = ops.select_centres(xyz, inds.contiguous(), npoint)
             idx = ops.ball_query(new_xyz, xyz, self.radius, self.nsample)
             new_features = ops.sa_fused_forward(xyz, new_xyz, idx, features, self._fused_params(xyz.device),
                                                 self.radius, self.use_xyz, self.normalize_xyz, point_major_out=True)

@@ -54,9 +54,12 @@ class PointNet2BackboneLight(nn.Module):
         out = ops.linear(rows, self._cov_cache[1], w.shape[0], None, self._cov_cache[2])
         return out.transpose(1, 2)                              # (B,C,M) view
 
-    def branch_forward(self, pts, npoints: List):
+    def branch_forward(self, pts, npoints: List, inds0=None):
+        """`inds0`: optional precomputed level-0 sample indices (B, npoints[0]) — the SA module accepts
+        caller-supplied indices exactly as the reference's does (pointnet2_modules.py:60,76-77); a pipelined
+        driver computes them for batch n+1 while batch n is in the dense kernels."""
         xyz, features = self._break_up_pc(pts)
-        xyz, features, inds0 = self.SA_modules[0](xyz=xyz, features=features, npoint=npoints[0])
+        xyz, features, inds0 = self.SA_modules[0](xyz=xyz, features=features, npoint=npoints[0], inds=inds0)
         xyz, features, inds1 = self.SA_modules[1](xyz=xyz, features=features, npoint=npoints[1])
         xyz, features, inds2 = self.SA_modules[2](xyz=xyz, features=features, npoint=npoints[2])
         point_features = self._cov_final(features)

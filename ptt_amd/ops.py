@@ -108,6 +108,21 @@ def gather_points_grad(grad_out, idx, N):
     return out
 
 
+def select_centres(xyz, idx, npoint, want_idx64=True):
+    """new_xyz (B,npoint,3) = xyz[b, idx[b,:]] (idx None: the first npoint points) and idx as int64, one launch.
+    Replaces the gather_operation + transposes + int64 cast of pointnet2_modules.py:79-81,90."""
+    _chk(xyz, "xyz", torch.float32, 3)
+    B, N, _ = xyz.shape
+    if idx is not None:
+        _chk(idx, "idx", torch.int32, 2)
+    new_xyz = torch.empty((B, int(npoint), 3), dtype=torch.float32, device=xyz.device)
+    idx64 = torch.empty((B, int(npoint)), dtype=torch.int64, device=xyz.device) if (want_idx64 and idx is not None) else None
+    with torch.cuda.device(xyz.device):
+        _lib.check(_lib.lib().ptt_select_centres_f32(_ptr(xyz), _ptr(idx), B, N, int(npoint), _ptr(new_xyz), _ptr(idx64),
+                                                     _stream()), "ptt_select_centres_f32")
+    return new_xyz, idx64
+
+
 def ball_query(new_xyz, xyz, radius, nsample):
     """centres first: (B,M,3), (B,N,3) -> (B,M,nsample) i32.  Replaces _ext.ball_query (pointnet2_utils.py:287)."""
     _chk(new_xyz, "new_xyz", torch.float32, 3)

@@ -74,3 +74,27 @@ def test_state_dict_keys_match_reference_contract():
         assert k in sd, k
     assert tuple(sd["vote_aggregation.mlp_module.layer0.conv.weight"].shape) == (256, 260, 1, 1)
     assert tuple(sd["backbone_3d.SA_modules.0.mlp_module.layer0.conv.weight"].shape) == (64, 3, 1, 1)
+
+
+def test_graphed_and_pipelined_drivers_match_eager(dev):
+    """hipGraph replay and the cross-batch software pipeline must return exactly what eager calls return."""
+    from ptt_amd.hot_path import GraphedHotPath, PipelinedHotPath
+    model = randomize_(FrameHotPath(kitti_model_cfg()), seed=7).to(dev).eval()
+    batches = [tuple(torch.from_numpy(a).to(dev) for a in synth.frames(100 + i, 2, 1024, 512)) for i in range(3)]
+    with torch.no_grad():
+        eager = [{k: v.clone() for k, v in model(s, t).items()} for s, t in batches]
+    g = GraphedHotPath(model, *batches[0])
+    for (s, t), ref in zip(batches, eager):
+        out = g(s, t)
+        torch.cuda.synchronize()
+        for k in ("search_inds", "search_feats", "box_feats", "pred_box_center"):
+            assert torch.equal(out[k], ref[k]), k
+    p = PipelinedHotPath(model, *batches[0])          # primed with batch 0
+    outs = []
+    for s, t in batches[1:]:
+        outs.append({k: v.clone() for k, v in p(s, t).items()})      # returns the previous batch's result
+    outs.append({k: v.clone() for k, v in p.flush().items()})
+    torch.cuda.synchronize()
+    for out, ref in zip(outs, eager):
+        for k in ("search_inds", "template_inds", "search_feats", "box_feats", "pred_box_center"):
+            assert torch.equal(out[k], ref[k]), k
