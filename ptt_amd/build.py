@@ -15,7 +15,7 @@ LIB = os.path.join(LIBDIR, "libptt_hip.so")
 
 HIP_SOURCES = ["errors.hip", "point_ops.hip", "mfma_ops.hip"]
 # FPS / ball query / kNN index parity needs un-fused fp32 arithmetic (see point_ops.hip header)
-EXTRA_FLAGS = {"point_ops.hip": ["-ffp-contract=off"]}
+EXTRA_FLAGS = {"point_ops.hip": ["-ffp-contract=off"], "mfma_ops.hip": os.environ.get("PTT_MFMA_FLAGS", "").split()}
 
 
 def _hipcc():

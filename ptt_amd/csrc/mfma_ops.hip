@@ -22,6 +22,10 @@
 #include <stdlib.h>
 #include "common.h"
 
+#ifndef PTT_PAIR_PF
+#define PTT_PAIR_PF 1
+#endif
+
 namespace ptt {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -98,7 +102,7 @@ __device__ __forceinline__ void gemm_mfma_block(const f32x4 (&a)[RT], const f32x
 // MFMA group, which drains the prefetch (measured 2-4x slower K-loops).
 // (A hand-pinned two-register-set pipeline with sched_barrier(0) was measured 4-6 % SLOWER than this
 //  form: the loop is bound by the L2->CU fetch path, not by load placement — see DESIGN.md.)
-template <int RT, int CT, int ACT, int CTS = 4>   // CTS: distance (in column tiles) between this wave's tiles
+template <int RT, int CT, int ACT, int CTS = 4, int PF = 1>   // CTS: distance (in column tiles) between this wave's tiles
 __device__ __forceinline__ void gemm_core(const float* Xs, int ldk, int nkb, const f32x4* __restrict__ Wp, int NT,
                                           int ct0, int lane, f32x16 (&acc)[RT][ACT]) {
     static_assert(CT <= ACT, "accumulator array too narrow");
@@ -107,21 +111,66 @@ __device__ __forceinline__ void gemm_core(const float* Xs, int ldk, int nkb, con
     const f32x4* bp = Wp + (size_t)ct0 * 64 + lane;
     const size_t bstep = (size_t)NT * 64;
 
-    f32x4 bcur[CT], bnxt[CT];
+    if constexpr (PF == 1) {
+        f32x4 bcur[CT], bnxt[CT];
+#ifdef PTT_NT_WEIGHTS
+#define PTT_WLOAD(ptr) __builtin_nontemporal_load(ptr)
+#else
+#define PTT_WLOAD(ptr) (*(ptr))
+#endif
 #pragma unroll
-    for (int u = 0; u < CT; ++u) { bcur[u] = bp[(size_t)u * CTS * 64]; bnxt[u] = bcur[u]; }
-    for (int kb = 0; kb < nkb; ++kb) {
-        if (kb + 1 < nkb) {
-            const f32x4* bn = bp + (size_t)(kb + 1) * bstep;
+        for (int u = 0; u < CT; ++u) { bcur[u] = PTT_WLOAD(bp + (size_t)u * CTS * 64); bnxt[u] = bcur[u]; }
+        for (int kb = 0; kb < nkb; ++kb) {
+            if (kb + 1 < nkb) {
+                const f32x4* bn = bp + (size_t)(kb + 1) * bstep;
 #pragma unroll
-            for (int u = 0; u < CT; ++u) bnxt[u] = bn[(size_t)u * CTS * 64];
+                for (int u = 0; u < CT; ++u) bnxt[u] = PTT_WLOAD(bn + (size_t)u * CTS * 64);
+            }
+            f32x4 a[RT];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) a[rt] = *reinterpret_cast<const f32x4*>(arow + rt * 32 * ldk + kb * 8);
+            gemm_mfma_block<RT, CT, ACT>(a, bcur, acc);
+#pragma unroll
+            for (int u = 0; u < CT; ++u) bcur[u] = bnxt[u];
         }
-        f32x4 a[RT];
+    } else {                                     // two K-blocks of weights in flight (needs nkb % 3 == 1 handling below)
+        f32x4 b0[CT], b1[CT], b2[CT];
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) a[rt] = *reinterpret_cast<const f32x4*>(arow + rt * 32 * ldk + kb * 8);
-        gemm_mfma_block<RT, CT, ACT>(a, bcur, acc);
+        for (int u = 0; u < CT; ++u) {
+            b0[u] = bp[(size_t)u * CTS * 64];
+            b1[u] = (nkb > 1) ? bp[bstep + (size_t)u * CTS * 64] : b0[u];
+            b2[u] = b0[u];
+        }
+        int kb = 0;
+        for (; kb + 3 <= nkb; kb += 3) {
+#define PTT_STAGE(CUR, FILL, OFF)                                                                         \
+            {                                                                                             \
+                if (kb + (OFF) + 2 < nkb) {                                                               \
+                    const f32x4* bn = bp + (size_t)(kb + (OFF) + 2) * bstep;                              \
+                    _Pragma("unroll") for (int u = 0; u < CT; ++u) FILL[u] = bn[(size_t)u * CTS * 64];    \
+                }                                                                                         \
+                f32x4 a[RT];                                                                              \
+                _Pragma("unroll") for (int rt = 0; rt < RT; ++rt)                                         \
+                    a[rt] = *reinterpret_cast<const f32x4*>(arow + rt * 32 * ldk + (kb + (OFF)) * 8);     \
+                gemm_mfma_block<RT, CT, ACT>(a, CUR, acc);                                                \
+            }
+            PTT_STAGE(b0, b2, 0)
+            PTT_STAGE(b1, b0, 1)
+            PTT_STAGE(b2, b1, 2)
+        }
+        // tail (nkb % 3): blocks kb, kb+1 are already in b0, b1
+        if (kb < nkb) {
+            f32x4 a[RT];
 #pragma unroll
-        for (int u = 0; u < CT; ++u) bcur[u] = bnxt[u];
+            for (int rt = 0; rt < RT; ++rt) a[rt] = *reinterpret_cast<const f32x4*>(arow + rt * 32 * ldk + kb * 8);
+            gemm_mfma_block<RT, CT, ACT>(a, b0, acc);
+            if (kb + 1 < nkb) {
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) a[rt] = *reinterpret_cast<const f32x4*>(arow + rt * 32 * ldk + (kb + 1) * 8);
+                gemm_mfma_block<RT, CT, ACT>(a, b1, acc);
+            }
+        }
+#undef PTT_STAGE
     }
 }
 
@@ -572,7 +621,7 @@ __global__ __launch_bounds__(256, 2) void pt_attn_pair_kernel(AttnParams p) {
     // ---- delta = fc_delta[2](h) ----
     f32x16 delta[1][CT];
     zero_acc(delta);
-    gemm_core<1, CT, CT>(Xs, LDK, NKB, reinterpret_cast<const f32x4*>(p.Wd2p), NT, w, lane, delta);
+    gemm_core<1, CT, CT, 4, PTT_PAIR_PF>(Xs, LDK, NKB, reinterpret_cast<const f32x4*>(p.Wd2p), NT, w, lane, delta);
 #pragma unroll
     for (int u = 0; u < CT; ++u) {
         const float bb = p.bd2[cols[u]];
@@ -607,7 +656,7 @@ __global__ __launch_bounds__(256, 2) void pt_attn_pair_kernel(AttnParams p) {
     {
         f32x16 acc[1][CT];
         zero_acc(acc);
-        gemm_core<1, CT, CT>(Xs, LDK, NKB, reinterpret_cast<const f32x4*>(p.Wg1p), NT, w, lane, acc);
+        gemm_core<1, CT, CT, 4, PTT_PAIR_PF>(Xs, LDK, NKB, reinterpret_cast<const f32x4*>(p.Wg1p), NT, w, lane, acc);
         PTT_STAMP(4);
         __syncthreads();
 #pragma unroll
@@ -623,7 +672,7 @@ __global__ __launch_bounds__(256, 2) void pt_attn_pair_kernel(AttnParams p) {
     f32x16 acc[1][CT];
     zero_acc(acc);
     PTT_STAMP(5);
-    gemm_core<1, CT, CT>(Xs, LDK, NKB, reinterpret_cast<const f32x4*>(p.Wg2p), NT, w, lane, acc);
+    gemm_core<1, CT, CT, 4, PTT_PAIR_PF>(Xs, LDK, NKB, reinterpret_cast<const f32x4*>(p.Wg2p), NT, w, lane, acc);
     PTT_STAMP(6);
     const float inv_sqrt_d = 1.0f / sqrtf((float)D);
 #pragma unroll
