@@ -145,9 +145,21 @@ def main():
     pair_avg_ms = sum(pair_ms) / max(n_launch, 1)
     flops_per_launch = flops_per_step / 2.0
     achieved = flops_per_launch / (pair_avg_ms * 1e-3) / 1e12 if n_launch else 0.0
+    # HBM-side traffic per launch: not measurable from inside this process; taken from the committed PMC passes
+    # (profiles/r01_pair_kernel_pmc.json: 2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction applied) when the
+    # workload matches the profiled one, else null.
+    traffic, traffic_src = None, None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pair_kernel_pmc.json")))["launches"]
+        if B == 48 and "B48_N128" in pmc and "B48_N64" in pmc:
+            traffic = (pmc["B48_N128"]["traffic_bytes"] + pmc["B48_N64"]["traffic_bytes"]) / 2.0
+            traffic_src = "profiles/r01_pair_kernel_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, mean of the two launches; fabric-side, Infinity-Cache hits included)"
+    except Exception:
+        pass
     roofline = {"kernel": "pt_attn_pair_kernel<512>", "bound": "mfma", "achieved": round(achieved, 2),
                 "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
-                "traffic": None, "avg_launch_ms": round(pair_avg_ms, 4), "launches": n_launch,
+                "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
+                "avg_launch_ms": round(pair_avg_ms, 4), "launches": n_launch,
                 "timing": "HIP events on the launch stream" + ("" if graphed is None else
                                                                ", eager pass of the same kernels after the graphed timed region"),
                 "alg_flops_per_launch": flops_per_launch}
