@@ -25,6 +25,9 @@
 #ifndef PTT_PAIR_PF
 #define PTT_PAIR_PF 1
 #endif
+// GEMM loop flavours (gemm_core's PF): 0 = two register sets pinned with sched_barrier (best for the SA
+// chain, measured), 1 = one-block prefetch scheduled by hipcc (best for the pair kernel and the linear
+// layers), 2 = two blocks in flight (slower everywhere: the L2->CU path saturates).
 
 namespace ptt {
 
@@ -111,7 +114,39 @@ __device__ __forceinline__ void gemm_core(const float* Xs, int ldk, int nkb, con
     const f32x4* bp = Wp + (size_t)ct0 * 64 + lane;
     const size_t bstep = (size_t)NT * 64;
 
-    if constexpr (PF == 1) {
+    if constexpr (PF == 0) {                     // two register sets, order pinned with sched_barrier
+        f32x4 a0[RT], a1[RT], b0[CT], b1[CT];
+#define PTT_LOAD_BLOCK(A, Bv, KB)                                                             \
+        {                                                                                     \
+            const f32x4* bsrc = bp + (size_t)(KB) * bstep;                                    \
+            _Pragma("unroll") for (int u = 0; u < CT; ++u) Bv[u] = bsrc[(size_t)u * CTS * 64]; \
+            _Pragma("unroll") for (int rt = 0; rt < RT; ++rt)                                 \
+                A[rt] = *reinterpret_cast<const f32x4*>(arow + rt * 32 * ldk + (KB) * 8);     \
+        }
+        PTT_LOAD_BLOCK(a0, b0, 0)
+        int kb = 0;
+#pragma unroll 1
+        for (; kb + 2 < nkb; kb += 2) {
+            PTT_LOAD_BLOCK(a1, b1, kb + 1)
+            __builtin_amdgcn_sched_barrier(0);
+            gemm_mfma_block<RT, CT, ACT>(a0, b0, acc);
+            __builtin_amdgcn_sched_barrier(0);
+            PTT_LOAD_BLOCK(a0, b0, kb + 2)
+            __builtin_amdgcn_sched_barrier(0);
+            gemm_mfma_block<RT, CT, ACT>(a1, b1, acc);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (kb + 1 < nkb) {
+            PTT_LOAD_BLOCK(a1, b1, kb + 1)
+            __builtin_amdgcn_sched_barrier(0);
+            gemm_mfma_block<RT, CT, ACT>(a0, b0, acc);
+            __builtin_amdgcn_sched_barrier(0);
+            gemm_mfma_block<RT, CT, ACT>(a1, b1, acc);
+        } else {
+            gemm_mfma_block<RT, CT, ACT>(a0, b0, acc);
+        }
+#undef PTT_LOAD_BLOCK
+    } else if constexpr (PF == 1) {
         f32x4 bcur[CT], bnxt[CT];
 #ifdef PTT_NT_WEIGHTS
 #define PTT_WLOAD(ptr) __builtin_nontemporal_load(ptr)
@@ -120,18 +155,24 @@ __device__ __forceinline__ void gemm_core(const float* Xs, int ldk, int nkb, con
 #endif
 #pragma unroll
         for (int u = 0; u < CT; ++u) { bcur[u] = PTT_WLOAD(bp + (size_t)u * CTS * 64); bnxt[u] = bcur[u]; }
-        for (int kb = 0; kb < nkb; ++kb) {
-            if (kb + 1 < nkb) {
-                const f32x4* bn = bp + (size_t)(kb + 1) * bstep;
+        // the last block is peeled so that the loop body has NO conditional load: with a load under control
+        // flow (run-time nkb) the waitcnt pass gives up counting and waits vmcnt(0) before every MFMA group
+        for (int kb = 0; kb + 1 < nkb; ++kb) {
+            const f32x4* bn = bp + (size_t)(kb + 1) * bstep;
 #pragma unroll
-                for (int u = 0; u < CT; ++u) bnxt[u] = PTT_WLOAD(bn + (size_t)u * CTS * 64);
-            }
+            for (int u = 0; u < CT; ++u) bnxt[u] = PTT_WLOAD(bn + (size_t)u * CTS * 64);
             f32x4 a[RT];
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) a[rt] = *reinterpret_cast<const f32x4*>(arow + rt * 32 * ldk + kb * 8);
             gemm_mfma_block<RT, CT, ACT>(a, bcur, acc);
 #pragma unroll
             for (int u = 0; u < CT; ++u) bcur[u] = bnxt[u];
+        }
+        {
+            f32x4 a[RT];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) a[rt] = *reinterpret_cast<const f32x4*>(arow + rt * 32 * ldk + (nkb - 1) * 8);
+            gemm_mfma_block<RT, CT, ACT>(a, bcur, acc);
         }
     } else {                                     // two K-blocks of weights in flight (needs nkb % 3 == 1 handling below)
         f32x4 b0[CT], b1[CT], b2[CT];
@@ -176,15 +217,15 @@ __device__ __forceinline__ void gemm_core(const float* Xs, int ldk, int nkb, con
 
 // Run the core on however many of this wave's (up to CT) column tiles exist: a wave-uniform
 // dispatch to compile-time tile counts.
-template <int RT, int CT>
+template <int RT, int CT, int PFM>
 __device__ __forceinline__ void gemm_tiles(const float* Xs, int ldk, int nkb, const f32x4* __restrict__ Wp, int NT,
                                            int ct0, int nvalid, int lane, f32x16 (&acc)[RT][CT]) {
-    if (nvalid >= CT) gemm_core<RT, CT, CT>(Xs, ldk, nkb, Wp, NT, ct0, lane, acc);
+    if (nvalid >= CT) gemm_core<RT, CT, CT, 4, PFM>(Xs, ldk, nkb, Wp, NT, ct0, lane, acc);
     else if constexpr (CT > 1) {
-        if (nvalid == 1) gemm_core<RT, 1, CT>(Xs, ldk, nkb, Wp, NT, ct0, lane, acc);
+        if (nvalid == 1) gemm_core<RT, 1, CT, 4, PFM>(Xs, ldk, nkb, Wp, NT, ct0, lane, acc);
         else if constexpr (CT > 2) {
-            if (nvalid == 2) gemm_core<RT, 2, CT>(Xs, ldk, nkb, Wp, NT, ct0, lane, acc);
-            else if (nvalid == 3) gemm_core<RT, 3, CT>(Xs, ldk, nkb, Wp, NT, ct0, lane, acc);
+            if (nvalid == 2) gemm_core<RT, 2, CT, 4, PFM>(Xs, ldk, nkb, Wp, NT, ct0, lane, acc);
+            else if (nvalid == 3) gemm_core<RT, 3, CT, 4, PFM>(Xs, ldk, nkb, Wp, NT, ct0, lane, acc);
         }
     }
 }
@@ -267,7 +308,7 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(LinearParams p) {
         float* cur = Xs + (c & 1) * BUF;
         if (c + 1 < nchunks) lin_fetch<RT, VEC>(p, row0, (c + 1) * LIN_KC, t, st);
         const int nkb_c = min(LIN_KC / 8, p.nkb - c * (LIN_KC / 8));
-        gemm_tiles<RT, 2>(cur, LIN_LDK, nkb_c, reinterpret_cast<const f32x4*>(p.Wp) + (size_t)c * (LIN_KC / 8) * bstep,
+        gemm_tiles<RT, 2, 1>(cur, LIN_LDK, nkb_c, reinterpret_cast<const f32x4*>(p.Wp) + (size_t)c * (LIN_KC / 8) * bstep,
                           p.NT, ctbase, nvalid, lane, acc);
         if (c + 1 < nchunks) {
             lin_stage<RT>(Xs + ((c + 1) & 1) * BUF, t, st);   // the other buffer: last read in chunk c-1
@@ -385,7 +426,7 @@ __device__ __forceinline__ void sa_layer(const SaParams& p, const SaLayerDev& L,
 #pragma unroll
     for (int u = 0; u < CT; ++u)
         if (w + 4 * u < L.NT) nvalid = u + 1;
-    gemm_tiles<2, CT>(Xs, p.ldk, L.nkb, reinterpret_cast<const f32x4*>(L.Wp), L.NT, w, nvalid, lane, acc);
+    gemm_tiles<2, CT, 0>(Xs, p.ldk, L.nkb, reinterpret_cast<const f32x4*>(L.Wp), L.NT, w, nvalid, lane, acc);
     __syncthreads();  // every wave has finished reading this layer's input tile
 
     const int half = lane >> 5;
