@@ -169,6 +169,36 @@ typedef struct ptt_sa_desc {
 int ptt_sa_fused_fwd_f32(const ptt_sa_desc* d, ptt_stream_t stream);
 
 /* ---------------------------------------------------------------------------------
+ * N1  P2B cosine-similarity feature augmentation, fused
+ * replaces CosineSimAug.forward up to the max over the template axis
+ *                                              similarity_modules/p2b_xcoor.py:25-42
+ *   fusion[b,:,i,j] = [cos(templ_i, search_j) | templ_xyz_i | templ_feat_i]  (never materialised)
+ *   out[b,:,j] = max_i SharedMLP(fusion)[b,:,i,j]
+ * Layer 0 is split: W0.fusion = w_sim*cos_ij + P[b,i,:], with P = W0[:,1:].[xyz_i;feat_i] computed
+ * once per template point by ptt_linear_f32. `layers` are the REMAINING SharedMLP layers.
+ * Nt = 64 template seeds is the instantiated configuration.
+ * ------------------------------------------------------------------------------- */
+typedef struct ptt_xcorr_desc {
+    const float* search_feat;           /* search_feat[b][n][c], element strides below      */
+    int64_t s_sb, s_sn, s_sc;
+    const float* templ_feat;            /* templ_feat[b][i][c]                               */
+    int64_t t_sb, t_sn, t_sc;
+    const float* P;                     /* (B,Nt,C0) contiguous, see above                   */
+    const float* w_sim;                 /* (C0) W0[:,0]                                      */
+    const float* scale0;                /* (C0) folded BN of layer 0 (NULL = 1 / 0)          */
+    const float* shift0;
+    float* out;                         /* out[b][c][j], element strides below               */
+    int64_t out_sb, out_sc, out_sn;
+    float* sim_out;                     /* optional (B,Nt,Ns) cosine map, or NULL            */
+    int B, Ns, Nt, C, C0;
+    float eps;                          /* CosineSimilarity eps (1e-8)                       */
+    int n_layers;
+    ptt_sa_layer layers[PTT_SA_MAX_LAYERS];
+} ptt_xcorr_desc;
+
+int ptt_xcorr_fused_fwd_f32(const ptt_xcorr_desc* d, ptt_stream_t stream);
+
+/* ---------------------------------------------------------------------------------
  * T2..T6 fused per-(point,neighbour) part of the Point-Transformer block:
  *   delta = fc_delta(xyz_i - xyz_j);  a = fc_gamma(q_i - k_j + delta);
  *   attn = softmax_j(a / sqrt(D));    res_i = sum_j attn * (v_j + delta)

@@ -117,3 +117,22 @@ def transformer_block(xyz, features, P, k, knn_idx=None):
     res = torch.einsum("bmnf,bmnf->bmf", attn, v + pos_enc)                                 # :163
     res = F.linear(res, P["fc2.weight"], P["fc2.bias"]) + pre                               # :164
     return res, attn
+
+
+def cosine_sim_aug(search_feats, template_feats, template_xyz, mlp_layers, conv):
+    """CosineSimAug.forward — similarity_modules/p2b_xcoor.py:25-46.
+    search_feats (B,f,n2), template_feats (B,f,n1), template_xyz (B,n1,3); mlp_layers as shared_mlp_eval;
+    conv: dict with conv0_weight (256,256,1), bn0_*, conv1_weight, conv1_bias (the Seq stack, :19-23)."""
+    b, f, n2 = search_feats.shape
+    n1 = template_feats.shape[-1]
+    sim = F.cosine_similarity(template_feats.unsqueeze(-1).expand(b, f, n1, n2),
+                              search_feats.unsqueeze(2).expand(b, f, n1, n2), dim=1)              # :35-36
+    txyz = template_xyz.transpose(1, 2).contiguous().unsqueeze(-1).expand(b, 3, n1, n2)           # :37
+    fusion = torch.cat((sim.unsqueeze(1), txyz), dim=1)                                           # :38
+    fusion = torch.cat((fusion, template_feats.unsqueeze(-1).expand(b, f, n1, n2)), dim=1)        # :39
+    fusion = shared_mlp_eval(fusion, mlp_layers)                                                  # :40
+    fusion = F.max_pool2d(fusion, kernel_size=[fusion.size(2), 1]).squeeze(2)                     # :41-42
+    y = F.conv1d(fusion, conv["conv0_weight"])
+    y = F.relu(F.batch_norm(y, conv["bn0_mean"], conv["bn0_var"], conv["bn0_weight"], conv["bn0_bias"], False, 0.0, 1e-5))
+    y = F.conv1d(y, conv["conv1_weight"], conv["conv1_bias"])                                     # :43
+    return y, sim

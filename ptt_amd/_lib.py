@@ -17,7 +17,7 @@ EXPORTS = [
     "ptt_fps_f32", "ptt_gather_f32", "ptt_gather_grad_f32", "ptt_select_centres_f32", "ptt_ball_query_f32",
     "ptt_group_f32", "ptt_group_grad_f32", "ptt_knn_f32",
     "ptt_packed_weight_elems", "ptt_pack_weight_f32", "ptt_pack_weight_rot_f32", "ptt_linear_f32",
-    "ptt_sa_fused_fwd_f32", "ptt_pt_attn_pair_f32",
+    "ptt_sa_fused_fwd_f32", "ptt_xcorr_fused_fwd_f32", "ptt_pt_attn_pair_f32",
 ]
 
 
@@ -33,6 +33,16 @@ class SaDesc(Structure):
                 ("B", c_int), ("N", c_int), ("M", c_int), ("nsample", c_int), ("C", c_int),
                 ("radius", c_float), ("use_xyz", c_int), ("normalize_xyz", c_int), ("n_layers", c_int),
                 ("layers", SaLayer * PTT_SA_MAX_LAYERS)]
+
+
+class XcorrDesc(Structure):
+    _fields_ = [("search_feat", c_void_p), ("s_sb", c_int64), ("s_sn", c_int64), ("s_sc", c_int64),
+                ("templ_feat", c_void_p), ("t_sb", c_int64), ("t_sn", c_int64), ("t_sc", c_int64),
+                ("P", c_void_p), ("w_sim", c_void_p), ("scale0", c_void_p), ("shift0", c_void_p),
+                ("out", c_void_p), ("out_sb", c_int64), ("out_sc", c_int64), ("out_sn", c_int64),
+                ("sim_out", c_void_p),
+                ("B", c_int), ("Ns", c_int), ("Nt", c_int), ("C", c_int), ("C0", c_int),
+                ("eps", c_float), ("n_layers", c_int), ("layers", SaLayer * PTT_SA_MAX_LAYERS)]
 
 
 class AttnDesc(Structure):
@@ -65,6 +75,7 @@ def _declare(lib):
         "ptt_pack_weight_rot_f32": [vp, i, i, i, vp, vp],
         "ptt_linear_f32": [vp, i, i, i, vp, i, vp, vp, i, vp, i, vp, i, vp],
         "ptt_sa_fused_fwd_f32": [POINTER(SaDesc), vp],
+        "ptt_xcorr_fused_fwd_f32": [POINTER(XcorrDesc), vp],
         "ptt_pt_attn_pair_f32": [POINTER(AttnDesc), vp],
     }
     for name, args in sigs.items():

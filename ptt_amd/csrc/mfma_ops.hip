@@ -20,6 +20,7 @@
 //     and the softmax over neighbours are register-local plus one lane^32 exchange.
 #include <math.h>
 #include <stdlib.h>
+#include <string.h>
 #include "common.h"
 
 #ifndef PTT_PAIR_PF
@@ -437,6 +438,7 @@ __device__ __forceinline__ void sa_layer(const SaParams& p, const SaLayerDev& L,
         const bool colok = col < L.Cout;
         const float sc = (L.scale && colok) ? L.scale[col] : 1.f;
         const float sh = (L.shift && colok) ? L.shift[col] : 0.f;
+        float m64 = -__builtin_inff();                 // NS == 64: one centre spans both row tiles
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
             float y[16];
@@ -449,6 +451,15 @@ __device__ __forceinline__ void sa_layer(const SaParams& p, const SaLayerDev& L,
             if (!last) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) Xs[(rt * 32 + tile_row(r, half)) * p.ldk + col] = y[r];
+            } else if (NS == 64) {
+                float m = y[0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) m = fmaxf(m, y[r]);
+                m64 = fmaxf(m64, max_halves(m));
+                if (rt == 1 && half == 0 && colok && ncentres > 0) {
+                    const int b = centre0 / p.M, mm = centre0 - b * p.M;
+                    p.out[b * p.osb + col * p.osc + mm * p.osm] = m64;
+                }
             } else if (NS == 32) {
                 float m = y[0];
 #pragma unroll
@@ -509,6 +520,79 @@ __global__ __launch_bounds__(256, 2) void sa_fused_kernel(SaParams p) {
         PTT_STAMP(2 + l);
     }
 #undef PTT_STAMP
+}
+
+// ------------------------------------------------------------------------------------------
+// N1: the P2B cosine-similarity feature augmentation (CosineSimAug.forward, similarity_modules/
+// p2b_xcoor.py:25-46) as one fused kernel on the same layer chain.
+//   fusion[b, :, i, j] = [ cos(template_i, search_j) | template_xyz_i (3) | template_feat_i (C) ]
+//   out[b, :, j]       = max_i  SharedMLP(fusion)[b, :, i, j]
+// Only the similarity channel depends on j, so layer 0 is split algebraically:
+//   W0 . fusion = w_sim * cos_ij + P[b, i, :],   P = W0[:, 1:] . [xyz_i ; feat_i]   (per template point, once
+// per frame, on the linear kernel). A workgroup owns one search point j = 64 (i) rows: it computes the 64
+// cosines, builds relu(bn0(w_sim * cos + P)) straight into the LDS tile and runs the remaining layers with the
+// max over the 64 template points in registers. The (B,260,64,128) fusion tensor never exists.
+// ------------------------------------------------------------------------------------------
+struct XcorrParams {
+    const float* sfeat; const float* tfeat; const float* P; const float* wsim; const float* scale0; const float* shift0;
+    float* sim_out;
+    long long s_sb, s_sn, s_sc, t_sb, t_sn, t_sc;
+    int C, C0, Nt;
+    float eps;
+    SaParams sa;     // B, M (= Ns), out strides, ldk, layers (the remaining SharedMLP layers), stagger
+};
+
+__global__ __launch_bounds__(256, 2) void xcorr_fused_kernel(XcorrParams q) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const SaParams& p = q.sa;
+    float* Xs = smem;                        // [64][ldk]
+    float* simv = smem + 64 * p.ldk;         // [64] cosine of each template point with this search point
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int j = blockIdx.x;                // flat search point b*Ns + jj
+    const int b = j / p.M, jj = j - b * p.M;
+    stagger_second_slot(p.first_wave, p.stagger);
+
+    // ---- 64 cosines: thread (i = t>>2, quarter = t&3) covers channels quarter, quarter+4, ... ----
+    {
+        const int i = t >> 2, qd = t & 3;
+        const float* a = q.tfeat + (long long)b * q.t_sb + (long long)i * q.t_sn;
+        const float* s = q.sfeat + (long long)b * q.s_sb + (long long)jj * q.s_sn;
+        float dot = 0.f, na = 0.f, ns = 0.f;
+        for (int c = qd; c < q.C; c += 4) {
+            const float av = a[(long long)c * q.t_sc], sv = s[(long long)c * q.s_sc];
+            dot += av * sv; na += av * av; ns += sv * sv;
+        }
+        dot += __shfl_xor(dot, 1, 64); dot += __shfl_xor(dot, 2, 64);
+        na += __shfl_xor(na, 1, 64);   na += __shfl_xor(na, 2, 64);
+        ns += __shfl_xor(ns, 1, 64);   ns += __shfl_xor(ns, 2, 64);
+        // torch.nn.functional.cosine_similarity: x1.x2 / (max(|x1|, eps) * max(|x2|, eps))
+        const float cs = dot / (fmaxf(sqrtf(na), q.eps) * fmaxf(sqrtf(ns), q.eps));
+        if (qd == 0) {
+            simv[i] = cs;
+            if (q.sim_out) q.sim_out[((long long)b * q.Nt + i) * p.M + jj] = cs;
+        }
+    }
+    __syncthreads();
+
+    // ---- layer 0: relu(bn0(w_sim * cos_i + P[b,i,:])) -> X ----
+    for (int c = t; c < q.C0; c += 256) {
+        const float wsim = q.wsim[c], sc = q.scale0 ? q.scale0[c] : 1.f, sh = q.shift0 ? q.shift0[c] : 0.f;
+        const float* pr = q.P + (long long)b * q.Nt * q.C0 + c;
+#pragma unroll 8
+        for (int i = 0; i < 64; ++i) {
+            const float v = (pr[(long long)i * q.C0] + wsim * simv[i]) * sc + sh;
+            Xs[i * p.ldk + c] = fmaxf(v, 0.f);
+        }
+    }
+    __syncthreads();
+
+    for (int l = 0; l < p.n_layers; ++l) {
+        const SaLayerDev& L = p.L[l];
+        const bool last = (l == p.n_layers - 1);
+        const int ctw = (L.NT + 3) >> 2;
+        if (ctw <= 1) sa_layer<64, 1>(p, L, last, Xs, lane, w, j, 1);
+        else sa_layer<64, 2>(p, L, last, Xs, lane, w, j, 1);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -898,6 +982,47 @@ extern "C" int ptt_sa_fused_fwd_f32(const ptt_sa_desc* d, ptt_stream_t stream) {
         hipLaunchKernelGGL((sa_fused_kernel<16>), dim3((total_centres + 3) / 4), dim3(256), lds, s, p);
     }
     return check_launch("sa_fused_kernel");
+}
+
+extern "C" int ptt_xcorr_fused_fwd_f32(const ptt_xcorr_desc* d, ptt_stream_t stream) {
+    if (!d) return fail(PTT_EINVAL, "ptt_xcorr_fused_fwd_f32: null descriptor");
+    if (d->B < 0 || d->Ns <= 0 || d->C <= 0 || d->C0 <= 0 || d->n_layers < 1 || d->n_layers > PTT_SA_MAX_LAYERS)
+        return fail(PTT_EINVAL, "ptt_xcorr_fused_fwd_f32: B=%d Ns=%d C=%d C0=%d layers=%d", d->B, d->Ns, d->C, d->C0,
+                    d->n_layers);
+    if (d->Nt != 64) return fail(PTT_EUNSUPPORTED, "ptt_xcorr_fused_fwd_f32: Nt=%d (64 template seeds is instantiated)", d->Nt);
+    if ((d->C0 % 8) != 0 || d->C0 > 256) return fail(PTT_EUNSUPPORTED, "ptt_xcorr_fused_fwd_f32: C0=%d", d->C0);
+    if (d->B == 0) return PTT_OK;
+    if (!d->search_feat || !d->templ_feat || !d->P || !d->w_sim || !d->out)
+        return fail(PTT_EINVAL, "ptt_xcorr_fused_fwd_f32: null pointer");
+    XcorrParams q;
+    q.sfeat = d->search_feat; q.tfeat = d->templ_feat; q.P = d->P; q.wsim = d->w_sim; q.scale0 = d->scale0;
+    q.shift0 = d->shift0; q.sim_out = d->sim_out;
+    q.s_sb = d->s_sb; q.s_sn = d->s_sn; q.s_sc = d->s_sc; q.t_sb = d->t_sb; q.t_sn = d->t_sn; q.t_sc = d->t_sc;
+    q.C = d->C; q.C0 = d->C0; q.Nt = d->Nt; q.eps = d->eps;
+    SaParams& p = q.sa;
+    memset(&p, 0, sizeof(p));
+    p.out = d->out; p.osb = d->out_sb; p.osc = d->out_sc; p.osm = d->out_sn;
+    p.B = d->B; p.M = d->Ns; p.n_layers = d->n_layers;
+    int maxk = d->C0, cin = d->C0;
+    for (int l = 0; l < d->n_layers; ++l) {
+        const ptt_sa_layer& s = d->layers[l];
+        if (s.Cin != cin) return fail(PTT_EINVAL, "ptt_xcorr_fused_fwd_f32: layer %d Cin=%d, expected %d", l, s.Cin, cin);
+        if (s.Cout <= 0 || (s.Cout % 32) != 0 || s.Cout > 256)
+            return fail(PTT_EUNSUPPORTED, "ptt_xcorr_fused_fwd_f32: layer %d Cout=%d", l, s.Cout);
+        if (!s.Wpacked) return fail(PTT_EINVAL, "ptt_xcorr_fused_fwd_f32: layer %d has no weights", l);
+        SaLayerDev& L = p.L[l];
+        L.Wp = s.Wpacked; L.scale = s.scale; L.shift = s.shift; L.Cin = s.Cin; L.Cout = s.Cout; L.relu = s.relu;
+        L.nkb = (s.Cin + 7) / 8; L.NT = s.Cout / 32;
+        if (l + 1 < d->n_layers && s.Cout > maxk) maxk = s.Cout;
+        cin = s.Cout;
+    }
+    p.ldk = ((maxk + 7) / 8) * 8 + 4;
+    p.first_wave = 1024; p.stagger = 2;
+    const int lds = (64 * p.ldk + 64) * (int)sizeof(float);
+    int rc = set_lds_limit(reinterpret_cast<const void*>(xcorr_fused_kernel), lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(xcorr_fused_kernel, dim3(d->B * d->Ns), dim3(256), lds, as_stream(stream), q);
+    return check_launch("xcorr_fused_kernel");
 }
 
 extern "C" int ptt_pt_attn_pair_f32(const ptt_attn_desc* d, ptt_stream_t stream) {

@@ -1,0 +1,104 @@
+"""Mirror of ptt/models/similarity_modules/p2b_xcoor.py: CosineSimAug (:9-46), the P2B template/search feature
+augmentation. Attribute names (`cosine`, `mlp`, `conv`) and state_dict keys are the reference's.
+
+Reference op sequence: cosine map (B,64,128) -> expand/concat to a (B,260,64,128) tensor -> SharedMLP
+[260,256,256,256] over all 8192 (template, search) pairs -> max over the template axis -> 2 x Conv1d.
+Eval mode on a HIP device: only the similarity channel of the 260 depends on the search point, so layer 0
+is split into a per-template-point part (one small MFMA linear) plus a rank-1 update inside the fused kernel
+(ptt_xcorr_fused_fwd_f32), which also computes the cosines, runs the remaining layers on fp32 MFMA and takes
+the max over the 64 template points in registers. The big fusion tensor never exists; layer-0 work drops from
+8192 x 260 x 256 to 64 x 259 x 256 MACs per frame (a third of the module's FLOPs).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ... import ops
+from ..backbones_3d.pointnet2 import pytorch_utils as layer_utils
+
+
+class CosineSimAug(nn.Module):
+    def __init__(self, model_cfg):
+        super().__init__()
+        self.model_cfg = model_cfg
+        self.cosine = nn.CosineSimilarity(dim=1)
+        self.mlp = layer_utils.SharedMLP(self.model_cfg.MLP.CHANNELS, bn=self.model_cfg.MLP.BN)
+        self.conv = (
+            layer_utils.Seq(self.model_cfg.CONV.CHANNELS[0])
+            .conv1d(self.model_cfg.CONV.CHANNELS[1], bn=self.model_cfg.CONV.BN)
+            .conv1d(self.model_cfg.CONV.CHANNELS[2], activation=None)
+        )
+        self._cache = None
+
+    # ------------------------------------------------------------------ fused-path parameters
+    def _fusable(self, search_feats, template_feats):
+        if self.training or not search_feats.is_cuda or template_feats.shape[-1] != 64:
+            return False
+        units = list(self.mlp)
+        if len(units) < 2 or len(units) > 5:
+            return False
+        for u in units:
+            if not hasattr(u, 'normlayer') or u.conv.weight.shape[0] % 32 or u.conv.weight.shape[0] > 256:
+                return False
+        return units[0].conv.weight.shape[1] == template_feats.shape[1] + 4 and len(self.conv) == 2
+
+    @staticmethod
+    def _fold(unit):
+        bn = unit.normlayer.bn
+        scale = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).float().contiguous()
+        shift = (bn.bias - bn.running_mean * scale).float().contiguous()
+        return scale, shift
+
+    def _params(self):
+        ts = [t for t in self.state_dict().values() if t.is_floating_point()]
+        key = tuple((t.data_ptr(), t._version) for t in ts)
+        if self._cache is not None and self._cache[0] == key:
+            return self._cache[1]
+        with torch.no_grad():
+            units = list(self.mlp)
+            w0 = units[0].conv.weight.reshape(units[0].conv.weight.shape[0], -1)       # (C0, 1 + 3 + C)
+            s0, t0 = self._fold(units[0])
+            layers = []
+            for u in units[1:]:
+                sc, sh = self._fold(u)
+                w = u.conv.weight
+                layers.append((ops.pack_weight(w), sc, sh, w.shape[1], w.shape[0], True))
+            c0, c1 = self.conv[0], self.conv[1]
+            cs, ct = self._fold(c0)
+            P = dict(w_sim=w0[:, 0].float().contiguous(), w_rest=ops.pack_weight(w0[:, 1:]), c0=w0.shape[0],
+                     scale0=s0, shift0=t0, layers=layers,
+                     conv0=ops.pack_weight(c0.conv.weight), conv0_scale=cs, conv0_shift=ct,
+                     conv0_relu=hasattr(c0, 'activation'),
+                     conv1=ops.pack_weight(c1.conv.weight),
+                     conv1_bias=c1.conv.bias.detach().float().contiguous() if c1.conv.bias is not None else None)
+        self._cache = (key, P)
+        return P
+
+    def forward(self, batch_dict):
+        search_feats = batch_dict['search_feats']            # (B,f,n2)
+        template_feats = batch_dict['template_feats']        # (B,f,n1)
+        template_xyz = batch_dict['template_seeds']          # (B,n1,3)
+        b, f, n2 = search_feats.shape
+        n1 = template_feats.shape[-1]
+
+        if self._fusable(search_feats, template_feats):
+            P = self._params()
+            rows = torch.cat((template_xyz, template_feats.transpose(1, 2)), dim=2)          # (B,n1,3+f)
+            pre = ops.linear(rows, P['w_rest'], P['c0'])                                      # (B,n1,C0)
+            fused, _ = ops.xcorr_fused(search_feats, template_feats, pre, P['w_sim'], P['scale0'], P['shift0'],
+                                       P['layers'], eps=self.cosine.eps)                      # (B,C,n2) view
+            y = ops.linear(fused.transpose(1, 2), P['conv0'], self.conv[0].conv.weight.shape[0],
+                           P['conv0_scale'], P['conv0_shift'], P['conv0_relu'])
+            y = ops.linear(y, P['conv1'], self.conv[1].conv.weight.shape[0], None, P['conv1_bias'])
+            batch_dict['cosine_feats'] = y.transpose(1, 2)                                    # (B,c,n2) view
+            return batch_dict
+
+        sim_feat = self.cosine(template_feats.unsqueeze(-1).expand(b, f, n1, n2),
+                               search_feats.unsqueeze(2).expand(b, f, n1, n2))
+        template_xyz_ = template_xyz.transpose(1, 2).contiguous().unsqueeze(-1).expand(b, 3, n1, n2)
+        fusion_feature = torch.cat((sim_feat.unsqueeze(1), template_xyz_), dim=1)
+        fusion_feature = torch.cat((fusion_feature, template_feats.unsqueeze(-1).expand(b, f, n1, n2)), dim=1)
+        fusion_feature = self.mlp(fusion_feature)
+        fusion_feature = F.max_pool2d(fusion_feature, kernel_size=[fusion_feature.size(2), 1]).squeeze(2)
+        batch_dict['cosine_feats'] = self.conv(fusion_feature)
+        return batch_dict

@@ -1,0 +1,82 @@
+"""Mirror of ptt/models/voting_heads/box_voting_head.py: BoxVotingHead (:10-112).
+Vote aggregation (a 4th set-abstraction level on the 128 votes: FPS 128->64, r=.3, ns=16, MLP [260,256,256,256]),
+the second Point-Track-Transformer block and a small Conv1d stack that regresses (dx,dy,dz,dtheta,score) per
+proposal. `vote_aggregation`, `refine_layer`, `transformer_block` are the checkpoint names."""
+import torch
+
+from ..backbones_3d.pointnet2 import pointnet2_modules
+from ..backbones_3d.pointnet2 import pytorch_utils as layer_utils
+from ..transformer_block import build_transformer
+from .voting_head_template import VotingHeadTemplate
+
+
+class BoxVotingHead(VotingHeadTemplate):
+    def __init__(self, model_cfg, **kwargs):
+        super().__init__(model_cfg)
+        sa = self.model_cfg.SA_CONFIG
+        self.vote_aggregation = pointnet2_modules.PointnetSAModuleVotes(
+            radius=sa.RADIUS, nsample=sa.NSAMPLE, mlp=sa.MLPS,          # the cfg list itself, mutated like the reference (:19)
+            use_xyz=sa.get('USE_XYZ', True), normalize_xyz=sa.get('NORMALIZE_XYZ', True),
+            sample_method=sa.SAMPLE_METHOD)
+        fc = self.model_cfg.FC
+        self.refine_layer = (layer_utils.Seq(fc[0])
+                             .conv1d(fc[1], bn=True)
+                             .conv1d(fc[2], bn=True)
+                             .conv1d(fc[3], activation=None))
+        if self.model_cfg.TRANSFORMER_BLOCK.ENABLE:
+            self.transformer_block = build_transformer(self.model_cfg.TRANSFORMER_BLOCK)
+
+    # ------------------------------------------------------------------ losses (reference :33-66)
+    def get_cls_layer_loss(self, forward_ret_dict):
+        weights = self.model_cfg.LOSS_CONFIG.LOSS_WEIGHTS
+        mask = forward_ret_dict['mask']
+        loss = self.cls_loss_func(forward_ret_dict['pred_boxes_cls'], forward_ret_dict['cls_label'])
+        loss = torch.sum(loss * mask) / (torch.sum(mask) + 1e-6)
+        tb_dict = {'boxes_cls_loss': loss.item()}
+        return loss.float() * weights['boxes_cls_weight'], tb_dict
+
+    def get_reg_layer_loss(self, forward_ret_dict):
+        weights = self.model_cfg.LOSS_CONFIG.LOSS_WEIGHTS
+        mask = forward_ret_dict['cls_label']
+        pred = forward_ret_dict['pred_boxes_reg']
+        target = forward_ret_dict['reg_label'][:, None, :].expand_as(pred)
+        loss = self.reg_loss_func(pred, target)
+        loss = (loss.mean(2) * mask).sum() / (mask.sum() + 1e-06)
+        tb_dict = {'boxes_reg_loss': loss.item()}
+        return loss.float() * weights['boxes_reg_weight'], tb_dict
+
+    def get_loss(self, tb_dict=None):
+        tb_dict = {} if tb_dict is None else tb_dict
+        loss_cls, tb1 = self.get_cls_layer_loss(self.forward_ret_dict)
+        loss_reg, tb2 = self.get_reg_layer_loss(self.forward_ret_dict)
+        tb_dict.update(tb1)
+        tb_dict.update(tb2)
+        return (loss_cls + loss_reg).float(), tb_dict
+
+    # ------------------------------------------------------------------ forward (reference :68-112)
+    def forward(self, batch_dict):
+        centres, feats, _ = self.vote_aggregation(xyz=batch_dict['pred_centroids_votes'],
+                                                  features=batch_dict['votes_feats'],
+                                                  npoint=self.model_cfg.SA_CONFIG.NPOINTS)
+        if hasattr(self, 'transformer_block'):
+            fused = self.transformer_block(xyz=centres, features=feats.transpose(1, 2).contiguous())[0]
+            feats = fused.transpose(1, 2).contiguous()
+
+        offsets = self.refine_layer(feats)                                                       # (B,5,M)
+        boxes = torch.cat((offsets[:, 0:3, :] + centres.transpose(1, 2).contiguous(), offsets[:, 3:, :]), dim=1)
+        batch_dict['pred_box_center'] = centres
+        batch_dict['pred_box_data'] = boxes.transpose(1, 2).contiguous()                         # (B,M,5)
+
+        if self.training:
+            dist = torch.sqrt(torch.sum((centres - batch_dict['reg_label'][:, None, 0:3]) ** 2, dim=-1) + 1e-6)
+            label = torch.zeros_like(dist, dtype=torch.float)
+            mask = torch.zeros_like(label, dtype=torch.float)
+            label[dist < 0.3] = 1
+            mask[dist < 0.3] = 1
+            mask[dist > 0.6] = 1
+            self.forward_ret_dict = {
+                'pred_boxes_cls': batch_dict['pred_box_data'][:, :, -1],
+                'pred_boxes_reg': batch_dict['pred_box_data'][:, :, :-1],
+                'mask': mask, 'cls_label': label, 'reg_label': batch_dict['reg_label'],
+            }
+        return batch_dict

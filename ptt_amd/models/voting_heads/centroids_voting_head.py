@@ -1,0 +1,86 @@
+"""Mirror of ptt/models/voting_heads/centroids_voting_head.py: CentroidVotingHead (:9-109).
+Seed-wise classification + vote regression on the 128 search seeds, preceded by the Point-Track-Transformer
+block (the hot-path kernel sequence of ptt_amd.models.transformer_block). The two 3-layer Conv1d stacks are
+tiny (0.05 GFLOP/frame) and stay on stock torch layers; names `cla_layer`, `vote_layer`, `transformer_block`
+are the checkpoint contract."""
+import torch
+
+from ..backbones_3d.pointnet2 import pytorch_utils as layer_utils
+from ..transformer_block import build_transformer
+from .voting_head_template import VotingHeadTemplate
+
+
+def _conv_stack(channels):
+    return (layer_utils.Seq(channels[0])
+            .conv1d(channels[1], bn=True)
+            .conv1d(channels[2], bn=True)
+            .conv1d(channels[3], activation=None))
+
+
+class CentroidVotingHead(VotingHeadTemplate):
+    def __init__(self, model_cfg, **kwargs):
+        super().__init__(model_cfg)
+        self.cla_layer = _conv_stack(self.model_cfg.CLS_FC.CHANNELS)
+        self.vote_layer = _conv_stack(self.model_cfg.REG_FC.CHANNELS)
+        if self.model_cfg.TRANSFORMER_BLOCK.ENABLE:
+            self.transformer_block = build_transformer(self.model_cfg.TRANSFORMER_BLOCK)
+
+    # ------------------------------------------------------------------ losses (reference :29-62)
+    def get_cls_layer_loss(self, forward_ret_dict):
+        weights = self.model_cfg.LOSS_CONFIG.LOSS_WEIGHTS
+        loss = self.cls_loss_func(forward_ret_dict['pred_centroids_cls'].view(-1),
+                                  forward_ret_dict['cls_label'].view(-1))
+        tb_dict = {'centroids_cls_loss': loss.item()}
+        return loss.float() * weights['centroids_cls_weight'], tb_dict
+
+    def get_reg_layer_loss(self, forward_ret_dict):
+        weights = self.model_cfg.LOSS_CONFIG.LOSS_WEIGHTS
+        mask = forward_ret_dict['cls_label']
+        pred = forward_ret_dict['pred_centroids_votes']
+        target = forward_ret_dict['reg_label'][:, None, :3].expand_as(pred)
+        loss = self.reg_loss_func(pred, target)
+        loss = (loss.mean(2) * mask).sum() / (mask.sum() + 1e-06)
+        tb_dict = {'centroids_reg_loss': loss.item()}
+        return loss.float() * weights['centroids_reg_weight'], tb_dict
+
+    def get_loss(self, tb_dict=None):
+        tb_dict = {} if tb_dict is None else tb_dict
+        loss_cls, tb1 = self.get_cls_layer_loss(self.forward_ret_dict)
+        loss_reg, tb2 = self.get_reg_layer_loss(self.forward_ret_dict)
+        tb_dict.update(tb1)
+        tb_dict.update(tb2)
+        return (loss_cls + loss_reg).float(), tb_dict
+
+    # ------------------------------------------------------------------ forward (reference :64-109)
+    def forward(self, batch_dict):
+        seeds_xyz = batch_dict['search_seeds'].transpose(1, 2).contiguous()      # (B,3,N)
+        feats = batch_dict['cosine_feats']                                        # (B,C,N)
+
+        if hasattr(self, 'transformer_block'):
+            fused = self.transformer_block(xyz=batch_dict['search_seeds'],
+                                           features=feats.transpose(1, 2).contiguous())[0]
+            feats = fused.transpose(1, 2).contiguous()
+
+        if getattr(self.model_cfg, 'CLS_USE_SEARCH_XYZ', False):
+            feats = torch.cat((seeds_xyz, feats), dim=1)
+            cls_out = self.cla_layer(feats).squeeze(1)
+            vote_in = feats
+        else:
+            cls_out = self.cla_layer(feats).squeeze(1)
+            vote_in = torch.cat((seeds_xyz, feats), dim=1)
+        cls_pred = cls_out.squeeze(0)
+        score = cls_out.sigmoid()
+        voted = vote_in + self.vote_layer(vote_in)
+
+        batch_dict['pred_centroids_cls'] = cls_pred
+        batch_dict['pred_centroids_votes'] = voted[:, 0:3, :].transpose(1, 2).contiguous()       # (B,N,3)
+        batch_dict['votes_feats'] = torch.cat((score.unsqueeze(1), voted[:, 3:, :]), dim=1)      # (B,1+C,N)
+
+        if self.training:
+            self.forward_ret_dict = {
+                'pred_centroids_cls': batch_dict['pred_centroids_cls'],
+                'pred_centroids_votes': batch_dict['pred_centroids_votes'],
+                'cls_label': batch_dict['cls_label'].gather(1, batch_dict['search_inds']),
+                'reg_label': batch_dict['reg_label'],
+            }
+        return batch_dict

@@ -11,7 +11,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import AttnDesc, SaDesc, SaLayer
+from ._lib import AttnDesc, SaDesc, SaLayer, XcorrDesc
 
 
 def _stream():
@@ -272,6 +272,46 @@ def sa_fused_forward(xyz, new_xyz, idx, features, layers, radius, use_xyz=True, 
     with torch.cuda.device(xyz.device), _timed('ptt_sa_fused_fwd_f32'):
         _lib.check(_lib.lib().ptt_sa_fused_fwd_f32(ctypes.byref(d), _stream()), "ptt_sa_fused_fwd_f32")
     return out
+
+
+def xcorr_fused(search_feats, templ_feats, P, w_sim, scale0, shift0, layers, eps=1e-8, want_sim=False):
+    """Fused CosineSimAug core (similarity_modules/p2b_xcoor.py:25-42): cosine map, concat, SharedMLP, max over
+    the template axis. search_feats (B,C,Ns) / templ_feats (B,C,Nt) in any strides; P (B,Nt,C0) = layer-0
+    pre-activation without the similarity term; layers = remaining (wpacked, scale, shift, cin, cout, relu).
+    Returns (out (B,Cout,Ns) as a view of point-major storage, sim (B,Nt,Ns) | None)."""
+    for t_, n_ in ((search_feats, "search_feats"), (templ_feats, "templ_feats")):
+        if not t_.is_cuda or t_.dtype != torch.float32 or t_.dim() != 3:
+            raise RuntimeError("%s must be a (B,C,N) float32 device tensor" % n_)
+    _chk(P, "P", torch.float32, 3)
+    B, C, Ns = search_feats.shape
+    Nt = templ_feats.shape[2]
+    C0 = P.shape[2]
+    cout = layers[-1][4]
+    store = torch.empty((B, Ns, cout), dtype=torch.float32, device=P.device)
+    out = store.transpose(1, 2)
+    sim = torch.empty((B, Nt, Ns), dtype=torch.float32, device=P.device) if want_sim else None
+    d = XcorrDesc()
+    d.search_feat = search_feats.data_ptr()
+    d.s_sb, d.s_sc, d.s_sn = search_feats.stride()
+    d.templ_feat = templ_feats.data_ptr()
+    d.t_sb, d.t_sc, d.t_sn = templ_feats.stride()
+    d.P, d.w_sim = P.data_ptr(), w_sim.data_ptr()
+    d.scale0 = scale0.data_ptr() if scale0 is not None else None
+    d.shift0 = shift0.data_ptr() if shift0 is not None else None
+    d.out = out.data_ptr()
+    d.out_sb, d.out_sc, d.out_sn = out.stride()
+    d.sim_out = sim.data_ptr() if sim is not None else None
+    d.B, d.Ns, d.Nt, d.C, d.C0, d.eps = B, Ns, Nt, C, C0, float(eps)
+    d.n_layers = len(layers)
+    for i, (wp, sc, sh, cin, co, relu) in enumerate(layers):
+        L = d.layers[i]
+        L.Wpacked = wp.data_ptr()
+        L.scale = sc.data_ptr() if sc is not None else None
+        L.shift = sh.data_ptr() if sh is not None else None
+        L.Cin, L.Cout, L.relu = int(cin), int(co), int(bool(relu))
+    with torch.cuda.device(P.device), _timed('ptt_xcorr_fused_fwd_f32'):
+        _lib.check(_lib.lib().ptt_xcorr_fused_fwd_f32(ctypes.byref(d), _stream()), "ptt_xcorr_fused_fwd_f32")
+    return out, sim
 
 
 def pt_attn_pair(xyz, knn_idx, qkv, wd1, bd1, wd2p, bd2, wg1p, bg1, wg2p, bg2, d_model, want_attn=True):

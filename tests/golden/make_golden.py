@@ -20,6 +20,8 @@ Fixtures:
   G5 transformer.npz       TransformerBlock res + attn samples, N=128 and N=64, duplicated points
   G7 index_ops.npz         op-level edge cases (duplicates, zero cloud, origin ball, under-filled balls)
   G8 knn_argsort.npz       kNN vs the reference's square_distance + argsort on tie-free inputs
+  G9 cosine_sim_aug.npz    CosineSimAug (N1): cosine map samples + cosine_feats
+  G6 ptt_forward.npz       full PTT.forward (eval) through the reference's own heads (N2) + state_dict key/shape list
 """
 import os
 import sys
@@ -36,7 +38,8 @@ sys.path.insert(0, ROOT)
 from oracle import dense_ref as R           # noqa: E402
 from oracle import index_ops as O           # noqa: E402
 from ptt_amd import synth                   # noqa: E402
-from tests.util import mlp_layers, transformer_params   # noqa: E402
+from tests.util import (cosine_sim_params, fill_state_dict_, load_cosine_sim, mlp_layers,   # noqa: E402
+                        transformer_params)
 
 
 def _install_stubs():
@@ -213,6 +216,44 @@ def main():
     assert np.array_equal(ref_idx.numpy(), mine_idx.astype(np.int64))
     save("G8_knn_argsort.npz", xyz=x8, knn=ref_idx.numpy().astype(np.int32))
     report.append("G8 kNN: oracle == reference square_distance+argsort on tie-free clouds")
+
+    # ---------------- G9 CosineSimAug (N1) ----------------
+    from ptt.models.similarity_modules.p2b_xcoor import CosineSimAug as RefCSA
+    mlp9, conv9 = cosine_sim_params(909)
+    csa = RefCSA(EasyDict(dict(DEBUG=False, MLP=dict(CHANNELS=[260, 256, 256, 256], BN=True),
+                               CONV=dict(CHANNELS=[256, 256, 256], BN=True)))).eval()
+    load_cosine_sim(csa, mlp9, conv9)
+    rs9 = np.random.RandomState(909)
+    sfe = rs9.standard_normal((2, 256, 128)).astype(np.float32)
+    tfe = rs9.standard_normal((2, 256, 64)).astype(np.float32)
+    tfe[1, :, 5] = 0.0                                                     # a zero template feature: cosine eps path
+    txy = rs9.uniform(-2, 2, (2, 64, 3)).astype(np.float32)
+    with torch.no_grad():
+        bd = csa({'search_feats': torch.from_numpy(sfe), 'template_feats': torch.from_numpy(tfe),
+                  'template_seeds': torch.from_numpy(txy)})
+    my, msim = R.cosine_sim_aug(torch.from_numpy(sfe), torch.from_numpy(tfe), torch.from_numpy(txy), mlp9, conv9)
+    d9 = float((bd['cosine_feats'] - my).abs().max())
+    assert d9 < 1e-5, d9
+    save("G9_cosine_sim_aug.npz", search_feats=sfe, template_feats=tfe, template_xyz=txy, seed=909,
+         cosine_feats=bd['cosine_feats'].numpy(), sim=msim.numpy())
+    report.append("G9 CosineSimAug: oracle vs reference max diff %.2e" % d9)
+
+    # ---------------- G6 full PTT.forward (N2) ----------------
+    from ptt.config import cfg_from_yaml_file as ref_cfg_from_yaml
+    from ptt.models import build_network as ref_build_network
+    from ptt_amd.config import StubDataset
+    rcfg = ref_cfg_from_yaml(os.path.join(REF, "tools/cfgs/kitti_models/ptt.yaml"), EasyDict())
+    ref_model = fill_state_dict_(ref_build_network(rcfg.MODEL, 1, StubDataset()), 606).eval()
+    s6, t6 = synth.frames(606, 2, 1024, 512)
+    with torch.no_grad():
+        out6 = ref_model({'search_points': torch.from_numpy(s6), 'template_points': torch.from_numpy(t6), 'batch_size': 2})
+    keys6 = sorted(ref_model.state_dict().keys())
+    save("G6_ptt_forward.npz", search=s6, template=t6, seed=606,
+         state_keys=np.array(keys6), state_shapes=np.array([str(tuple(ref_model.state_dict()[k].shape)) for k in keys6]),
+         **{k: out6[k].numpy() for k in ('search_inds', 'template_inds', 'cosine_feats', 'pred_centroids_cls',
+                                         'pred_centroids_votes', 'votes_feats', 'pred_box_center', 'pred_box_data')})
+    report.append("G6 full PTT.forward written: %d state_dict keys, %d parameters" %
+                  (len(keys6), sum(p.numel() for p in ref_model.parameters())))
 
     # ---------------- G7 op-level edge cases (authored here; no reference implementation exists) ----------------
     rs7 = np.random.RandomState(707)

@@ -11,7 +11,7 @@ import torch
 
 from oracle import dense_ref as R
 from oracle import index_ops as O
-from tests.util import mlp_layers, transformer_params
+from tests.util import cosine_sim_params, mlp_layers, transformer_params
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -70,6 +70,16 @@ def test_G5_transformer_block(N):
     np.testing.assert_allclose(res.numpy(), g["res%d" % N], atol=2e-5, rtol=2e-5)
     np.testing.assert_allclose(attn[:, ::16, :, ::32].numpy(), g["attn_sample%d" % N], atol=1e-6, rtol=1e-5)
     np.testing.assert_allclose(attn.sum(-2).numpy(), 1.0, atol=1e-5)     # softmax over the neighbour axis
+
+
+def test_G9_cosine_sim_aug():
+    g = _g("G9_cosine_sim_aug.npz")
+    mlp, conv = cosine_sim_params(int(g["seed"]))
+    y, sim = R.cosine_sim_aug(torch.from_numpy(g["search_feats"]), torch.from_numpy(g["template_feats"]),
+                              torch.from_numpy(g["template_xyz"]), mlp, conv)
+    np.testing.assert_allclose(y.numpy(), g["cosine_feats"], atol=1e-5, rtol=1e-5)
+    np.testing.assert_allclose(sim.numpy(), g["sim"], atol=1e-6)
+    assert np.abs(g["sim"][1, 5]).max() == 0.0            # zero template feature -> cosine 0 (eps clamp), not NaN
 
 
 def test_G7_index_op_edge_cases():
@@ -160,3 +170,29 @@ def test_state_dict_keys_match_reference_contract():
     assert tuple(sd["backbone_3d.SA_modules.0.mlp_module.layer0.conv.weight"].shape) == (64, 3, 1, 1)
     tb = sum(v.numel() for k, v in sd.items() if k.startswith("box_transformer."))
     assert tb == 1839360                                                    # SURVEY.md §8a T3 [probe]
+
+
+def test_G6_state_dict_keys_and_shapes_equal_the_reference_model():
+    """N2: our assembled PTT has exactly the reference model's state_dict (175 keys, every shape) — checkpoints load."""
+    from ptt_amd.config import StubDataset, ptt_model_cfg
+    from ptt_amd.models import build_network
+    g = _g("G6_ptt_forward.npz")
+    m = build_network(ptt_model_cfg(), 1, StubDataset())
+    sd = m.state_dict()
+    assert sorted(sd.keys()) == list(g["state_keys"])
+    assert [str(tuple(sd[k].shape)) for k in sorted(sd.keys())] == list(g["state_shapes"])
+    assert sum(p.numel() for p in m.parameters()) == 4903113
+
+
+def test_config_mirror_semantics(tmp_path):
+    from ptt_amd.config import EasyDict, cfg_from_list, cfg_from_yaml_file
+    base = tmp_path / "base.yaml"
+    base.write_text("A: {x: 1, y: [1, 2]}\nB: hello\n")
+    top = tmp_path / "top.yaml"
+    top.write_text("_BASE_CONFIG_: %s\nA: {x: 5}\nC: {d: {e: 0.5}}\n" % base)
+    c = cfg_from_yaml_file(str(top), EasyDict())
+    assert c.A.x == 5 and c.A.y == [1, 2] and c.B == "hello" and c.C.d.e == 0.5
+    cfg_from_list(["A.x", "7", "A.y", "3,4", "B", "bye"], c)
+    assert c.A.x == 7 and c.A.y == [3, 4] and c.B == "bye"
+    with pytest.raises(AssertionError):
+        cfg_from_list(["A.nope", "1"], c)

@@ -56,3 +56,58 @@ def fold_layers(layers, dev, ops):
         out.append((ops.pack_weight(w, rot), scale.to(dev).contiguous(), shift.to(dev).contiguous(),
                     w.shape[1], w.shape[0], True))
     return out
+
+
+def cosine_sim_params(seed):
+    """Weights of CosineSimAug (SharedMLP [260,256,256,256] + Seq conv stack) as oracle.dense_ref.cosine_sim_aug wants."""
+    rs = np.random.RandomState(seed)
+    mlp = mlp_layers(seed, [260, 256, 256, 256])
+    t = lambda a: torch.from_numpy(a.astype(np.float32))
+    conv = {"conv0_weight": t(rs.standard_normal((256, 256, 1)) / 16), "bn0_weight": t(rs.uniform(0.5, 1.5, 256)),
+            "bn0_bias": t(rs.standard_normal(256) * 0.1), "bn0_mean": t(rs.standard_normal(256) * 0.2),
+            "bn0_var": t(rs.uniform(0.5, 1.5, 256)), "conv1_weight": t(rs.standard_normal((256, 256, 1)) / 16),
+            "conv1_bias": t(rs.standard_normal(256) * 0.1)}
+    return mlp, conv
+
+
+def load_cosine_sim(module, mlp, conv):
+    """Copy those weights into a CosineSimAug module (reference's or ours: same attribute names)."""
+    with torch.no_grad():
+        for unit, L in zip(module.mlp, mlp):
+            unit.conv.weight.copy_(L["conv_weight"])
+            bn = unit.normlayer.bn
+            bn.weight.copy_(L["bn_weight"]); bn.bias.copy_(L["bn_bias"])
+            bn.running_mean.copy_(L["bn_mean"]); bn.running_var.copy_(L["bn_var"])
+        c0, c1 = module.conv[0], module.conv[1]
+        c0.conv.weight.copy_(conv["conv0_weight"])
+        c0.normlayer.bn.weight.copy_(conv["bn0_weight"]); c0.normlayer.bn.bias.copy_(conv["bn0_bias"])
+        c0.normlayer.bn.running_mean.copy_(conv["bn0_mean"]); c0.normlayer.bn.running_var.copy_(conv["bn0_var"])
+        c1.conv.weight.copy_(conv["conv1_weight"]); c1.conv.bias.copy_(conv["conv1_bias"])
+
+
+def fill_state_dict_(model, seed):
+    """Deterministic numpy-seeded values for EVERY entry of model.state_dict(), in sorted key order, so that two
+    models with the same key set (the reference's and ours) end up with identical weights on any box."""
+    rs = np.random.RandomState(seed)
+    sd = model.state_dict()
+    new = {}
+    for k in sorted(sd.keys()):
+        v = sd[k]
+        shape = tuple(v.shape)
+        if not v.is_floating_point():
+            new[k] = torch.zeros_like(v)
+        elif k.endswith("running_var"):
+            new[k] = torch.from_numpy(rs.uniform(0.5, 1.5, shape).astype(np.float32))
+        elif k.endswith("running_mean"):
+            new[k] = torch.from_numpy((rs.standard_normal(shape) * 0.2).astype(np.float32))
+        elif k.endswith("bn.weight"):
+            new[k] = torch.from_numpy(rs.uniform(0.5, 1.5, shape).astype(np.float32))
+        elif k.endswith("pos_weight"):
+            new[k] = v.clone()
+        elif len(shape) >= 2:
+            fan_in = int(np.prod(shape[1:]))
+            new[k] = torch.from_numpy((rs.standard_normal(shape) * np.sqrt(2.0 / fan_in)).astype(np.float32))
+        else:
+            new[k] = torch.from_numpy((rs.standard_normal(shape) * 0.1).astype(np.float32))
+    model.load_state_dict(new)
+    return model
