@@ -61,6 +61,7 @@ def main():
     ap.add_argument("--nt", type=int, default=1024, help="template points per frame")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--no-full-model", action="store_true", help="skip the secondary full PTT.forward measurement")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="do not overlap the FPS of batch n+1 with the dense kernels of batch n")
     ap.add_argument("--cpu-frames", type=int, default=8)
@@ -179,6 +180,26 @@ def main():
     index_ops = {"fps": {"alg_GBps": fps_gbs, "ms_per_step": fps_ms, "frac_of_hbm_peak": (fps_gbs or 0) / PEAK_HBM_GBS},
                  "ball_query": {"alg_GBps": bq_gbs, "ms_per_step": bq_ms, "frac_of_hbm_peak": (bq_gbs or 0) / PEAK_HBM_GBS}}
 
+    # ---- secondary line: the FULL tracker forward (hot path + CosineSimAug + both heads), same batch, graph replay ----
+    full = None
+    if rank == 0 and world == 1 and not args.no_full_model:
+        from ptt_amd.config import StubDataset, ptt_model_cfg
+        from ptt_amd.models import build_network
+        tracker = randomize_(build_network(ptt_model_cfg(), 1, StubDataset()), seed=0).to(dev).eval()
+        gfull = GraphedHotPath(lambda s, t: tracker({'search_points': s, 'template_points': t, 'batch_size': B}),
+                               search, template)
+        for _ in range(3):
+            gfull()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            gfull()
+        torch.cuda.synchronize()
+        dtf = time.perf_counter() - t1
+        full = {"metric": "full PTT.forward frames/sec (eval; backbone + CosineSimAug + centroid and box heads)",
+                "value": round(B * args.steps / dtf, 2), "ms_per_step": round(dtf / args.steps * 1e3, 4),
+                "launch": "hipGraph replay, not pipelined across batches"}
+
     # ---- CPU baseline: rank 0, N=1 only, bounded sample ----
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -237,6 +258,7 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
             "index_ops": index_ops,
+            "full_model": full,
             "kernel_ms_per_step": kernel_ms,
         }
         if cpu:

@@ -129,6 +129,8 @@ class GraphedHotPath(object):
     launches. Inputs are copied into static buffers; outputs are the captured tensors."""
 
     def __init__(self, model, search_points, template_points, warmup=3):
+        """`model`: any callable (search (B,NS,3), template (B,NT,3)) -> outputs, e.g. FrameHotPath or a full tracker
+        wrapped as lambda s, t: tracker({'search_points': s, 'template_points': t})."""
         self.model = model
         self.search = search_points.clone()
         self.template = template_points.clone()
