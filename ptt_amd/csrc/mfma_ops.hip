@@ -26,6 +26,9 @@
 #ifndef PTT_PAIR_PF
 #define PTT_PAIR_PF 1
 #endif
+#ifndef PTT_SA_WAVES        // waves per SIMD the SA chain kernel is register-budgeted for
+#define PTT_SA_WAVES 2
+#endif
 // GEMM loop flavours (gemm_core's PF): 0 = two register sets pinned with sched_barrier (best for the SA
 // chain, measured), 1 = one-block prefetch scheduled by hipcc (best for the pair kernel and the linear
 // layers), 2 = two blocks in flight (slower everywhere: the L2->CU path saturates).
@@ -494,7 +497,7 @@ __device__ __forceinline__ void sa_layer(const SaParams& p, const SaLayerDev& L,
 }
 
 template <int NS>
-__global__ __launch_bounds__(256, 2) void sa_fused_kernel(SaParams p) {
+__global__ __launch_bounds__(256, PTT_SA_WAVES) void sa_fused_kernel(SaParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Xs = smem;                                      // [64][ldk]
     constexpr int CPW = 64 / NS;
