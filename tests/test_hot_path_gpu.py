@@ -98,3 +98,69 @@ def test_graphed_and_pipelined_drivers_match_eager(dev):
     for out, ref in zip(outs, eager):
         for k in ("search_inds", "template_inds", "search_feats", "box_feats", "pred_box_center"):
             assert torch.equal(out[k], ref[k]), k
+
+
+def _cfg5():
+    """BASELINE.json configs[4] geometry: 16384-pt search / 4096-pt template, 3 SA levels, KITTI radii/MLPs."""
+    cfg = kitti_model_cfg()
+    cfg.BACKBONE_3D.SA_CONFIG.NPOINTS_SEARCH = [8192, 4096, 2048]
+    cfg.BACKBONE_3D.SA_CONFIG.NPOINTS_TEMPLATE = [2048, 1024, 512]
+    return cfg
+
+
+def test_config5_stress_shapes_match_oracle(dev):
+    """Largest configuration (register-resident FPS at N=16384, kNN at N=2048, 2048-seed transformer) vs the oracle."""
+    cfg = _cfg5()
+    model = randomize_(FrameHotPath(cfg), seed=11).eval()
+    s, t = synth.frames(31, 1, 16384, 4096, kind="dense")
+    with torch.no_grad():
+        ref = frame_ref.frame(model.state_dict(), cfg, torch.from_numpy(s), torch.from_numpy(t))
+        got = model.to(dev)(torch.from_numpy(s).to(dev), torch.from_numpy(t).to(dev))
+    for k in ("search_inds", "template_inds"):
+        np.testing.assert_array_equal(got[k].cpu().numpy(), ref[k].numpy())
+    assert tuple(got["search_feats"].shape) == (1, 256, 2048)
+    for k in ("search_feats", "template_feats", "centroid_feats", "box_feats"):
+        np.testing.assert_allclose(got[k].cpu().numpy(), ref[k].numpy(), err_msg=k, **TOL)
+
+
+def test_full_size_batch_properties(dev):
+    """BASELINE configs[1] and [2] at full batch (48 frames): properties that need no oracle."""
+    model = randomize_(FrameHotPath(kitti_model_cfg()), seed=5).to(dev).eval()
+    for kind, K in (("car", (600, 300)), ("ped", (60, 40))):
+        s, t = synth.frames(77, 48, 2048, 1024, K_s=K[0], K_t=K[1], kind=kind, zero_clouds=1 if kind == "ped" else 0)
+        sd, td = torch.from_numpy(s).to(dev), torch.from_numpy(t).to(dev)
+        with torch.no_grad():
+            out = model(sd, td)
+            out_half = model(sd[:24].contiguous(), td[:24].contiguous())
+        inds = out["search_inds"]
+        assert inds.dtype == torch.int64 and int(inds.min()) >= 0 and int(inds.max()) < 2048
+        # seeds are the gathered raw points (index composition, pointnet2_backbone.py:48)
+        seeds = torch.gather(sd, 1, inds[..., None].expand(-1, -1, 3))
+        assert torch.equal(seeds, out["search_seeds"])
+        for k in ("search_feats", "box_feats", "centroid_feats"):
+            assert torch.isfinite(out[k]).all(), k
+            # frames are independent: a half batch gives bit-identical results for its frames
+            assert torch.equal(out[k][:24], out_half[k]), k
+        if kind == "ped":                                   # the all-zero cloud: every index 0, finite features
+            assert int(inds[-1].abs().max()) == 0
+
+
+def test_full_tracker_training_step_runs(dev):
+    """N3 (today's form): train mode = the reference op sequence on the HIP ops + stock layers, autograd through
+    gather/group; one forward + backward + Adam step of the whole tracker."""
+    from ptt_amd.config import StubDataset, ptt_model_cfg
+    from ptt_amd.models import build_network
+    model = build_network(ptt_model_cfg(), 1, StubDataset(training=True)).to(dev).train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, betas=(0.5, 0.999), eps=1e-6)
+    s, t = synth.frames(3, 4, 1024, 512)
+    batch = {'search_points': torch.from_numpy(s).to(dev), 'template_points': torch.from_numpy(t).to(dev),
+             'batch_size': 4, 'cls_label': (torch.rand(4, 1024, device=dev) > 0.7).float(),
+             'reg_label': torch.randn(4, 4, device=dev) * 0.3}
+    ret, tb, disp = model(batch)
+    loss = ret['loss'].mean()
+    assert torch.isfinite(loss)
+    loss.backward()
+    torch.nn.utils.clip_grad_norm_(model.parameters(), 10)
+    opt.step()
+    g = model.backbone_3d.SA_modules[1].mlp_module.layer0.conv.weight.grad
+    assert g is not None and torch.isfinite(g).all() and float(g.abs().sum()) > 0
