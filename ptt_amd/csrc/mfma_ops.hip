@@ -26,6 +26,9 @@
 #ifndef PTT_PAIR_PF
 #define PTT_PAIR_PF 1
 #endif
+#ifndef PTT_GATHER_BATCH     // feature rows a wave keeps in flight while grouping
+#define PTT_GATHER_BATCH 16
+#endif
 #ifndef PTT_SA_WAVES        // waves per SIMD the SA chain kernel is register-budgeted for
 #define PTT_SA_WAVES 2
 #endif
@@ -391,16 +394,16 @@ __device__ __forceinline__ void sa_gather_rows(const SaParams& p, float* Xt, int
     if (p.vec_gather) {                                  // point-major rows: one float4 per lane per row
         const int nq = p.C >> 2;
 #pragma unroll
-        for (int base = 0; base < ROWS; base += 16) {
-            f32x4 v[16];
+        for (int base = 0; base < ROWS; base += PTT_GATHER_BATCH) {
+            f32x4 v[PTT_GATHER_BATCH];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
+            for (int i = 0; i < PTT_GATHER_BATCH; ++i) {
                 const int bb = __builtin_amdgcn_readlane(b_l, base + i), nn = __builtin_amdgcn_readlane(n_l, base + i);
                 const float* src = p.feat + (long long)bb * p.fsb + (long long)nn * p.fsn;
                 if (lane < nq) v[i] = *reinterpret_cast<const f32x4*>(src + lane * 4);
             }
 #pragma unroll
-            for (int i = 0; i < 16; ++i)
+            for (int i = 0; i < PTT_GATHER_BATCH; ++i)
                 if (lane < nq) *reinterpret_cast<f32x4*>(Xt + (row0 + base + i) * p.ldk + lane * 4) = v[i];
         }
     } else {                                             // any strides: 64/ROWS lane groups stride over the channels

@@ -113,3 +113,46 @@ def test_full_size_properties(dev):
     assert float(d2.max()) < 0.3 * 0.3 + 1e-6          # every returned neighbour is inside the ball
     first = bq[..., :1]
     assert (bq >= first).all()                          # first slot is the lowest-index hit
+
+
+def test_randomised_shapes_against_oracle(dev):
+    """40 random (B, N, npoint / M, radius, nsample / k) draws incl. tiny clouds, N not a multiple of the wave size,
+    heavy duplication and coarse grids (exact ties): indices must stay bit-identical to the oracle."""
+    rs = np.random.RandomState(2024)
+    for trial in range(40):
+        B = int(rs.randint(1, 5))
+        N = int(rs.choice([1, 2, 3, 7, 31, 63, 64, 65, 100, 127, 129, 255, 257, 500, 777, 1023, 1025, 1500, 3000, 5000]))
+        mode = trial % 4
+        if mode == 0:
+            xyz = rs.uniform(-3, 3, (B, N, 3)).astype(np.float32)
+        elif mode == 1:
+            base = rs.uniform(-3, 3, (B, max(1, N // 5), 3)).astype(np.float32)
+            xyz = np.stack([base[b][rs.randint(0, base.shape[1], N)] for b in range(B)])          # duplicates
+        elif mode == 2:
+            xyz = rs.uniform(-1, 1, (B, N, 3)).round(1).astype(np.float32)                          # grid: exact ties
+        else:
+            xyz = rs.uniform(-0.05, 0.05, (B, N, 3)).astype(np.float32)                             # mostly inside the origin ball
+        npoint = int(rs.randint(1, N + 1))
+        t = _dev(xyz, dev)
+        np.testing.assert_array_equal(ops.furthest_point_sampling(t, npoint).cpu().numpy(), O.fps(xyz, npoint),
+                                      err_msg="fps trial %d N=%d npoint=%d mode=%d" % (trial, N, npoint, mode))
+        M = int(rs.randint(1, min(N, 200) + 1))
+        centres = xyz[:, rs.randint(0, N, M)] + rs.uniform(-0.1, 0.1, (B, M, 3)).astype(np.float32)
+        r, ns = float(rs.choice([0.05, 0.3, 0.7, 2.0])), int(rs.choice([1, 4, 16, 32, 50]))
+        np.testing.assert_array_equal(ops.ball_query(_dev(centres, dev), t, r, ns).cpu().numpy(),
+                                      O.ball_query(centres, xyz, r, ns), err_msg="ball query trial %d" % trial)
+        if N <= 1100:                                    # the O(N^2 k) oracle gets slow beyond this
+            k = int(rs.randint(1, min(N, 20) + 1))
+            np.testing.assert_array_equal(ops.knn(t, k).cpu().numpy(), O.knn(xyz, k), err_msg="knn trial %d" % trial)
+
+
+def test_argument_errors_are_loud(dev):
+    t = torch.zeros(1, 8, 3, device=dev)
+    with pytest.raises(RuntimeError):
+        ops.knn(t, 9)                                    # k > N
+    with pytest.raises(RuntimeError):
+        ops.ball_query(t, t.double(), 0.3, 4)            # dtype
+    with pytest.raises(RuntimeError):
+        ops.furthest_point_sampling(t.transpose(1, 2), 4)   # non-contiguous
+    with pytest.raises(RuntimeError):
+        ops.group_points(torch.zeros(1, 4, 8, device=dev), torch.zeros(1, 2, 3, device=dev), )   # idx dtype
