@@ -292,21 +292,23 @@ __device__ __forceinline__ void lin_stage(float* Xs, int t, const f32x4 (&st)[RT
     }
 }
 
-template <int RT, bool VEC>
+template <int RT, bool VEC, int CT>   // a workgroup owns RT*32 rows x CT*128 columns
 __global__ __launch_bounds__(256, 2) void linear_kernel(LinearParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Xs = smem;                                    // 2 x [RT*32][LIN_LDK]
     constexpr int BUF = RT * 32 * LIN_LDK;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int row0 = blockIdx.x * 32 * RT;
-    const int ctbase = blockIdx.y * 8 + w;               // this wave's first column tile, the second is +4
+    const int ctbase = blockIdx.y * (4 * CT) + w;        // this wave's first column tile, the next is +4
     int nvalid = 0;
-    if (ctbase < p.NT) nvalid = (ctbase + 4 < p.NT) ? 2 : 1;
+#pragma unroll
+    for (int u = 0; u < CT; ++u)
+        if (ctbase + 4 * u < p.NT) nvalid = u + 1;
     const int nchunks = (p.nkb * 8 + LIN_KC - 1) / LIN_KC;
     const size_t bstep = (size_t)p.NT * 64;
 
     f32x4 st[RT * 4];
-    f32x16 acc[RT][2];
+    f32x16 acc[RT][CT];
     zero_acc(acc);
     lin_fetch<RT, VEC>(p, row0, 0, t, st);
     lin_stage<RT>(Xs, t, st);
@@ -315,7 +317,7 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(LinearParams p) {
         float* cur = Xs + (c & 1) * BUF;
         if (c + 1 < nchunks) lin_fetch<RT, VEC>(p, row0, (c + 1) * LIN_KC, t, st);
         const int nkb_c = min(LIN_KC / 8, p.nkb - c * (LIN_KC / 8));
-        gemm_tiles<RT, 2, 1>(cur, LIN_LDK, nkb_c, reinterpret_cast<const f32x4*>(p.Wp) + (size_t)c * (LIN_KC / 8) * bstep,
+        gemm_tiles<RT, CT, 1>(cur, LIN_LDK, nkb_c, reinterpret_cast<const f32x4*>(p.Wp) + (size_t)c * (LIN_KC / 8) * bstep,
                           p.NT, ctbase, nvalid, lane, acc);
         if (c + 1 < nchunks) {
             lin_stage<RT>(Xs + ((c + 1) & 1) * BUF, t, st);   // the other buffer: last read in chunk c-1
@@ -326,7 +328,7 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(LinearParams p) {
 
     const int half = lane >> 5;
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < CT; ++u) {
         if (u >= nvalid) break;
         const int col = (ctbase + 4 * u) * 32 + (lane & 31);
         if (col >= p.Cout) continue;
@@ -893,22 +895,25 @@ extern "C" int ptt_linear_f32(const float* X, int rows, int K, int ldx, const fl
     p.rows = rows; p.K = K; p.ldx = ldx; p.Cout = Cout; p.relu = relu; p.ldr = ldr; p.ldo = ldo;
     p.nkb = (K + 7) / 8; p.NT = (Cout + 31) / 32;
     p.vec_ok = ((ldx & 3) == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0) ? 1 : 0;
-    const int colgroups = (p.NT + 7) / 8;
-    // 64-row tiles halve the weight traffic per FLOP; keep 32-row tiles when that would leave CUs idle
-    const bool big = (long long)((rows + 63) / 64) * colgroups >= 512;
-    hipStream_t s = as_stream(stream);
+    // Tile choice (measured on all six GEMM shapes of the path, scripts/kernel_bench.py SWEEP_LINEAR=1): the smallest
+    // tile, 32 rows x 128 columns, wins everywhere (qkv 93 vs 75 TFLOP/s for 64x256): these launches are only
+    // 1-10 GFLOP, so workgroup count (>= 4 per CU, fine-grained tails) matters more than weight reuse per workgroup.
     const bool vec = p.vec_ok && (K & 3) == 0;
-    const int lds = 2 * (big ? 64 : 32) * LIN_LDK * (int)sizeof(float);
-    const void* fn;
-    if (big) fn = vec ? reinterpret_cast<const void*>(linear_kernel<2, true>) : reinterpret_cast<const void*>(linear_kernel<2, false>);
-    else fn = vec ? reinterpret_cast<const void*>(linear_kernel<1, true>) : reinterpret_cast<const void*>(linear_kernel<1, false>);
-    int rc = set_lds_limit(fn, lds);
-    if (rc) return rc;
-    const dim3 grid(big ? (rows + 63) / 64 : (rows + 31) / 32, colgroups);
-    if (big && vec) hipLaunchKernelGGL((linear_kernel<2, true>), grid, dim3(256), lds, s, p);
-    else if (big) hipLaunchKernelGGL((linear_kernel<2, false>), grid, dim3(256), lds, s, p);
-    else if (vec) hipLaunchKernelGGL((linear_kernel<1, true>), grid, dim3(256), lds, s, p);
-    else hipLaunchKernelGGL((linear_kernel<1, false>), grid, dim3(256), lds, s, p);
+    const int rt64 = (rows + 63) / 64, rt32 = (rows + 31) / 32, cg256 = (p.NT + 7) / 8, cg128 = (p.NT + 3) / 4;
+    int RT = 1, CT = 1;
+    if (const char* e = getenv("PTT_LINEAR_TILE")) { RT = (e[0] == '2') ? 2 : 1; CT = (e[1] == '2') ? 2 : 1; }   // dev: "11","12","21","22"
+    const int lds = 2 * (RT * 32) * LIN_LDK * (int)sizeof(float);
+    const dim3 grid(RT == 2 ? rt64 : rt32, CT == 2 ? cg256 : cg128);
+    hipStream_t s = as_stream(stream);
+    int rc = PTT_OK;
+#define PTT_LIN_CASE(R, V, C)                                                                                  \
+    if (RT == R && vec == V && CT == C) {                                                                      \
+        if ((rc = set_lds_limit(reinterpret_cast<const void*>(linear_kernel<R, V, C>), lds))) return rc;       \
+        hipLaunchKernelGGL((linear_kernel<R, V, C>), grid, dim3(256), lds, s, p);                              \
+    }
+    PTT_LIN_CASE(1, true, 1) PTT_LIN_CASE(1, true, 2) PTT_LIN_CASE(2, true, 1) PTT_LIN_CASE(2, true, 2)
+    PTT_LIN_CASE(1, false, 1) PTT_LIN_CASE(1, false, 2) PTT_LIN_CASE(2, false, 1) PTT_LIN_CASE(2, false, 2)
+#undef PTT_LIN_CASE
     return check_launch("linear_kernel");
 }
 

@@ -83,7 +83,7 @@ def main():
 
     # ---- linear ----
     for name, rows, K, Cout in (("lin_fc1", B * 128, 256, 512), ("lin_qkv", B * 128, 512, 1536), ("lin_fc2", B * 128, 512, 256),
-                                ("lin_cov", B * 128, 256, 256)):
+                                ("lin_cov", B * 128, 256, 256), ("lin_qkv64", B * 64, 512, 1536), ("lin_fc2_64", B * 64, 512, 256)):
         if not want(name):
             continue
         x = torch.randn(rows, K, device=dev)
@@ -92,6 +92,12 @@ def main():
         fn = lambda: ops.linear(x, w, Cout, None, b)
         ms = timeit(fn, a.iters)
         print("%-14s %8.4f ms  %7.2f TFLOP/s" % (name, ms, 2.0 * rows * K * Cout / ms / 1e9))
+        if os.environ.get("SWEEP_LINEAR"):
+            for tile in ("11", "12", "21", "22"):
+                os.environ["PTT_LINEAR_TILE"] = tile
+                ms = timeit(fn, a.iters)
+                print("   tile RT,CT=%s %8.4f ms  %7.2f TFLOP/s" % (tile, ms, 2.0 * rows * K * Cout / ms / 1e9))
+            os.environ.pop("PTT_LINEAR_TILE")
 
     # ---- FPS ----
     for name, N, m in (("fps_2048", 2048, 512), ("fps_1024", 1024, 256), ("fps_128", 128, 64)):
