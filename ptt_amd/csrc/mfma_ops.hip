@@ -371,7 +371,8 @@ struct SaParams {
 // ------------------------------------------------------------------------------------------
 template <int NS, int ROWS>
 __device__ __forceinline__ void sa_gather_rows(const SaParams& p, float* Xt, int row0, int centre0, int lane) {
-    static_assert(ROWS == 16 || ROWS == 32, "rows per wave");
+    static_assert(ROWS == 8 || ROWS == 16 || ROWS == 32, "rows per wave");
+    constexpr int GB = ROWS < PTT_GATHER_BATCH ? ROWS : PTT_GATHER_BATCH;
     const int total_centres = p.B * p.M;
     const int Kpad0 = p.L[0].nkb * 8;
     int b_l = 0, n_l = 0;
@@ -396,16 +397,16 @@ __device__ __forceinline__ void sa_gather_rows(const SaParams& p, float* Xt, int
     if (p.vec_gather) {                                  // point-major rows: one float4 per lane per row
         const int nq = p.C >> 2;
 #pragma unroll
-        for (int base = 0; base < ROWS; base += PTT_GATHER_BATCH) {
-            f32x4 v[PTT_GATHER_BATCH];
+        for (int base = 0; base < ROWS; base += GB) {
+            f32x4 v[GB];
 #pragma unroll
-            for (int i = 0; i < PTT_GATHER_BATCH; ++i) {
+            for (int i = 0; i < GB; ++i) {
                 const int bb = __builtin_amdgcn_readlane(b_l, base + i), nn = __builtin_amdgcn_readlane(n_l, base + i);
                 const float* src = p.feat + (long long)bb * p.fsb + (long long)nn * p.fsn;
                 if (lane < nq) v[i] = *reinterpret_cast<const f32x4*>(src + lane * 4);
             }
 #pragma unroll
-            for (int i = 0; i < PTT_GATHER_BATCH; ++i)
+            for (int i = 0; i < GB; ++i)
                 if (lane < nq) *reinterpret_cast<f32x4*>(Xt + (row0 + base + i) * p.ldk + lane * 4) = v[i];
         }
     } else {                                             // any strides: 64/ROWS lane groups stride over the channels
@@ -426,16 +427,17 @@ __device__ __forceinline__ void sa_gather_rows(const SaParams& p, float* Xt, int
     }
 }
 
-template <int NS, int CT>
+template <int NS, int CT, int RT = 2>
 __device__ __forceinline__ void sa_layer(const SaParams& p, const SaLayerDev& L, bool last, float* Xs, int lane, int w,
                                          int centre0, int ncentres) {
-    f32x16 acc[2][CT];
+    static_assert(NS != 64 || RT == 2, "a 64-neighbour centre spans two row tiles");
+    f32x16 acc[RT][CT];
     zero_acc(acc);
     int nvalid = 0;
 #pragma unroll
     for (int u = 0; u < CT; ++u)
         if (w + 4 * u < L.NT) nvalid = u + 1;
-    gemm_tiles<2, CT, 0>(Xs, p.ldk, L.nkb, reinterpret_cast<const f32x4*>(L.Wp), L.NT, w, nvalid, lane, acc);
+    gemm_tiles<RT, CT, 0>(Xs, p.ldk, L.nkb, reinterpret_cast<const f32x4*>(L.Wp), L.NT, w, nvalid, lane, acc);
     __syncthreads();  // every wave has finished reading this layer's input tile
 
     const int half = lane >> 5;
@@ -448,7 +450,7 @@ __device__ __forceinline__ void sa_layer(const SaParams& p, const SaLayerDev& L,
         const float sh = (L.shift && colok) ? L.shift[col] : 0.f;
         float m64 = -__builtin_inff();                 // NS == 64: one centre spans both row tiles
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
+        for (int rt = 0; rt < RT; ++rt) {
             float y[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -464,7 +466,7 @@ __device__ __forceinline__ void sa_layer(const SaParams& p, const SaLayerDev& L,
 #pragma unroll
                 for (int r = 1; r < 16; ++r) m = fmaxf(m, y[r]);
                 m64 = fmaxf(m64, max_halves(m));
-                if (rt == 1 && half == 0 && colok && ncentres > 0) {
+                if (rt == RT - 1 && half == 0 && colok && ncentres > 0) {
                     const int b = centre0 / p.M, mm = centre0 - b * p.M;
                     p.out[b * p.osb + col * p.osc + mm * p.osm] = m64;
                 }
@@ -501,11 +503,11 @@ __device__ __forceinline__ void sa_layer(const SaParams& p, const SaLayerDev& L,
     if (!last) __syncthreads();
 }
 
-template <int NS>
+template <int NS, int RT>
 __global__ __launch_bounds__(256, PTT_SA_WAVES) void sa_fused_kernel(SaParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Xs = smem;                                      // [64][ldk]
-    constexpr int CPW = 64 / NS;
+    float* Xs = smem;                                      // [32*RT][ldk]
+    constexpr int CPW = 32 * RT / NS;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int total_centres = p.B * p.M;
     const int centre0 = blockIdx.x * CPW;
@@ -514,8 +516,8 @@ __global__ __launch_bounds__(256, PTT_SA_WAVES) void sa_fused_kernel(SaParams p)
 #define PTT_STAMP(i) do { if (p.dbg && t == 0 && blockIdx.x < 4096) p.dbg[blockIdx.x * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
     PTT_STAMP(0);
 
-    // ---- group: neighbour features + relative (normalised) coordinates -> X; wave w fills rows 16w..16w+15 ----
-    sa_gather_rows<NS, 16>(p, Xs, w * 16, centre0, lane);
+    // ---- group: neighbour features + relative (normalised) coordinates -> X; wave w fills 8*RT consecutive rows ----
+    sa_gather_rows<NS, 8 * RT>(p, Xs, w * 8 * RT, centre0, lane);
     __syncthreads();
 
     PTT_STAMP(1);
@@ -523,8 +525,8 @@ __global__ __launch_bounds__(256, PTT_SA_WAVES) void sa_fused_kernel(SaParams p)
         const SaLayerDev& L = p.L[l];
         const bool last = (l == p.n_layers - 1);
         const int ctw = (L.NT + 3) >> 2;
-        if (ctw <= 1) sa_layer<NS, 1>(p, L, last, Xs, lane, w, centre0, ncentres);
-        else sa_layer<NS, 2>(p, L, last, Xs, lane, w, centre0, ncentres);
+        if (ctw <= 1) sa_layer<NS, 1, RT>(p, L, last, Xs, lane, w, centre0, ncentres);
+        else sa_layer<NS, 2, RT>(p, L, last, Xs, lane, w, centre0, ncentres);
         PTT_STAMP(2 + l);
     }
 #undef PTT_STAMP
@@ -983,15 +985,19 @@ extern "C" int ptt_sa_fused_fwd_f32(const ptt_sa_desc* d, ptt_stream_t stream) {
         }
         return check_launch("sa_wave_kernel");
     }
-    const int lds = 64 * p.ldk * (int)sizeof(float);
+    int RT = 2;                                          // rows per workgroup = 32 * RT
+    if (const char* e = getenv("PTT_SA_RT")) RT = (atoi(e) == 1) ? 1 : 2;      // dev: A/B switch
+    const int lds = 32 * RT * p.ldk * (int)sizeof(float);
     if (lds > 160 * 1024) return fail(PTT_EUNSUPPORTED, "ptt_sa_fused_fwd_f32: %d B of LDS per workgroup", lds);
-    if (d->nsample == 32) {
-        if ((rc = set_lds_limit(reinterpret_cast<const void*>(sa_fused_kernel<32>), lds))) return rc;
-        hipLaunchKernelGGL((sa_fused_kernel<32>), dim3((total_centres + 1) / 2), dim3(256), lds, s, p);
-    } else {
-        if ((rc = set_lds_limit(reinterpret_cast<const void*>(sa_fused_kernel<16>), lds))) return rc;
-        hipLaunchKernelGGL((sa_fused_kernel<16>), dim3((total_centres + 3) / 4), dim3(256), lds, s, p);
+    const int cpw = 32 * RT / d->nsample;
+    const dim3 grid((total_centres + cpw - 1) / cpw);
+#define PTT_SA_CASE(NSV, RTV)                                                                                   \
+    if (d->nsample == NSV && RT == RTV) {                                                                       \
+        if ((rc = set_lds_limit(reinterpret_cast<const void*>(sa_fused_kernel<NSV, RTV>), lds))) return rc;     \
+        hipLaunchKernelGGL((sa_fused_kernel<NSV, RTV>), grid, dim3(256), lds, s, p);                            \
     }
+    PTT_SA_CASE(32, 2) PTT_SA_CASE(32, 1) PTT_SA_CASE(16, 2) PTT_SA_CASE(16, 1)
+#undef PTT_SA_CASE
     return check_launch("sa_fused_kernel");
 }
 
