@@ -924,8 +924,8 @@ extern "C" int ptt_sa_fused_fwd_f32(const ptt_sa_desc* d, ptt_stream_t stream) {
     if (d->B < 0 || d->N <= 0 || d->M < 0 || d->C < 0 || d->n_layers < 1 || d->n_layers > PTT_SA_MAX_LAYERS)
         return fail(PTT_EINVAL, "ptt_sa_fused_fwd_f32: B=%d N=%d M=%d C=%d layers=%d", d->B, d->N, d->M, d->C,
                     d->n_layers);
-    if (d->nsample != 16 && d->nsample != 32)
-        return fail(PTT_EUNSUPPORTED, "ptt_sa_fused_fwd_f32: nsample=%d (16 and 32 are instantiated)", d->nsample);
+    if (d->nsample != 16 && d->nsample != 32 && d->nsample != 64)
+        return fail(PTT_EUNSUPPORTED, "ptt_sa_fused_fwd_f32: nsample=%d (16, 32 and 64 are instantiated)", d->nsample);
     if (d->B == 0 || d->M == 0) return PTT_OK;
     if (!d->xyz || !d->new_xyz || !d->idx || !d->out || (d->C > 0 && !d->feat))
         return fail(PTT_EINVAL, "ptt_sa_fused_fwd_f32: null pointer");
@@ -972,7 +972,7 @@ extern "C" int ptt_sa_fused_fwd_f32(const ptt_sa_desc* d, ptt_stream_t stream) {
         if (!(nt == 1 || nt == 2 || nt == 4)) wave_ok = false;
     }
     if (const char* e = getenv("PTT_SA_WAVE")) wave_ok = wave_ok && atoi(e) != 0;   // dev: A/B switch
-    if (wave_ok && wbytes <= 64 * 1024) {
+    if (wave_ok && wbytes <= 64 * 1024 && d->nsample <= 32) {
         const int lds = 4 * 32 * p.ldk * (int)sizeof(float);
         const int cpw = 32 / d->nsample, per_wg = 4 * cpw;
         const dim3 grid((total_centres + per_wg - 1) / per_wg);
@@ -987,6 +987,7 @@ extern "C" int ptt_sa_fused_fwd_f32(const ptt_sa_desc* d, ptt_stream_t stream) {
     }
     int RT = 2;                                          // rows per workgroup = 32 * RT
     if (const char* e = getenv("PTT_SA_RT")) RT = (atoi(e) == 1) ? 1 : 2;      // dev: A/B switch
+    if (d->nsample == 64) RT = 2;                        // one centre = two row tiles
     const int lds = 32 * RT * p.ldk * (int)sizeof(float);
     if (lds > 160 * 1024) return fail(PTT_EUNSUPPORTED, "ptt_sa_fused_fwd_f32: %d B of LDS per workgroup", lds);
     const int cpw = 32 * RT / d->nsample;
@@ -996,7 +997,7 @@ extern "C" int ptt_sa_fused_fwd_f32(const ptt_sa_desc* d, ptt_stream_t stream) {
         if ((rc = set_lds_limit(reinterpret_cast<const void*>(sa_fused_kernel<NSV, RTV>), lds))) return rc;     \
         hipLaunchKernelGGL((sa_fused_kernel<NSV, RTV>), grid, dim3(256), lds, s, p);                            \
     }
-    PTT_SA_CASE(32, 2) PTT_SA_CASE(32, 1) PTT_SA_CASE(16, 2) PTT_SA_CASE(16, 1)
+    PTT_SA_CASE(32, 2) PTT_SA_CASE(32, 1) PTT_SA_CASE(16, 2) PTT_SA_CASE(16, 1) PTT_SA_CASE(64, 2)
 #undef PTT_SA_CASE
     return check_launch("sa_fused_kernel");
 }

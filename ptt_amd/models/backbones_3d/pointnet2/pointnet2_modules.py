@@ -59,7 +59,7 @@ class PointnetSAModuleVotes(nn.Module):
 
     # ------------------------------------------------------------------ fused-path parameters
     def _fusable(self, xyz, features):
-        if self.training or not xyz.is_cuda or self.sample_uniformly or self.nsample not in (16, 32):
+        if self.training or not xyz.is_cuda or self.sample_uniformly or self.nsample not in (16, 32, 64):
             return False
         if features is not None and features.dtype != torch.float32:
             return False

@@ -52,6 +52,7 @@ SA_CASES = [
     (256, 128, 256, [259, 128, 128, 256], 0.7, 32),
     (128, 64, 257, [260, 256, 256, 256], 0.3, 16),
     (200, 50, 5, [8, 32, 96], 0.4, 16),
+    (300, 40, 12, [15, 64, 128], 0.6, 64),      # nsample 64: one centre spans both row tiles
 ]
 
 
