@@ -810,14 +810,18 @@ __global__ __launch_bounds__(256, 2) void pt_attn_pair_kernel(AttnParams p) {
     gemm_core<1, CT, CT, 4, PTT_PAIR_PF>(Xs, LDK, NKB, reinterpret_cast<const f32x4*>(p.Wg2p), NT, w, lane, acc);
     PTT_STAMP(6);
     const float inv_sqrt_d = 1.0f / sqrtf((float)D);
+    // all 64 neighbour values of this lane are requested before any softmax arithmetic: one L2 round trip
+    // instead of eight (the gathers, not the math, were the length of this phase)
+    float vv[CT][16];
+#pragma unroll
+    for (int u = 0; u < CT; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) vv[u][r] = p.qkv[(size_t)nrow[r] * 3 * D + 2 * D + cols[u]];
 #pragma unroll
     for (int u = 0; u < CT; ++u) {
         const float bb = p.bg2[cols[u]];
 #pragma unroll
         for (int pp = 0; pp < 2; ++pp) {
-            float vv[8];                                   // neighbour values: in flight while the softmax is computed
-#pragma unroll
-            for (int r = 0; r < 8; ++r) vv[r] = p.qkv[(size_t)nrow[pp * 8 + r] * 3 * D + 2 * D + cols[u]];
             float s[8];
             float m = -__builtin_inff();
 #pragma unroll
@@ -836,7 +840,7 @@ __global__ __launch_bounds__(256, 2) void pt_attn_pair_kernel(AttnParams p) {
             for (int r = 0; r < 8; ++r) {
                 const int rr = pp * 8 + r;
                 const float a = s[r] * rsum;
-                o += a * (vv[r] + delta[0][u][rr]);
+                o += a * (vv[u][rr] + delta[0][u][rr]);
                 if (p.attn && pp < npts) {
                     const int row = tile_row(rr, half);  // = pp*16 + j
                     p.attn[((size_t)(pt0 + pp) * KNN + (row & 15)) * D + cols[u]] = a;
