@@ -103,6 +103,11 @@ int ptt_group_grad_f32(const float* grad_out, const int32_t* idx, int B, int C, 
  * ------------------------------------------------------------------------------- */
 int ptt_knn_f32(const float* xyz, int B, int N, int k, int32_t* idx_out,
                 ptt_stream_t stream);
+/* Same, additionally writing rel_out (B,N,k,3) = xyz_i - xyz_neighbour, the input of fc_delta
+ * (variants.py:158 `xyz[:, :, None] - knn_xyz`): the pair kernel then starts without a dependent
+ * index -> coordinate round trip. rel_out may be NULL. */
+int ptt_knn_rel_f32(const float* xyz, int B, int N, int k, int32_t* idx_out, float* rel_out,
+                    ptt_stream_t stream);
 
 /* ---------------------------------------------------------------------------------
  * Weight packing for the fp32-MFMA kernels.
@@ -209,6 +214,7 @@ int ptt_xcorr_fused_fwd_f32(const ptt_xcorr_desc* d, ptt_stream_t stream);
  * ------------------------------------------------------------------------------- */
 typedef struct ptt_attn_desc {
     const float* xyz;      /* (B,N,3) */
+    const float* rel;      /* (B,N,k,3) from ptt_knn_rel_f32, or NULL (computed from xyz and knn) */
     const int32_t* knn;    /* (B,N,k) */
     const float* qkv;      /* (B,N,3*D) */
     const float* Wd1;      /* fc_delta[0].weight (D,3) row-major, unpacked */

@@ -15,7 +15,7 @@ PTT_SA_MAX_LAYERS = 4
 EXPORTS = [
     "ptt_version", "ptt_error_name", "ptt_last_error_string",
     "ptt_fps_f32", "ptt_gather_f32", "ptt_gather_grad_f32", "ptt_select_centres_f32", "ptt_ball_query_f32",
-    "ptt_group_f32", "ptt_group_grad_f32", "ptt_knn_f32",
+    "ptt_group_f32", "ptt_group_grad_f32", "ptt_knn_f32", "ptt_knn_rel_f32",
     "ptt_packed_weight_elems", "ptt_pack_weight_f32", "ptt_pack_weight_rot_f32", "ptt_linear_f32",
     "ptt_sa_fused_fwd_f32", "ptt_xcorr_fused_fwd_f32", "ptt_pt_attn_pair_f32",
 ]
@@ -46,7 +46,7 @@ class XcorrDesc(Structure):
 
 
 class AttnDesc(Structure):
-    _fields_ = [("xyz", c_void_p), ("knn", c_void_p), ("qkv", c_void_p),
+    _fields_ = [("xyz", c_void_p), ("rel", c_void_p), ("knn", c_void_p), ("qkv", c_void_p),
                 ("Wd1", c_void_p), ("bd1", c_void_p), ("Wd2p", c_void_p), ("bd2", c_void_p),
                 ("Wg1p", c_void_p), ("bg1", c_void_p), ("Wg2p", c_void_p), ("bg2", c_void_p),
                 ("res", c_void_p), ("attn", c_void_p),
@@ -71,6 +71,7 @@ def _declare(lib):
         "ptt_group_f32": [vp, vp, i, i, i, i, i, vp, vp],
         "ptt_group_grad_f32": [vp, vp, i, i, i, i, i, vp, vp],
         "ptt_knn_f32": [vp, i, i, i, vp, vp],
+        "ptt_knn_rel_f32": [vp, i, i, i, vp, vp, vp],
         "ptt_pack_weight_f32": [vp, i, i, vp, vp],
         "ptt_pack_weight_rot_f32": [vp, i, i, i, vp, vp],
         "ptt_linear_f32": [vp, i, i, i, vp, i, vp, vp, i, vp, i, vp, i, vp],

@@ -693,7 +693,7 @@ __global__ __launch_bounds__(256, 3) void sa_wave_kernel(SaParams p) {
 // and all D = 512 channels; wave w owns column tiles w, w+4, w+8, w+12.
 // ------------------------------------------------------------------------------------------
 struct AttnParams {
-    const float* xyz; const int32_t* knn; const float* qkv; const float* Wd1; const float* bd1;
+    const float* xyz; const float* rel; const int32_t* knn; const float* qkv; const float* Wd1; const float* bd1;
     const float* Wd2p; const float* bd2; const float* Wg1p; const float* bg1; const float* Wg2p; const float* bg2;
     float* res; float* attn;
     int BN, N, first_wave, stagger;
@@ -729,9 +729,14 @@ __global__ __launch_bounds__(256, 2) void pt_attn_pair_kernel(AttnParams p) {
         const int n = p.knn[(size_t)pt * KNN + (t & 15)];
         const int flat = b * p.N + n;
         nb[t] = flat;
-        dxyz[t * 3 + 0] = p.xyz[(size_t)pt * 3 + 0] - p.xyz[(size_t)flat * 3 + 0];
-        dxyz[t * 3 + 1] = p.xyz[(size_t)pt * 3 + 1] - p.xyz[(size_t)flat * 3 + 1];
-        dxyz[t * 3 + 2] = p.xyz[(size_t)pt * 3 + 2] - p.xyz[(size_t)flat * 3 + 2];
+        if (p.rel) {                                   // precomputed by the kNN kernel: no index -> xyz dependency
+            const float* rl = p.rel + ((size_t)pt * KNN + (t & 15)) * 3;
+            dxyz[t * 3 + 0] = rl[0]; dxyz[t * 3 + 1] = rl[1]; dxyz[t * 3 + 2] = rl[2];
+        } else {
+            dxyz[t * 3 + 0] = p.xyz[(size_t)pt * 3 + 0] - p.xyz[(size_t)flat * 3 + 0];
+            dxyz[t * 3 + 1] = p.xyz[(size_t)pt * 3 + 1] - p.xyz[(size_t)flat * 3 + 1];
+            dxyz[t * 3 + 2] = p.xyz[(size_t)pt * 3 + 2] - p.xyz[(size_t)flat * 3 + 2];
+        }
     }
     __syncthreads();
 
@@ -1057,7 +1062,7 @@ extern "C" int ptt_pt_attn_pair_f32(const ptt_attn_desc* d, ptt_stream_t stream)
         !d->Wg2p || !d->bg2 || !d->res)
         return fail(PTT_EINVAL, "ptt_pt_attn_pair_f32: null pointer");
     AttnParams p;
-    p.xyz = d->xyz; p.knn = d->knn; p.qkv = d->qkv; p.Wd1 = d->Wd1; p.bd1 = d->bd1; p.Wd2p = d->Wd2p; p.bd2 = d->bd2;
+    p.xyz = d->xyz; p.rel = d->rel; p.knn = d->knn; p.qkv = d->qkv; p.Wd1 = d->Wd1; p.bd1 = d->bd1; p.Wd2p = d->Wd2p; p.bd2 = d->bd2;
     p.Wg1p = d->Wg1p; p.bg1 = d->bg1; p.Wg2p = d->Wg2p; p.bg2 = d->bg2; p.res = d->res; p.attn = d->attn;
     p.BN = d->B * d->N; p.N = d->N;
     p.first_wave = 512; p.stagger = 8;

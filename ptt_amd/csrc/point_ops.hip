@@ -257,7 +257,7 @@ static inline int grid_for(size_t total, int block) {
 // ------------------------------------------------------------------------------------------
 template <int P>
 __global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ xyz, int BN, int N, int k,
-                                                  int32_t* __restrict__ idx_out) {
+                                                  int32_t* __restrict__ idx_out, float* __restrict__ rel_out) {
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q >= BN) return;
     const int lane = threadIdx.x & 63;
@@ -283,6 +283,10 @@ __global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ xyz,
         const float wmin = wave_min_f32(best);
         const int sel = wave_min_i32((best == wmin) ? besti : INT_MAX);
         if (lane == 0) out[r] = sel;
+        if (rel_out && lane == (sel & 63)) {           // the owning lane also emits xyz_query - xyz_neighbour
+            float* ro = rel_out + ((size_t)q * k + r) * 3;
+            ro[0] = qx - pts[3 * sel + 0]; ro[1] = qy - pts[3 * sel + 1]; ro[2] = qz - pts[3 * sel + 2];
+        }
         // retire the winner: it can never be the minimum again
 #pragma unroll
         for (int i = 0; i < P; ++i)
@@ -399,7 +403,15 @@ extern "C" int ptt_group_grad_f32(const float* grad_out, const int32_t* idx, int
     return check_launch("group_grad_kernel");
 }
 
+extern "C" int ptt_knn_rel_f32(const float* xyz, int B, int N, int k, int32_t* idx_out, float* rel_out,
+                               ptt_stream_t stream);
+
 extern "C" int ptt_knn_f32(const float* xyz, int B, int N, int k, int32_t* idx_out, ptt_stream_t stream) {
+    return ptt_knn_rel_f32(xyz, B, N, k, idx_out, nullptr, stream);
+}
+
+extern "C" int ptt_knn_rel_f32(const float* xyz, int B, int N, int k, int32_t* idx_out, float* rel_out,
+                               ptt_stream_t stream) {
     if (B < 0 || N <= 0 || k <= 0 || k > N) return fail(PTT_EINVAL, "ptt_knn_f32: B=%d N=%d k=%d", B, N, k);
     if (B == 0) return PTT_OK;
     if (!xyz || !idx_out) return fail(PTT_EINVAL, "ptt_knn_f32: null pointer");
@@ -408,7 +420,7 @@ extern "C" int ptt_knn_f32(const float* xyz, int B, int N, int k, int32_t* idx_o
     hipStream_t s = as_stream(stream);
 #define PTT_KNN_CASE(P)                                                                          \
     if (N <= 64 * P) {                                                                           \
-        hipLaunchKernelGGL((knn_kernel<P>), grid, block, 0, s, xyz, BN, N, k, idx_out);          \
+        hipLaunchKernelGGL((knn_kernel<P>), grid, block, 0, s, xyz, BN, N, k, idx_out, rel_out); \
         return check_launch("knn_kernel");                                                       \
     }
     PTT_KNN_CASE(1) PTT_KNN_CASE(2) PTT_KNN_CASE(4) PTT_KNN_CASE(8) PTT_KNN_CASE(16) PTT_KNN_CASE(32) PTT_KNN_CASE(64)

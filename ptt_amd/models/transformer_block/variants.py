@@ -72,11 +72,11 @@ class TransformerBlock(nn.Module):
             P = self._params()
             D = self.d_model
             xyz = xyz.contiguous()
-            knn_idx = ops.knn(xyz, self.k)
+            knn_idx, rel = ops.knn(xyz, self.k, want_rel=True)
             x = ops.linear(features, P['fc1'], D, None, P['fc1_b'])
             qkv = ops.linear(x, P['qkv'], 3 * D)
             res, attn = ops.pt_attn_pair(xyz, knn_idx, qkv, P['wd1'], P['bd1'], P['wd2'], P['bd2'], P['wg1'],
-                                         P['bg1'], P['wg2'], P['bg2'], D, self.materialize_attn)
+                                         P['bg1'], P['wg2'], P['bg2'], D, self.materialize_attn, rel=rel)
             res = ops.linear(res, P['fc2'], self.d_points, None, P['fc2_b'], False, features)
             return res, attn
 

@@ -175,15 +175,17 @@ furthest_point_sampling_with_dist = _unreached("furthest_point_sampling_with_dis
 
 
 # --------------------------------------------------------------------------- fused / MFMA ops
-def knn(xyz, k):
+def knn(xyz, k, want_rel=False):
     """(B,N,3) f32 -> (B,N,k) i32 ascending by (squared distance, index).
-    Replaces square_distance(xyz, xyz).argsort()[:, :, :k] (transformer_block/variants.py:150-151)."""
+    Replaces square_distance(xyz, xyz).argsort()[:, :, :k] (transformer_block/variants.py:150-151).
+    want_rel: also return rel (B,N,k,3) = xyz_i - xyz_neighbour (variants.py:158), for pt_attn_pair."""
     _chk(xyz, "xyz", torch.float32, 3)
     B, N, _ = xyz.shape
     out = torch.empty((B, N, int(k)), dtype=torch.int32, device=xyz.device)
+    rel = torch.empty((B, N, int(k), 3), dtype=torch.float32, device=xyz.device) if want_rel else None
     with torch.cuda.device(xyz.device), _timed('ptt_knn_f32'):
-        _lib.check(_lib.lib().ptt_knn_f32(_ptr(xyz), B, N, int(k), _ptr(out), _stream()), "ptt_knn_f32")
-    return out
+        _lib.check(_lib.lib().ptt_knn_rel_f32(_ptr(xyz), B, N, int(k), _ptr(out), _ptr(rel), _stream()), "ptt_knn_rel_f32")
+    return (out, rel) if want_rel else out
 
 
 def pack_weight(weight, rot=0):
@@ -314,7 +316,7 @@ def xcorr_fused(search_feats, templ_feats, P, w_sim, scale0, shift0, layers, eps
     return out, sim
 
 
-def pt_attn_pair(xyz, knn_idx, qkv, wd1, bd1, wd2p, bd2, wg1p, bg1, wg2p, bg2, d_model, want_attn=True):
+def pt_attn_pair(xyz, knn_idx, qkv, wd1, bd1, wd2p, bd2, wg1p, bg1, wg2p, bg2, d_model, want_attn=True, rel=None):
     """Fused per-(point,neighbour) part of TransformerBlock.forward (variants.py:158-163).
     Returns (res (B,N,D), attn (B,N,k,D) | None)."""
     _chk(xyz, "xyz", torch.float32, 3)
@@ -327,6 +329,7 @@ def pt_attn_pair(xyz, knn_idx, qkv, wd1, bd1, wd2p, bd2, wg1p, bg1, wg2p, bg2, d
     attn = torch.empty((B, N, k, D), dtype=torch.float32, device=xyz.device) if want_attn else None
     d = AttnDesc()
     d.xyz, d.knn, d.qkv = xyz.data_ptr(), knn_idx.data_ptr(), qkv.data_ptr()
+    d.rel = rel.data_ptr() if rel is not None else None
     d.Wd1, d.bd1, d.Wd2p, d.bd2 = wd1.data_ptr(), bd1.data_ptr(), wd2p.data_ptr(), bd2.data_ptr()
     d.Wg1p, d.bg1, d.Wg2p, d.bg2 = wg1p.data_ptr(), bg1.data_ptr(), wg2p.data_ptr(), bg2.data_ptr()
     d.res = res.data_ptr()
