@@ -114,7 +114,9 @@ __device__ __forceinline__ void gemm_mfma_block(const f32x4 (&a)[RT], const f32x
 //  form: the loop is bound by the L2->CU fetch path, not by load placement — see DESIGN.md.)
 template <int RT, int CT, int ACT, int CTS = 4, int PF = 1>   // CTS: distance (in column tiles) between this wave's tiles
 __device__ __forceinline__ void gemm_core(const float* Xs, int ldk, int nkb, const f32x4* __restrict__ Wp, int NT,
-                                          int ct0, int lane, f32x16 (&acc)[RT][ACT]) {
+                                          int ct0, int lane, f32x16 (&acc)[RT][ACT], const f32x4* pre = nullptr) {
+    // `pre` (PF == 0 only): the first K-block's CT weight fragments, already requested by the caller — issued
+    // before the previous layer's epilogue and barriers so that a layer does not start with an exposed L2 round trip
     static_assert(CT <= ACT, "accumulator array too narrow");
     const int row = lane & 31, half = lane >> 5;
     const float* arow = Xs + row * ldk + 4 * half;
@@ -130,7 +132,14 @@ __device__ __forceinline__ void gemm_core(const float* Xs, int ldk, int nkb, con
             _Pragma("unroll") for (int rt = 0; rt < RT; ++rt)                                 \
                 A[rt] = *reinterpret_cast<const f32x4*>(arow + rt * 32 * ldk + (KB) * 8);     \
         }
-        PTT_LOAD_BLOCK(a0, b0, 0)
+        if (pre) {
+#pragma unroll
+            for (int u = 0; u < CT; ++u) b0[u] = pre[u];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) a0[rt] = *reinterpret_cast<const f32x4*>(arow + rt * 32 * ldk);
+        } else {
+            PTT_LOAD_BLOCK(a0, b0, 0)
+        }
         int kb = 0;
 #pragma unroll 1
         for (; kb + 2 < nkb; kb += 2) {
@@ -226,15 +235,31 @@ __device__ __forceinline__ void gemm_core(const float* Xs, int ldk, int nkb, con
 // dispatch to compile-time tile counts.
 template <int RT, int CT, int PFM>
 __device__ __forceinline__ void gemm_tiles(const float* Xs, int ldk, int nkb, const f32x4* __restrict__ Wp, int NT,
-                                           int ct0, int nvalid, int lane, f32x16 (&acc)[RT][CT]) {
-    if (nvalid >= CT) gemm_core<RT, CT, CT, 4, PFM>(Xs, ldk, nkb, Wp, NT, ct0, lane, acc);
+                                           int ct0, int nvalid, int lane, f32x16 (&acc)[RT][CT],
+                                           const f32x4* pre = nullptr) {
+    if (nvalid >= CT) gemm_core<RT, CT, CT, 4, PFM>(Xs, ldk, nkb, Wp, NT, ct0, lane, acc, pre);
     else if constexpr (CT > 1) {
-        if (nvalid == 1) gemm_core<RT, 1, CT, 4, PFM>(Xs, ldk, nkb, Wp, NT, ct0, lane, acc);
+        if (nvalid == 1) gemm_core<RT, 1, CT, 4, PFM>(Xs, ldk, nkb, Wp, NT, ct0, lane, acc, pre);
         else if constexpr (CT > 2) {
-            if (nvalid == 2) gemm_core<RT, 2, CT, 4, PFM>(Xs, ldk, nkb, Wp, NT, ct0, lane, acc);
-            else if (nvalid == 3) gemm_core<RT, 3, CT, 4, PFM>(Xs, ldk, nkb, Wp, NT, ct0, lane, acc);
+            if (nvalid == 2) gemm_core<RT, 2, CT, 4, PFM>(Xs, ldk, nkb, Wp, NT, ct0, lane, acc, pre);
+            else if (nvalid == 3) gemm_core<RT, 3, CT, 4, PFM>(Xs, ldk, nkb, Wp, NT, ct0, lane, acc, pre);
         }
     }
+}
+
+// Workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not wait for outstanding
+// global loads (vmcnt), so weight fragments requested for the NEXT layer stay in flight across it.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// First K-block of a layer's weights for this wave's (up to 2) column tiles w, w+4.
+__device__ __forceinline__ void prefetch_first_block(const float* Wp, int NT, int w, int lane, f32x4 (&pre)[2]) {
+    const f32x4* bp = reinterpret_cast<const f32x4*>(Wp) + (size_t)w * 64 + lane;
+    if (w < NT) pre[0] = bp[0];
+    if (w + 4 < NT) pre[1] = bp[4 * 64];
 }
 
 template <int RT, int CT>
@@ -429,7 +454,7 @@ __device__ __forceinline__ void sa_gather_rows(const SaParams& p, float* Xt, int
 
 template <int NS, int CT, int RT = 2>
 __device__ __forceinline__ void sa_layer(const SaParams& p, const SaLayerDev& L, bool last, float* Xs, int lane, int w,
-                                         int centre0, int ncentres) {
+                                         int centre0, int ncentres, f32x4 (&pre)[2], const SaLayerDev* Lnext) {
     static_assert(NS != 64 || RT == 2, "a 64-neighbour centre spans two row tiles");
     f32x16 acc[RT][CT];
     zero_acc(acc);
@@ -437,8 +462,9 @@ __device__ __forceinline__ void sa_layer(const SaParams& p, const SaLayerDev& L,
 #pragma unroll
     for (int u = 0; u < CT; ++u)
         if (w + 4 * u < L.NT) nvalid = u + 1;
-    gemm_tiles<RT, CT, 0>(Xs, p.ldk, L.nkb, reinterpret_cast<const f32x4*>(L.Wp), L.NT, w, nvalid, lane, acc);
-    __syncthreads();  // every wave has finished reading this layer's input tile
+    gemm_tiles<RT, CT, 0>(Xs, p.ldk, L.nkb, reinterpret_cast<const f32x4*>(L.Wp), L.NT, w, nvalid, lane, acc, pre);
+    if (Lnext) prefetch_first_block(Lnext->Wp, Lnext->NT, w, lane, pre);   // in flight across the epilogue + barriers
+    lds_barrier();    // every wave has finished reading this layer's input tile
 
     const int half = lane >> 5;
 #pragma unroll
@@ -500,7 +526,7 @@ __device__ __forceinline__ void sa_layer(const SaParams& p, const SaLayerDev& L,
             }
         }
     }
-    if (!last) __syncthreads();
+    if (!last) lds_barrier();
 }
 
 template <int NS, int RT>
@@ -516,17 +542,21 @@ __global__ __launch_bounds__(256, PTT_SA_WAVES) void sa_fused_kernel(SaParams p)
 #define PTT_STAMP(i) do { if (p.dbg && t == 0 && blockIdx.x < 4096) p.dbg[blockIdx.x * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
     PTT_STAMP(0);
 
+    f32x4 pre[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    prefetch_first_block(p.L[0].Wp, p.L[0].NT, w, lane, pre);      // layer 0's first weight block rides along the gather
+
     // ---- group: neighbour features + relative (normalised) coordinates -> X; wave w fills 8*RT consecutive rows ----
     sa_gather_rows<NS, 8 * RT>(p, Xs, w * 8 * RT, centre0, lane);
-    __syncthreads();
+    lds_barrier();
 
     PTT_STAMP(1);
     for (int l = 0; l < p.n_layers; ++l) {
         const SaLayerDev& L = p.L[l];
         const bool last = (l == p.n_layers - 1);
         const int ctw = (L.NT + 3) >> 2;
-        if (ctw <= 1) sa_layer<NS, 1, RT>(p, L, last, Xs, lane, w, centre0, ncentres);
-        else sa_layer<NS, 2, RT>(p, L, last, Xs, lane, w, centre0, ncentres);
+        const SaLayerDev* Ln = last ? nullptr : &p.L[l + 1];
+        if (ctw <= 1) sa_layer<NS, 1, RT>(p, L, last, Xs, lane, w, centre0, ncentres, pre, Ln);
+        else sa_layer<NS, 2, RT>(p, L, last, Xs, lane, w, centre0, ncentres, pre, Ln);
         PTT_STAMP(2 + l);
     }
 #undef PTT_STAMP
@@ -561,6 +591,8 @@ __global__ __launch_bounds__(256, 2) void xcorr_fused_kernel(XcorrParams q) {
     const int j = blockIdx.x;                // flat search point b*Ns + jj
     const int b = j / p.M, jj = j - b * p.M;
     stagger_second_slot(p.first_wave, p.stagger);
+    f32x4 pre[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    prefetch_first_block(p.L[0].Wp, p.L[0].NT, w, lane, pre);
 
     // ---- 64 cosines: thread (i = t>>2, quarter = t&3) covers channels quarter, quarter+4, ... ----
     {
@@ -600,8 +632,9 @@ __global__ __launch_bounds__(256, 2) void xcorr_fused_kernel(XcorrParams q) {
         const SaLayerDev& L = p.L[l];
         const bool last = (l == p.n_layers - 1);
         const int ctw = (L.NT + 3) >> 2;
-        if (ctw <= 1) sa_layer<64, 1>(p, L, last, Xs, lane, w, j, 1);
-        else sa_layer<64, 2>(p, L, last, Xs, lane, w, j, 1);
+        const SaLayerDev* Ln = last ? nullptr : &p.L[l + 1];
+        if (ctw <= 1) sa_layer<64, 1>(p, L, last, Xs, lane, w, j, 1, pre, Ln);
+        else sa_layer<64, 2>(p, L, last, Xs, lane, w, j, 1, pre, Ln);
     }
 }
 
