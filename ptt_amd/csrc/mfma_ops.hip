@@ -115,7 +115,7 @@ __device__ __forceinline__ void gemm_mfma_block(const f32x4 (&a)[RT], const f32x
 template <int RT, int CT, int ACT, int CTS = 4, int PF = 1>   // CTS: distance (in column tiles) between this wave's tiles
 __device__ __forceinline__ void gemm_core(const float* Xs, int ldk, int nkb, const f32x4* __restrict__ Wp, int NT,
                                           int ct0, int lane, f32x16 (&acc)[RT][ACT], const f32x4* pre = nullptr) {
-    // `pre` (PF == 0 only): the first K-block's CT weight fragments, already requested by the caller — issued
+    // `pre` (PF 0 and 1): the first K-block's CT weight fragments, already requested by the caller — issued
     // before the previous layer's epilogue and barriers so that a layer does not start with an exposed L2 round trip
     static_assert(CT <= ACT, "accumulator array too narrow");
     const int row = lane & 31, half = lane >> 5;
@@ -170,7 +170,7 @@ __device__ __forceinline__ void gemm_core(const float* Xs, int ldk, int nkb, con
 #define PTT_WLOAD(ptr) (*(ptr))
 #endif
 #pragma unroll
-        for (int u = 0; u < CT; ++u) { bcur[u] = PTT_WLOAD(bp + (size_t)u * CTS * 64); bnxt[u] = bcur[u]; }
+        for (int u = 0; u < CT; ++u) { bcur[u] = pre ? pre[u] : PTT_WLOAD(bp + (size_t)u * CTS * 64); bnxt[u] = bcur[u]; }
         // the last block is peeled so that the loop body has NO conditional load: with a load under control
         // flow (run-time nkb) the waitcnt pass gives up counting and waits vmcnt(0) before every MFMA group
         for (int kb = 0; kb + 1 < nkb; ++kb) {
@@ -253,6 +253,14 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+}
+
+// First K-block of a GEMM's weights for this wave's CT column tiles w, w+4, ... (all exist).
+template <int CT>
+__device__ __forceinline__ void prefetch_first_block_full(const float* Wp, int w, int lane, f32x4 (&pre)[CT]) {
+    const f32x4* bp = reinterpret_cast<const f32x4*>(Wp) + (size_t)w * 64 + lane;
+#pragma unroll
+    for (int u = 0; u < CT; ++u) pre[u] = bp[(size_t)u * 4 * 64];
 }
 
 // First K-block of a layer's weights for this wave's (up to 2) column tiles w, w+4.
@@ -752,6 +760,8 @@ __global__ __launch_bounds__(256, 2) void pt_attn_pair_kernel(AttnParams p) {
         wd1[cc][0] = p.Wd1[c * 3 + 0]; wd1[cc][1] = p.Wd1[c * 3 + 1]; wd1[cc][2] = p.Wd1[c * 3 + 2];
         wd1[cc][3] = p.bd1[c];
     }
+    f32x4 pre[CT];
+    prefetch_first_block_full<CT>(p.Wd2p, w, lane, pre);    // fc_delta[2]'s first weight block rides along phase 0
     stagger_second_slot(p.first_wave, p.stagger);
     PTT_STAMP(0);
 
@@ -771,7 +781,7 @@ __global__ __launch_bounds__(256, 2) void pt_attn_pair_kernel(AttnParams p) {
             dxyz[t * 3 + 2] = p.xyz[(size_t)pt * 3 + 2] - p.xyz[(size_t)flat * 3 + 2];
         }
     }
-    __syncthreads();
+    lds_barrier();
 
     // fc_delta[0] + ReLU (K = 3) on the vector ALU, straight into the LDS tile
 #pragma unroll
@@ -784,7 +794,7 @@ __global__ __launch_bounds__(256, 2) void pt_attn_pair_kernel(AttnParams p) {
             Xs[r * LDK + c] = fmaxf(h, 0.f);
         }
     }
-    __syncthreads();
+    lds_barrier();
 
     PTT_STAMP(1);
     int cols[CT];
@@ -794,7 +804,8 @@ __global__ __launch_bounds__(256, 2) void pt_attn_pair_kernel(AttnParams p) {
     // ---- delta = fc_delta[2](h) ----
     f32x16 delta[1][CT];
     zero_acc(delta);
-    gemm_core<1, CT, CT, 4, PTT_PAIR_PF>(Xs, LDK, NKB, reinterpret_cast<const f32x4*>(p.Wd2p), NT, w, lane, delta);
+    gemm_core<1, CT, CT, 4, PTT_PAIR_PF>(Xs, LDK, NKB, reinterpret_cast<const f32x4*>(p.Wd2p), NT, w, lane, delta, pre);
+    prefetch_first_block_full<CT>(p.Wg1p, w, lane, pre);    // next GEMM's first block: in flight across the epilogue
 #pragma unroll
     for (int u = 0; u < CT; ++u) {
         const float bb = p.bd2[cols[u]];
@@ -806,7 +817,7 @@ __global__ __launch_bounds__(256, 2) void pt_attn_pair_kernel(AttnParams p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) nrow[r] = nb[tile_row(r, half)];
 
-    __syncthreads();  // all waves done with h
+    lds_barrier();  // all waves done with h
     // t = (q_i - k_j) + delta  -> X
     {
         const int pa = pt0, pb = (npts > 1) ? pt0 + 1 : pt0;
@@ -822,30 +833,31 @@ __global__ __launch_bounds__(256, 2) void pt_attn_pair_kernel(AttnParams p) {
             }
         }
     }
-    __syncthreads();
+    lds_barrier();
 
     PTT_STAMP(3);
     // ---- g = relu(fc_gamma[0](t)) -> X ----
     {
         f32x16 acc[1][CT];
         zero_acc(acc);
-        gemm_core<1, CT, CT, 4, PTT_PAIR_PF>(Xs, LDK, NKB, reinterpret_cast<const f32x4*>(p.Wg1p), NT, w, lane, acc);
+        gemm_core<1, CT, CT, 4, PTT_PAIR_PF>(Xs, LDK, NKB, reinterpret_cast<const f32x4*>(p.Wg1p), NT, w, lane, acc, pre);
+        prefetch_first_block_full<CT>(p.Wg2p, w, lane, pre);
         PTT_STAMP(4);
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int u = 0; u < CT; ++u) {
             const float bb = p.bg1[cols[u]];
 #pragma unroll
             for (int r = 0; r < 16; ++r) Xs[tile_row(r, half) * LDK + cols[u]] = fmaxf(acc[0][u][r] + bb, 0.f);
         }
-        __syncthreads();
+        lds_barrier();
     }
 
     // ---- a = fc_gamma[2](g); softmax over the 16 neighbours; res = sum attn * (v + delta) ----
     f32x16 acc[1][CT];
     zero_acc(acc);
     PTT_STAMP(5);
-    gemm_core<1, CT, CT, 4, PTT_PAIR_PF>(Xs, LDK, NKB, reinterpret_cast<const f32x4*>(p.Wg2p), NT, w, lane, acc);
+    gemm_core<1, CT, CT, 4, PTT_PAIR_PF>(Xs, LDK, NKB, reinterpret_cast<const f32x4*>(p.Wg2p), NT, w, lane, acc, pre);
     PTT_STAMP(6);
     const float inv_sqrt_d = 1.0f / sqrtf((float)D);
     // all 64 neighbour values of this lane are requested before any softmax arithmetic: one L2 round trip
