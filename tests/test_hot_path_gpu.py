@@ -164,3 +164,45 @@ def test_full_tracker_training_step_runs(dev):
     opt.step()
     g = model.backbone_3d.SA_modules[1].mlp_module.layer0.conv.weight.grad
     assert g is not None and torch.isfinite(g).all() and float(g.abs().sum()) > 0
+
+
+@pytest.mark.parametrize("variant", ["ptt", "p2b"])
+def test_full_tracker_eval_fused_equals_reference_op_sequence(dev, variant):
+    """Whole tracker in eval mode, module by module: the fused HIP kernels vs the reference's own op sequence (unfused
+    module paths on the HIP index ops + stock torch layers). Each module of the unfused pass consumes the fused pass's
+    inputs, so data-dependent index decisions (FPS / ball query / kNN on predicted votes) see identical coordinates.
+    'p2b' is tools/cfgs/kitti_models/p2b.yaml's MODEL section: transformers off, 'sequence' sampling everywhere."""
+    from ptt_amd.config import StubDataset, ptt_model_cfg
+    from ptt_amd.models import build_network
+    cfg = ptt_model_cfg()
+    if variant == "p2b":
+        cfg.BACKBONE_3D.SA_CONFIG.SAMPLE_METHOD = ['sequence', 'sequence', 'sequence']
+        cfg.CENTROID_HEAD.TRANSFORMER_BLOCK.ENABLE = False
+        cfg.BOX_HEAD.TRANSFORMER_BLOCK.ENABLE = False
+    model = randomize_(build_network(cfg, 1, StubDataset()), seed=11).to(dev).eval()
+    assert hasattr(model.box_voting_head, 'transformer_block') == (variant == "ptt")
+    s, t = synth.frames(21, 3, 1024, 512)
+    state = {'search_points': torch.from_numpy(s).to(dev), 'template_points': torch.from_numpy(t).to(dev),
+             'batch_size': 3}
+    stages = []
+    with torch.no_grad():
+        for module in model.module_list:
+            before = dict(state)
+            state = module(dict(state))
+            stages.append((module, before, state))
+        assert tuple(state['pred_box_data'].shape) == (3, 64, 5)
+        checked = set()
+        for module, before, after in stages:
+            for m in module.modules():
+                if hasattr(m, '_fusable'):
+                    m._fusable = lambda *a, **k: False
+            plain = module(dict(before))
+            for k in plain:
+                if k in before or not torch.is_tensor(plain[k]):
+                    continue
+                checked.add(k)
+                if plain[k].dtype.is_floating_point:
+                    np.testing.assert_allclose(after[k].cpu().numpy(), plain[k].cpu().numpy(), err_msg=k, **TOL)
+                else:
+                    np.testing.assert_array_equal(after[k].cpu().numpy(), plain[k].cpu().numpy(), err_msg=k)
+    assert {'search_feats', 'search_inds', 'cosine_feats', 'pred_centroids_votes', 'pred_box_data'} <= checked
