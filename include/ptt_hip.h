@@ -169,6 +169,17 @@ typedef struct ptt_sa_desc {
     int normalize_xyz;    /* divide them by radius (pointnet2_utils.py:353-354)        */
     int n_layers;
     ptt_sa_layer layers[PTT_SA_MAX_LAYERS];
+    /* Optional: layer 0 of the SharedMLP hoisted out of the grouped stage. The first Conv2d is linear in
+     * [rel ; f_n], so  layer0(centre i, neighbour n) = act(T[b][n][:] + Wx . rel(i,n))  with
+     *   T  = scale0 * (W0[:,3:] . f_n) + shift0     one row per POINT (ptt_linear_f32), (B,N,C0) contiguous
+     *   Wx = (scale0 * W0[:, 0:3])^T                (3,C0)
+     * which moves 2*C*C0 flop per grouped row (N*... rows instead of M*nsample) out of the kernel.
+     * When l0_point_term != NULL: use_xyz must be 1, feat/C are ignored and `layers` holds the REMAINING layers
+     * (layers[0].Cin == l0_channels). NULL = layer 0 runs inside the kernel on the gathered rows. */
+    const float* l0_point_term;
+    const float* l0_xyz_weight;
+    int l0_channels;
+    int l0_relu;
 } ptt_sa_desc;
 
 int ptt_sa_fused_fwd_f32(const ptt_sa_desc* d, ptt_stream_t stream);

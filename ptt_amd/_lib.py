@@ -32,7 +32,8 @@ class SaDesc(Structure):
                 ("out", c_void_p), ("out_sb", c_int64), ("out_sc", c_int64), ("out_sm", c_int64),
                 ("B", c_int), ("N", c_int), ("M", c_int), ("nsample", c_int), ("C", c_int),
                 ("radius", c_float), ("use_xyz", c_int), ("normalize_xyz", c_int), ("n_layers", c_int),
-                ("layers", SaLayer * PTT_SA_MAX_LAYERS)]
+                ("layers", SaLayer * PTT_SA_MAX_LAYERS),
+                ("l0_point_term", c_void_p), ("l0_xyz_weight", c_void_p), ("l0_channels", c_int), ("l0_relu", c_int)]
 
 
 class XcorrDesc(Structure):

@@ -389,6 +389,8 @@ struct SaParams {
     const float* xyz; const float* new_xyz; const int32_t* idx; const float* feat; float* out;
     long long fsb, fsc, fsn, osb, osc, osm;
     int B, N, M, C, use_xyz, normalize, n_layers, ldk, K0, first_wave, stagger, vec_gather;
+    int hoist, l0_relu;   // layer 0 hoisted: feat = per-point term (B,N,C), wx = (3,C) weights of the relative coordinates
+    const float* wx;
     float radius;
     long long* dbg;   // dev only (PTT_DEBUG_STAMPS)
     SaLayerDev L[PTT_SA_MAX_LAYERS];
@@ -409,6 +411,7 @@ __device__ __forceinline__ void sa_gather_rows(const SaParams& p, float* Xt, int
     const int total_centres = p.B * p.M;
     const int Kpad0 = p.L[0].nkb * 8;
     int b_l = 0, n_l = 0;
+    float dx = 0.f, dy = 0.f, dz = 0.f;
     if (lane < ROWS) {
         const int r = row0 + lane;
         int c = centre0 + r / NS;
@@ -417,18 +420,26 @@ __device__ __forceinline__ void sa_gather_rows(const SaParams& p, float* Xt, int
         n_l = p.idx[(size_t)c * NS + (r % NS)];
         if (p.use_xyz) {
             const size_t flat = (size_t)b_l * p.N + n_l;
-            float dx = p.xyz[flat * 3 + 0] - p.new_xyz[(size_t)c * 3 + 0];
-            float dy = p.xyz[flat * 3 + 1] - p.new_xyz[(size_t)c * 3 + 1];
-            float dz = p.xyz[flat * 3 + 2] - p.new_xyz[(size_t)c * 3 + 2];
+            dx = p.xyz[flat * 3 + 0] - p.new_xyz[(size_t)c * 3 + 0];
+            dy = p.xyz[flat * 3 + 1] - p.new_xyz[(size_t)c * 3 + 1];
+            dz = p.xyz[flat * 3 + 2] - p.new_xyz[(size_t)c * 3 + 2];
             if (p.normalize) { dx /= p.radius; dy /= p.radius; dz /= p.radius; }
-            float* x = Xt + r * p.ldk + p.C;
-            x[0] = dx; x[1] = dy; x[2] = dz;
+            if (!p.hoist) {
+                float* x = Xt + r * p.ldk + p.C;
+                x[0] = dx; x[1] = dy; x[2] = dz;
+            }
         }
         for (int c2 = p.K0; c2 < Kpad0; ++c2) Xt[r * p.ldk + c2] = 0.f;
     }
     if (p.C == 0) return;
     if (p.vec_gather) {                                  // point-major rows: one float4 per lane per row
         const int nq = p.C >> 2;
+        f32x4 wx0 = {0.f, 0.f, 0.f, 0.f}, wx1 = wx0, wx2 = wx0;
+        if (p.hoist && lane < nq) {
+            wx0 = *reinterpret_cast<const f32x4*>(p.wx + lane * 4);
+            wx1 = *reinterpret_cast<const f32x4*>(p.wx + p.C + lane * 4);
+            wx2 = *reinterpret_cast<const f32x4*>(p.wx + 2 * p.C + lane * 4);
+        }
 #pragma unroll
         for (int base = 0; base < ROWS; base += GB) {
             f32x4 v[GB];
@@ -439,8 +450,19 @@ __device__ __forceinline__ void sa_gather_rows(const SaParams& p, float* Xt, int
                 if (lane < nq) v[i] = *reinterpret_cast<const f32x4*>(src + lane * 4);
             }
 #pragma unroll
-            for (int i = 0; i < GB; ++i)
+            for (int i = 0; i < GB; ++i) {
+                if (p.hoist) {            // layer 0 of the MLP: per-point term + Wx . rel, activation — straight into the tile
+                    const float rx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dx), base + i));
+                    const float ry = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dy), base + i));
+                    const float rz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dz), base + i));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float y = v[i][j] + (wx0[j] * rx + wx1[j] * ry + wx2[j] * rz);
+                        v[i][j] = p.l0_relu ? fmaxf(y, 0.f) : y;
+                    }
+                }
                 if (lane < nq) *reinterpret_cast<f32x4*>(Xt + (row0 + base + i) * p.ldk + lane * 4) = v[i];
+            }
         }
     } else {                                             // any strides: 64/ROWS lane groups stride over the channels
         constexpr int G = 64 / ROWS;
@@ -981,9 +1003,18 @@ extern "C" int ptt_sa_fused_fwd_f32(const ptt_sa_desc* d, ptt_stream_t stream) {
     if (d->nsample != 16 && d->nsample != 32 && d->nsample != 64)
         return fail(PTT_EUNSUPPORTED, "ptt_sa_fused_fwd_f32: nsample=%d (16, 32 and 64 are instantiated)", d->nsample);
     if (d->B == 0 || d->M == 0) return PTT_OK;
-    if (!d->xyz || !d->new_xyz || !d->idx || !d->out || (d->C > 0 && !d->feat))
+    const bool hoist = d->l0_point_term != nullptr;
+    if (!d->xyz || !d->new_xyz || !d->idx || !d->out || (!hoist && d->C > 0 && !d->feat))
         return fail(PTT_EINVAL, "ptt_sa_fused_fwd_f32: null pointer");
     if (!d->use_xyz && d->C == 0) return fail(PTT_EINVAL, "ptt_sa_fused_fwd_f32: no xyz and no features");
+    if (hoist) {
+        const int c0 = d->l0_channels;
+        if (!d->use_xyz || !d->l0_xyz_weight || c0 <= 0 || (c0 % 32) != 0 || c0 > 256 ||
+            (reinterpret_cast<uintptr_t>(d->l0_point_term) & 15) != 0 ||
+            (reinterpret_cast<uintptr_t>(d->l0_xyz_weight) & 15) != 0)
+            return fail(PTT_EINVAL, "ptt_sa_fused_fwd_f32: hoisted layer 0 needs use_xyz, 16-byte aligned (B,N,C0) and "
+                        "(3,C0) arrays and C0 a multiple of 32 <= 256 (C0=%d)", c0);
+    }
 
     SaParams p;
     p.xyz = d->xyz; p.new_xyz = d->new_xyz; p.idx = d->idx; p.feat = d->feat; p.out = d->out;
@@ -992,6 +1023,11 @@ extern "C" int ptt_sa_fused_fwd_f32(const ptt_sa_desc* d, ptt_stream_t stream) {
     p.B = d->B; p.N = d->N; p.M = d->M; p.C = d->C; p.use_xyz = d->use_xyz ? 1 : 0;
     p.normalize = d->normalize_xyz ? 1 : 0; p.n_layers = d->n_layers; p.radius = d->radius;
     p.K0 = (d->use_xyz ? 3 : 0) + d->C;
+    p.hoist = hoist ? 1 : 0; p.l0_relu = d->l0_relu ? 1 : 0; p.wx = d->l0_xyz_weight;
+    if (hoist) {      // the tile starts as layer 0's output: rows of the per-point term, C0 channels
+        p.feat = d->l0_point_term; p.C = d->l0_channels; p.K0 = p.C;
+        p.fsc = 1; p.fsn = p.C; p.fsb = (long long)d->N * p.C;
+    }
     int maxk = 0, cin = p.K0;
     for (int l = 0; l < d->n_layers; ++l) {
         const ptt_sa_layer& s = d->layers[l];
@@ -1008,8 +1044,8 @@ extern "C" int ptt_sa_fused_fwd_f32(const ptt_sa_desc* d, ptt_stream_t stream) {
         cin = s.Cout;
     }
     p.ldk = maxk + 4;
-    p.vec_gather = (d->C > 0 && d->feat_sc == 1 && (d->C & 3) == 0 && d->C <= 256 && (d->feat_sn & 3) == 0 &&
-                    (d->feat_sb & 3) == 0 && (reinterpret_cast<uintptr_t>(d->feat) & 15) == 0) ? 1 : 0;
+    p.vec_gather = (p.C > 0 && p.fsc == 1 && (p.C & 3) == 0 && p.C <= 256 && (p.fsn & 3) == 0 &&
+                    (p.fsb & 3) == 0 && (reinterpret_cast<uintptr_t>(p.feat) & 15) == 0) ? 1 : 0;
     p.first_wave = 1024; p.stagger = 2;
     if (const char* e = getenv("PTT_SA_STAGGER")) p.stagger = atoi(e);
     p.dbg = nullptr;

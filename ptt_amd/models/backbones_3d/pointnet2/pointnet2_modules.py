@@ -13,6 +13,7 @@ Two execution paths, chosen per call:
   * training mode (BatchNorm needs batch statistics): the reference's op sequence on the HIP
     ops + stock torch conv/BN, with autograd through gather/group.
 """
+import os
 from typing import List
 
 import torch
@@ -99,8 +100,18 @@ class PointnetSAModuleVotes(nn.Module):
                 elif unit.conv.bias is not None:
                     shift = unit.conv.bias.detach().float().contiguous()
                 layers.append((ops.pack_weight(w, rot), scale, shift, cin, cout, hasattr(unit, 'activation')))
-        self._fused_cache = (key, layers)
-        return layers
+            # Layer 0 is linear in [rel ; f_n]: its feature half is evaluated once per POINT (N rows on the linear
+            # kernel) instead of once per (centre, neighbour) row; the kernel adds the 3 relative-coordinate terms.
+            hoist = None
+            w0 = self.mlp_module[0].conv.weight
+            if (self.use_xyz and len(layers) >= 2 and w0.shape[1] > 3 and layers[0][4] <= 256
+                    and os.environ.get('PTT_SA_HOIST', '1') != '0'):
+                w2 = w0.reshape(w0.shape[0], w0.shape[1]).float()
+                scale0 = layers[0][1]
+                wx = w2[:, 0:3] if scale0 is None else w2[:, 0:3] * scale0[:, None]
+                hoist = (ops.pack_weight(w2[:, 3:].contiguous()), wx.t().contiguous(), layers[0][4], layers[0][5])
+        self._fused_cache = (key, (layers, hoist))
+        return layers, hoist
 
     # ------------------------------------------------------------------ forward (reference :57-90)
     def forward(self, xyz: torch.Tensor, features: torch.Tensor, npoint: int, inds: torch.Tensor = None):
@@ -128,8 +139,17 @@ class PointnetSAModuleVotes(nn.Module):
             else:
                 new_xyz, inds64 = ops.select_centres(xyz, inds.contiguous(), npoint)
             idx = ops.ball_query(new_xyz, xyz, self.radius, self.nsample)
-            new_features = ops.sa_fused_forward(xyz, new_xyz, idx, features, self._fused_params(xyz.device),
-                                                self.radius, self.use_xyz, self.normalize_xyz, point_major_out=True)
+            layers, hoist = self._fused_params(xyz.device)
+            if hoist is not None and features is not None:
+                wf_packed, wx, c0, relu0 = hoist
+                rows = features.transpose(1, 2)                       # (B,N,C): contiguous when point-major
+                term = ops.linear(rows if rows.is_contiguous() else rows.contiguous(), wf_packed, c0,
+                                  layers[0][1], layers[0][2], relu=False)
+                new_features = ops.sa_fused_forward(xyz, new_xyz, idx, None, layers[1:], self.radius, True,
+                                                    self.normalize_xyz, point_major_out=True, l0=(term, wx, relu0))
+            else:
+                new_features = ops.sa_fused_forward(xyz, new_xyz, idx, features, layers, self.radius, self.use_xyz,
+                                                    self.normalize_xyz, point_major_out=True)
             return new_xyz, new_features, inds64
 
         xyz_flipped = xyz.transpose(1, 2).contiguous()

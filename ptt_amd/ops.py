@@ -231,13 +231,15 @@ def linear(x, wpacked, cout, scale=None, shift=None, relu=False, residual=None, 
 
 
 def sa_fused_forward(xyz, new_xyz, idx, features, layers, radius, use_xyz=True, normalize_xyz=False,
-                     point_major_out=True):
+                     point_major_out=True, l0=None):
     """Fused group -> normalise -> SharedMLP(eval) -> max-pool (QueryAndGroup + SharedMLP + max_pool2d,
     pointnet2_utils.py:320-380, pytorch_utils.py:12-36, pointnet2_modules.py:84-88).
 
     xyz (B,N,3), new_xyz (B,M,3), idx (B,M,ns) i32, features (B,C,N) in ANY strides (a transposed
     view of point-major storage gathers coalesced) or None.
     layers: list of (wpacked, scale|None, shift|None, cin, cout, relu); layers[0] packed with rot=3 if use_xyz.
+    l0: optional (point_term (B,N,C0) contiguous, xyz_weight (3,C0), relu) — layer 0 hoisted to one row per point
+    (include/ptt_hip.h, ptt_sa_desc.l0_*); then features must be None and `layers` are the remaining layers.
     Returns (B,Cout,M); with point_major_out it is a transposed view of (B,M,Cout) storage."""
     _chk(xyz, "xyz", torch.float32, 3)
     _chk(new_xyz, "new_xyz", torch.float32, 3)
@@ -271,6 +273,16 @@ def sa_fused_forward(xyz, new_xyz, idx, features, layers, radius, use_xyz=True, 
         L.scale = sc.data_ptr() if sc is not None else None
         L.shift = sh.data_ptr() if sh is not None else None
         L.Cin, L.Cout, L.relu = int(cin), int(co), int(bool(relu))
+    if l0 is not None:
+        term, wx, l0_relu = l0
+        if features is not None:
+            raise RuntimeError("with a hoisted layer 0 the point features are already inside l0[0]")
+        _chk(term, "l0 point term", torch.float32, 3)
+        _chk(wx, "l0 xyz weight", torch.float32, 2)
+        if term.shape[0] != B or term.shape[1] != N or wx.shape[0] != 3 or wx.shape[1] != term.shape[2]:
+            raise RuntimeError("l0 point term must be (B,N,C0) and the xyz weight (3,C0)")
+        d.l0_point_term, d.l0_xyz_weight = term.data_ptr(), wx.data_ptr()
+        d.l0_channels, d.l0_relu = term.shape[2], int(bool(l0_relu))
     with torch.cuda.device(xyz.device), _timed('ptt_sa_fused_fwd_f32'):
         _lib.check(_lib.lib().ptt_sa_fused_fwd_f32(ctypes.byref(d), _stream()), "ptt_sa_fused_fwd_f32")
     return out

@@ -84,6 +84,35 @@ def test_sa_fused(dev, N, M, C, spec, radius, ns, point_major):
     np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), **TOL)
 
 
+@pytest.mark.parametrize("N,M,C,spec,radius,ns", [c for c in SA_CASES if c[2] > 0])
+def test_sa_fused_hoisted_layer0(dev, N, M, C, spec, radius, ns):
+    """ptt_sa_desc.l0_*: layer 0's feature half evaluated once per point on the linear kernel, the kernel adds the
+    three relative-coordinate terms — same oracle, same tolerance as the in-kernel layer 0."""
+    B = 3
+    rs = np.random.RandomState(N + C)
+    s, _ = synth.frames(N, B, N, 64, K_s=max(16, N // 2))
+    s[2] = 0.0
+    xyz = torch.from_numpy(s)
+    inds = torch.from_numpy(O.fps(s, M))
+    new_xyz = torch.gather(xyz, 1, inds.long()[..., None].expand(-1, -1, 3)).contiguous()
+    feats = torch.from_numpy(rs.standard_normal((B, C, N)).astype(np.float32))
+    layers = mlp_layers(N, spec)
+    grouped, _, idx = R.query_and_group(xyz, new_xyz, feats, radius, ns, True, True)
+    ref = F.max_pool2d(R.shared_mlp_eval(grouped, layers), kernel_size=[1, ns]).squeeze(-1)
+
+    folded = fold_layers(layers, dev, ops)
+    w0 = layers[0]["conv_weight"].reshape(spec[1], spec[0]).to(dev)
+    scale0, shift0 = folded[0][1], folded[0][2]
+    rows = feats.to(dev).transpose(1, 2).contiguous()                                   # (B,N,C)
+    term = ops.linear(rows, ops.pack_weight(w0[:, 3:].contiguous()), spec[1], scale0, shift0, relu=False)
+    wx = (w0[:, 0:3] * scale0[:, None]).t().contiguous()                                # (3,C0)
+    idx_dev = ops.ball_query(new_xyz.to(dev), xyz.to(dev), radius, ns)
+    got = ops.sa_fused_forward(xyz.to(dev), new_xyz.to(dev), idx_dev, None, folded[1:], radius, True, True,
+                               l0=(term, wx, True))
+    assert tuple(got.shape) == (B, spec[-1], M)
+    np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), **TOL)
+
+
 @pytest.mark.parametrize("N", [128, 64])
 def test_transformer_pair_kernel(dev, N):
     B, D, k = 2, 512, 16
