@@ -8,7 +8,7 @@ TransformerBlock is Point-Transformer *vector* attention over the k nearest neig
 Parameter names (fc1, fc2, fc_delta.{0,2}, fc_gamma.{0,2}, w_qs, w_ks, w_vs) are the reference's,
 so its checkpoints load unchanged.
 
-Eval mode on a HIP device runs five kernels: kNN, fc1, stacked q|k|v projection, the fused pair
+Eval mode on a HIP device runs four kernels: kNN, the q|k|v projection with fc1 folded in, the fused pair
 kernel (fc_delta[2], fc_gamma[0], fc_gamma[2] on fp32 MFMA + softmax + weighted sum, with every
 (B,N,k,d_model) intermediate kept in LDS/registers) and fc2+residual. The reference returns
 `(res, attn)`; both heads keep only `[0]` (centroids_voting_head.py:76, box_voting_head.py:86), so
@@ -55,9 +55,12 @@ class TransformerBlock(nn.Module):
             return self._cache[1]
         with torch.no_grad():
             f = lambda t: t.detach().float().contiguous()
+            # fc1 has no activation and only feeds w_qs / w_ks / w_vs (variants.py:155-156), so the two linear maps
+            # are one: [q|k|v] = (W_qkv W_1) f + W_qkv b_1 — 256 -> 1536 instead of 256 -> 512 -> 1536 (product in f64)
+            wqkv = torch.cat([self.w_qs.weight, self.w_ks.weight, self.w_vs.weight], 0).double()
             P = dict(
-                fc1=ops.pack_weight(self.fc1.weight), fc1_b=f(self.fc1.bias),
-                qkv=ops.pack_weight(torch.cat([self.w_qs.weight, self.w_ks.weight, self.w_vs.weight], 0)),
+                qkv=ops.pack_weight((wqkv @ self.fc1.weight.double()).float().contiguous()),
+                qkv_b=(wqkv @ self.fc1.bias.double()).float().contiguous(),
                 wd1=f(self.fc_delta[0].weight), bd1=f(self.fc_delta[0].bias),
                 wd2=ops.pack_weight(self.fc_delta[2].weight), bd2=f(self.fc_delta[2].bias),
                 wg1=ops.pack_weight(self.fc_gamma[0].weight), bg1=f(self.fc_gamma[0].bias),
@@ -73,8 +76,7 @@ class TransformerBlock(nn.Module):
             D = self.d_model
             xyz = xyz.contiguous()
             knn_idx, rel = ops.knn(xyz, self.k, want_rel=True)
-            x = ops.linear(features, P['fc1'], D, None, P['fc1_b'])
-            qkv = ops.linear(x, P['qkv'], 3 * D)
+            qkv = ops.linear(features, P['qkv'], 3 * D, None, P['qkv_b'])
             res, attn = ops.pt_attn_pair(xyz, knn_idx, qkv, P['wd1'], P['bd1'], P['wd2'], P['bd2'], P['wg1'],
                                          P['bg1'], P['wg2'], P['bg2'], D, self.materialize_attn, rel=rel)
             res = ops.linear(res, P['fc2'], self.d_points, None, P['fc2_b'], False, features)
