@@ -69,11 +69,23 @@ def main():
         feats = torch.randn(B, N, C, device=dev).transpose(1, 2) if C else None
         if name == "sa_box":
             feats = feats.contiguous()                     # channel-major, as the box head hands it over
-        layers = fold_layers(mlp_layers(3, spec), dev, ops)
+        raw = mlp_layers(3, spec)
+        layers = fold_layers(raw, dev, ops)
         fn = lambda: ops.sa_fused_forward(xyz, new_xyz, idx, feats, layers, r, True, True)
         ms = timeit(fn, a.iters)
         fl = 2.0 * B * M * ns * sum(ci * co for ci, co in zip(spec[:-1], spec[1:]))
         print("%-14s %8.4f ms  %7.2f TFLOP/s" % (name, ms, fl / ms / 1e9))
+        if C:       # layer 0 hoisted (what the module runs): per-point linear + the two remaining layers
+            w0 = raw[0]["conv_weight"].reshape(spec[1], spec[0]).to(dev)
+            rows = feats.transpose(1, 2).contiguous()
+            wf = ops.pack_weight(w0[:, 3:].contiguous())
+            wx = (w0[:, 0:3] * layers[0][1][:, None]).t().contiguous()
+            lin = lambda: ops.linear(rows, wf, spec[1], layers[0][1], layers[0][2], relu=False)
+            term = lin()
+            fn = lambda: ops.sa_fused_forward(xyz, new_xyz, idx, None, layers[1:], r, True, True, l0=(term, wx, True))
+            ms_l, ms_h = timeit(lin, a.iters), timeit(fn, a.iters)
+            fl_h = 2.0 * B * M * ns * sum(ci * co for ci, co in zip(spec[1:-1], spec[2:]))
+            print("%-14s %8.4f ms  %7.2f TFLOP/s   (+ per-point linear %.4f ms)" % (name + "_hoist", ms_h, fl_h / ms_h / 1e9, ms_l))
         if os.environ.get("SWEEP_SA_STAGGER"):
             for sg in (1, 2, 3, 4, 6):
                 os.environ["PTT_SA_STAGGER"] = str(sg)
@@ -82,7 +94,7 @@ def main():
             os.environ.pop("PTT_SA_STAGGER")
 
     # ---- linear ----
-    for name, rows, K, Cout in (("lin_fc1", B * 128, 256, 512), ("lin_qkv", B * 128, 512, 1536), ("lin_fc2", B * 128, 512, 256),
+    for name, rows, K, Cout in (("lin_qkvf", B * 128, 256, 1536), ("lin_qkvf64", B * 64, 256, 1536), ("lin_fc1", B * 128, 256, 512), ("lin_qkv", B * 128, 512, 1536), ("lin_fc2", B * 128, 512, 256),
                                 ("lin_cov", B * 128, 256, 256), ("lin_qkv64", B * 64, 512, 1536), ("lin_fc2_64", B * 64, 512, 256)):
         if not want(name):
             continue
