@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PTT_ABI_VERSION 1
+#define PTT_ABI_VERSION 2
 
 enum {
     PTT_OK = 0,
@@ -228,14 +228,15 @@ typedef struct ptt_attn_desc {
     const float* rel;      /* (B,N,k,3) from ptt_knn_rel_f32, or NULL (computed from xyz and knn) */
     const int32_t* knn;    /* (B,N,k) */
     const float* qkv;      /* (B,N,3*D) */
-    const float* Wd1;      /* fc_delta[0].weight (D,3) row-major, unpacked */
-    const float* bd1;      /* (D) */
+    const float* Wd1p;     /* packed (ptt_pack_weight_f32, K = 4) [fc_delta[0].weight (D,3) | fc_delta[0].bias (D)]:
+                              layer 0 of the position encoding runs as one MFMA K-block on rows [rel.xyz 1]   */
     const float* Wd2p;     /* packed fc_delta[2].weight */
     const float* bd2;
     const float* Wg1p;     /* packed fc_gamma[0].weight */
     const float* bg1;
     const float* Wg2p;     /* packed fc_gamma[2].weight */
-    const float* bg2;
+    const float* bg2;      /* fc_gamma[2].bias: accepted, never read — a per-channel constant over the
+                              neighbours cancels in softmax_j                                               */
     float* res;            /* (B,N,D) */
     float* attn;           /* (B,N,k,D) or NULL */
     int B, N, k, D;

@@ -10,6 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libptt_hip.so")
 
 PTT_SA_MAX_LAYERS = 4
+ABI_VERSION = 2            # PTT_ABI_VERSION of include/ptt_hip.h these structures mirror
 
 # every symbol include/ptt_hip.h declares (tests check the library exports all of them)
 EXPORTS = [
@@ -48,7 +49,7 @@ class XcorrDesc(Structure):
 
 class AttnDesc(Structure):
     _fields_ = [("xyz", c_void_p), ("rel", c_void_p), ("knn", c_void_p), ("qkv", c_void_p),
-                ("Wd1", c_void_p), ("bd1", c_void_p), ("Wd2p", c_void_p), ("bd2", c_void_p),
+                ("Wd1p", c_void_p), ("Wd2p", c_void_p), ("bd2", c_void_p),
                 ("Wg1p", c_void_p), ("bg1", c_void_p), ("Wg2p", c_void_p), ("bg2", c_void_p),
                 ("res", c_void_p), ("attn", c_void_p),
                 ("B", c_int), ("N", c_int), ("k", c_int), ("D", c_int)]
@@ -104,6 +105,9 @@ def lib():
         except OSError as e:  # e.g. no ROCm runtime on this host
             raise RuntimeError("ptt_amd: cannot load %s: %s" % (LIB_PATH, e))
         _declare(loaded)
+        if loaded.ptt_version() != ABI_VERSION:
+            raise RuntimeError("ptt_amd: %s has ABI version %d, this package expects %d — rebuild it with "
+                               "`python -m ptt_amd.build`" % (LIB_PATH, loaded.ptt_version(), ABI_VERSION))
         _lib = loaded
     return _lib
 

@@ -514,7 +514,8 @@ __device__ __forceinline__ void sa_layer(const SaParams& p, const SaLayerDev& L,
         if (w + 4 * u < L.NT) nvalid = u + 1;
     gemm_tiles<RT, CT, 0>(Xs, p.ldk, L.nkb, reinterpret_cast<const f32x4*>(L.Wp), L.NT, w, nvalid, lane, acc, pre);
     if (Lnext) prefetch_first_block(Lnext->Wp, Lnext->NT, w, lane, pre);   // in flight across the epilogue + barriers
-    if (!last) lds_barrier();    // every wave has finished reading this layer's input tile (the last layer writes no LDS)
+    if (!last) lds_barrier();
+    // every wave has finished reading this layer's input tile (the last layer writes no LDS)
 
     const int half = lane >> 5;
 #pragma unroll
@@ -776,7 +777,7 @@ __global__ __launch_bounds__(256, 3) void sa_wave_kernel(SaParams p) {
 // and all D = 512 channels; wave w owns column tiles w, w+4, w+8, w+12.
 // ------------------------------------------------------------------------------------------
 struct AttnParams {
-    const float* xyz; const float* rel; const int32_t* knn; const float* qkv; const float* Wd1; const float* bd1;
+    const float* xyz; const float* rel; const int32_t* knn; const float* qkv; const float* Wd1p;
     const float* Wd2p; const float* bd2; const float* Wg1p; const float* bg1; const float* Wg2p; const float* bg2;
     float* res; float* attn;
     int BN, N, first_wave, stagger;
@@ -789,21 +790,14 @@ __global__ __launch_bounds__(256, 2) void pt_attn_pair_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Xs = smem;                                       // [32][LDK]
     int* nb = reinterpret_cast<int*>(smem + 32 * LDK);      // [32] flat neighbour row (b*N + n)
-    float* dxyz = smem + 32 * LDK + 32;                     // [32][3]
+    constexpr int LDR = 12;                                 // [rel.x rel.y rel.z 1 | 0 0 0 0] + pad (stride = 4 mod 8)
+    float* relt = smem + 32 * LDK + 32;                     // [32][LDR]: the A operand of fc_delta[0]
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, half = lane >> 5;
     const int pt0 = logical_block() * 2;                     // flat point index of tile row 0
     const int npts = min(2, p.BN - pt0);
 #define PTT_STAMP(i) do { if (p.dbg && t == 0 && blockIdx.x < 4096) p.dbg[blockIdx.x * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
-    // fc_delta[0] rows of this thread's two channels: requested before anything depends on them
-    float wd1[D / 256][4];
-#pragma unroll
-    for (int cc = 0; cc < D / 256; ++cc) {
-        const int c = t + cc * 256;
-        wd1[cc][0] = p.Wd1[c * 3 + 0]; wd1[cc][1] = p.Wd1[c * 3 + 1]; wd1[cc][2] = p.Wd1[c * 3 + 2];
-        wd1[cc][3] = p.bd1[c];
-    }
     f32x4 pre[CT];
-    prefetch_first_block_full<CT>(p.Wd2p, w, lane, pre);    // fc_delta[2]'s first weight block rides along phase 0
+    prefetch_first_block_full<CT>(p.Wd1p, w, lane, pre);    // fc_delta[0]'s only weight block: requested first
     stagger_second_slot(p.first_wave, p.stagger);
     PTT_STAMP(0);
 
@@ -814,35 +808,39 @@ __global__ __launch_bounds__(256, 2) void pt_attn_pair_kernel(AttnParams p) {
         const int n = p.knn[(size_t)pt * KNN + (t & 15)];
         const int flat = b * p.N + n;
         nb[t] = flat;
+        f32x4 r4;
         if (p.rel) {                                   // precomputed by the kNN kernel: no index -> xyz dependency
             const float* rl = p.rel + ((size_t)pt * KNN + (t & 15)) * 3;
-            dxyz[t * 3 + 0] = rl[0]; dxyz[t * 3 + 1] = rl[1]; dxyz[t * 3 + 2] = rl[2];
+            r4 = f32x4{rl[0], rl[1], rl[2], 1.f};
         } else {
-            dxyz[t * 3 + 0] = p.xyz[(size_t)pt * 3 + 0] - p.xyz[(size_t)flat * 3 + 0];
-            dxyz[t * 3 + 1] = p.xyz[(size_t)pt * 3 + 1] - p.xyz[(size_t)flat * 3 + 1];
-            dxyz[t * 3 + 2] = p.xyz[(size_t)pt * 3 + 2] - p.xyz[(size_t)flat * 3 + 2];
+            r4 = f32x4{p.xyz[(size_t)pt * 3 + 0] - p.xyz[(size_t)flat * 3 + 0],
+                       p.xyz[(size_t)pt * 3 + 1] - p.xyz[(size_t)flat * 3 + 1],
+                       p.xyz[(size_t)pt * 3 + 2] - p.xyz[(size_t)flat * 3 + 2], 1.f};
         }
+        *reinterpret_cast<f32x4*>(relt + t * LDR) = r4;
+        *reinterpret_cast<f32x4*>(relt + t * LDR + 4) = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     lds_barrier();
 
-    // fc_delta[0] + ReLU (K = 3) on the vector ALU, straight into the LDS tile
-#pragma unroll
-    for (int cc = 0; cc < D / 256; ++cc) {
-        const int c = t + cc * 256;
-        const float w0 = wd1[cc][0], w1 = wd1[cc][1], w2 = wd1[cc][2], bb = wd1[cc][3];
-#pragma unroll 8
-        for (int r = 0; r < 32; ++r) {
-            const float h = ((dxyz[r * 3 + 0] * w0 + dxyz[r * 3 + 1] * w1) + dxyz[r * 3 + 2] * w2) + bb;
-            Xs[r * LDK + c] = fmaxf(h, 0.f);
-        }
-    }
-    lds_barrier();
-
-    PTT_STAMP(1);
     int cols[CT];
 #pragma unroll
     for (int u = 0; u < CT; ++u) cols[u] = (w + 4 * u) * 32 + (lane & 31);
 
+    // fc_delta[0] + ReLU: h = relu([rel 1] . [W | b]^T) as ONE K-block of MFMAs (K = 4, zero-padded to 8) instead of
+    // ~500 vector-ALU instructions per wave — next to the other workgroup's MFMA stream those crawl (DESIGN.md lesson 8)
+    {
+        f32x16 h[1][CT];
+        zero_acc(h);
+        gemm_core<1, CT, CT, 4, 1>(relt, LDR, 1, reinterpret_cast<const f32x4*>(p.Wd1p), NT, w, lane, h, pre);
+        prefetch_first_block_full<CT>(p.Wd2p, w, lane, pre);    // fc_delta[2]'s first weight block
+#pragma unroll
+        for (int u = 0; u < CT; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Xs[tile_row(r, half) * LDK + cols[u]] = fmaxf(h[0][u][r], 0.f);
+    }
+    lds_barrier();
+
+    PTT_STAMP(1);
     // ---- delta = fc_delta[2](h) ----
     f32x16 delta[1][CT];
     zero_acc(delta);
@@ -901,7 +899,10 @@ __global__ __launch_bounds__(256, 2) void pt_attn_pair_kernel(AttnParams p) {
     PTT_STAMP(5);
     gemm_core<1, CT, CT, 4, PTT_PAIR_PF>(Xs, LDK, NKB, reinterpret_cast<const f32x4*>(p.Wg2p), NT, w, lane, acc, pre);
     PTT_STAMP(6);
-    const float inv_sqrt_d = 1.0f / sqrtf((float)D);
+    // softmax_j((a_j + b) / sqrt(D)) over the 16 neighbours of a point: the bias b is the same for every neighbour, so
+    // it cancels (fc_gamma[2].bias is never read); 1/sqrt(D) and log2(e) are one constant inside exp2; the weighted sum
+    // is normalised once at the end. Fewer vector-ALU instructions next to the other workgroup's MFMA stream.
+    const float kexp = 1.4426950408889634f / sqrtf((float)D);
     // all 64 neighbour values of this lane are requested before any softmax arithmetic: one L2 round trip
     // instead of eight (the gathers, not the math, were the length of this phase)
     float vv[CT][16];
@@ -911,35 +912,32 @@ __global__ __launch_bounds__(256, 2) void pt_attn_pair_kernel(AttnParams p) {
         for (int r = 0; r < 16; ++r) vv[u][r] = p.qkv[(size_t)nrow[r] * 3 * D + 2 * D + cols[u]];
 #pragma unroll
     for (int u = 0; u < CT; ++u) {
-        const float bb = p.bg2[cols[u]];
 #pragma unroll
         for (int pp = 0; pp < 2; ++pp) {
             float s[8];
-            float m = -__builtin_inff();
+            float m = acc[0][u][pp * 8];
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                s[r] = (acc[0][u][pp * 8 + r] + bb) * inv_sqrt_d;
-                m = fmaxf(m, s[r]);
-            }
+            for (int r = 1; r < 8; ++r) m = fmaxf(m, acc[0][u][pp * 8 + r]);
             m = max_halves(m);
-            float sum = 0.f;
-#pragma unroll
-            for (int r = 0; r < 8; ++r) { s[r] = __expf(s[r] - m); sum += s[r]; }
-            sum = add_halves(sum);
-            const float rsum = __builtin_amdgcn_rcpf(sum);
-            float o = 0.f;
+            float sum = 0.f, o = 0.f;
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
                 const int rr = pp * 8 + r;
-                const float a = s[r] * rsum;
-                o += a * (vv[u][rr] + delta[0][u][rr]);
-                if (p.attn && pp < npts) {
-                    const int row = tile_row(rr, half);  // = pp*16 + j
-                    p.attn[((size_t)(pt0 + pp) * KNN + (row & 15)) * D + cols[u]] = a;
+                s[r] = __builtin_amdgcn_exp2f((acc[0][u][rr] - m) * kexp);
+                sum += s[r];
+                o += s[r] * (vv[u][rr] + delta[0][u][rr]);
+            }
+            sum = add_halves(sum);
+            o = add_halves(o);
+            const float rsum = __builtin_amdgcn_rcpf(sum);
+            if (p.attn && pp < npts) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const int row = tile_row(pp * 8 + r, half);  // = pp*16 + j
+                    p.attn[((size_t)(pt0 + pp) * KNN + (row & 15)) * D + cols[u]] = s[r] * rsum;
                 }
             }
-            o = add_halves(o);
-            if (half == 0 && pp < npts) p.res[(size_t)(pt0 + pp) * D + cols[u]] = o;
+            if (half == 0 && pp < npts) p.res[(size_t)(pt0 + pp) * D + cols[u]] = o * rsum;
         }
     }
     PTT_STAMP(7);
@@ -1159,11 +1157,11 @@ extern "C" int ptt_pt_attn_pair_f32(const ptt_attn_desc* d, ptt_stream_t stream)
     if (d->D != 512 || d->k != 16)
         return fail(PTT_EUNSUPPORTED, "ptt_pt_attn_pair_f32: D=%d k=%d (D=512, k=16 is instantiated)", d->D, d->k);
     if (d->B == 0) return PTT_OK;
-    if (!d->xyz || !d->knn || !d->qkv || !d->Wd1 || !d->bd1 || !d->Wd2p || !d->bd2 || !d->Wg1p || !d->bg1 ||
-        !d->Wg2p || !d->bg2 || !d->res)
+    if (!d->xyz || !d->knn || !d->qkv || !d->Wd1p || !d->Wd2p || !d->bd2 || !d->Wg1p || !d->bg1 ||
+        !d->Wg2p || !d->res)
         return fail(PTT_EINVAL, "ptt_pt_attn_pair_f32: null pointer");
     AttnParams p;
-    p.xyz = d->xyz; p.rel = d->rel; p.knn = d->knn; p.qkv = d->qkv; p.Wd1 = d->Wd1; p.bd1 = d->bd1; p.Wd2p = d->Wd2p; p.bd2 = d->bd2;
+    p.xyz = d->xyz; p.rel = d->rel; p.knn = d->knn; p.qkv = d->qkv; p.Wd1p = d->Wd1p; p.Wd2p = d->Wd2p; p.bd2 = d->bd2;
     p.Wg1p = d->Wg1p; p.bg1 = d->bg1; p.Wg2p = d->Wg2p; p.bg2 = d->bg2; p.res = d->res; p.attn = d->attn;
     p.BN = d->B * d->N; p.N = d->N;
     p.first_wave = 512; p.stagger = 8;
@@ -1173,7 +1171,7 @@ extern "C" int ptt_pt_attn_pair_f32(const ptt_attn_desc* d, ptt_stream_t stream)
     if ((d->N & 1) != 0)
         return fail(PTT_EUNSUPPORTED, "ptt_pt_attn_pair_f32: N=%d must be even (a tile holds two points of one cloud)",
                     d->N);
-    int lds = (32 * (512 + 4) + 32 + 96) * (int)sizeof(float);
+    int lds = (32 * (512 + 4) + 32 + 32 * 12) * (int)sizeof(float);
     if (const char* e = getenv("PTT_PAIR_LDS_PAD")) lds += atoi(e);   // dev: force 1 workgroup per CU
     int rc = set_lds_limit(reinterpret_cast<const void*>(pt_attn_pair_kernel<512>), lds);
     if (rc) return rc;

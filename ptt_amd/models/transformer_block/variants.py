@@ -61,7 +61,7 @@ class TransformerBlock(nn.Module):
             P = dict(
                 qkv=ops.pack_weight((wqkv @ self.fc1.weight.double()).float().contiguous()),
                 qkv_b=(wqkv @ self.fc1.bias.double()).float().contiguous(),
-                wd1=f(self.fc_delta[0].weight), bd1=f(self.fc_delta[0].bias),
+                wd1=ops.pack_delta0(self.fc_delta[0].weight, self.fc_delta[0].bias),
                 wd2=ops.pack_weight(self.fc_delta[2].weight), bd2=f(self.fc_delta[2].bias),
                 wg1=ops.pack_weight(self.fc_gamma[0].weight), bg1=f(self.fc_gamma[0].bias),
                 wg2=ops.pack_weight(self.fc_gamma[2].weight), bg2=f(self.fc_gamma[2].bias),
@@ -77,7 +77,7 @@ class TransformerBlock(nn.Module):
             xyz = xyz.contiguous()
             knn_idx, rel = ops.knn(xyz, self.k, want_rel=True)
             qkv = ops.linear(features, P['qkv'], 3 * D, None, P['qkv_b'])
-            res, attn = ops.pt_attn_pair(xyz, knn_idx, qkv, P['wd1'], P['bd1'], P['wd2'], P['bd2'], P['wg1'],
+            res, attn = ops.pt_attn_pair(xyz, knn_idx, qkv, P['wd1'], P['wd2'], P['bd2'], P['wg1'],
                                          P['bg1'], P['wg2'], P['bg2'], D, self.materialize_attn, rel=rel)
             res = ops.linear(res, P['fc2'], self.d_points, None, P['fc2_b'], False, features)
             return res, attn

@@ -328,8 +328,15 @@ def xcorr_fused(search_feats, templ_feats, P, w_sim, scale0, shift0, layers, eps
     return out, sim
 
 
-def pt_attn_pair(xyz, knn_idx, qkv, wd1, bd1, wd2p, bd2, wg1p, bg1, wg2p, bg2, d_model, want_attn=True, rel=None):
+def pack_delta0(weight, bias):
+    """[fc_delta[0].weight (D,3) | fc_delta[0].bias (D)] in packed MFMA order (K = 4): ptt_attn_desc.Wd1p."""
+    return pack_weight(torch.cat([weight.detach().float().reshape(weight.shape[0], 3),
+                                  bias.detach().float().reshape(-1, 1)], dim=1).contiguous())
+
+
+def pt_attn_pair(xyz, knn_idx, qkv, wd1p, wd2p, bd2, wg1p, bg1, wg2p, bg2, d_model, want_attn=True, rel=None):
     """Fused per-(point,neighbour) part of TransformerBlock.forward (variants.py:158-163).
+    wd1p = pack_delta0(fc_delta[0].weight, fc_delta[0].bias); the other weights from pack_weight.
     Returns (res (B,N,D), attn (B,N,k,D) | None)."""
     _chk(xyz, "xyz", torch.float32, 3)
     _chk(knn_idx, "knn_idx", torch.int32, 3)
@@ -342,7 +349,7 @@ def pt_attn_pair(xyz, knn_idx, qkv, wd1, bd1, wd2p, bd2, wg1p, bg1, wg2p, bg2, d
     d = AttnDesc()
     d.xyz, d.knn, d.qkv = xyz.data_ptr(), knn_idx.data_ptr(), qkv.data_ptr()
     d.rel = rel.data_ptr() if rel is not None else None
-    d.Wd1, d.bd1, d.Wd2p, d.bd2 = wd1.data_ptr(), bd1.data_ptr(), wd2p.data_ptr(), bd2.data_ptr()
+    d.Wd1p, d.Wd2p, d.bd2 = wd1p.data_ptr(), wd2p.data_ptr(), bd2.data_ptr()
     d.Wg1p, d.bg1, d.Wg2p, d.bg2 = wg1p.data_ptr(), bg1.data_ptr(), wg2p.data_ptr(), bg2.data_ptr()
     d.res = res.data_ptr()
     d.attn = attn.data_ptr() if attn is not None else None

@@ -49,7 +49,8 @@ def main():
         knn = ops.knn(xyz, 16)
         qkv = torch.randn(B, N, 1536, device=dev)
         packs = [ops.pack_weight(P[k]) for k in ("fc_delta.2.weight", "fc_gamma.0.weight", "fc_gamma.2.weight")]
-        fn = lambda: ops.pt_attn_pair(xyz, knn, qkv, P["fc_delta.0.weight"], P["fc_delta.0.bias"], packs[0],
+        wd1p = ops.pack_delta0(P["fc_delta.0.weight"], P["fc_delta.0.bias"])
+        fn = lambda: ops.pt_attn_pair(xyz, knn, qkv, wd1p, packs[0],
                                       P["fc_delta.2.bias"], packs[1], P["fc_gamma.0.bias"], packs[2],
                                       P["fc_gamma.2.bias"], 512, False)
         ms = timeit(fn, a.iters)

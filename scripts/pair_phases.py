@@ -10,7 +10,8 @@ P = {k: v.to(dev).contiguous() for k, v in transformer_params(1).items()}
 s, _ = synth.frames(1, B, N, 64, K_s=N); xyz = torch.from_numpy(s).to(dev)
 knn = ops.knn(xyz, 16); qkv = torch.randn(B, N, 1536, device=dev)
 packs = [ops.pack_weight(P[k]) for k in ("fc_delta.2.weight", "fc_gamma.0.weight", "fc_gamma.2.weight")]
-fn = lambda: ops.pt_attn_pair(xyz, knn, qkv, P["fc_delta.0.weight"], P["fc_delta.0.bias"], packs[0], P["fc_delta.2.bias"], packs[1], P["fc_gamma.0.bias"], packs[2], P["fc_gamma.2.bias"], 512, False)
+wd1p = ops.pack_delta0(P["fc_delta.0.weight"], P["fc_delta.0.bias"])
+fn = lambda: ops.pt_attn_pair(xyz, knn, qkv, wd1p, packs[0], P["fc_delta.2.bias"], packs[1], P["fc_gamma.0.bias"], packs[2], P["fc_gamma.2.bias"], 512, False)
 for _ in range(3): fn()
 if len(sys.argv) > 1: os.environ["PTT_PAIR_LDS_PAD"] = sys.argv[1]
 buf = torch.zeros(4096 * 8, dtype=torch.int64, device=dev)

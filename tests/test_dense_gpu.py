@@ -128,7 +128,7 @@ def test_transformer_pair_kernel(dev, N):
     x = ops.linear(feats.to(dev), ops.pack_weight(d("fc1.weight")), D, None, d("fc1.bias"))
     wqkv = torch.cat([P["w_qs.weight"], P["w_ks.weight"], P["w_vs.weight"]], 0).to(dev)
     qkv = ops.linear(x, ops.pack_weight(wqkv), 3 * D)
-    res, attn = ops.pt_attn_pair(xyz.to(dev), knn, qkv, d("fc_delta.0.weight"), d("fc_delta.0.bias"),
+    res, attn = ops.pt_attn_pair(xyz.to(dev), knn, qkv, ops.pack_delta0(d("fc_delta.0.weight"), d("fc_delta.0.bias")),
                                  ops.pack_weight(d("fc_delta.2.weight")), d("fc_delta.2.bias"),
                                  ops.pack_weight(d("fc_gamma.0.weight")), d("fc_gamma.0.bias"),
                                  ops.pack_weight(d("fc_gamma.2.weight")), d("fc_gamma.2.bias"), D, True)
@@ -136,7 +136,7 @@ def test_transformer_pair_kernel(dev, N):
     np.testing.assert_allclose(attn.cpu().numpy(), ref_attn.numpy(), **TOL)
     np.testing.assert_allclose(out.cpu().numpy(), ref_res.numpy(), **TOL)
     # attn=None path gives the same res
-    res2, none = ops.pt_attn_pair(xyz.to(dev), knn, qkv, d("fc_delta.0.weight"), d("fc_delta.0.bias"),
+    res2, none = ops.pt_attn_pair(xyz.to(dev), knn, qkv, ops.pack_delta0(d("fc_delta.0.weight"), d("fc_delta.0.bias")),
                                   ops.pack_weight(d("fc_delta.2.weight")), d("fc_delta.2.bias"),
                                   ops.pack_weight(d("fc_gamma.0.weight")), d("fc_gamma.0.bias"),
                                   ops.pack_weight(d("fc_gamma.2.weight")), d("fc_gamma.2.bias"), D, False)

@@ -134,7 +134,8 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     lib.ptt_version.restype = ctypes.c_int
-    assert lib.ptt_version() == 1
+    version = int(re.search(r"#define PTT_ABI_VERSION (\d+)", header).group(1))
+    assert lib.ptt_version() == version == _lib.ABI_VERSION
 
 
 def test_product_path_never_imports_the_oracle():
