@@ -8,6 +8,7 @@ state_dict entries by key and shape): a unit is an nn.Sequential with children `
 `layer0`, `layer1`, ... Parameters are initialised as the reference does (kaiming-normal conv
 weights, BN weight 1 / bias 0, no conv bias when BN follows).
 """
+import torch
 import torch.nn as nn
 
 
@@ -153,3 +154,68 @@ class Seq(nn.Sequential):
         self.add_module(str(self.count), nn.Dropout(p=p))
         self.count += 1
         return self
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Eval-mode execution of a Conv1d(k=1)(+BatchNorm)(+ReLU) stack on point-major rows (no reference counterpart: the
+# reference runs these as stock cuDNN convs on (B,C,N) tensors). One ptt_linear_f32 launch per layer with the
+# BatchNorm folded from its running statistics, instead of conv + batch_norm + relu (+ layout copies) per layer.
+# ---------------------------------------------------------------------------------------------------------------
+def rows_fusable(seq, rows):
+    if seq.training or not rows.is_cuda or rows.dtype != torch.float32:
+        return False
+    for unit in seq:
+        conv = getattr(unit, 'conv', None)
+        if not isinstance(conv, nn.Conv1d) or conv.kernel_size != (1,) or conv.stride != (1,) or conv.padding != (0,):
+            return False
+        if list(unit._modules.keys())[0] != 'conv':                       # pre-activation units are not folded
+            return False
+        if hasattr(unit, 'activation') and not isinstance(unit.activation, nn.ReLU):
+            return False
+        if hasattr(unit, 'normlayer') and not isinstance(getattr(unit.normlayer, 'bn', None), nn.BatchNorm1d):
+            return False
+    return len(seq) > 0
+
+
+def _rows_params(seq):
+    from .... import ops
+    tensors = []
+    for unit in seq:
+        tensors.append(unit.conv.weight)
+        if unit.conv.bias is not None:
+            tensors.append(unit.conv.bias)
+        if hasattr(unit, 'normlayer'):
+            bn = unit.normlayer.bn
+            tensors += [bn.weight, bn.bias, bn.running_mean, bn.running_var]
+    key = tuple((t.data_ptr(), t._version) for t in tensors)
+    cache = getattr(seq, '_rows_cache', None)
+    if cache is not None and cache[0] == key:
+        return cache[1]
+    layers = []
+    with torch.no_grad():
+        for unit in seq:
+            w = unit.conv.weight
+            scale = shift = None
+            if hasattr(unit, 'normlayer'):
+                bn = unit.normlayer.bn
+                scale = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).float().contiguous()
+                shift = (bn.bias - bn.running_mean * scale).float().contiguous()
+                if unit.conv.bias is not None:
+                    shift = (shift + unit.conv.bias * scale).contiguous()
+            elif unit.conv.bias is not None:
+                shift = unit.conv.bias.detach().float().contiguous()
+            layers.append((ops.pack_weight(w.reshape(w.shape[0], w.shape[1])), w.shape[0], scale, shift,
+                           hasattr(unit, 'activation')))
+    object.__setattr__(seq, '_rows_cache', (key, layers))
+    return layers
+
+
+def rows_forward(seq, rows, residual=None):
+    """seq(rows^T)^T for an eval-mode Conv1d(k=1) stack: rows (..., Cin) -> (..., Cout); `residual` (..., Cout) is
+    added to the last layer's output. Call only when rows_fusable(seq, rows)."""
+    from .... import ops
+    layers = _rows_params(seq)
+    x = rows
+    for i, (wp, cout, scale, shift, relu) in enumerate(layers):
+        x = ops.linear(x, wp, cout, scale, shift, relu, residual if i == len(layers) - 1 else None)
+    return x

@@ -54,10 +54,23 @@ class BoxVotingHead(VotingHeadTemplate):
         return (loss_cls + loss_reg).float(), tb_dict
 
     # ------------------------------------------------------------------ forward (reference :68-112)
+    def _fusable(self, feats):
+        return not self.training and layer_utils.rows_fusable(self.refine_layer, feats)
+
     def forward(self, batch_dict):
         centres, feats, _ = self.vote_aggregation(xyz=batch_dict['pred_centroids_votes'],
                                                   features=batch_dict['votes_feats'],
                                                   npoint=self.model_cfg.SA_CONFIG.NPOINTS)
+        if self._fusable(feats):
+            # eval mode on a HIP device: stay on point-major rows (the SA output already is), one folded-BN linear
+            # launch per refine layer, and the (B,M,5) result is produced directly in the layout the caller wants
+            rows = feats.transpose(1, 2)                                                         # (B,M,C)
+            if hasattr(self, 'transformer_block'):
+                rows = self.transformer_block(xyz=centres, features=rows.contiguous())[0]
+            offsets = layer_utils.rows_forward(self.refine_layer, rows)                          # (B,M,5)
+            batch_dict['pred_box_center'] = centres
+            batch_dict['pred_box_data'] = torch.cat((offsets[..., 0:3] + centres, offsets[..., 3:]), dim=2)
+            return batch_dict
         if hasattr(self, 'transformer_block'):
             fused = self.transformer_block(xyz=centres, features=feats.transpose(1, 2).contiguous())[0]
             feats = fused.transpose(1, 2).contiguous()

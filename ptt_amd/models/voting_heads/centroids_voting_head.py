@@ -1,8 +1,8 @@
 """Mirror of ptt/models/voting_heads/centroids_voting_head.py: CentroidVotingHead (:9-109).
 Seed-wise classification + vote regression on the 128 search seeds, preceded by the Point-Track-Transformer
 block (the hot-path kernel sequence of ptt_amd.models.transformer_block). The two 3-layer Conv1d stacks are
-tiny (0.05 GFLOP/frame) and stay on stock torch layers; names `cla_layer`, `vote_layer`, `transformer_block`
-are the checkpoint contract."""
+tiny (0.05 GFLOP/frame): stock torch layers in training, folded-BN linear launches on point-major rows in eval mode
+on a HIP device; names `cla_layer`, `vote_layer`, `transformer_block` are the checkpoint contract."""
 import torch
 
 from ..backbones_3d.pointnet2 import pytorch_utils as layer_utils
@@ -52,7 +52,32 @@ class CentroidVotingHead(VotingHeadTemplate):
         return (loss_cls + loss_reg).float(), tb_dict
 
     # ------------------------------------------------------------------ forward (reference :64-109)
+    def _forward_rows(self, batch_dict):
+        """Eval mode on a HIP device: the same computation on point-major rows — the transformer already works on
+        (B,N,C) rows, the two Conv1d stacks run as folded-BN linear layers (one launch each), and `votes_feats` is
+        handed to the box head as the (B,1+C,N) view of (B,N,1+C) storage, which its grouping kernel gathers
+        coalesced. No layout copies."""
+        seeds = batch_dict['search_seeds']                                        # (B,N,3)
+        rows = batch_dict['cosine_feats'].transpose(1, 2)                         # (B,N,C)
+        if hasattr(self, 'transformer_block'):
+            rows = self.transformer_block(xyz=seeds, features=rows.contiguous())[0]
+        with_xyz = torch.cat((seeds, rows), dim=2)                                # (B,N,3+C)
+        cls_in = with_xyz if getattr(self.model_cfg, 'CLS_USE_SEARCH_XYZ', False) else rows
+        cls_out = layer_utils.rows_forward(self.cla_layer, cls_in).squeeze(-1)    # (B,N)
+        voted = layer_utils.rows_forward(self.vote_layer, with_xyz, residual=with_xyz)
+        batch_dict['pred_centroids_cls'] = cls_out.squeeze(0)
+        batch_dict['pred_centroids_votes'] = voted[..., 0:3].contiguous()         # (B,N,3)
+        batch_dict['votes_feats'] = torch.cat((cls_out.sigmoid().unsqueeze(-1), voted[..., 3:]),
+                                              dim=2).transpose(1, 2)              # (B,1+C,N) view
+        return batch_dict
+
+    def _fusable(self, feats):
+        return (not self.training and layer_utils.rows_fusable(self.cla_layer, feats)
+                and layer_utils.rows_fusable(self.vote_layer, feats))
+
     def forward(self, batch_dict):
+        if self._fusable(batch_dict['cosine_feats']):
+            return self._forward_rows(batch_dict)
         seeds_xyz = batch_dict['search_seeds'].transpose(1, 2).contiguous()      # (B,3,N)
         feats = batch_dict['cosine_feats']                                        # (B,C,N)
 
