@@ -156,5 +156,7 @@ class PointnetSAModuleVotes(nn.Module):
         new_xyz = pointnet2_utils.gather_operation(xyz_flipped, inds).transpose(1, 2).contiguous()
         grouped_features, grouped_xyz = self.grouper(xyz, new_xyz, features)      # (B,C,M,ns)
         y = self.mlp_module(grouped_features)
-        y = F.max_pool2d(y, kernel_size=[1, y.size(3)]).squeeze(-1)               # (B,Cout,M)
+        # reference: F.max_pool2d(y, kernel_size=[1, nsample]).squeeze(-1) (:85-88); max over the last axis routes the
+        # gradient to one arg-max the same way and avoids torch's NCHW pooling kernel (6 ms per training step here)
+        y = y.max(dim=3)[0]                                                       # (B,Cout,M)
         return new_xyz, y, inds.to(torch.int64)

@@ -99,6 +99,6 @@ class CosineSimAug(nn.Module):
         fusion_feature = torch.cat((sim_feat.unsqueeze(1), template_xyz_), dim=1)
         fusion_feature = torch.cat((fusion_feature, template_feats.unsqueeze(-1).expand(b, f, n1, n2)), dim=1)
         fusion_feature = self.mlp(fusion_feature)
-        fusion_feature = F.max_pool2d(fusion_feature, kernel_size=[fusion_feature.size(2), 1]).squeeze(2)
+        fusion_feature = fusion_feature.max(dim=2)[0]        # = F.max_pool2d(., [n1, 1]).squeeze(2) (reference :41-42)
         batch_dict['cosine_feats'] = self.conv(fusion_feature)
         return batch_dict
