@@ -6,6 +6,7 @@ from ptt_amd import synth
 from ptt_amd.config import StubDataset, ptt_model_cfg
 from ptt_amd.models import build_network
 dev = torch.device("cuda:0"); B = int(os.environ.get("B", 48))
+if os.environ.get("NO_MIOPEN"): torch.backends.cudnn.enabled = False
 torch.manual_seed(1)
 model = build_network(ptt_model_cfg(), 1, StubDataset(training=True)).to(dev).train()
 opt = torch.optim.Adam(model.parameters(), lr=1e-3, betas=(0.5, 0.999), eps=1e-6)

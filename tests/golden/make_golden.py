@@ -22,6 +22,7 @@ Fixtures:
   G8 knn_argsort.npz       kNN vs the reference's square_distance + argsort on tie-free inputs
   G9 cosine_sim_aug.npz    CosineSimAug (N1): cosine map samples + cosine_feats
   G6 ptt_forward.npz       full PTT.forward (eval) through the reference's own heads (N2) + state_dict key/shape list
+  G10 train_step.npz       one training forward + backward of the full tracker (N3): loss, gradient norms, 8 full gradients
 """
 import os
 import sys
@@ -254,6 +255,32 @@ def main():
                                          'pred_centroids_votes', 'votes_feats', 'pred_box_center', 'pred_box_data')})
     report.append("G6 full PTT.forward written: %d state_dict keys, %d parameters" %
                   (len(keys6), sum(p.numel() for p in ref_model.parameters())))
+
+    # ---------------- G10 one training step of the full tracker (N3: loss + gradients, BN on batch statistics) ----------------
+    # a fresh cfg: the reference's constructor mutates the MLPS list of the cfg it is given (pointnet2_modules.py:51-53)
+    rcfg10 = ref_cfg_from_yaml(os.path.join(REF, "tools/cfgs/kitti_models/ptt.yaml"), EasyDict())
+    ref_train = fill_state_dict_(ref_build_network(rcfg10.MODEL, 1, StubDataset(training=True)), 1010).train()
+    s10, t10 = synth.frames(1010, 3, 1024, 512)
+    rs10 = np.random.RandomState(1010)
+    cls10 = (rs10.uniform(size=(3, 1024)) > 0.7).astype(np.float32)
+    reg10 = (rs10.standard_normal((3, 4)) * 0.3).astype(np.float32)
+    ret10, _, _ = ref_train({'search_points': torch.from_numpy(s10), 'template_points': torch.from_numpy(t10),
+                             'batch_size': 3, 'cls_label': torch.from_numpy(cls10), 'reg_label': torch.from_numpy(reg10)})
+    loss10 = ret10['loss'].mean()
+    loss10.backward()
+    named = dict(ref_train.named_parameters())
+    gkeys = sorted(k for k, p_ in named.items() if p_.grad is not None)
+    full = ['backbone_3d.SA_modules.0.mlp_module.layer0.conv.weight', 'backbone_3d.SA_modules.2.mlp_module.layer2.conv.weight',
+            'backbone_3d.cov_final.bias', 'centroid_voting_head.transformer_block.fc_delta.0.weight',
+            'centroid_voting_head.transformer_block.w_ks.weight', 'box_voting_head.transformer_block.fc_gamma.2.bias',
+            'similarity_module.mlp.layer0.conv.weight', 'box_voting_head.refine_layer.2.conv.weight']
+    full = [k for k in full if k in named and named[k].grad is not None]
+    save("G10_train_step.npz", search=s10, template=t10, cls_label=cls10, reg_label=reg10, seed=1010,
+         loss=np.float64(loss10.item()), grad_keys=np.array(gkeys),
+         grad_norms=np.array([float(named[k].grad.double().norm()) for k in gkeys]),
+         full_keys=np.array(full), **{"grad_%d" % i: named[k].grad.numpy() for i, k in enumerate(full)},
+         bn_mean_after=ref_train.state_dict()['backbone_3d.SA_modules.1.mlp_module.layer1.normlayer.bn.running_mean'].numpy())
+    report.append("G10 training step written: loss %.6f, %d parameter gradients (%d in full)" % (loss10.item(), len(gkeys), len(full)))
 
     # ---------------- G7 op-level edge cases (authored here; no reference implementation exists) ----------------
     rs7 = np.random.RandomState(707)
