@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PTT_ABI_VERSION 2
+#define PTT_ABI_VERSION 3
 
 enum {
     PTT_OK = 0,
@@ -94,6 +94,18 @@ int ptt_group_f32(const float* feat, const int32_t* idx, int B, int C, int N, in
                   int ns, float* out, ptt_stream_t stream);
 int ptt_group_grad_f32(const float* grad_out, const int32_t* idx, int B, int C, int N,
                        int M, int ns, float* grad_feat, ptt_stream_t stream);
+
+/* ---------------------------------------------------------------------------------
+ * N3  deterministic scatter-add: the backward of gather_points (E = M) and group_points (E = M*nsample)
+ * replaces _ext.gather_points_grad / _ext.group_points_grad   pointnet2_utils.py:118,257
+ *   out[b,c,n] = sum of src[b,c,e] over the entries e with idx[b,e] == n, added in ascending e, i.e. the
+ *   result of the sequential loop — bit-identical run to run (upstream's atomicAdd kernels are not).
+ *   idx (B,E) i32 in [0,N); src (B,C,E); out (B,C,N); E <= 16384.
+ *   workspace: ptt_scatter_add_det_workspace(B,N,E) bytes of device memory (PTT_EWORKSPACE if smaller).
+ * ------------------------------------------------------------------------------- */
+size_t ptt_scatter_add_det_workspace(int B, int N, int E);
+int ptt_scatter_add_det_f32(const float* src, const int32_t* idx, int B, int C, int N, int E, float* out,
+                            void* workspace, size_t workspace_bytes, ptt_stream_t stream);
 
 /* ---------------------------------------------------------------------------------
  * T1  k nearest neighbours inside one cloud

@@ -10,13 +10,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libptt_hip.so")
 
 PTT_SA_MAX_LAYERS = 4
-ABI_VERSION = 2            # PTT_ABI_VERSION of include/ptt_hip.h these structures mirror
+ABI_VERSION = 3            # PTT_ABI_VERSION of include/ptt_hip.h these structures mirror
 
 # every symbol include/ptt_hip.h declares (tests check the library exports all of them)
 EXPORTS = [
     "ptt_version", "ptt_error_name", "ptt_last_error_string",
     "ptt_fps_f32", "ptt_gather_f32", "ptt_gather_grad_f32", "ptt_select_centres_f32", "ptt_ball_query_f32",
-    "ptt_group_f32", "ptt_group_grad_f32", "ptt_knn_f32", "ptt_knn_rel_f32",
+    "ptt_group_f32", "ptt_group_grad_f32", "ptt_scatter_add_det_workspace", "ptt_scatter_add_det_f32",
+    "ptt_knn_f32", "ptt_knn_rel_f32",
     "ptt_packed_weight_elems", "ptt_pack_weight_f32", "ptt_pack_weight_rot_f32", "ptt_linear_f32",
     "ptt_sa_fused_fwd_f32", "ptt_xcorr_fused_fwd_f32", "ptt_pt_attn_pair_f32",
 ]
@@ -72,6 +73,7 @@ def _declare(lib):
         "ptt_ball_query_f32": [vp, vp, i, i, i, f, i, vp, vp],
         "ptt_group_f32": [vp, vp, i, i, i, i, i, vp, vp],
         "ptt_group_grad_f32": [vp, vp, i, i, i, i, i, vp, vp],
+        "ptt_scatter_add_det_f32": [vp, vp, i, i, i, i, vp, vp, c_size_t, vp],
         "ptt_knn_f32": [vp, i, i, i, vp, vp],
         "ptt_knn_rel_f32": [vp, i, i, i, vp, vp, vp],
         "ptt_pack_weight_f32": [vp, i, i, vp, vp],
@@ -87,6 +89,8 @@ def _declare(lib):
         fn.argtypes = args
     lib.ptt_packed_weight_elems.restype = c_size_t
     lib.ptt_packed_weight_elems.argtypes = [i, i]
+    lib.ptt_scatter_add_det_workspace.restype = c_size_t
+    lib.ptt_scatter_add_det_workspace.argtypes = [i, i, i]
 
 
 def lib():

@@ -253,6 +253,71 @@ __global__ __launch_bounds__(512) void group_grad_lds_kernel(const float* __rest
     for (int i = threadIdx.x; i < cc * N; i += blockDim.x) o[i] = acc[i];
 }
 
+// ------------------------------------------------------------------------------------------
+// Deterministic scatter-add (N3): out[b,c,n] = sum over the entries e of cloud b with idx[b,e] == n of src[b,c,e],
+// added in ASCENDING e — the order of a sequential loop, so the result is bit-identical run to run and to the CPU
+// oracle. Two kernels:
+//   scatter_csr_kernel   one workgroup per cloud sorts the keys idx*Epad + e in LDS (bitonic) and writes the entry
+//                        order plus the start of every bin (lower_bound per bin) — shared by all C channels;
+//   scatter_add_det_kernel  a workgroup owns cloud b and a chunk of channels: per channel it stages the E source
+//                        values in LDS with coalesced loads, then thread n walks bin n's entries in order.
+// E <= 16384 entries per cloud (64 KB of keys); larger problems stay on the atomic kernels.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void scatter_csr_kernel(const int32_t* __restrict__ idx, int N, int E, int Epad,
+                                                           int32_t* __restrict__ order, int32_t* __restrict__ start) {
+    extern __shared__ unsigned keys[];                   // [Epad]
+    const int b = blockIdx.x;
+    const int32_t* ib = idx + (size_t)b * E;
+    for (int e = threadIdx.x; e < Epad; e += blockDim.x)
+        keys[e] = (e < E) ? (unsigned)ib[e] * (unsigned)Epad + (unsigned)e : 0xffffffffu;
+    __syncthreads();
+    for (int k = 2; k <= Epad; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < Epad; i += blockDim.x) {
+                const int x = i ^ j;
+                if (x > i) {
+                    const unsigned a = keys[i], c = keys[x];
+                    const bool up = (i & k) == 0;
+                    if (up ? (a > c) : (a < c)) { keys[i] = c; keys[x] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    for (int e = threadIdx.x; e < E; e += blockDim.x) order[(size_t)b * E + e] = (int32_t)(keys[e] & (unsigned)(Epad - 1));
+    for (int n = threadIdx.x; n <= N; n += blockDim.x) {  // first sorted slot whose bin is >= n
+        const unsigned want = (unsigned)n * (unsigned)Epad;
+        int lo = 0, hi = E;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (keys[mid] < want) lo = mid + 1; else hi = mid;
+        }
+        start[(size_t)b * (N + 1) + n] = (n == N) ? E : lo;
+    }
+}
+
+__global__ __launch_bounds__(512) void scatter_add_det_kernel(const float* __restrict__ src, const int32_t* __restrict__ order,
+                                                              const int32_t* __restrict__ start, int C, int N, int E,
+                                                              int CC, int nchunks, float* __restrict__ out) {
+    extern __shared__ float row[];                       // [E] source values of one channel, then [E] ints: the order
+    int* ord = reinterpret_cast<int*>(row + E);
+    const int b = blockIdx.x / nchunks, c0 = (blockIdx.x % nchunks) * CC;
+    const int cc = min(CC, C - c0);
+    for (int e = threadIdx.x; e < E; e += blockDim.x) ord[e] = order[(size_t)b * E + e];
+    const int32_t* st = start + (size_t)b * (N + 1);
+    for (int ci = 0; ci < cc; ++ci) {
+        const float* g = src + ((size_t)b * C + c0 + ci) * E;
+        __syncthreads();                                  // previous channel's readers are done (and ord is in place)
+        for (int e = threadIdx.x; e < E; e += blockDim.x) row[e] = g[e];
+        __syncthreads();
+        float* o = out + ((size_t)b * C + c0 + ci) * N;
+        for (int n = threadIdx.x; n < N; n += blockDim.x) {
+            float acc = 0.f;
+            for (int p = st[n], pe = st[n + 1]; p < pe; ++p) acc += row[ord[p]];
+            o[n] = acc;
+        }
+    }
+}
+
 // centres of one SA level in a single launch: new_xyz[b,m,:] = xyz[b, idx[b,m], :] (idx NULL = the first M
 // points, the 'sequence' sampling of pointnet2_modules.py:70-71) and the int64 copy of the indices the
 // module returns (pointnet2_modules.py:90).
@@ -435,6 +500,48 @@ extern "C" int ptt_group_grad_f32(const float* grad_out, const int32_t* idx, int
     hipLaunchKernelGGL(group_grad_kernel, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), grad_out, idx,
                        C, N, M, ns, grad_feat, total);
     return check_launch("group_grad_kernel");
+}
+
+extern "C" size_t ptt_scatter_add_det_workspace(int B, int N, int E) {
+    if (B <= 0 || N <= 0 || E <= 0) return 0;
+    return ((size_t)B * E + (size_t)B * (N + 1)) * sizeof(int32_t);
+}
+
+extern "C" int ptt_scatter_add_det_f32(const float* src, const int32_t* idx, int B, int C, int N, int E, float* out,
+                                       void* workspace, size_t workspace_bytes, ptt_stream_t stream) {
+    if (B < 0 || C < 0 || N <= 0 || E < 0) return fail(PTT_EINVAL, "ptt_scatter_add_det_f32: bad sizes");
+    const size_t nout = (size_t)B * C * N;
+    if (nout == 0) return PTT_OK;
+    if (!out) return fail(PTT_EINVAL, "ptt_scatter_add_det_f32: null pointer");
+    hipStream_t s = as_stream(stream);
+    if (E == 0) {
+        if (hipMemsetAsync(out, 0, nout * sizeof(float), s) != hipSuccess) return check_launch("scatter_add_det memset");
+        return PTT_OK;
+    }
+    if (!src || !idx) return fail(PTT_EINVAL, "ptt_scatter_add_det_f32: null pointer");
+    if (E > 16384 || (unsigned long long)N * 16384ull > 0xffffffffull)
+        return fail(PTT_EUNSUPPORTED, "ptt_scatter_add_det_f32: E=%d N=%d (at most 16384 entries per cloud)", E, N);
+    const size_t need = ptt_scatter_add_det_workspace(B, N, E);
+    if (!workspace || workspace_bytes < need)
+        return fail(PTT_EWORKSPACE, "ptt_scatter_add_det_f32: workspace of %zu bytes, %zu needed", workspace_bytes, need);
+    int Epad = 2;
+    while (Epad < E) Epad <<= 1;
+    int32_t* order = static_cast<int32_t*>(workspace);
+    int32_t* start = order + (size_t)B * E;
+    hipLaunchKernelGGL(scatter_csr_kernel, dim3(B), dim3(1024), (size_t)Epad * sizeof(unsigned), s, idx, N, E, Epad, order,
+                       start);
+    int rc = check_launch("scatter_csr_kernel");
+    if (rc) return rc;
+    const int CC = 8, nchunks = (C + CC - 1) / CC;
+    const size_t lds = (size_t)E * (sizeof(float) + sizeof(int));
+    if (lds > 64 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(scatter_add_det_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return check_launch("hipFuncSetAttribute(scatter_add_det_kernel)");
+    }
+    hipLaunchKernelGGL(scatter_add_det_kernel, dim3(B * nchunks), dim3(512), lds, s, src, order, start, C, N, E, CC, nchunks,
+                       out);
+    return check_launch("scatter_add_det_kernel");
 }
 
 extern "C" int ptt_knn_rel_f32(const float* xyz, int B, int N, int k, int32_t* idx_out, float* rel_out,

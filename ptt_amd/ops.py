@@ -7,6 +7,7 @@ fp32 / int32, contiguous. Kernels are enqueued on the current torch stream; noth
 synchronises. The second group exposes the fused fp32-MFMA kernels.
 """
 import ctypes
+import os
 
 import torch
 
@@ -96,11 +97,32 @@ def gather_points(features, idx):
     return out
 
 
+def scatter_add_det(src, idx, N):
+    """Deterministic out[b,c,n] = sum_{e: idx[b,e]==n} src[b,c,e] in ascending e (ptt_scatter_add_det_f32).
+    src (B,C,E) f32, idx (B,E) i32 -> (B,C,N); E <= 16384."""
+    B, C, E = src.shape
+    out = torch.empty((B, C, int(N)), dtype=torch.float32, device=src.device)
+    nbytes = _lib.lib().ptt_scatter_add_det_workspace(B, int(N), E)
+    ws = torch.empty((max(1, (nbytes + 3) // 4),), dtype=torch.int32, device=src.device)
+    with torch.cuda.device(src.device):
+        _lib.check(_lib.lib().ptt_scatter_add_det_f32(_ptr(src), _ptr(idx), B, C, int(N), E, _ptr(out), _ptr(ws),
+                                                      ws.numel() * 4, _stream()), "ptt_scatter_add_det_f32")
+    return out
+
+
+def _det_grads(entries):
+    """The backward scatter-adds run in a fixed summation order (bit-reproducible, equal to the sequential loop) unless
+    PTT_ATOMIC_GRADS=1 asks for upstream's atomicAdd behaviour or a cloud has more than 16384 entries."""
+    return entries <= 16384 and os.environ.get("PTT_ATOMIC_GRADS", "0") != "1"
+
+
 def gather_points_grad(grad_out, idx, N):
     """(B,C,M) f32, (B,M) i32 -> (B,C,N).  Replaces _ext.gather_points_grad (pointnet2_utils.py:118)."""
     _chk(grad_out, "grad_out", torch.float32, 3)
     _chk(idx, "idx", torch.int32, 2)
     B, C, M = grad_out.shape
+    if M > 0 and _det_grads(M):
+        return scatter_add_det(grad_out, idx, N)
     out = torch.empty((B, C, int(N)), dtype=torch.float32, device=grad_out.device)
     with torch.cuda.device(grad_out.device):
         _lib.check(_lib.lib().ptt_gather_grad_f32(_ptr(grad_out), _ptr(idx), B, C, int(N), M, _ptr(out), _stream()),
@@ -154,6 +176,8 @@ def group_points_grad(grad_out, idx, N):
     _chk(grad_out, "grad_out", torch.float32, 4)
     _chk(idx, "idx", torch.int32, 3)
     B, C, M, ns = grad_out.shape
+    if M * ns > 0 and _det_grads(M * ns):
+        return scatter_add_det(grad_out.view(B, C, M * ns), idx.view(B, M * ns), N)
     out = torch.empty((B, C, int(N)), dtype=torch.float32, device=grad_out.device)
     with torch.cuda.device(grad_out.device):
         _lib.check(_lib.lib().ptt_group_grad_f32(_ptr(grad_out), _ptr(idx), B, C, int(N), M, ns, _ptr(out),
