@@ -232,3 +232,36 @@ def test_G10_module_mirror_training_step_equals_reference_on_cpu(monkeypatch):
         ref = g["grad_%d" % i]
         np.testing.assert_allclose(named[k].grad.numpy(), ref, atol=1e-5 * float(np.abs(ref).max()) + 1e-9, rtol=1e-4,
                                    err_msg=k)
+
+
+def test_checkpoint_helpers_partial_and_full_load(tmp_path):
+    """N2: load_params_from_file takes every entry whose key AND shape match (tracker3d_template.py:96-124) and leaves the
+    rest; load_params_with_optimizer restores model + optimizer + (it, epoch) (:126-155)."""
+    import logging
+    from ptt_amd.config import StubDataset, ptt_model_cfg
+    from ptt_amd.models import build_network
+    from tests.util import fill_state_dict_
+    src = fill_state_dict_(build_network(ptt_model_cfg(), 1, StubDataset()), 5)
+    sd = {k: v.clone() for k, v in src.state_dict().items()}
+    odd = 'backbone_3d.cov_final.bias'
+    sd[odd] = torch.zeros(7)                               # wrong shape: must be skipped, not raise
+    sd['not.in.the.model'] = torch.zeros(3)
+    ck = tmp_path / "ckpt.pth"
+    torch.save({'model_state': sd, 'version': 'test', 'epoch': 3, 'it': 17}, str(ck))
+    dst = fill_state_dict_(build_network(ptt_model_cfg(), 1, StubDataset()), 6)
+    before = dst.state_dict()[odd].clone()
+    dst.load_params_from_file(str(ck), logging.getLogger("ckpt"), to_cpu=True)
+    got = dst.state_dict()
+    for k, v in src.state_dict().items():
+        if k == odd:
+            assert torch.equal(got[k], before)
+        else:
+            assert torch.equal(got[k], v), k
+    # full load with optimizer state
+    opt = torch.optim.Adam(src.parameters(), lr=1e-3)
+    torch.save({'model_state': src.state_dict(), 'optimizer_state': opt.state_dict(), 'epoch': 3, 'it': 17}, str(ck))
+    dst2 = build_network(ptt_model_cfg(), 1, StubDataset())
+    opt2 = torch.optim.Adam(dst2.parameters(), lr=5e-2)
+    it, epoch = dst2.load_params_with_optimizer(str(ck), to_cpu=True, optimizer=opt2, logger=logging.getLogger("ckpt"))
+    assert (it, epoch) == (17, 3) and opt2.param_groups[0]['lr'] == 1e-3
+    assert all(torch.equal(a, b) for a, b in zip(dst2.state_dict().values(), src.state_dict().values()))
