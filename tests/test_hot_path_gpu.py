@@ -166,7 +166,7 @@ def test_full_tracker_training_step_runs(dev):
     assert g is not None and torch.isfinite(g).all() and float(g.abs().sum()) > 0
 
 
-@pytest.mark.parametrize("variant", ["ptt", "p2b"])
+@pytest.mark.parametrize("variant", ["ptt", "p2b", "cls_xyz"])
 def test_full_tracker_eval_fused_equals_reference_op_sequence(dev, variant):
     """Whole tracker in eval mode, module by module: the fused HIP kernels vs the reference's own op sequence (unfused
     module paths on the HIP index ops + stock torch layers). Each module of the unfused pass consumes the fused pass's
@@ -179,8 +179,11 @@ def test_full_tracker_eval_fused_equals_reference_op_sequence(dev, variant):
         cfg.BACKBONE_3D.SA_CONFIG.SAMPLE_METHOD = ['sequence', 'sequence', 'sequence']
         cfg.CENTROID_HEAD.TRANSFORMER_BLOCK.ENABLE = False
         cfg.BOX_HEAD.TRANSFORMER_BLOCK.ENABLE = False
+    if variant == "cls_xyz":                                # the classifier also sees the seed coordinates (:78-86)
+        cfg.CENTROID_HEAD.CLS_USE_SEARCH_XYZ = True
+        cfg.CENTROID_HEAD.CLS_FC.CHANNELS = [259, 256, 256, 1]
     model = randomize_(build_network(cfg, 1, StubDataset()), seed=11).to(dev).eval()
-    assert hasattr(model.box_voting_head, 'transformer_block') == (variant == "ptt")
+    assert hasattr(model.box_voting_head, 'transformer_block') == (variant != "p2b")
     s, t = synth.frames(21, 3, 1024, 512)
     state = {'search_points': torch.from_numpy(s).to(dev), 'template_points': torch.from_numpy(t).to(dev),
              'batch_size': 3}
