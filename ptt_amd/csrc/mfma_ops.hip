@@ -112,6 +112,21 @@ __global__ void pack_weight_kernel(const float* __restrict__ W, int Cout, int K,
 }
 
 // One K-block: 4 * RT * CT MFMAs on the first CT column tiles of acc (ACT >= CT columns wide).
+// Weight fragments are fetched with raw buffer loads: address = descriptor base (SGPRs) + per-lane byte offset (one
+// VGPR, constant for the whole GEMM) + wave-uniform byte offset (SGPR, advanced by the scalar unit). The flat
+// global_load form made hipcc recompute a 64-bit VGPR address per fragment (v_add_co / v_addc pairs): ~10 vector-ALU
+// instructions per K-block that steal issue time from the fp32 MFMAs sharing the SIMD (DESIGN.md lesson 8).
+// -DPTT_BUFFER_WEIGHTS=0 restores the flat loads.
+#ifndef PTT_BUFFER_WEIGHTS
+#define PTT_BUFFER_WEIGHTS 1
+#endif
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t weight_rsrc(const void* p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);   // raw, 32-bit data format
+}
+__device__ __forceinline__ f32x4 weight_load(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+
 template <int RT, int CT, int ACT>
 __device__ __forceinline__ void gemm_mfma_block(const f32x4 (&a)[RT], const f32x4 (&b)[CT], f32x16 (&acc)[RT][ACT]) {
 #pragma unroll
@@ -142,13 +157,20 @@ __device__ __forceinline__ void gemm_core(const float* Xs, int ldk, int nkb, con
     const float* arow = Xs + row * ldk + 4 * half;
     const f32x4* bp = Wp + (size_t)ct0 * 64 + lane;
     const size_t bstep = (size_t)NT * 64;
+#if PTT_BUFFER_WEIGHTS
+    const __amdgpu_buffer_rsrc_t wr = weight_rsrc(Wp);
+    const int wvoff = (ct0 * 64 + lane) * 16;             // this lane's byte offset inside a K-block row of fragments
+    const int wkstep = NT * 1024;                          // bytes per K-block
+#define PTT_WFRAG(KB, U) weight_load(wr, wvoff, (KB) * wkstep + (U) * CTS * 1024)
+#else
+#define PTT_WFRAG(KB, U) (bp[(size_t)(KB) * bstep + (size_t)(U) * CTS * 64])
+#endif
 
     if constexpr (PF == 0) {                     // two register sets, order pinned with sched_barrier
         f32x4 a0[RT], a1[RT], b0[CT], b1[CT];
 #define PTT_LOAD_BLOCK(A, Bv, KB)                                                             \
         {                                                                                     \
-            const f32x4* bsrc = bp + (size_t)(KB) * bstep;                                    \
-            _Pragma("unroll") for (int u = 0; u < CT; ++u) Bv[u] = bsrc[(size_t)u * CTS * 64]; \
+            _Pragma("unroll") for (int u = 0; u < CT; ++u) Bv[u] = PTT_WFRAG(KB, u);          \
             _Pragma("unroll") for (int rt = 0; rt < RT; ++rt)                                 \
                 A[rt] = *reinterpret_cast<const f32x4*>(arow + rt * 32 * ldk + (KB) * 8);     \
         }
@@ -184,19 +206,13 @@ __device__ __forceinline__ void gemm_core(const float* Xs, int ldk, int nkb, con
 #undef PTT_LOAD_BLOCK
     } else if constexpr (PF == 1) {
         f32x4 bcur[CT], bnxt[CT];
-#ifdef PTT_NT_WEIGHTS
-#define PTT_WLOAD(ptr) __builtin_nontemporal_load(ptr)
-#else
-#define PTT_WLOAD(ptr) (*(ptr))
-#endif
 #pragma unroll
-        for (int u = 0; u < CT; ++u) { bcur[u] = pre ? pre[u] : PTT_WLOAD(bp + (size_t)u * CTS * 64); bnxt[u] = bcur[u]; }
+        for (int u = 0; u < CT; ++u) { bcur[u] = pre ? pre[u] : PTT_WFRAG(0, u); bnxt[u] = bcur[u]; }
         // the last block is peeled so that the loop body has NO conditional load: with a load under control
         // flow (run-time nkb) the waitcnt pass gives up counting and waits vmcnt(0) before every MFMA group
         for (int kb = 0; kb + 1 < nkb; ++kb) {
-            const f32x4* bn = bp + (size_t)(kb + 1) * bstep;
 #pragma unroll
-            for (int u = 0; u < CT; ++u) bnxt[u] = PTT_WLOAD(bn + (size_t)u * CTS * 64);
+            for (int u = 0; u < CT; ++u) bnxt[u] = PTT_WFRAG(kb + 1, u);
             f32x4 a[RT];
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) a[rt] = *reinterpret_cast<const f32x4*>(arow + rt * 32 * ldk + kb * 8);
@@ -249,6 +265,7 @@ __device__ __forceinline__ void gemm_core(const float* Xs, int ldk, int nkb, con
         }
 #undef PTT_STAGE
     }
+#undef PTT_WFRAG
 }
 
 // Run the core on however many of this wave's (up to CT) column tiles exist: a wave-uniform
