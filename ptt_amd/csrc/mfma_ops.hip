@@ -80,6 +80,9 @@ __device__ __forceinline__ void stagger_second_slot(int first_wave_blocks, int q
 // neighbourhoods) hit in that XCD's L2. Measured on the pair kernel (profiles/README.md): fabric traffic per
 // launch 443 -> 88 MB (55 MB compulsory), L2 hit rate 95.6 -> 99.1 %, kernel time -2 %.
 // -DPTT_XCD_REMAP=0 restores the plain numbering.
+#ifndef PTT_LINEAR_PF
+#define PTT_LINEAR_PF 1
+#endif
 #ifndef PTT_XCD_REMAP
 #define PTT_XCD_REMAP 1
 #endif
@@ -387,7 +390,7 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(LinearParams p) {
         float* cur = Xs + (c & 1) * BUF;
         if (c + 1 < nchunks) lin_fetch<RT, VEC>(p, row0, (c + 1) * LIN_KC, t, st);
         const int nkb_c = min(LIN_KC / 8, p.nkb - c * (LIN_KC / 8));
-        gemm_tiles<RT, CT, 1>(cur, LIN_LDK, nkb_c, reinterpret_cast<const f32x4*>(p.Wp) + (size_t)c * (LIN_KC / 8) * bstep,
+        gemm_tiles<RT, CT, PTT_LINEAR_PF>(cur, LIN_LDK, nkb_c, reinterpret_cast<const f32x4*>(p.Wp) + (size_t)c * (LIN_KC / 8) * bstep,
                           p.NT, ctbase, nvalid, lane, acc);
         if (c + 1 < nchunks) {
             lin_stage<RT>(Xs + ((c + 1) & 1) * BUF, t, st);   // the other buffer: last read in chunk c-1
@@ -824,7 +827,7 @@ __global__ __launch_bounds__(256, 2) void pt_attn_pair_kernel(AttnParams p) {
         const int b = pt / p.N;
         const int n = p.knn[(size_t)pt * KNN + (t & 15)];
         const int flat = b * p.N + n;
-        nb[t] = flat;
+        nb[t] = n * (3 * D * (int)sizeof(float));      // byte offset of the neighbour's q|k|v row inside its cloud
         f32x4 r4;
         if (p.rel) {                                   // precomputed by the kNN kernel: no index -> xyz dependency
             const float* rl = p.rel + ((size_t)pt * KNN + (t & 15)) * 3;
@@ -870,9 +873,14 @@ __global__ __launch_bounds__(256, 2) void pt_attn_pair_kernel(AttnParams p) {
         for (int r = 0; r < 16; ++r) delta[0][u][r] += bb;
     }
     PTT_STAMP(2);
-    int nrow[16];  // flat neighbour row of each of this lane's 16 tile rows
+    // Gathers of neighbour k / v rows: raw buffer loads on a descriptor based at the cloud's first q|k|v row. The
+    // per-(row, lane) byte offset is ONE 32-bit VGPR per tile row; channel group and the k / v column block are
+    // immediates or an SGPR — a flat 64-bit address per load costs 3-4 vector-ALU instructions, 64 loads per phase.
+    const int cloud = ((pt0 < p.BN ? pt0 : p.BN - 1) / p.N);
+    const __amdgpu_buffer_rsrc_t rq = weight_rsrc(p.qkv + (size_t)cloud * p.N * 3 * D);
+    int nrow[16];  // byte offset of (neighbour row, this lane's first column) for each of this lane's 16 tile rows
 #pragma unroll
-    for (int r = 0; r < 16; ++r) nrow[r] = nb[tile_row(r, half)];
+    for (int r = 0; r < 16; ++r) nrow[r] = nb[tile_row(r, half)] + (w * 32 + (lane & 31)) * (int)sizeof(float);
 
     lds_barrier();  // all waves done with h
     // t = (q_i - k_j) + delta  -> X
@@ -884,7 +892,8 @@ __global__ __launch_bounds__(256, 2) void pt_attn_pair_kernel(AttnParams p) {
             const float qb = p.qkv[(size_t)pb * 3 * D + cols[u]];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float kv = p.qkv[(size_t)nrow[r] * 3 * D + D + cols[u]];
+                const float kv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                    rq, nrow[r] + (D + u * 128) * (int)sizeof(float), 0, 0));
                 const float q = (r < 8) ? qa : qb;
                 Xs[tile_row(r, half) * LDK + cols[u]] = (q - kv) + delta[0][u][r];
             }
@@ -926,7 +935,9 @@ __global__ __launch_bounds__(256, 2) void pt_attn_pair_kernel(AttnParams p) {
 #pragma unroll
     for (int u = 0; u < CT; ++u)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) vv[u][r] = p.qkv[(size_t)nrow[r] * 3 * D + 2 * D + cols[u]];
+        for (int r = 0; r < 16; ++r)
+            vv[u][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                rq, nrow[r] + u * 128 * (int)sizeof(float), 2 * D * (int)sizeof(float), 0));
 #pragma unroll
     for (int u = 0; u < CT; ++u) {
 #pragma unroll
