@@ -303,11 +303,20 @@ __device__ __forceinline__ void prefetch_first_block_full(const float* Wp, int w
     for (int u = 0; u < CT; ++u) pre[u] = bp[(size_t)u * 4 * 64];
 }
 
-// First K-block of a layer's weights for this wave's (up to 2) column tiles w, w+4.
-__device__ __forceinline__ void prefetch_first_block(const float* Wp, int NT, int w, int lane, f32x4* pre) {
+// What a wave requests ahead of a layer of the chained kernels: the first K-block of the weights of its (up to 2)
+// column tiles w, w+4, and — when the layer has no separate scale (BatchNorm folded into the packed weights) — the
+// per-column shift, which then INITIALISES the accumulators instead of being added in the epilogue.
+struct SaPre { f32x4 w[2]; float sh[2]; };
+__device__ __forceinline__ void prefetch_first_block(const float* Wp, const float* scale, const float* shift, int NT, int w,
+                                                     int lane, SaPre& pre) {
     const f32x4* bp = reinterpret_cast<const f32x4*>(Wp) + (size_t)w * 64 + lane;
-    if (w < NT) pre[0] = bp[0];
-    if (w + 4 < NT) pre[1] = bp[4 * 64];
+    pre.sh[0] = pre.sh[1] = 0.f;
+    if (w < NT) pre.w[0] = bp[0];
+    if (w + 4 < NT) pre.w[1] = bp[4 * 64];
+    if (shift && !scale) {
+        if (w < NT) pre.sh[0] = shift[w * 32 + (lane & 31)];
+        if (w + 4 < NT) pre.sh[1] = shift[(w + 4) * 32 + (lane & 31)];
+    }
 }
 
 template <int RT, int CT>
@@ -524,16 +533,27 @@ __device__ __forceinline__ void sa_gather_rows(const SaParams& p, float* Xt, int
 
 template <int NS, int CT, int RT = 2>
 __device__ __forceinline__ void sa_layer(const SaParams& p, const SaLayerDev& L, bool last, float* Xs, int lane, int w,
-                                         int centre0, int ncentres, f32x4* pre, const SaLayerDev* Lnext) {
+                                         int centre0, int ncentres, SaPre& pre, const SaLayerDev* Lnext) {
     static_assert(NS != 64 || RT == 2, "a 64-neighbour centre spans two row tiles");
+    // Everything outside the MFMA loop costs matrix time (fp32 MFMA and the vector ALU are one resource, DESIGN.md
+    // lesson 8), so the epilogue is kept to one instruction per value where the layer allows it: with the BatchNorm
+    // scale folded into the packed weights (L.scale == NULL) the shift starts the accumulators, an inner layer is
+    // max(acc, 0) + one LDS write per value, and the last layer pools FIRST and applies the ReLU to the pooled value
+    // (max and ReLU commute).
+    const bool affine = L.scale != nullptr;              // wave-uniform: separate scale (and shift) in the epilogue
     f32x16 acc[RT][CT];
-    zero_acc(acc);
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int u = 0; u < CT; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[rt][u][r] = pre.sh[u];          // 0 unless the shift rides in the accumulator
     int nvalid = 0;
 #pragma unroll
     for (int u = 0; u < CT; ++u)
         if (w + 4 * u < L.NT) nvalid = u + 1;
-    gemm_tiles<RT, CT, 0>(Xs, p.ldk, L.nkb, reinterpret_cast<const f32x4*>(L.Wp), L.NT, w, nvalid, lane, acc, pre);
-    if (Lnext) prefetch_first_block(Lnext->Wp, Lnext->NT, w, lane, pre);   // in flight across the epilogue + barriers
+    gemm_tiles<RT, CT, 0>(Xs, p.ldk, L.nkb, reinterpret_cast<const f32x4*>(L.Wp), L.NT, w, nvalid, lane, acc, pre.w);
+    if (Lnext) prefetch_first_block(Lnext->Wp, Lnext->scale, Lnext->shift, Lnext->NT, w, lane, pre);   // in flight across the epilogue + barriers
     if (!last) lds_barrier();
     // every wave has finished reading this layer's input tile (the last layer writes no LDS)
 
@@ -541,39 +561,36 @@ __device__ __forceinline__ void sa_layer(const SaParams& p, const SaLayerDev& L,
 #pragma unroll
     for (int u = 0; u < CT; ++u) {
         if (u >= nvalid) break;
-        const int col = (w + 4 * u) * 32 + (lane & 31);
-        const bool colok = col < L.Cout;
-        const float sc = (L.scale && colok) ? L.scale[col] : 1.f;
-        const float sh = (L.shift && colok) ? L.shift[col] : 0.f;
+        const int col = (w + 4 * u) * 32 + (lane & 31);  // < Cout: the host admits only Cout % 32 == 0
+        float sc = 1.f, sh = 0.f;
+        if (affine) { sc = L.scale[col]; sh = L.shift ? L.shift[col] : 0.f; }
         float m64 = -__builtin_inff();                 // NS == 64: one centre spans both row tiles
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
             float y[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v = acc[rt][u][r] * sc + sh;
-                if (L.relu) v = fmaxf(v, 0.f);
-                y[r] = colok ? v : 0.f;
-            }
+            for (int r = 0; r < 16; ++r) y[r] = affine ? acc[rt][u][r] * sc + sh : acc[rt][u][r];
             if (!last) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) Xs[(rt * 32 + tile_row(r, half)) * p.ldk + col] = y[r];
+                for (int r = 0; r < 16; ++r)
+                    Xs[(rt * 32 + tile_row(r, half)) * p.ldk + col] = L.relu ? fmaxf(y[r], 0.f) : y[r];
             } else if (NS == 64) {
                 float m = y[0];
 #pragma unroll
                 for (int r = 1; r < 16; ++r) m = fmaxf(m, y[r]);
                 m64 = fmaxf(m64, max_halves(m));
-                if (rt == RT - 1 && half == 0 && colok && ncentres > 0) {
+                if (rt == RT - 1 && half == 0 && ncentres > 0) {
                     const int b = centre0 / p.M, mm = centre0 - b * p.M;
-                    p.out[b * p.osb + col * p.osc + mm * p.osm] = m64;
+                    p.out[b * p.osb + col * p.osc + mm * p.osm] = L.relu ? fmaxf(m64, 0.f) : m64;
                 }
             } else if (NS == 32) {
                 float m = y[0];
 #pragma unroll
                 for (int r = 1; r < 16; ++r) m = fmaxf(m, y[r]);
                 m = max_halves(m);
+                if (L.relu) m = fmaxf(m, 0.f);
                 const int c = centre0 + rt;
-                if (half == 0 && colok && rt < ncentres) {
+                if (half == 0 && rt < ncentres) {
                     const int b = c / p.M, mm = c - b * p.M;
                     p.out[b * p.osb + col * p.osc + mm * p.osm] = m;
                 }
@@ -583,7 +600,8 @@ __device__ __forceinline__ void sa_layer(const SaParams& p, const SaLayerDev& L,
                 for (int r = 1; r < 8; ++r) { m0 = fmaxf(m0, y[r]); m1 = fmaxf(m1, y[8 + r]); }
                 m0 = max_halves(m0);
                 m1 = max_halves(m1);
-                if (half == 0 && colok) {
+                if (L.relu) { m0 = fmaxf(m0, 0.f); m1 = fmaxf(m1, 0.f); }
+                if (half == 0) {
                     const int ca = rt * 2, cb = rt * 2 + 1;
                     if (ca < ncentres) {
                         const int c = centre0 + ca; const int b = c / p.M, mm = c - b * p.M;
@@ -613,8 +631,9 @@ __global__ __launch_bounds__(256, PTT_SA_WAVES) void sa_fused_kernel(SaParams p)
 #define PTT_STAMP(i) do { if (p.dbg && t == 0 && blockIdx.x < 4096) p.dbg[blockIdx.x * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
     PTT_STAMP(0);
 
-    f32x4 pre[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    prefetch_first_block(p.L[0].Wp, p.L[0].NT, w, lane, pre);      // layer 0's first weight block rides along the gather
+    SaPre pre;
+    pre.w[0] = pre.w[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    prefetch_first_block(p.L[0].Wp, p.L[0].scale, p.L[0].shift, p.L[0].NT, w, lane, pre);      // layer 0's first weight block rides along the gather
 
     // ---- group: neighbour features + relative (normalised) coordinates -> X; wave w fills 8*RT consecutive rows ----
     sa_gather_rows<NS, 8 * RT>(p, Xs, w * 8 * RT, centre0, lane);
@@ -662,8 +681,9 @@ __global__ __launch_bounds__(256, 2) void xcorr_fused_kernel(XcorrParams q) {
     const int j = logical_block();           // flat search point b*Ns + jj
     const int b = j / p.M, jj = j - b * p.M;
     stagger_second_slot(p.first_wave, p.stagger);
-    f32x4 pre[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    prefetch_first_block(p.L[0].Wp, p.L[0].NT, w, lane, pre);
+    SaPre pre;
+    pre.w[0] = pre.w[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    prefetch_first_block(p.L[0].Wp, p.L[0].scale, p.L[0].shift, p.L[0].NT, w, lane, pre);
 
     // ---- 64 cosines: thread (i = t>>2, quarter = t&3) covers channels quarter, quarter+4, ... ----
     {
@@ -716,34 +736,43 @@ __global__ __launch_bounds__(256, 2) void xcorr_fused_kernel(XcorrParams q) {
 // chain runs without a single workgroup barrier and all four waves do the same amount of work
 // (the column-split kernel leaves half the waves idle when a layer has only two column tiles).
 // ------------------------------------------------------------------------------------------
-template <int NS, int CT>
+template <int NS, int CT, bool AFFINE>
 __device__ __forceinline__ void sa_wave_layer(const SaParams& p, const SaLayerDev& L, bool last, float* Xw, int lane,
                                               int centre0, int ncentres) {
+    // same epilogue economy as sa_layer: shift in the accumulator when there is no separate scale (AFFINE false),
+    // ReLU after the pool. (The shift is fetched here, not a layer ahead: at 3 waves per SIMD the other waves cover
+    // the round trip, and the extra live registers would spill at the 168-VGPR bound of this kernel.)
     f32x16 acc[1][CT];
-    zero_acc(acc);
+#pragma unroll
+    for (int u = 0; u < CT; ++u) {
+        const float s0 = (!AFFINE && L.shift) ? L.shift[u * 32 + (lane & 31)] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][u][r] = s0;
+    }
     gemm_core<1, CT, CT, 1>(Xw, p.ldk, L.nkb, reinterpret_cast<const f32x4*>(L.Wp), L.NT, 0, lane, acc);
     __builtin_amdgcn_wave_barrier();
     const int half = lane >> 5;
 #pragma unroll
     for (int u = 0; u < CT; ++u) {
         const int col = u * 32 + (lane & 31);
-        const float sc = L.scale ? L.scale[col] : 1.f;
-        const float sh = L.shift ? L.shift[col] : 0.f;
         float y[16];
+        if constexpr (AFFINE) {
+            const float sc = L.scale[col], sv = L.shift ? L.shift[col] : 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float v = acc[0][u][r] * sc + sh;
-            if (L.relu) v = fmaxf(v, 0.f);
-            y[r] = v;
+            for (int r = 0; r < 16; ++r) y[r] = acc[0][u][r] * sc + sv;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) y[r] = acc[0][u][r];
         }
         if (!last) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) Xw[tile_row(r, half) * p.ldk + col] = y[r];
+            for (int r = 0; r < 16; ++r) Xw[tile_row(r, half) * p.ldk + col] = L.relu ? fmaxf(y[r], 0.f) : y[r];
         } else if (NS == 32) {
             float m = y[0];
 #pragma unroll
             for (int r = 1; r < 16; ++r) m = fmaxf(m, y[r]);
             m = max_halves(m);
+            if (L.relu) m = fmaxf(m, 0.f);
             if (half == 0 && ncentres > 0) {
                 const int b = centre0 / p.M, mm = centre0 - b * p.M;
                 p.out[b * p.osb + col * p.osc + mm * p.osm] = m;
@@ -754,6 +783,7 @@ __device__ __forceinline__ void sa_wave_layer(const SaParams& p, const SaLayerDe
             for (int r = 1; r < 8; ++r) { m0 = fmaxf(m0, y[r]); m1 = fmaxf(m1, y[8 + r]); }
             m0 = max_halves(m0);
             m1 = max_halves(m1);
+            if (L.relu) { m0 = fmaxf(m0, 0.f); m1 = fmaxf(m1, 0.f); }
             if (half == 0) {
                 if (ncentres > 0) {
                     const int b = centre0 / p.M, mm = centre0 - b * p.M;
@@ -786,9 +816,13 @@ __global__ __launch_bounds__(256, 3) void sa_wave_kernel(SaParams p) {
     for (int l = 0; l < p.n_layers; ++l) {
         const SaLayerDev& L = p.L[l];
         const bool last = (l == p.n_layers - 1);
-        if (L.NT == 1) sa_wave_layer<NS, 1>(p, L, last, Xw, lane, centre0, ncentres);
-        else if (L.NT == 2) sa_wave_layer<NS, 2>(p, L, last, Xw, lane, centre0, ncentres);
-        else sa_wave_layer<NS, 4>(p, L, last, Xw, lane, centre0, ncentres);
+#define PTT_WAVE_LAYER(CTV)                                                                         \
+        { if (L.scale) sa_wave_layer<NS, CTV, true>(p, L, last, Xw, lane, centre0, ncentres);           \
+          else sa_wave_layer<NS, CTV, false>(p, L, last, Xw, lane, centre0, ncentres); }
+        if (L.NT == 1) PTT_WAVE_LAYER(1)
+        else if (L.NT == 2) PTT_WAVE_LAYER(2)
+        else PTT_WAVE_LAYER(4)
+#undef PTT_WAVE_LAYER
     }
 }
 

@@ -99,7 +99,11 @@ class PointnetSAModuleVotes(nn.Module):
                         shift = (shift + unit.conv.bias * scale).contiguous()
                 elif unit.conv.bias is not None:
                     shift = unit.conv.bias.detach().float().contiguous()
-                layers.append((ops.pack_weight(w, rot), scale, shift, cin, cout, hasattr(unit, 'activation')))
+                # the BatchNorm scale is folded into the packed weights: the kernels then start their accumulators at
+                # `shift` and the epilogue is a bare ReLU (every vector-ALU instruction outside the MFMA loop costs
+                # matrix time on gfx950). raw_scale stays available for the hoisted layer 0.
+                wq = w if scale is None else w * scale.view(-1, 1, 1, 1)
+                layers.append((ops.pack_weight(wq, rot), None, shift, cin, cout, hasattr(unit, 'activation'), scale))
             # Layer 0 is linear in [rel ; f_n]: its feature half is evaluated once per POINT (N rows on the linear
             # kernel) instead of once per (centre, neighbour) row; the kernel adds the 3 relative-coordinate terms.
             hoist = None
@@ -107,7 +111,7 @@ class PointnetSAModuleVotes(nn.Module):
             if (self.use_xyz and len(layers) >= 2 and w0.shape[1] > 3 and layers[0][4] <= 256
                     and os.environ.get('PTT_SA_HOIST', '1') != '0'):
                 w2 = w0.reshape(w0.shape[0], w0.shape[1]).float()
-                scale0 = layers[0][1]
+                scale0 = layers[0][6]
                 wx = w2[:, 0:3] if scale0 is None else w2[:, 0:3] * scale0[:, None]
                 hoist = (ops.pack_weight(w2[:, 3:].contiguous()), wx.t().contiguous(), layers[0][4], layers[0][5])
         self._fused_cache = (key, (layers, hoist))
@@ -144,12 +148,12 @@ class PointnetSAModuleVotes(nn.Module):
                 wf_packed, wx, c0, relu0 = hoist
                 rows = features.transpose(1, 2)                       # (B,N,C): contiguous when point-major
                 term = ops.linear(rows if rows.is_contiguous() else rows.contiguous(), wf_packed, c0,
-                                  layers[0][1], layers[0][2], relu=False)
-                new_features = ops.sa_fused_forward(xyz, new_xyz, idx, None, layers[1:], self.radius, True,
+                                  layers[0][6], layers[0][2], relu=False)
+                new_features = ops.sa_fused_forward(xyz, new_xyz, idx, None, [L[:6] for L in layers[1:]], self.radius, True,
                                                     self.normalize_xyz, point_major_out=True, l0=(term, wx, relu0))
             else:
-                new_features = ops.sa_fused_forward(xyz, new_xyz, idx, features, layers, self.radius, self.use_xyz,
-                                                    self.normalize_xyz, point_major_out=True)
+                new_features = ops.sa_fused_forward(xyz, new_xyz, idx, features, [L[:6] for L in layers], self.radius,
+                                                    self.use_xyz, self.normalize_xyz, point_major_out=True)
             return new_xyz, new_features, inds64
 
         xyz_flipped = xyz.transpose(1, 2).contiguous()

@@ -62,7 +62,8 @@ class CosineSimAug(nn.Module):
             for u in units[1:]:
                 sc, sh = self._fold(u)
                 w = u.conv.weight
-                layers.append((ops.pack_weight(w), sc, sh, w.shape[1], w.shape[0], True))
+                # BatchNorm scale folded into the packed weights: the kernel starts its accumulators at the shift
+                layers.append((ops.pack_weight(w * sc.view(-1, 1, 1, 1)), None, sh, w.shape[1], w.shape[0], True))
             c0, c1 = self.conv[0], self.conv[1]
             cs, ct = self._fold(c0)
             P = dict(w_sim=w0[:, 0].float().contiguous(), w_rest=ops.pack_weight(w0[:, 1:]), c0=w0.shape[0],

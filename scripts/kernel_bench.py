@@ -71,7 +71,7 @@ def main():
         if name == "sa_box":
             feats = feats.contiguous()                     # channel-major, as the box head hands it over
         raw = mlp_layers(3, spec)
-        layers = fold_layers(raw, dev, ops)
+        layers = fold_layers(raw, dev, ops, scale_in_weights=True)
         fn = lambda: ops.sa_fused_forward(xyz, new_xyz, idx, feats, layers, r, True, True)
         ms = timeit(fn, a.iters)
         fl = 2.0 * B * M * ns * sum(ci * co for ci, co in zip(spec[:-1], spec[1:]))
@@ -80,8 +80,9 @@ def main():
             w0 = raw[0]["conv_weight"].reshape(spec[1], spec[0]).to(dev)
             rows = feats.transpose(1, 2).contiguous()
             wf = ops.pack_weight(w0[:, 3:].contiguous())
-            wx = (w0[:, 0:3] * layers[0][1][:, None]).t().contiguous()
-            lin = lambda: ops.linear(rows, wf, spec[1], layers[0][1], layers[0][2], relu=False)
+            sc0 = fold_layers(raw[:1], dev, ops)[0][1]
+            wx = (w0[:, 0:3] * sc0[:, None]).t().contiguous()
+            lin = lambda: ops.linear(rows, wf, spec[1], sc0, layers[0][2], relu=False)
             term = lin()
             fn = lambda: ops.sa_fused_forward(xyz, new_xyz, idx, None, layers[1:], r, True, True, l0=(term, wx, True))
             ms_l, ms_h = timeit(lin, a.iters), timeit(fn, a.iters)

@@ -14,13 +14,13 @@ for name in sys.argv[1:] or ["sa1", "sa2", "box"]:
     new_xyz = xyz[:, :M].contiguous(); idx = ops.ball_query(new_xyz, xyz, r, ns)
     feats = torch.randn(B, N, C, device=dev).transpose(1, 2)
     if name == "box": feats = feats.contiguous()
-    layers = fold_layers(mlp_layers(3, spec), dev, ops)
+    layers = fold_layers(mlp_layers(3, spec), dev, ops, scale_in_weights=True)
     fn = lambda: ops.sa_fused_forward(xyz, new_xyz, idx, feats, layers, r, True, True)
     if os.environ.get("HOIST", "1") != "0":      # what the module runs: layer 0 as a per-point term
         w0 = mlp_layers(3, spec)[0]["conv_weight"].reshape(spec[1], spec[0]).to(dev)
         term = ops.linear(feats.transpose(1, 2).contiguous(), ops.pack_weight(w0[:, 3:].contiguous()), spec[1],
-                          layers[0][1], layers[0][2], relu=False)
-        wx = (w0[:, 0:3] * layers[0][1][:, None]).t().contiguous()
+                          fold_layers(mlp_layers(3, [cases[name][3][0], cases[name][3][1]]), dev, ops)[0][1], layers[0][2], relu=False)
+        wx = (w0[:, 0:3] * fold_layers(mlp_layers(3, [cases[name][3][0], cases[name][3][1]]), dev, ops)[0][1][:, None]).t().contiguous()
         fn = lambda: ops.sa_fused_forward(xyz, new_xyz, idx, None, layers[1:], r, True, True, l0=(term, wx, True))
         spec = spec[1:]
     for _ in range(3): fn()

@@ -57,8 +57,8 @@ SA_CASES = [
 
 
 @pytest.mark.parametrize("N,M,C,spec,radius,ns", SA_CASES)
-@pytest.mark.parametrize("point_major", [False, True])
-def test_sa_fused(dev, N, M, C, spec, radius, ns, point_major):
+@pytest.mark.parametrize("point_major,scale_in_weights", [(False, False), (True, False), (True, True)])
+def test_sa_fused(dev, N, M, C, spec, radius, ns, point_major, scale_in_weights):
     B = 3
     rs = np.random.RandomState(N + C)
     s, _ = synth.frames(N, B, N, 64, K_s=max(16, N // 2))
@@ -78,8 +78,9 @@ def test_sa_fused(dev, N, M, C, spec, radius, ns, point_major):
             f_dev = f_dev.transpose(1, 2).contiguous().transpose(1, 2)
     idx_dev = ops.ball_query(new_xyz.to(dev), xyz.to(dev), radius, ns)
     np.testing.assert_array_equal(idx_dev.cpu().numpy(), idx.numpy())
-    got = ops.sa_fused_forward(xyz.to(dev), new_xyz.to(dev), idx_dev, f_dev, fold_layers(layers, dev, ops), radius,
-                               True, True, point_major_out=point_major)
+    got = ops.sa_fused_forward(xyz.to(dev), new_xyz.to(dev), idx_dev, f_dev,
+                               fold_layers(layers, dev, ops, scale_in_weights), radius, True, True,
+                               point_major_out=point_major)
     assert tuple(got.shape) == (B, spec[-1], M)
     np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), **TOL)
 

@@ -45,16 +45,22 @@ def transformer_params(seed, d_points=256, d_model=512):
     return P
 
 
-def fold_layers(layers, dev, ops):
-    """oracle layer dicts -> the (wpacked, scale, shift, cin, cout, relu) tuples of ops.sa_fused_forward."""
+def fold_layers(layers, dev, ops, scale_in_weights=False):
+    """oracle layer dicts -> the (wpacked, scale, shift, cin, cout, relu) tuples of ops.sa_fused_forward.
+    scale_in_weights: the BatchNorm scale multiplied into the packed weights (scale = None), which is what the modules
+    pass; the default keeps the separate-scale form of the C ABI covered."""
     out = []
     for li, L in enumerate(layers):
         w = L["conv_weight"].to(dev)
         rot = 3 if (li == 0 and w.shape[1] > 3) else 0      # the fused kernel's row layout is [features | xyz]
         scale = (L["bn_weight"] / torch.sqrt(L["bn_var"] + L["eps"]))
         shift = L["bn_bias"] - L["bn_mean"] * scale
-        out.append((ops.pack_weight(w, rot), scale.to(dev).contiguous(), shift.to(dev).contiguous(),
-                    w.shape[1], w.shape[0], True))
+        if scale_in_weights:
+            out.append((ops.pack_weight(w * scale.to(dev).view(-1, 1, 1, 1), rot), None, shift.to(dev).contiguous(),
+                        w.shape[1], w.shape[0], True))
+        else:
+            out.append((ops.pack_weight(w, rot), scale.to(dev).contiguous(), shift.to(dev).contiguous(),
+                        w.shape[1], w.shape[0], True))
     return out
 
 
