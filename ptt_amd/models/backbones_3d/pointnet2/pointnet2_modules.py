@@ -114,6 +114,7 @@ class PointnetSAModuleVotes(nn.Module):
                 scale0 = layers[0][6]
                 wx = w2[:, 0:3] if scale0 is None else w2[:, 0:3] * scale0[:, None]
                 hoist = (ops.pack_weight(w2[:, 3:].contiguous()), wx.t().contiguous(), layers[0][4], layers[0][5])
+        ops.publish_params(device)
         self._fused_cache = (key, (layers, hoist))
         return layers, hoist
 
@@ -129,6 +130,7 @@ class PointnetSAModuleVotes(nn.Module):
             if key not in self._arange_cache:          # search and template branches alternate (B, npoint)
                 self._arange_cache[key] = torch.arange(npoint, dtype=torch.int64, device=xyz.device).repeat(
                     xyz.size(0), 1)
+                ops.publish_params(xyz.device)
             inds64 = self._arange_cache[key]
         elif inds is None:
             inds = self._sample(xyz, features, npoint)

@@ -206,6 +206,7 @@ def _rows_params(seq):
                 shift = unit.conv.bias.detach().float().contiguous()
             layers.append((ops.pack_weight(w.reshape(w.shape[0], w.shape[1])), w.shape[0], scale, shift,
                            hasattr(unit, 'activation')))
+    ops.publish_params(layers[0][0].device)
     object.__setattr__(seq, '_rows_cache', (key, layers))
     return layers
 

@@ -50,6 +50,7 @@ class PointNet2BackboneLight(nn.Module):
         key = (w.data_ptr(), w._version, b.data_ptr(), b._version)
         if self._cov_cache is None or self._cov_cache[0] != key:
             self._cov_cache = (key, ops.pack_weight(w), b.detach().float().contiguous())
+            ops.publish_params(w.device)
         rows = features.transpose(1, 2)                        # (B,M,C); contiguous when point-major
         out = ops.linear(rows, self._cov_cache[1], w.shape[0], None, self._cov_cache[2])
         return out.transpose(1, 2)                              # (B,C,M) view

@@ -72,6 +72,7 @@ class CosineSimAug(nn.Module):
                      conv0_relu=hasattr(c0, 'activation'),
                      conv1=ops.pack_weight(c1.conv.weight),
                      conv1_bias=c1.conv.bias.detach().float().contiguous() if c1.conv.bias is not None else None)
+        ops.publish_params(self.conv[0].conv.weight.device)
         self._cache = (key, P)
         return P
 

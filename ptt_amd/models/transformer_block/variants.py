@@ -73,6 +73,7 @@ class TransformerBlock(nn.Module):
                 wg1=ops.pack_weight(self.fc_gamma[0].weight), bg1=f(self.fc_gamma[0].bias),
                 wg2=ops.pack_weight(self.fc_gamma[2].weight), bg2=f(self.fc_gamma[2].bias),
                 fc2=ops.pack_weight(self.fc2.weight), fc2_b=f(self.fc2.bias))
+        ops.publish_params(self.fc1.weight.device)
         self._cache = (key, P)
         return P
 

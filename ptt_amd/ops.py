@@ -55,6 +55,15 @@ class _timed(object):
             _timing[self.name].append(self.ev)
 
 
+def publish_params(device):
+    """Called by the modules right after they (re)build a cached set of packed / folded parameters: blocks the host
+    until the kernels that produced them have finished. The caches are shared by every stream that later runs the
+    module (the search and template branches run on two streams and share their SA modules), and a cache entry built
+    on one stream must not be read by a kernel on another stream before it is complete. Once per weight version."""
+    if device.type == 'cuda' and not torch.cuda.is_current_stream_capturing():
+        torch.cuda.current_stream(device).synchronize()
+
+
 def _chk(t, name, dtype, ndim=None):
     if not isinstance(t, torch.Tensor):
         raise TypeError("%s must be a torch.Tensor" % name)
