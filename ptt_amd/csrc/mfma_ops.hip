@@ -481,6 +481,47 @@ __device__ __forceinline__ void sa_gather_rows(const SaParams& p, float* Xt, int
         for (int c2 = p.K0; c2 < Kpad0; ++c2) Xt[r * p.ldk + c2] = 0.f;
     }
     if (p.C == 0) return;
+    if (p.hoist == 2) {
+        // Hoisted layer 0 with 128 channels: a row is 32 float4, so ONE wave instruction handles TWO rows (lanes 0-31 /
+        // 32-63). Row index, cloud and relative coordinates reach the lanes by ds_bpermute; the per-point terms come
+        // through a buffer descriptor with one 32-bit offset per lane. ~17 instructions per row pair instead of ~36
+        // for two single rows — in this phase the wave gets about one issue slot per MFMA of the co-resident
+        // workgroup (DESIGN.md lesson 8), so the instruction count IS the duration of the phase.
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        constexpr int NP = ROWS / 2;
+        const int sub = lane >> 5, q = lane & 31;
+        const __amdgpu_buffer_rsrc_t rf = weight_rsrc(p.feat);
+        const f32x4 wx0 = *reinterpret_cast<const f32x4*>(p.wx + q * 4);
+        const f32x4 wx1 = *reinterpret_cast<const f32x4*>(p.wx + 128 + q * 4);
+        const f32x4 wx2 = *reinterpret_cast<const f32x4*>(p.wx + 256 + q * 4);
+        int off[NP];
+        float rx[NP], ry[NP], rz[NP];
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int r = 2 * i + sub;
+            const int nn = __shfl(n_l, r, 64), bb = __shfl(b_l, r, 64);
+            off[i] = ((bb * p.N + nn) * 128 + q * 4) * (int)sizeof(float);
+            rx[i] = __shfl(dx, r, 64); ry[i] = __shfl(dy, r, 64); rz[i] = __shfl(dz, r, 64);
+        }
+        f32x4 v[NP];
+#pragma unroll
+        for (int i = 0; i < NP; ++i) v[i] = weight_load(rf, off[i], 0);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const f32x2 rx2 = {rx[i], rx[i]}, ry2 = {ry[i], ry[i]}, rz2 = {rz[i], rz[i]};
+#pragma unroll
+            for (int j = 0; j < 4; j += 2) {
+                f32x2 y = {v[i][j], v[i][j + 1]};
+                y = __builtin_elementwise_fma(f32x2{wx0[j], wx0[j + 1]}, rx2, y);
+                y = __builtin_elementwise_fma(f32x2{wx1[j], wx1[j + 1]}, ry2, y);
+                y = __builtin_elementwise_fma(f32x2{wx2[j], wx2[j + 1]}, rz2, y);
+                v[i][j] = p.l0_relu ? fmaxf(y[0], 0.f) : y[0];
+                v[i][j + 1] = p.l0_relu ? fmaxf(y[1], 0.f) : y[1];
+            }
+            *reinterpret_cast<f32x4*>(Xt + (row0 + 2 * i + sub) * p.ldk + q * 4) = v[i];
+        }
+        return;
+    }
     if (p.vec_gather) {                                  // point-major rows: one float4 per lane per row
         const int nq = p.C >> 2;
         f32x4 wx0 = {0.f, 0.f, 0.f, 0.f}, wx1 = wx0, wx2 = wx0;
@@ -1111,6 +1152,9 @@ extern "C" int ptt_sa_fused_fwd_f32(const ptt_sa_desc* d, ptt_stream_t stream) {
     p.normalize = d->normalize_xyz ? 1 : 0; p.n_layers = d->n_layers; p.radius = d->radius;
     p.K0 = (d->use_xyz ? 3 : 0) + d->C;
     p.hoist = hoist ? 1 : 0; p.l0_relu = d->l0_relu ? 1 : 0; p.wx = d->l0_xyz_weight;
+    if (hoist && d->l0_channels == 128 && (unsigned long long)d->B * d->N * 128ull * sizeof(float) < 0x7fffffffull &&
+        !getenv("PTT_SA_GATHER1"))
+        p.hoist = 2;                                      // two rows per wave instruction, 32-bit buffer offsets
     if (hoist) {      // the tile starts as layer 0's output: rows of the per-point term, C0 channels
         p.feat = d->l0_point_term; p.C = d->l0_channels; p.K0 = p.C;
         p.fsc = 1; p.fsn = p.C; p.fsb = (long long)d->N * p.C;
