@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PTT_ABI_VERSION 3
+#define PTT_ABI_VERSION 4
 
 enum {
     PTT_OK = 0,
@@ -218,6 +218,8 @@ typedef struct ptt_xcorr_desc {
     float* out;                         /* out[b][c][j], element strides below               */
     int64_t out_sb, out_sc, out_sn;
     float* sim_out;                     /* optional (B,Nt,Ns) cosine map, or NULL            */
+    const float* cos_t;                 /* optional (B,Ns,Nt) cosine map from ptt_cosine_map_f32: the kernel then skips
+                                           its own cosine phase (search_feat / templ_feat may be NULL)               */
     int B, Ns, Nt, C, C0;
     float eps;                          /* CosineSimilarity eps (1e-8)                       */
     int n_layers;
@@ -225,6 +227,12 @@ typedef struct ptt_xcorr_desc {
 } ptt_xcorr_desc;
 
 int ptt_xcorr_fused_fwd_f32(const ptt_xcorr_desc* d, ptt_stream_t stream);
+
+/* cos_t[b][j][i] = <templ_i, search_j> / (max(|templ_i|, eps) * max(|search_j|, eps))   (F.cosine_similarity, p2b_xcoor.py:35-36)
+ * search_feat[b][n][c] / templ_feat[b][i][c] with element strides; cos_t (B,Ns,Nt) contiguous. */
+int ptt_cosine_map_f32(const float* search_feat, int64_t s_sb, int64_t s_sn, int64_t s_sc, const float* templ_feat,
+                       int64_t t_sb, int64_t t_sn, int64_t t_sc, int B, int Ns, int Nt, int C, float eps,
+                       float* cos_t, ptt_stream_t stream);
 
 /* ---------------------------------------------------------------------------------
  * T2..T6 fused per-(point,neighbour) part of the Point-Transformer block:

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libptt_hip.so")
 
 PTT_SA_MAX_LAYERS = 4
-ABI_VERSION = 3            # PTT_ABI_VERSION of include/ptt_hip.h these structures mirror
+ABI_VERSION = 4            # PTT_ABI_VERSION of include/ptt_hip.h these structures mirror
 
 # every symbol include/ptt_hip.h declares (tests check the library exports all of them)
 EXPORTS = [
@@ -19,7 +19,7 @@ EXPORTS = [
     "ptt_group_f32", "ptt_group_grad_f32", "ptt_scatter_add_det_workspace", "ptt_scatter_add_det_f32",
     "ptt_knn_f32", "ptt_knn_rel_f32",
     "ptt_packed_weight_elems", "ptt_pack_weight_f32", "ptt_pack_weight_rot_f32", "ptt_linear_f32",
-    "ptt_sa_fused_fwd_f32", "ptt_xcorr_fused_fwd_f32", "ptt_pt_attn_pair_f32",
+    "ptt_sa_fused_fwd_f32", "ptt_xcorr_fused_fwd_f32", "ptt_cosine_map_f32", "ptt_pt_attn_pair_f32",
 ]
 
 
@@ -43,7 +43,7 @@ class XcorrDesc(Structure):
                 ("templ_feat", c_void_p), ("t_sb", c_int64), ("t_sn", c_int64), ("t_sc", c_int64),
                 ("P", c_void_p), ("w_sim", c_void_p), ("scale0", c_void_p), ("shift0", c_void_p),
                 ("out", c_void_p), ("out_sb", c_int64), ("out_sc", c_int64), ("out_sn", c_int64),
-                ("sim_out", c_void_p),
+                ("sim_out", c_void_p), ("cos_t", c_void_p),
                 ("B", c_int), ("Ns", c_int), ("Nt", c_int), ("C", c_int), ("C0", c_int),
                 ("eps", c_float), ("n_layers", c_int), ("layers", SaLayer * PTT_SA_MAX_LAYERS)]
 
@@ -81,6 +81,7 @@ def _declare(lib):
         "ptt_linear_f32": [vp, i, i, i, vp, i, vp, vp, i, vp, i, vp, i, vp],
         "ptt_sa_fused_fwd_f32": [POINTER(SaDesc), vp],
         "ptt_xcorr_fused_fwd_f32": [POINTER(XcorrDesc), vp],
+        "ptt_cosine_map_f32": [vp, c_int64, c_int64, c_int64, vp, c_int64, c_int64, c_int64, i, i, i, i, f, vp, vp],
         "ptt_pt_attn_pair_f32": [POINTER(AttnDesc), vp],
     }
     for name, args in sigs.items():

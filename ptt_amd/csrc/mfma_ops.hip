@@ -714,11 +714,48 @@ __global__ __launch_bounds__(256, PTT_SA_WAVES) void sa_fused_kernel(SaParams p)
 struct XcorrParams {
     const float* sfeat; const float* tfeat; const float* P; const float* wsim; const float* scale0; const float* shift0;
     float* sim_out;
+    const float* cos_t;   // optional (B,Ns,Nt) cosine map from cos_map_kernel: the kernel then skips its own cosine phase
     long long s_sb, s_sn, s_sc, t_sb, t_sn, t_sc;
     int C, C0, Nt;
     float eps;
     SaParams sa;     // B, M (= Ns), out strides, ldk, layers (the remaining SharedMLP layers), stagger
 };
+
+// Cosine map of one frame batch: cos_t[b][j][i] = <templ_i, search_j> / (max(|templ_i|, eps) * max(|search_j|, eps))
+// (torch.nn.functional.cosine_similarity, p2b_xcoor.py:35-36). One wave per search point, lane i = template point.
+// 4 MFLOP per frame: a separate 10-us launch instead of a phase of every xcorr workgroup.
+struct CosParams {
+    const float* sfeat; const float* tfeat; float* cos_t;
+    long long s_sb, s_sn, s_sc, t_sb, t_sn, t_sc;
+    int B, Ns, Nt, C;
+    float eps;
+};
+__global__ __launch_bounds__(256) void cos_map_kernel(CosParams q) {
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);       // flat search point
+    if (j >= q.B * q.Ns) return;
+    const int b = j / q.Ns, jj = j - b * q.Ns;
+    const float* s = q.sfeat + (long long)b * q.s_sb + (long long)jj * q.s_sn;
+    for (int i0 = 0; i0 < q.Nt; i0 += 64) {
+        const int i = i0 + lane;
+        const float* a = q.tfeat + (long long)b * q.t_sb + (long long)(i < q.Nt ? i : q.Nt - 1) * q.t_sn;
+        float dot = 0.f, na = 0.f, ns = 0.f;
+        if (q.t_sc == 1 && q.s_sc == 1 && (q.C & 3) == 0 && ((q.t_sn | q.t_sb | q.s_sn | q.s_sb) & 3) == 0 &&
+            ((reinterpret_cast<uintptr_t>(q.tfeat) | reinterpret_cast<uintptr_t>(q.sfeat)) & 15) == 0) {
+            for (int c = 0; c < q.C; c += 4) {
+                const f32x4 av = *reinterpret_cast<const f32x4*>(a + c), sv = *reinterpret_cast<const f32x4*>(s + c);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { dot += av[k] * sv[k]; na += av[k] * av[k]; ns += sv[k] * sv[k]; }
+            }
+        } else {
+            for (int c = 0; c < q.C; ++c) {
+                const float av = a[(long long)c * q.t_sc], sv = s[(long long)c * q.s_sc];
+                dot += av * sv; na += av * av; ns += sv * sv;
+            }
+        }
+        if (i < q.Nt) q.cos_t[((long long)b * q.Ns + jj) * q.Nt + i] = dot / (fmaxf(sqrtf(na), q.eps) * fmaxf(sqrtf(ns), q.eps));
+    }
+}
 
 __global__ __launch_bounds__(256, 2) void xcorr_fused_kernel(XcorrParams q) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -733,6 +770,15 @@ __global__ __launch_bounds__(256, 2) void xcorr_fused_kernel(XcorrParams q) {
     pre.w[0] = pre.w[1] = f32x4{0.f, 0.f, 0.f, 0.f};
     prefetch_first_block(p.L[0].Wp, p.L[0].scale, p.L[0].shift, p.L[0].NT, w, lane, pre);
 
+    if (q.cos_t) {
+        // the cosine map of the whole batch was computed once by cos_map_kernel: 64 values to fetch instead of ~340
+        // vector-ALU / load instructions per wave in a phase that runs beside another workgroup's MFMA stream
+        if (t < 64) {
+            const float cs = q.cos_t[((long long)b * p.M + jj) * q.Nt + t];
+            simv[t] = cs;
+            if (q.sim_out) q.sim_out[((long long)b * q.Nt + t) * p.M + jj] = cs;
+        }
+    } else {
     // ---- 64 cosines: thread (i = t>>2, quarter = t&3) covers channels quarter, quarter+4, ... ----
     {
         const int i = t >> 2, qd = t & 3;
@@ -753,9 +799,27 @@ __global__ __launch_bounds__(256, 2) void xcorr_fused_kernel(XcorrParams q) {
             if (q.sim_out) q.sim_out[((long long)b * q.Nt + i) * p.M + jj] = cs;
         }
     }
+    }
     __syncthreads();
 
     // ---- layer 0: relu(bn0(w_sim * cos_i + P[b,i,:])) -> X ----
+    if (!q.scale0 && !q.shift0 && (q.C0 & 3) == 0) {
+        // BatchNorm already folded into P and w_sim by the caller: relu(P'_i + w' * cos_i), four channels per lane
+        // (one 16-byte load, two packed FMAs, four max, one 16-byte LDS write) — 8 instructions per 4 values
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const int nq = q.C0 >> 2;
+        for (int e = t; e < 64 * nq; e += 256) {
+            const int i = e / nq, c4 = e - i * nq;
+            const f32x4 pv = *reinterpret_cast<const f32x4*>(q.P + ((long long)b * q.Nt + i) * q.C0 + c4 * 4);
+            const f32x4 w4 = *reinterpret_cast<const f32x4*>(q.wsim + c4 * 4);
+            const float cs = simv[i];
+            const f32x2 c2 = {cs, cs};
+            f32x2 lo = __builtin_elementwise_fma(f32x2{w4[0], w4[1]}, c2, f32x2{pv[0], pv[1]});
+            f32x2 hi = __builtin_elementwise_fma(f32x2{w4[2], w4[3]}, c2, f32x2{pv[2], pv[3]});
+            *reinterpret_cast<f32x4*>(Xs + i * p.ldk + c4 * 4) =
+                f32x4{fmaxf(lo[0], 0.f), fmaxf(lo[1], 0.f), fmaxf(hi[0], 0.f), fmaxf(hi[1], 0.f)};
+        }
+    } else {
     for (int c = t; c < q.C0; c += 256) {
         const float wsim = q.wsim[c], sc = q.scale0 ? q.scale0[c] : 1.f, sh = q.shift0 ? q.shift0[c] : 0.f;
         const float* pr = q.P + (long long)b * q.Nt * q.C0 + c;
@@ -764,6 +828,7 @@ __global__ __launch_bounds__(256, 2) void xcorr_fused_kernel(XcorrParams q) {
             const float v = (pr[(long long)i * q.C0] + wsim * simv[i]) * sc + sh;
             Xs[i * p.ldk + c] = fmaxf(v, 0.f);
         }
+    }
     }
     __syncthreads();
 
@@ -1231,11 +1296,11 @@ extern "C" int ptt_xcorr_fused_fwd_f32(const ptt_xcorr_desc* d, ptt_stream_t str
     if (d->Nt != 64) return fail(PTT_EUNSUPPORTED, "ptt_xcorr_fused_fwd_f32: Nt=%d (64 template seeds is instantiated)", d->Nt);
     if ((d->C0 % 8) != 0 || d->C0 > 256) return fail(PTT_EUNSUPPORTED, "ptt_xcorr_fused_fwd_f32: C0=%d", d->C0);
     if (d->B == 0) return PTT_OK;
-    if (!d->search_feat || !d->templ_feat || !d->P || !d->w_sim || !d->out)
+    if ((!d->cos_t && (!d->search_feat || !d->templ_feat)) || !d->P || !d->w_sim || !d->out)
         return fail(PTT_EINVAL, "ptt_xcorr_fused_fwd_f32: null pointer");
     XcorrParams q;
     q.sfeat = d->search_feat; q.tfeat = d->templ_feat; q.P = d->P; q.wsim = d->w_sim; q.scale0 = d->scale0;
-    q.shift0 = d->shift0; q.sim_out = d->sim_out;
+    q.shift0 = d->shift0; q.sim_out = d->sim_out; q.cos_t = d->cos_t;
     q.s_sb = d->s_sb; q.s_sn = d->s_sn; q.s_sc = d->s_sc; q.t_sb = d->t_sb; q.t_sn = d->t_sn; q.t_sc = d->t_sc;
     q.C = d->C; q.C0 = d->C0; q.Nt = d->Nt; q.eps = d->eps;
     SaParams& p = q.sa;
@@ -1262,6 +1327,20 @@ extern "C" int ptt_xcorr_fused_fwd_f32(const ptt_xcorr_desc* d, ptt_stream_t str
     if (rc) return rc;
     hipLaunchKernelGGL(xcorr_fused_kernel, dim3(d->B * d->Ns), dim3(256), lds, as_stream(stream), q);
     return check_launch("xcorr_fused_kernel");
+}
+
+extern "C" int ptt_cosine_map_f32(const float* search_feat, int64_t s_sb, int64_t s_sn, int64_t s_sc, const float* templ_feat,
+                                  int64_t t_sb, int64_t t_sn, int64_t t_sc, int B, int Ns, int Nt, int C, float eps,
+                                  float* cos_t, ptt_stream_t stream) {
+    if (B < 0 || Ns <= 0 || Nt <= 0 || C <= 0) return fail(PTT_EINVAL, "ptt_cosine_map_f32: B=%d Ns=%d Nt=%d C=%d", B, Ns, Nt, C);
+    if (B == 0) return PTT_OK;
+    if (!search_feat || !templ_feat || !cos_t) return fail(PTT_EINVAL, "ptt_cosine_map_f32: null pointer");
+    CosParams q;
+    q.sfeat = search_feat; q.tfeat = templ_feat; q.cos_t = cos_t;
+    q.s_sb = s_sb; q.s_sn = s_sn; q.s_sc = s_sc; q.t_sb = t_sb; q.t_sn = t_sn; q.t_sc = t_sc;
+    q.B = B; q.Ns = Ns; q.Nt = Nt; q.C = C; q.eps = eps;
+    hipLaunchKernelGGL(cos_map_kernel, dim3((B * Ns + 3) / 4), dim3(256), 0, as_stream(stream), q);
+    return check_launch("cos_map_kernel");
 }
 
 extern "C" int ptt_pt_attn_pair_f32(const ptt_attn_desc* d, ptt_stream_t stream) {

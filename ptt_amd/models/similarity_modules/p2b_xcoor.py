@@ -66,7 +66,9 @@ class CosineSimAug(nn.Module):
                 layers.append((ops.pack_weight(w * sc.view(-1, 1, 1, 1)), None, sh, w.shape[1], w.shape[0], True))
             c0, c1 = self.conv[0], self.conv[1]
             cs, ct = self._fold(c0)
-            P = dict(w_sim=w0[:, 0].float().contiguous(), w_rest=ops.pack_weight(w0[:, 1:]), c0=w0.shape[0],
+            # layer 0's BatchNorm is folded into its two halves: the per-template-point term comes out of the linear
+            # kernel as s0 * (W0[:,1:] . [xyz;feat]) + t0, the similarity column as s0 * w_sim
+            P = dict(w_sim=(w0[:, 0].float() * s0).contiguous(), w_rest=ops.pack_weight(w0[:, 1:]), c0=w0.shape[0],
                      scale0=s0, shift0=t0, layers=layers,
                      conv0=ops.pack_weight(c0.conv.weight), conv0_scale=cs, conv0_shift=ct,
                      conv0_relu=hasattr(c0, 'activation'),
@@ -86,9 +88,10 @@ class CosineSimAug(nn.Module):
         if self._fusable(search_feats, template_feats):
             P = self._params()
             rows = torch.cat((template_xyz, template_feats.transpose(1, 2)), dim=2)          # (B,n1,3+f)
-            pre = ops.linear(rows, P['w_rest'], P['c0'])                                      # (B,n1,C0)
-            fused, _ = ops.xcorr_fused(search_feats, template_feats, pre, P['w_sim'], P['scale0'], P['shift0'],
-                                       P['layers'], eps=self.cosine.eps)                      # (B,C,n2) view
+            pre = ops.linear(rows, P['w_rest'], P['c0'], P['scale0'], P['shift0'])            # (B,n1,C0), BN folded in
+            cos_t = ops.cosine_map(search_feats, template_feats, eps=self.cosine.eps)         # (B,n2,n1), one launch
+            fused, _ = ops.xcorr_fused(search_feats, template_feats, pre, P['w_sim'], None, None,
+                                       P['layers'], eps=self.cosine.eps, cos_t=cos_t)         # (B,C,n2) view
             y = ops.linear(fused.transpose(1, 2), P['conv0'], self.conv[0].conv.weight.shape[0],
                            P['conv0_scale'], P['conv0_shift'], P['conv0_relu'])
             y = ops.linear(y, P['conv1'], self.conv[1].conv.weight.shape[0], None, P['conv1_bias'])

@@ -321,7 +321,22 @@ def sa_fused_forward(xyz, new_xyz, idx, features, layers, radius, use_xyz=True, 
     return out
 
 
-def xcorr_fused(search_feats, templ_feats, P, w_sim, scale0, shift0, layers, eps=1e-8, want_sim=False):
+def cosine_map(search_feats, templ_feats, eps=1e-8):
+    """cos_t (B,Ns,Nt) = F.cosine_similarity(templ_i, search_j) for every pair (p2b_xcoor.py:35-36); inputs (B,C,N) in
+    any strides."""
+    B, C, Ns = search_feats.shape
+    Nt = templ_feats.shape[2]
+    out = torch.empty((B, Ns, Nt), dtype=torch.float32, device=search_feats.device)
+    ssb, ssc, ssn = search_feats.stride()
+    tsb, tsc, tsn = templ_feats.stride()
+    with torch.cuda.device(out.device), _timed('ptt_cosine_map_f32'):
+        _lib.check(_lib.lib().ptt_cosine_map_f32(search_feats.data_ptr(), ssb, ssn, ssc, templ_feats.data_ptr(), tsb, tsn,
+                                                 tsc, B, Ns, Nt, C, float(eps), out.data_ptr(), _stream()),
+                   "ptt_cosine_map_f32")
+    return out
+
+
+def xcorr_fused(search_feats, templ_feats, P, w_sim, scale0, shift0, layers, eps=1e-8, want_sim=False, cos_t=None):
     """Fused CosineSimAug core (similarity_modules/p2b_xcoor.py:25-42): cosine map, concat, SharedMLP, max over
     the template axis. search_feats (B,C,Ns) / templ_feats (B,C,Nt) in any strides; P (B,Nt,C0) = layer-0
     pre-activation without the similarity term; layers = remaining (wpacked, scale, shift, cin, cout, relu).
@@ -348,6 +363,7 @@ def xcorr_fused(search_feats, templ_feats, P, w_sim, scale0, shift0, layers, eps
     d.out = out.data_ptr()
     d.out_sb, d.out_sc, d.out_sn = out.stride()
     d.sim_out = sim.data_ptr() if sim is not None else None
+    d.cos_t = cos_t.data_ptr() if cos_t is not None else None
     d.B, d.Ns, d.Nt, d.C, d.C0, d.eps = B, Ns, Nt, C, C0, float(eps)
     d.n_layers = len(layers)
     for i, (wp, sc, sh, cin, co, relu) in enumerate(layers):
