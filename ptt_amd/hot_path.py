@@ -69,7 +69,6 @@ class FrameHotPath(nn.Module):
         # FPS is a latency-bound chain on B workgroups; running the template branch on a second HIP
         # stream lets its kernels fill the CUs the search branch's FPS leaves idle (and vice versa).
         self.overlap_branches = True
-        self._side_stream = None
 
     @staticmethod
     def bridge(seeds, feats_bnc):
@@ -80,35 +79,11 @@ class FrameHotPath(nn.Module):
     def sample(self, search_points, template_points):
         """Level-0 furthest point sampling of both clouds -> (inds_search, inds_template) int32. Split out so
         that a driver can run it for the NEXT batch on a side stream (PipelinedHotPath)."""
-        from .models.backbones_3d.pointnet2 import pointnet2_utils
-        sa = self.backbone_3d.model_cfg.SA_CONFIG
-        assert sa.SAMPLE_METHOD[0] == 'fps'
-        return (pointnet2_utils.furthest_point_sample(search_points[..., 0:3].contiguous(), sa.NPOINTS_SEARCH[0]),
-                pointnet2_utils.furthest_point_sample(template_points[..., 0:3].contiguous(), sa.NPOINTS_TEMPLATE[0]))
+        return self.backbone_3d.sample(search_points, template_points)
 
     def _backbone(self, search_points, template_points, inds=None):
-        bb = self.backbone_3d
-        sa = bb.model_cfg.SA_CONFIG
-        i_s, i_t = inds if inds is not None else (None, None)
-        if not (self.overlap_branches and search_points.is_cuda and not self.training):
-            if inds is None:
-                return bb({'search_points': search_points, 'template_points': template_points})
-            s_seeds, s_feats, s_inds = bb.branch_forward(search_points, sa.NPOINTS_SEARCH, i_s)
-            t_seeds, t_feats, t_inds = bb.branch_forward(template_points, sa.NPOINTS_TEMPLATE, i_t)
-            return {'search_seeds': s_seeds, 'search_feats': s_feats, 'search_inds': s_inds,
-                    'template_seeds': t_seeds, 'template_feats': t_feats, 'template_inds': t_inds}
-        if self._side_stream is None or self._side_stream.device != search_points.device:
-            self._side_stream = torch.cuda.Stream(device=search_points.device)
-        main, side = torch.cuda.current_stream(search_points.device), self._side_stream
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            t_seeds, t_feats, t_inds = bb.branch_forward(template_points, sa.NPOINTS_TEMPLATE, i_t)
-        s_seeds, s_feats, s_inds = bb.branch_forward(search_points, sa.NPOINTS_SEARCH, i_s)
-        main.wait_stream(side)
-        for t in (t_seeds, t_feats, t_inds, template_points):
-            t.record_stream(main)
-        return {'search_seeds': s_seeds, 'search_feats': s_feats, 'search_inds': s_inds,
-                'template_seeds': t_seeds, 'template_feats': t_feats, 'template_inds': t_inds}
+        self.backbone_3d.overlap_branches = self.overlap_branches
+        return self.backbone_3d.forward_branches(search_points, template_points, inds)
 
     def forward(self, search_points, template_points, inds=None):
         d = self._backbone(search_points, template_points, inds)
@@ -121,6 +96,25 @@ class FrameHotPath(nn.Module):
         d['pred_box_center'] = centres
         d['box_feats'] = box_feats
         return d
+
+
+class TrackerThroughput(object):
+    """Adapter giving a full tracker (ptt_amd.models.trackers.PTT) the (sample, forward-with-indices) interface of
+    FrameHotPath, so that GraphedHotPath / PipelinedHotPath can drive it:
+        pipe = PipelinedHotPath(TrackerThroughput(tracker), search0, template0)"""
+
+    def __init__(self, tracker):
+        self.tracker = tracker
+
+    def sample(self, search_points, template_points):
+        return self.tracker.backbone_3d.sample(search_points, template_points)
+
+    def __call__(self, search_points, template_points, inds=None):
+        batch = {'search_points': search_points, 'template_points': template_points,
+                 'batch_size': search_points.shape[0]}
+        if inds is not None:
+            batch['fps_inds'] = inds
+        return self.tracker(batch)
 
 
 class GraphedHotPath(object):

@@ -35,6 +35,8 @@ class PointNet2BackboneLight(nn.Module):
         self.cov_final = nn.Conv1d(256, 256, kernel_size=1)
         self.num_point_features = sa.MLPS[-1][-1]
         self._cov_cache = None
+        self.overlap_branches = True
+        self._side_stream = None
 
     @staticmethod
     def _break_up_pc(pc):
@@ -68,12 +70,42 @@ class PointNet2BackboneLight(nn.Module):
         inds = inds0.gather(1, inds1).gather(1, inds2)
         return xyz, point_features, inds
 
-    def forward(self, batch_dict):
+    def sample(self, search_points, template_points):
+        """Level-0 furthest point sampling of both clouds -> (inds_search, inds_template) int32: the stage a throughput
+        driver runs for the NEXT batch on a side stream (ptt_amd.hot_path.PipelinedHotPath)."""
+        from .pointnet2 import pointnet2_utils
         sa = self.model_cfg.SA_CONFIG
-        batch_dict['search_seeds'], batch_dict['search_feats'], batch_dict['search_inds'] = \
-            self.branch_forward(batch_dict['search_points'], sa.NPOINTS_SEARCH)
-        batch_dict['template_seeds'], batch_dict['template_feats'], batch_dict['template_inds'] = \
-            self.branch_forward(batch_dict['template_points'], sa.NPOINTS_TEMPLATE)
+        assert sa.SAMPLE_METHOD[0] == 'fps'
+        return (pointnet2_utils.furthest_point_sample(search_points[..., 0:3].contiguous(), sa.NPOINTS_SEARCH[0]),
+                pointnet2_utils.furthest_point_sample(template_points[..., 0:3].contiguous(), sa.NPOINTS_TEMPLATE[0]))
+
+    def forward_branches(self, search_points, template_points, inds=None):
+        """Both branches -> the six batch_dict entries of the reference's forward (:56-63). Eval mode on a HIP device:
+        the template branch runs on a second stream — FPS is a latency-bound chain on B workgroups, so each branch's
+        kernels fill the CUs the other's FPS leaves idle. `inds` = optional (search, template) level-0 FPS indices."""
+        sa = self.model_cfg.SA_CONFIG
+        i_s, i_t = inds if inds is not None else (None, None)
+        if not (self.overlap_branches and search_points.is_cuda and not self.training):
+            s_seeds, s_feats, s_inds = self.branch_forward(search_points, sa.NPOINTS_SEARCH, i_s)
+            t_seeds, t_feats, t_inds = self.branch_forward(template_points, sa.NPOINTS_TEMPLATE, i_t)
+        else:
+            if self._side_stream is None or self._side_stream.device != search_points.device:
+                self._side_stream = torch.cuda.Stream(device=search_points.device)
+            main, side = torch.cuda.current_stream(search_points.device), self._side_stream
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                t_seeds, t_feats, t_inds = self.branch_forward(template_points, sa.NPOINTS_TEMPLATE, i_t)
+            s_seeds, s_feats, s_inds = self.branch_forward(search_points, sa.NPOINTS_SEARCH, i_s)
+            main.wait_stream(side)
+            for t in (t_seeds, t_feats, t_inds, template_points):
+                t.record_stream(main)
+        return {'search_seeds': s_seeds, 'search_feats': s_feats, 'search_inds': s_inds,
+                'template_seeds': t_seeds, 'template_feats': t_feats, 'template_inds': t_inds}
+
+    def forward(self, batch_dict):
+        # 'fps_inds' is an extension of the key contract: level-0 sample indices computed ahead by a pipelined driver
+        batch_dict.update(self.forward_branches(batch_dict['search_points'], batch_dict['template_points'],
+                                                batch_dict.pop('fps_inds', None)))
         batch_dict.pop('search_points')
         batch_dict.pop('template_points')
         return batch_dict

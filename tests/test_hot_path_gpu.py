@@ -100,6 +100,33 @@ def test_graphed_and_pipelined_drivers_match_eager(dev):
             assert torch.equal(out[k], ref[k]), k
 
 
+def test_pipelined_driver_on_the_full_tracker(dev):
+    """TrackerThroughput + PipelinedHotPath: the whole tracker (two-stream backbone, 'fps_inds' handed in by the driver)
+    replayed as a graph returns what an eager call on the same batch returns."""
+    from ptt_amd.config import StubDataset, ptt_model_cfg
+    from ptt_amd.hot_path import PipelinedHotPath, TrackerThroughput
+    from ptt_amd.models import build_network
+    tracker = randomize_(build_network(ptt_model_cfg(), 1, StubDataset()), seed=4).to(dev).eval()
+    batches = [tuple(torch.from_numpy(a).to(dev) for a in synth.frames(300 + i, 2, 1024, 512)) for i in range(3)]
+    keys = ('search_inds', 'template_inds', 'cosine_feats', 'pred_centroids_votes', 'pred_box_center', 'pred_box_data')
+    with torch.no_grad():
+        eager = []
+        for s, t in batches:
+            o = tracker({'search_points': s, 'template_points': t, 'batch_size': 2})
+            eager.append({k: o[k].clone() for k in keys})
+    p = PipelinedHotPath(TrackerThroughput(tracker), *batches[0])
+    outs = []
+    for s, t in batches[1:]:
+        o = p(s, t)                                        # ONE replay: results of the previous batch
+        outs.append({k: o[k].clone() for k in keys})
+    o = p.flush()
+    outs.append({k: o[k].clone() for k in keys})
+    torch.cuda.synchronize()
+    for out, ref in zip(outs, eager):
+        for k in keys:
+            assert torch.equal(out[k], ref[k]), k
+
+
 def _cfg5():
     """BASELINE.json configs[4] geometry: 16384-pt search / 4096-pt template, 3 SA levels, KITTI radii/MLPs."""
     cfg = kitti_model_cfg()
