@@ -849,62 +849,64 @@ __global__ __launch_bounds__(256, 2) void xcorr_fused_kernel(XcorrParams q) {
 // chain runs without a single workgroup barrier and all four waves do the same amount of work
 // (the column-split kernel leaves half the waves idle when a layer has only two column tiles).
 // ------------------------------------------------------------------------------------------
-template <int NS, int CT, bool AFFINE>
+template <int NS, int CT, bool AFFINE, int RT>
 __device__ __forceinline__ void sa_wave_layer(const SaParams& p, const SaLayerDev& L, bool last, float* Xw, int lane,
                                               int centre0, int ncentres) {
     // same epilogue economy as sa_layer: shift in the accumulator when there is no separate scale (AFFINE false),
-    // ReLU after the pool. (The shift is fetched here, not a layer ahead: at 3 waves per SIMD the other waves cover
-    // the round trip, and the extra live registers would spill at the 168-VGPR bound of this kernel.)
-    f32x16 acc[1][CT];
+    // ReLU after the pool. (The shift is fetched here, not a layer ahead: the other waves of the SIMD cover the
+    // round trip, and the extra live registers would spill at the VGPR bound of this kernel.)
+    f32x16 acc[RT][CT];
 #pragma unroll
     for (int u = 0; u < CT; ++u) {
         const float s0 = (!AFFINE && L.shift) ? L.shift[u * 32 + (lane & 31)] : 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[0][u][r] = s0;
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[rt][u][r] = s0;
     }
-    gemm_core<1, CT, CT, 1>(Xw, p.ldk, L.nkb, reinterpret_cast<const f32x4*>(L.Wp), L.NT, 0, lane, acc);
+    gemm_core<RT, CT, CT, 1>(Xw, p.ldk, L.nkb, reinterpret_cast<const f32x4*>(L.Wp), L.NT, 0, lane, acc);
     __builtin_amdgcn_wave_barrier();
     const int half = lane >> 5;
 #pragma unroll
     for (int u = 0; u < CT; ++u) {
         const int col = u * 32 + (lane & 31);
-        float y[16];
-        if constexpr (AFFINE) {
-            const float sc = L.scale[col], sv = L.shift ? L.shift[col] : 0.f;
+        float sc = 1.f, sv = 0.f;
+        if constexpr (AFFINE) { sc = L.scale[col]; sv = L.shift ? L.shift[col] : 0.f; }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) y[r] = acc[0][u][r] * sc + sv;
-        } else {
+        for (int rt = 0; rt < RT; ++rt) {
+            float y[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) y[r] = acc[0][u][r];
-        }
-        if (!last) {
+            for (int r = 0; r < 16; ++r) y[r] = AFFINE ? acc[rt][u][r] * sc + sv : acc[rt][u][r];
+            if (!last) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) Xw[tile_row(r, half) * p.ldk + col] = L.relu ? fmaxf(y[r], 0.f) : y[r];
-        } else if (NS == 32) {
-            float m = y[0];
+                for (int r = 0; r < 16; ++r)
+                    Xw[(rt * 32 + tile_row(r, half)) * p.ldk + col] = L.relu ? fmaxf(y[r], 0.f) : y[r];
+            } else if (NS == 32) {
+                float m = y[0];
 #pragma unroll
-            for (int r = 1; r < 16; ++r) m = fmaxf(m, y[r]);
-            m = max_halves(m);
-            if (L.relu) m = fmaxf(m, 0.f);
-            if (half == 0 && ncentres > 0) {
-                const int b = centre0 / p.M, mm = centre0 - b * p.M;
-                p.out[b * p.osb + col * p.osc + mm * p.osm] = m;
-            }
-        } else {
-            float m0 = y[0], m1 = y[8];
-#pragma unroll
-            for (int r = 1; r < 8; ++r) { m0 = fmaxf(m0, y[r]); m1 = fmaxf(m1, y[8 + r]); }
-            m0 = max_halves(m0);
-            m1 = max_halves(m1);
-            if (L.relu) { m0 = fmaxf(m0, 0.f); m1 = fmaxf(m1, 0.f); }
-            if (half == 0) {
-                if (ncentres > 0) {
-                    const int b = centre0 / p.M, mm = centre0 - b * p.M;
-                    p.out[b * p.osb + col * p.osc + mm * p.osm] = m0;
+                for (int r = 1; r < 16; ++r) m = fmaxf(m, y[r]);
+                m = max_halves(m);
+                if (L.relu) m = fmaxf(m, 0.f);
+                if (half == 0 && rt < ncentres) {
+                    const int c = centre0 + rt; const int b = c / p.M, mm = c - b * p.M;
+                    p.out[b * p.osb + col * p.osc + mm * p.osm] = m;
                 }
-                if (ncentres > 1) {
-                    const int c = centre0 + 1; const int b = c / p.M, mm = c - b * p.M;
-                    p.out[b * p.osb + col * p.osc + mm * p.osm] = m1;
+            } else {
+                float m0 = y[0], m1 = y[8];
+#pragma unroll
+                for (int r = 1; r < 8; ++r) { m0 = fmaxf(m0, y[r]); m1 = fmaxf(m1, y[8 + r]); }
+                m0 = max_halves(m0);
+                m1 = max_halves(m1);
+                if (L.relu) { m0 = fmaxf(m0, 0.f); m1 = fmaxf(m1, 0.f); }
+                if (half == 0) {
+                    if (2 * rt < ncentres) {
+                        const int c = centre0 + 2 * rt; const int b = c / p.M, mm = c - b * p.M;
+                        p.out[b * p.osb + col * p.osc + mm * p.osm] = m0;
+                    }
+                    if (2 * rt + 1 < ncentres) {
+                        const int c = centre0 + 2 * rt + 1; const int b = c / p.M, mm = c - b * p.M;
+                        p.out[b * p.osb + col * p.osc + mm * p.osm] = m1;
+                    }
                 }
             }
         }
@@ -912,26 +914,28 @@ __device__ __forceinline__ void sa_wave_layer(const SaParams& p, const SaLayerDe
     __builtin_amdgcn_wave_barrier();
 }
 
-template <int NS>
-__global__ __launch_bounds__(256, 3) void sa_wave_kernel(SaParams p) {
+// RT row tiles (32 * RT grouped rows) per wave; only RT = 1 is launched (see the host entry point).
+template <int NS, int RT>
+__global__ __launch_bounds__(256, RT == 1 ? 3 : 2) void sa_wave_kernel(SaParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int CPW = 32 / NS;                             // centres per wave
+    constexpr int CPW = 32 * RT / NS;                        // centres per wave
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    float* Xw = smem + w * 32 * p.ldk;                       // this wave's private [32][ldk] tile
+    float* Xw = smem + w * 32 * RT * p.ldk;                  // this wave's private [32*RT][ldk] tile
     const int total_centres = p.B * p.M;
     const int centre0 = (logical_block() * 4 + w) * CPW;
     if (centre0 >= total_centres) return;
     const int ncentres = min(CPW, total_centres - centre0);
 
-    sa_gather_rows<NS, 32>(p, Xw, 0, centre0, lane);
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) sa_gather_rows<NS, 32>(p, Xw, rt * 32, centre0, lane);
     __builtin_amdgcn_wave_barrier();
 
     for (int l = 0; l < p.n_layers; ++l) {
         const SaLayerDev& L = p.L[l];
         const bool last = (l == p.n_layers - 1);
 #define PTT_WAVE_LAYER(CTV)                                                                         \
-        { if (L.scale) sa_wave_layer<NS, CTV, true>(p, L, last, Xw, lane, centre0, ncentres);           \
-          else sa_wave_layer<NS, CTV, false>(p, L, last, Xw, lane, centre0, ncentres); }
+        { if (L.scale) sa_wave_layer<NS, CTV, true, RT>(p, L, last, Xw, lane, centre0, ncentres);       \
+          else sa_wave_layer<NS, CTV, false, RT>(p, L, last, Xw, lane, centre0, ncentres); }
         if (L.NT == 1) PTT_WAVE_LAYER(1)
         else if (L.NT == 2) PTT_WAVE_LAYER(2)
         else PTT_WAVE_LAYER(4)
@@ -1259,15 +1263,17 @@ extern "C" int ptt_sa_fused_fwd_f32(const ptt_sa_desc* d, ptt_stream_t stream) {
     }
     if (const char* e = getenv("PTT_SA_WAVE")) wave_ok = wave_ok && atoi(e) != 0;   // dev: A/B switch
     if (wave_ok && wbytes <= 64 * 1024 && d->nsample <= 32) {
+        // one 32-row tile per wave; two (each weight fragment feeding two row tiles) was measured slower — 75 vs 98
+        // TFLOP/s: the 128 accumulator registers of the 128-column layer spill and only two waves fit a SIMD
         const int lds = 4 * 32 * p.ldk * (int)sizeof(float);
         const int cpw = 32 / d->nsample, per_wg = 4 * cpw;
         const dim3 grid((total_centres + per_wg - 1) / per_wg);
         if (d->nsample == 32) {
-            if ((rc = set_lds_limit(reinterpret_cast<const void*>(sa_wave_kernel<32>), lds))) return rc;
-            hipLaunchKernelGGL((sa_wave_kernel<32>), grid, dim3(256), lds, s, p);
+            if ((rc = set_lds_limit(reinterpret_cast<const void*>(sa_wave_kernel<32, 1>), lds))) return rc;
+            hipLaunchKernelGGL((sa_wave_kernel<32, 1>), grid, dim3(256), lds, s, p);
         } else {
-            if ((rc = set_lds_limit(reinterpret_cast<const void*>(sa_wave_kernel<16>), lds))) return rc;
-            hipLaunchKernelGGL((sa_wave_kernel<16>), grid, dim3(256), lds, s, p);
+            if ((rc = set_lds_limit(reinterpret_cast<const void*>(sa_wave_kernel<16, 1>), lds))) return rc;
+            hipLaunchKernelGGL((sa_wave_kernel<16, 1>), grid, dim3(256), lds, s, p);
         }
         return check_launch("sa_wave_kernel");
     }
