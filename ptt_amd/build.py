@@ -16,6 +16,9 @@ LIB = os.path.join(LIBDIR, "libptt_hip.so")
 HIP_SOURCES = ["errors.hip", "point_ops.hip", "mfma_ops.hip"]
 # FPS / ball query / kNN index parity needs un-fused fp32 arithmetic (see point_ops.hip header)
 EXTRA_FLAGS = {"point_ops.hip": ["-ffp-contract=off"], "mfma_ops.hip": os.environ.get("PTT_MFMA_FLAGS", "").split()}
+# build-time only: flags for every source, e.g. PTT_HIP_FLAGS="-DPTT_DEV" for a developer build that reads the PTT_*
+# A/B switches from the environment and keeps the kernels' cycle-stamp hooks (a release build has neither)
+COMMON_FLAGS = os.environ.get("PTT_HIP_FLAGS", "").split()
 
 
 def _hipcc():
@@ -42,7 +45,7 @@ def build_hip(force=False, verbose=False):
         objs.append(o)
         if force or _stale(o, [s] + headers):
             cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", s, "-o", o]
-            cmd += EXTRA_FLAGS.get(src, [])
+            cmd += EXTRA_FLAGS.get(src, []) + COMMON_FLAGS
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)

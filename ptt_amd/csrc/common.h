@@ -14,6 +14,30 @@ int check_launch(const char* what);
 
 static inline hipStream_t as_stream(ptt_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Developer A/B switches (DESIGN.md §4 "Developer switches"). A release build of the library has none: the
+// structure holds the measured-best defaults as constants, no entry point calls getenv, and the per-phase cycle
+// stamps of the chained kernels are compiled out. A build with -DPTT_DEV (PTT_HIP_FLAGS="-DPTT_DEV" python -m
+// ptt_amd.build --force) reads the PTT_* environment variables (per call, so sweep scripts can flip them between
+// launches) and keeps the stamp hooks; scripts/kernel_bench.py sweeps, scripts/sa_phases.py and
+// scripts/pair_phases.py need such a build.
+struct DevSwitches {
+    int linear_rt = 1, linear_ct = 1;    // PTT_LINEAR_TILE="11|12|21|22"
+    int sa_gather1 = 0;                  // PTT_SA_GATHER1: one row per gather instruction
+    int sa_stagger = 2;                  // PTT_SA_STAGGER
+    int sa_wave = 1;                     // PTT_SA_WAVE=0: column-split kernel for small-weight levels
+    int sa_rt = 2;                       // PTT_SA_RT=1: 32-row workgroups
+    int pair_stagger = 8;                // PTT_PAIR_STAGGER
+    int pair_lds_pad = 0;                // PTT_PAIR_LDS_PAD: extra LDS bytes (forces one workgroup per CU)
+    int fps_t = 0;                       // PTT_FPS_T: FPS threads per cloud at N <= 2048
+    int group_grad_global = 0;           // PTT_GROUP_GRAD_GLOBAL: global atomics in ptt_group_grad_f32
+    long long* stamps = nullptr;         // PTT_DEBUG_STAMPS=<hex device pointer> (PTT_DEV builds only)
+};
+const DevSwitches& dev_switches();
+
+// hipFuncAttributeMaxDynamicSharedMemorySize, raised at most once per (kernel, device, size): the launch paths
+// call this on every launch and it is a table lookup after the first.
+int set_lds_limit(const void* fn, int bytes);
+
 // ---- wave64 cross-lane reductions on DPP (no LDS traffic) -------------------------
 // After 4 row-local butterfly steps every lane of a 16-lane row holds the row result;
 // row_bcast:15 / row_bcast:31 then fold the four rows into lane 63.

@@ -1,6 +1,8 @@
 // Error reporting for the C ABI: thread-local message buffer, no exceptions, no allocation.
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
+#include <mutex>
 #include "common.h"
 
 namespace ptt {
@@ -21,6 +23,53 @@ int check_launch(const char* what) {
     const hipError_t e = hipGetLastError();
     if (e == hipSuccess) return PTT_OK;
     return fail(PTT_ELAUNCH, "%s: %s", what, hipGetErrorString(e));
+}
+
+#ifdef PTT_DEV
+static DevSwitches read_switches() {
+    DevSwitches d;
+    if (const char* e = getenv("PTT_LINEAR_TILE")) { d.linear_rt = (e[0] == '2') ? 2 : 1; d.linear_ct = (e[0] && e[1] == '2') ? 2 : 1; }
+    if (getenv("PTT_SA_GATHER1")) d.sa_gather1 = 1;
+    if (const char* e = getenv("PTT_SA_STAGGER")) d.sa_stagger = atoi(e);
+    if (const char* e = getenv("PTT_SA_WAVE")) d.sa_wave = atoi(e) != 0;
+    if (const char* e = getenv("PTT_SA_RT")) d.sa_rt = (atoi(e) == 1) ? 1 : 2;
+    if (const char* e = getenv("PTT_PAIR_STAGGER")) d.pair_stagger = atoi(e);
+    if (const char* e = getenv("PTT_PAIR_LDS_PAD")) d.pair_lds_pad = atoi(e);
+    if (const char* e = getenv("PTT_FPS_T")) d.fps_t = atoi(e);
+    if (getenv("PTT_GROUP_GRAD_GLOBAL")) d.group_grad_global = 1;
+    if (const char* e = getenv("PTT_DEBUG_STAMPS")) d.stamps = reinterpret_cast<long long*>(strtoull(e, nullptr, 16));
+    return d;
+}
+const DevSwitches& dev_switches() {
+    static thread_local DevSwitches d;                  // developer build: re-read per call so that the sweep scripts
+    d = read_switches();                                // (scripts/kernel_bench.py, *_phases.py) can flip a switch
+    return d;                                           // between launches
+}
+#else
+const DevSwitches& dev_switches() {
+    static const DevSwitches d;                         // the measured-best defaults; nothing is read from the environment
+    return d;
+}
+#endif
+
+int set_lds_limit(const void* fn, int bytes) {
+    if (bytes <= 48 * 1024) return PTT_OK;
+    struct Entry { const void* fn; int dev; int bytes; };
+    static Entry table[64];
+    static int used = 0;
+    static std::mutex mu;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return check_launch("hipGetDevice");
+    std::lock_guard<std::mutex> g(mu);
+    Entry* slot = nullptr;
+    for (int i = 0; i < used; ++i)
+        if (table[i].fn == fn && table[i].dev == dev) { slot = &table[i]; break; }
+    if (slot && slot->bytes >= bytes) return PTT_OK;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess)
+        return check_launch("hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+    if (!slot && used < 64) slot = &table[used++];
+    if (slot) { slot->fn = fn; slot->dev = dev; slot->bytes = bytes; }
+    return PTT_OK;
 }
 
 }  // namespace ptt

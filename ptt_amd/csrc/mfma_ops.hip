@@ -38,6 +38,14 @@
 
 namespace ptt {
 
+// Per-phase cycle stamps of the chained kernels (scripts/sa_phases.py, scripts/pair_phases.py): only in -DPTT_DEV
+// builds; a release kernel has neither the pointer test nor the store.
+#ifdef PTT_DEV
+#define PTT_STAMP(i) do { if (p.dbg && threadIdx.x == 0 && blockIdx.x < 4096) p.dbg[blockIdx.x * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define PTT_STAMP(i) do { } while (0)
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -676,7 +684,6 @@ __global__ __launch_bounds__(256, PTT_SA_WAVES) void sa_fused_kernel(SaParams p)
     const int centre0 = logical_block() * CPW;
     const int ncentres = min(CPW, total_centres - centre0);
     stagger_second_slot(p.first_wave, p.stagger);
-#define PTT_STAMP(i) do { if (p.dbg && t == 0 && blockIdx.x < 4096) p.dbg[blockIdx.x * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
     PTT_STAMP(0);
 
     SaPre pre;
@@ -697,7 +704,6 @@ __global__ __launch_bounds__(256, PTT_SA_WAVES) void sa_fused_kernel(SaParams p)
         else sa_layer<NS, 2, RT>(p, L, last, Xs, lane, w, centre0, ncentres, pre, Ln);
         PTT_STAMP(2 + l);
     }
-#undef PTT_STAMP
 }
 
 // ------------------------------------------------------------------------------------------
@@ -966,7 +972,6 @@ __global__ __launch_bounds__(256, 2) void pt_attn_pair_kernel(AttnParams p) {
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, half = lane >> 5;
     const int pt0 = logical_block() * 2;                     // flat point index of tile row 0
     const int npts = min(2, p.BN - pt0);
-#define PTT_STAMP(i) do { if (p.dbg && t == 0 && blockIdx.x < 4096) p.dbg[blockIdx.x * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
     f32x4 pre[CT];
     prefetch_first_block_full<CT>(p.Wd1p, w, lane, pre);    // fc_delta[0]'s only weight block: requested first
     stagger_second_slot(p.first_wave, p.stagger);
@@ -1120,14 +1125,6 @@ __global__ __launch_bounds__(256, 2) void pt_attn_pair_kernel(AttnParams p) {
         }
     }
     PTT_STAMP(7);
-#undef PTT_STAMP
-}
-
-static int set_lds_limit(const void* fn, int bytes) {
-    if (bytes <= 48 * 1024) return PTT_OK;
-    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess)
-        return check_launch("hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
-    return PTT_OK;
 }
 
 }  // namespace ptt
@@ -1175,8 +1172,7 @@ extern "C" int ptt_linear_f32(const float* X, int rows, int K, int ldx, const fl
     // 1-10 GFLOP, so workgroup count (>= 4 per CU, fine-grained tails) matters more than weight reuse per workgroup.
     const bool vec = p.vec_ok && (K & 3) == 0;
     const int rt64 = (rows + 63) / 64, rt32 = (rows + 31) / 32, cg256 = (p.NT + 7) / 8, cg128 = (p.NT + 3) / 4;
-    int RT = 1, CT = 1;
-    if (const char* e = getenv("PTT_LINEAR_TILE")) { RT = (e[0] == '2') ? 2 : 1; CT = (e[1] == '2') ? 2 : 1; }   // dev: "11","12","21","22"
+    const int RT = dev_switches().linear_rt, CT = dev_switches().linear_ct;
     const int lds = 2 * (RT * 32) * LIN_LDK * (int)sizeof(float);
     const dim3 grid(RT == 2 ? rt64 : rt32, CT == 2 ? cg256 : cg128);
     hipStream_t s = as_stream(stream);
@@ -1222,7 +1218,7 @@ extern "C" int ptt_sa_fused_fwd_f32(const ptt_sa_desc* d, ptt_stream_t stream) {
     p.K0 = (d->use_xyz ? 3 : 0) + d->C;
     p.hoist = hoist ? 1 : 0; p.l0_relu = d->l0_relu ? 1 : 0; p.wx = d->l0_xyz_weight;
     if (hoist && d->l0_channels == 128 && (unsigned long long)d->B * d->N * 128ull * sizeof(float) < 0x7fffffffull &&
-        !getenv("PTT_SA_GATHER1"))
+        !dev_switches().sa_gather1)
         p.hoist = 2;                                      // two rows per wave instruction, 32-bit buffer offsets
     if (hoist) {      // the tile starts as layer 0's output: rows of the per-point term, C0 channels
         p.feat = d->l0_point_term; p.C = d->l0_channels; p.K0 = p.C;
@@ -1246,10 +1242,8 @@ extern "C" int ptt_sa_fused_fwd_f32(const ptt_sa_desc* d, ptt_stream_t stream) {
     p.ldk = maxk + 4;
     p.vec_gather = (p.C > 0 && p.fsc == 1 && (p.C & 3) == 0 && p.C <= 256 && (p.fsn & 3) == 0 &&
                     (p.fsb & 3) == 0 && (reinterpret_cast<uintptr_t>(p.feat) & 15) == 0) ? 1 : 0;
-    p.first_wave = 1024; p.stagger = 2;
-    if (const char* e = getenv("PTT_SA_STAGGER")) p.stagger = atoi(e);
-    p.dbg = nullptr;
-    if (const char* e = getenv("PTT_DEBUG_STAMPS")) p.dbg = reinterpret_cast<long long*>(strtoull(e, nullptr, 16));
+    p.first_wave = 1024; p.stagger = dev_switches().sa_stagger;
+    p.dbg = dev_switches().stamps;
     const int total_centres = d->B * d->M;
     hipStream_t s = as_stream(stream);
     int rc;
@@ -1261,7 +1255,7 @@ extern "C" int ptt_sa_fused_fwd_f32(const ptt_sa_desc* d, ptt_stream_t stream) {
         const int nt = d->layers[l].Cout / 32;
         if (!(nt == 1 || nt == 2 || nt == 4)) wave_ok = false;
     }
-    if (const char* e = getenv("PTT_SA_WAVE")) wave_ok = wave_ok && atoi(e) != 0;   // dev: A/B switch
+    wave_ok = wave_ok && dev_switches().sa_wave;
     if (wave_ok && wbytes <= 64 * 1024 && d->nsample <= 32) {
         // one 32-row tile per wave; two (each weight fragment feeding two row tiles) was measured slower — 75 vs 98
         // TFLOP/s: the 128 accumulator registers of the 128-column layer spill and only two waves fit a SIMD
@@ -1277,8 +1271,7 @@ extern "C" int ptt_sa_fused_fwd_f32(const ptt_sa_desc* d, ptt_stream_t stream) {
         }
         return check_launch("sa_wave_kernel");
     }
-    int RT = 2;                                          // rows per workgroup = 32 * RT
-    if (const char* e = getenv("PTT_SA_RT")) RT = (atoi(e) == 1) ? 1 : 2;      // dev: A/B switch
+    int RT = dev_switches().sa_rt;                       // rows per workgroup = 32 * RT (2 unless a dev build says 1)
     if (d->nsample == 64) RT = 2;                        // one centre = two row tiles
     const int lds = 32 * RT * p.ldk * (int)sizeof(float);
     if (lds > 160 * 1024) return fail(PTT_EUNSUPPORTED, "ptt_sa_fused_fwd_f32: %d B of LDS per workgroup", lds);
@@ -1362,15 +1355,13 @@ extern "C" int ptt_pt_attn_pair_f32(const ptt_attn_desc* d, ptt_stream_t stream)
     p.xyz = d->xyz; p.rel = d->rel; p.knn = d->knn; p.qkv = d->qkv; p.Wd1p = d->Wd1p; p.Wd2p = d->Wd2p; p.bd2 = d->bd2;
     p.Wg1p = d->Wg1p; p.bg1 = d->bg1; p.Wg2p = d->Wg2p; p.bg2 = d->bg2; p.res = d->res; p.attn = d->attn;
     p.BN = d->B * d->N; p.N = d->N;
-    p.first_wave = 512; p.stagger = 8;
-    if (const char* e = getenv("PTT_PAIR_STAGGER")) p.stagger = atoi(e);
-    p.dbg = nullptr;
-    if (const char* e = getenv("PTT_DEBUG_STAMPS")) p.dbg = reinterpret_cast<long long*>(strtoull(e, nullptr, 16));
+    p.first_wave = 512; p.stagger = dev_switches().pair_stagger;
+    p.dbg = dev_switches().stamps;
     if ((d->N & 1) != 0)
         return fail(PTT_EUNSUPPORTED, "ptt_pt_attn_pair_f32: N=%d must be even (a tile holds two points of one cloud)",
                     d->N);
     int lds = (32 * (512 + 4) + 32 + 32 * 12) * (int)sizeof(float);
-    if (const char* e = getenv("PTT_PAIR_LDS_PAD")) lds += atoi(e);   // dev: force 1 workgroup per CU
+    lds += dev_switches().pair_lds_pad;                               // dev: force 1 workgroup per CU
     int rc = set_lds_limit(reinterpret_cast<const void*>(pt_attn_pair_kernel<512>), lds);
     if (rc) return rc;
     hipLaunchKernelGGL((pt_attn_pair_kernel<512>), dim3((p.BN + 1) / 2), dim3(256), lds, as_stream(stream), p);

@@ -400,8 +400,7 @@ extern "C" int ptt_fps_f32(const float* xyz, int B, int N, int npoint, int32_t* 
     if (N <= 512) return launch_fps<256, 2>(xyz, B, N, npoint, idx_out, s);
     if (N <= 1024) return launch_fps<256, 4>(xyz, B, N, npoint, idx_out, s);
     if (N <= 2048) {
-        if (const char* e = getenv("PTT_FPS_T")) {      // dev: workgroup-size sweep
-            const int T = atoi(e);
+        if (const int T = dev_switches().fps_t) {       // dev: workgroup-size sweep
             if (T == 256) return launch_fps<256, 8>(xyz, B, N, npoint, idx_out, s);
             if (T == 1024) return launch_fps<1024, 2>(xyz, B, N, npoint, idx_out, s);
             if (T == 128) return launch_fps<128, 16>(xyz, B, N, npoint, idx_out, s);
@@ -485,7 +484,7 @@ extern "C" int ptt_group_grad_f32(const float* grad_out, const int32_t* idx, int
     if (!grad_feat) return fail(PTT_EINVAL, "ptt_group_grad_f32: null pointer");
     const size_t total = (size_t)B * C * M * ns;
     if (total > 0 && (!grad_out || !idx)) return fail(PTT_EINVAL, "ptt_group_grad_f32: null pointer");
-    if (total > 0 && N <= 16384 && !getenv("PTT_GROUP_GRAD_GLOBAL")) {       // accumulate in LDS (<= 64 KB per workgroup)
+    if (total > 0 && N <= 16384 && !dev_switches().group_grad_global) {       // accumulate in LDS (<= 64 KB per workgroup)
         int CC = 65536 / (4 * N);
         if (CC > 16) CC = 16;
         if (CC > C) CC = C;
@@ -534,11 +533,7 @@ extern "C" int ptt_scatter_add_det_f32(const float* src, const int32_t* idx, int
     if (rc) return rc;
     const int CC = 8, nchunks = (C + CC - 1) / CC;
     const size_t lds = (size_t)E * (sizeof(float) + sizeof(int));
-    if (lds > 64 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(scatter_add_det_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return check_launch("hipFuncSetAttribute(scatter_add_det_kernel)");
-    }
+    if ((rc = set_lds_limit(reinterpret_cast<const void*>(scatter_add_det_kernel), (int)lds))) return rc;
     hipLaunchKernelGGL(scatter_add_det_kernel, dim3(B * nchunks), dim3(512), lds, s, src, order, start, C, N, E, CC, nchunks,
                        out);
     return check_launch("scatter_add_det_kernel");

@@ -60,17 +60,35 @@ class PointnetSAModuleVotes(nn.Module):
 
     # ------------------------------------------------------------------ fused-path parameters
     def _fusable(self, xyz, features):
-        if self.training or not xyz.is_cuda or self.sample_uniformly or self.nsample not in (16, 32, 64):
+        """Eval mode on a HIP device, a shape ptt_sa_fused_fwd_f32 instantiates, and no autograd graph being recorded
+        (the kernels have none: with gradients enabled and anything requiring them the call stays on the
+        differentiable stock-torch path, as the reference's eval mode is). An eval-mode HIP call that is turned away
+        says so once (ops.note_unfused)."""
+        if self.training or not xyz.is_cuda:
             return False
-        if features is not None and features.dtype != torch.float32:
-            return False
+        name = 'PointnetSAModuleVotes(nsample=%s, mlp=%s)' % (self.nsample, [u.conv.weight.shape[0] for u in self.mlp_module
+                                                                              if hasattr(u, 'conv')])
+        if ops.autograd_recording(self, xyz, features):
+            return ops.note_unfused(name, 'autograd is recording (wrap inference in torch.no_grad())')
+        if self.sample_uniformly or self.nsample not in (16, 32, 64):
+            return ops.note_unfused(name, 'nsample must be 16, 32 or 64 and sample_uniformly off')
+        if xyz.dtype != torch.float32 or (features is not None and features.dtype != torch.float32):
+            return ops.note_unfused(name, 'inputs must be float32')
+        if len(self.mlp_module) > 4:
+            return ops.note_unfused(name, 'more than 4 SharedMLP layers')
         for unit in self.mlp_module:
             conv = getattr(unit, 'conv', None)
             if conv is None or conv.kernel_size != (1, 1) or conv.weight.shape[0] % 32 != 0 or conv.weight.shape[0] > 256:
-                return False
+                return ops.note_unfused(name, 'layer widths must be multiples of 32, at most 256, 1x1 convolutions')
             if list(unit._modules.keys())[0] != 'conv':     # pre-activation units are not folded
-                return False
-        return len(self.mlp_module) <= 4
+                return ops.note_unfused(name, 'pre-activation units')
+        return True
+
+    def train(self, mode=True):
+        # a train-mode forward updates the BatchNorm running statistics through raw pointers on some torch builds
+        # (no _version bump): drop the folded / packed parameters whenever the mode changes
+        self._fused_cache = None
+        return super().train(mode)
 
     def _fused_params(self, device):
         tensors = []
@@ -81,6 +99,8 @@ class PointnetSAModuleVotes(nn.Module):
             if hasattr(unit, 'normlayer'):
                 bn = unit.normlayer.bn
                 tensors += [bn.weight, bn.bias, bn.running_mean, bn.running_var]
+                if bn.num_batches_tracked is not None:
+                    tensors.append(bn.num_batches_tracked)     # bumped by every train-mode forward
         key = (str(device),) + tuple((t.data_ptr(), t._version) for t in tensors)
         if self._fused_cache is not None and self._fused_cache[0] == key:
             return self._fused_cache[1]

@@ -162,18 +162,24 @@ class Seq(nn.Sequential):
 # BatchNorm folded from its running statistics, instead of conv + batch_norm + relu (+ layout copies) per layer.
 # ---------------------------------------------------------------------------------------------------------------
 def rows_fusable(seq, rows):
-    if seq.training or not rows.is_cuda or rows.dtype != torch.float32:
+    from .... import ops
+    if seq.training or not rows.is_cuda:
         return False
+    name = 'Conv1d stack %s' % [u.conv.weight.shape[0] for u in seq if hasattr(u, 'conv')]
+    if ops.autograd_recording(seq, rows):
+        return ops.note_unfused(name, 'autograd is recording (wrap inference in torch.no_grad())')
+    if rows.dtype != torch.float32:
+        return ops.note_unfused(name, 'inputs must be float32')
     for unit in seq:
         conv = getattr(unit, 'conv', None)
         if not isinstance(conv, nn.Conv1d) or conv.kernel_size != (1,) or conv.stride != (1,) or conv.padding != (0,):
-            return False
+            return ops.note_unfused(name, 'not a stack of 1x1 Conv1d units')
         if list(unit._modules.keys())[0] != 'conv':                       # pre-activation units are not folded
-            return False
+            return ops.note_unfused(name, 'pre-activation units')
         if hasattr(unit, 'activation') and not isinstance(unit.activation, nn.ReLU):
-            return False
+            return ops.note_unfused(name, 'activation other than ReLU')
         if hasattr(unit, 'normlayer') and not isinstance(getattr(unit.normlayer, 'bn', None), nn.BatchNorm1d):
-            return False
+            return ops.note_unfused(name, 'normalisation other than BatchNorm1d')
     return len(seq) > 0
 
 
@@ -187,6 +193,8 @@ def _rows_params(seq):
         if hasattr(unit, 'normlayer'):
             bn = unit.normlayer.bn
             tensors += [bn.weight, bn.bias, bn.running_mean, bn.running_var]
+            if bn.num_batches_tracked is not None:
+                tensors.append(bn.num_batches_tracked)         # bumped by every train-mode forward
     key = tuple((t.data_ptr(), t._version) for t in tensors)
     cache = getattr(seq, '_rows_cache', None)
     if cache is not None and cache[0] == key:

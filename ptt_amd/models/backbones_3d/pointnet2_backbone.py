@@ -48,6 +48,9 @@ class PointNet2BackboneLight(nn.Module):
         """features (B,256,M). Eval + HIP + point-major storage: MFMA linear; else stock Conv1d."""
         if self.training or not features.is_cuda:
             return self.cov_final(features)
+        if ops.autograd_recording(self.cov_final, features) or features.dtype != torch.float32:
+            ops.note_unfused('PointNet2BackboneLight.cov_final', 'autograd is recording or input is not float32')
+            return self.cov_final(features)
         w, b = self.cov_final.weight, self.cov_final.bias
         key = (w.data_ptr(), w._version, b.data_ptr(), b._version)
         if self._cov_cache is None or self._cov_cache[0] != key:

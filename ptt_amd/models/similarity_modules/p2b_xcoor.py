@@ -32,15 +32,34 @@ class CosineSimAug(nn.Module):
 
     # ------------------------------------------------------------------ fused-path parameters
     def _fusable(self, search_feats, template_feats):
-        if self.training or not search_feats.is_cuda or template_feats.shape[-1] != 64:
+        """Eval mode on a HIP device, float32 features, 64 template seeds, BatchNorm'd SharedMLP / first Conv1d (their
+        folding is what `_params` implements) and no autograd graph being recorded; an eval-mode HIP call that is
+        turned away says so once (ops.note_unfused)."""
+        if self.training or not search_feats.is_cuda:
             return False
+        name = 'CosineSimAug'
+        if ops.autograd_recording(self, search_feats, template_feats):
+            return ops.note_unfused(name, 'autograd is recording (wrap inference in torch.no_grad())')
+        if search_feats.dtype != torch.float32 or template_feats.dtype != torch.float32:
+            return ops.note_unfused(name, 'features must be float32')
+        if template_feats.shape[-1] != 64:
+            return ops.note_unfused(name, 'ptt_xcorr_fused_fwd_f32 instantiates 64 template seeds (got %d)'
+                                    % template_feats.shape[-1])
         units = list(self.mlp)
         if len(units) < 2 or len(units) > 5:
-            return False
+            return ops.note_unfused(name, 'SharedMLP depth %d' % len(units))
         for u in units:
             if not hasattr(u, 'normlayer') or u.conv.weight.shape[0] % 32 or u.conv.weight.shape[0] > 256:
-                return False
-        return units[0].conv.weight.shape[1] == template_feats.shape[1] + 4 and len(self.conv) == 2
+                return ops.note_unfused(name, 'SharedMLP needs BatchNorm and widths that are multiples of 32, <= 256')
+        if len(self.conv) != 2 or not hasattr(self.conv[0], 'normlayer') or hasattr(self.conv[1], 'normlayer'):
+            return ops.note_unfused(name, 'CONV must be [Conv1d+BN(+ReLU), Conv1d] (CONV.BN: True)')
+        if units[0].conv.weight.shape[1] != template_feats.shape[1] + 4:
+            return ops.note_unfused(name, 'first SharedMLP layer does not take 1 + 3 + C channels')
+        return True
+
+    def train(self, mode=True):
+        self._cache = None          # BatchNorm running statistics may change without a _version bump in train mode
+        return super().train(mode)
 
     @staticmethod
     def _fold(unit):
@@ -50,7 +69,7 @@ class CosineSimAug(nn.Module):
         return scale, shift
 
     def _params(self):
-        ts = [t for t in self.state_dict().values() if t.is_floating_point()]
+        ts = list(self.state_dict().values())         # incl. num_batches_tracked: bumped by every train-mode forward
         key = tuple((t.data_ptr(), t._version) for t in ts)
         if self._cache is not None and self._cache[0] == key:
             return self._cache[1]

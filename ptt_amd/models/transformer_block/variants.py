@@ -49,8 +49,20 @@ class TransformerBlock(nn.Module):
 
     # ---------------------------------------------------------------- fused-path parameters
     def _fusable(self, xyz, features):
-        return (not self.training and xyz.is_cuda and self.d_model == 512 and self.k == 16
-                and xyz.shape[1] % 2 == 0 and xyz.shape[1] >= self.k and features.dtype == torch.float32)
+        """Eval mode on a HIP device, the instantiated shape (d_model 512, k 16, an even number of points) and no
+        autograd graph being recorded; an eval-mode HIP call that is turned away says so once (ops.note_unfused)."""
+        if self.training or not xyz.is_cuda:
+            return False
+        name = 'TransformerBlock(d_model=%d, k=%d)' % (self.d_model, self.k)
+        if ops.autograd_recording(self, xyz, features):
+            return ops.note_unfused(name, 'autograd is recording (wrap inference in torch.no_grad())')
+        if self.d_model != 512 or self.k != 16:
+            return ops.note_unfused(name, 'ptt_pt_attn_pair_f32 instantiates d_model 512, k 16')
+        if xyz.shape[1] % 2 != 0 or xyz.shape[1] < self.k:
+            return ops.note_unfused(name, 'needs an even number of points >= k (got %d)' % xyz.shape[1])
+        if features.dtype != torch.float32 or xyz.dtype != torch.float32:
+            return ops.note_unfused(name, 'inputs must be float32')
+        return True
 
     def _params(self):
         ts = [self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, self.w_qs.weight, self.w_ks.weight,

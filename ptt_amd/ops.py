@@ -55,6 +55,38 @@ class _timed(object):
             _timing[self.name].append(self.ev)
 
 
+# --------------------------------------------------------------------------- which path runs, and saying so
+# The fused kernels have no autograd graph. A module takes them only when (a) it is in eval mode on a HIP device,
+# (b) its shape is one the library instantiates and (c) nothing in the call is being recorded by autograd. When an
+# eval-mode call on a HIP device has to take the stock-torch path instead, the module says so ONCE per reason
+# (warnings.warn) and counts it here, so nobody benchmarks MIOpen/rocBLAS believing it is the hand-written path.
+unfused_calls = {}          # (module name, reason) -> number of eval-mode HIP calls that took the stock-torch path
+
+
+def autograd_recording(module, *tensors):
+    """True when this call must stay differentiable: grad mode is on and an input or a parameter requires grad
+    (eval-mode fine-tuning with frozen BatchNorm, saliency / adversarial gradients w.r.t. the points, ...). The
+    reference stays differentiable in eval mode; inference wraps the model in torch.no_grad()
+    (tools/eval_utils/eval_tracking_utils.py:33)."""
+    if not torch.is_grad_enabled():
+        return False
+    if any(t is not None and t.requires_grad for t in tensors):
+        return True
+    return module is not None and any(p.requires_grad for p in module.parameters())
+
+
+def note_unfused(name, reason):
+    """An eval-mode call on a HIP device is leaving the hand-written kernels: count it, warn once per (name, reason)."""
+    key = (name, reason)
+    n = unfused_calls.get(key, 0)
+    unfused_calls[key] = n + 1
+    if n == 0:
+        import warnings
+        warnings.warn("ptt_amd: %s runs on stock torch ops, not the fused HIP kernels: %s" % (name, reason),
+                      RuntimeWarning, stacklevel=3)
+    return False
+
+
 def publish_params(device):
     """Called by the modules right after they (re)build a cached set of packed / folded parameters: blocks the host
     until the kernels that produced them have finished. The caches are shared by every stream that later runs the
@@ -119,10 +151,25 @@ def scatter_add_det(src, idx, N):
     return out
 
 
-def _det_grads(entries):
+_ATOMIC_GRADS = os.environ.get("PTT_ATOMIC_GRADS", "0")      # read once at import; set_atomic_grads() at run time
+
+
+def set_atomic_grads(on):
+    """Backward of gather / group with upstream's atomicAdd behaviour (True) or in the fixed summation order (False,
+    default). Returns the previous setting."""
+    global _ATOMIC_GRADS
+    prev = _ATOMIC_GRADS == "1"
+    _ATOMIC_GRADS = "1" if on else "0"
+    return prev
+
+
+def _det_grads(entries, N):
     """The backward scatter-adds run in a fixed summation order (bit-reproducible, equal to the sequential loop) unless
-    PTT_ATOMIC_GRADS=1 asks for upstream's atomicAdd behaviour or a cloud has more than 16384 entries."""
-    return entries <= 16384 and os.environ.get("PTT_ATOMIC_GRADS", "0") != "1"
+    PTT_ATOMIC_GRADS=1 asks for upstream's atomicAdd behaviour, a cloud has more than 16384 entries, or the sort key
+    idx * 16384 + e would not fit 32 bits (N >= 262144): those cases take the atomic kernels."""
+    if int(N) * 16384 > 0xffffffff:
+        return False
+    return entries <= 16384 and _ATOMIC_GRADS != "1"
 
 
 def gather_points_grad(grad_out, idx, N):
@@ -130,7 +177,7 @@ def gather_points_grad(grad_out, idx, N):
     _chk(grad_out, "grad_out", torch.float32, 3)
     _chk(idx, "idx", torch.int32, 2)
     B, C, M = grad_out.shape
-    if M > 0 and _det_grads(M):
+    if M > 0 and _det_grads(M, N):
         return scatter_add_det(grad_out, idx, N)
     out = torch.empty((B, C, int(N)), dtype=torch.float32, device=grad_out.device)
     with torch.cuda.device(grad_out.device):
@@ -185,7 +232,7 @@ def group_points_grad(grad_out, idx, N):
     _chk(grad_out, "grad_out", torch.float32, 4)
     _chk(idx, "idx", torch.int32, 3)
     B, C, M, ns = grad_out.shape
-    if M * ns > 0 and _det_grads(M * ns):
+    if M * ns > 0 and _det_grads(M * ns, N):
         return scatter_add_det(grad_out.view(B, C, M * ns), idx.view(B, M * ns), N)
     out = torch.empty((B, C, int(N)), dtype=torch.float32, device=grad_out.device)
     with torch.cuda.device(grad_out.device):
@@ -324,6 +371,11 @@ def sa_fused_forward(xyz, new_xyz, idx, features, layers, radius, use_xyz=True, 
 def cosine_map(search_feats, templ_feats, eps=1e-8):
     """cos_t (B,Ns,Nt) = F.cosine_similarity(templ_i, search_j) for every pair (p2b_xcoor.py:35-36); inputs (B,C,N) in
     any strides."""
+    for t_, n_ in ((search_feats, "search_feats"), (templ_feats, "templ_feats")):
+        if not isinstance(t_, torch.Tensor) or not t_.is_cuda or t_.dtype != torch.float32 or t_.dim() != 3:
+            raise RuntimeError("%s must be a (B,C,N) float32 device tensor" % n_)
+    if search_feats.shape[:2] != templ_feats.shape[:2] or search_feats.device != templ_feats.device:
+        raise RuntimeError("search_feats and templ_feats must share batch size, channel count and device")
     B, C, Ns = search_feats.shape
     Nt = templ_feats.shape[2]
     out = torch.empty((B, Ns, Nt), dtype=torch.float32, device=search_feats.device)
@@ -345,9 +397,16 @@ def xcorr_fused(search_feats, templ_feats, P, w_sim, scale0, shift0, layers, eps
         if not t_.is_cuda or t_.dtype != torch.float32 or t_.dim() != 3:
             raise RuntimeError("%s must be a (B,C,N) float32 device tensor" % n_)
     _chk(P, "P", torch.float32, 3)
+    _chk(w_sim, "w_sim", torch.float32, 1)
     B, C, Ns = search_feats.shape
     Nt = templ_feats.shape[2]
     C0 = P.shape[2]
+    if Nt != 64:
+        raise RuntimeError("xcorr_fused: Nt=%d (ptt_xcorr_fused_fwd_f32 instantiates 64 template seeds)" % Nt)
+    if P.shape[0] != B or P.shape[1] != Nt or w_sim.shape[0] != C0 or templ_feats.shape[:2] != search_feats.shape[:2]:
+        raise RuntimeError("xcorr_fused: inconsistent shapes")
+    if cos_t is not None:
+        _chk(cos_t, "cos_t", torch.float32, 3)
     cout = layers[-1][4]
     store = torch.empty((B, Ns, cout), dtype=torch.float32, device=P.device)
     out = store.transpose(1, 2)

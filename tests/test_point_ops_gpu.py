@@ -83,9 +83,9 @@ def test_gather_group_and_grads(dev):
 
 @pytest.mark.parametrize("B,C,N,M,ns", [(4, 131, 512, 256, 32), (2, 7, 2048, 512, 32), (3, 260, 128, 64, 16),
                                          (2, 5, 300, 37, 5), (1, 3, 16, 1, 1)])
-def test_scatter_grads_deterministic_and_atomic(dev, monkeypatch, B, C, N, M, ns):
+def test_scatter_grads_deterministic_and_atomic(dev, B, C, N, M, ns):
     """Backward of group_points at the training shapes (and ragged ones): the deterministic path equals the oracle bit
-    for bit, twice in a row; upstream's atomicAdd behaviour (PTT_ATOMIC_GRADS=1: LDS-accumulating kernel, global atomics
+    for bit, twice in a row; upstream's atomicAdd behaviour (ops.set_atomic_grads: LDS-accumulating kernel, global atomics
     beyond N = 16384) agrees to fp32 rounding. Heavy duplication: indices drawn from a quarter of the points."""
     rs = np.random.RandomState(B * 1000 + N)
     idx = rs.randint(0, max(1, N // 4), (B, M, ns)).astype(np.int32)
@@ -96,12 +96,15 @@ def test_scatter_grads_deterministic_and_atomic(dev, monkeypatch, B, C, N, M, ns
     b = ops.group_points_grad(_dev(go, dev), _dev(idx, dev), N).cpu().numpy()
     np.testing.assert_array_equal(a, ref)
     np.testing.assert_array_equal(a, b)
-    monkeypatch.setenv("PTT_ATOMIC_GRADS", "1")
-    c = ops.group_points_grad(_dev(go, dev), _dev(idx, dev), N).cpu().numpy()
-    np.testing.assert_allclose(c, ref, rtol=1e-4, atol=1e-4)
-    g1 = rs.standard_normal((B, C, M)).astype(np.float32)
-    np.testing.assert_allclose(ops.gather_points_grad(_dev(g1, dev), _dev(idx[:, :, 0].copy(), dev), N).cpu().numpy(),
-                               O.gather_grad(g1, idx[:, :, 0].copy(), N), rtol=1e-4, atol=1e-4)
+    prev = ops.set_atomic_grads(True)
+    try:
+        c = ops.group_points_grad(_dev(go, dev), _dev(idx, dev), N).cpu().numpy()
+        np.testing.assert_allclose(c, ref, rtol=1e-4, atol=1e-4)
+        g1 = rs.standard_normal((B, C, M)).astype(np.float32)
+        np.testing.assert_allclose(ops.gather_points_grad(_dev(g1, dev), _dev(idx[:, :, 0].copy(), dev), N).cpu().numpy(),
+                                   O.gather_grad(g1, idx[:, :, 0].copy(), N), rtol=1e-4, atol=1e-4)
+    finally:
+        ops.set_atomic_grads(prev)
 
 
 @pytest.mark.parametrize("N,k", [(64, 16), (128, 16), (100, 7), (512, 16), (2048, 16)])
