@@ -1,45 +1,111 @@
 #!/usr/bin/env python
 """bench.py — tracklet frames/sec of PTT's per-frame hot path on N MI355X (one process per GPU).
 
-A *step* = one pass of the hot path (ptt_amd.hot_path.FrameHotPath, eval mode) over one batch of
-synthetic frames already resident in HBM. Workload = BASELINE.json configs[1]: KITTI-Car shaped
-input, batch 48 per GPU, 2048 search + 1024 template points, constants of
-tools/cfgs/kitti_models/ptt.yaml. Frames are independent, so N GPUs = N ranks each running its own
-batch with NO data-path collective (weak scaling); torch.distributed (RCCL) is used only for the
-barrier and the max-over-ranks of the elapsed time.
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload car|ped|stress|train]
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     — the dominant kernel (pt_attn_pair_kernel, fp32 MFMA): algorithmic FLOPs per launch
-                  / mean launch duration measured live with HIP events on the
-                 launch stream, against the 157.3 TFLOP/s dense fp32-MFMA peak.
-  cpu_baseline — the CPU oracle path (oracle/: C index ops + torch-CPU dense restatement, kind "port";
-                 the reference itself has no CPU implementation of FPS/ball-query/group) timed on this
-                 host's cores over a bounded sample of the same workload.
+A *step* = one pass of the hot path (ptt_amd.hot_path.FrameHotPath, eval mode) over one batch of synthetic frames
+already resident in HBM. Workloads (BASELINE.json `configs`):
+  car    configs[1]  KITTI-Car shaped, batch 48 per GPU, 2048 search + 1024 template points   (default, the headline)
+  ped    configs[2]  KITTI-Pedestrian sparse: 60 / 40 unique points resampled to 2048 / 1024, one all-zero frame in 48
+  stress configs[4]  16384-pt search / 4096-pt template, 3 SA levels [8192,4096,2048] / [2048,1024,512], 32 per GPU
+  train  configs[3]  nuScenes-Car shaped training step of the FULL tracker: fwd + bwd + clip + Adam, batch 48 per GPU,
+                     DistributedDataParallel gradient all-reduce (19.6 MB, one bucket) over RCCL when N > 1
+Frames are independent, so for car/ped/stress N GPUs = N ranks each running its own batch with NO data-path
+collective (weak scaling); torch.distributed (RCCL) carries only the barrier, the max-over-ranks of the elapsed time
+and a one-element all-reduce of ones (`rccl_ranks_seen`).
+
+Launch: under `python -m torch.distributed.run ...` (WORLD_SIZE set) each process is one rank. With WORLD_SIZE unset
+and --gpus N > 1 this script re-executes ITSELF under torch.distributed.run with N ranks on 127.0.0.1 (what
+scripts/train_ddp.sh:9 does for the reference's tools/train_tracking.py).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with, besides the contract keys:
+  roofline     the dominant kernel (pt_attn_pair_kernel, fp32 MFMA): algorithmic FLOPs per launch
+               / mean launch duration measured live with HIP events on the launch stream, against the 157.3 TFLOP/s
+               dense fp32-MFMA peak. `traffic` is null: HBM bytes need rocprofv3 --pmc passes, which this process
+               cannot collect on itself (profiles/ holds them).
+  cpu_baseline the CPU oracle path (oracle/: C index ops + torch-CPU dense restatement, kind "port"; the reference has
+               no CPU implementation of FPS/ball-query/group) timed on this host's cores over a bounded sample.
+  sustained    the same step replayed for >= --sustain seconds right after the K-step timed region (K steps are only
+               tens of milliseconds; this is the number at sustained clocks).
+  latency_b1   (car, N=1) per-frame latency of ONE frame (B = 1) — the reference's sequential tracking loop
+               (tools/eval_utils/eval_tracking_utils.py:140-152) runs the model that way.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from ptt_amd import ops, synth                      # noqa: E402
-from ptt_amd.hot_path import (FrameHotPath, GraphedHotPath, PipelinedHotPath, TrackerThroughput, kitti_model_cfg,   # noqa: E402
-                              randomize_)
-
 PEAK_FP32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: dense f32-input MFMA peak
 PEAK_HBM_GBS = 8000.0               # spec; ~6300 achievable
 
+WORKLOADS = {
+    "car": dict(ref="BASELINE.json configs[1]", batch=48, ns=2048, nt=1024, K_s=600, K_t=300, kind="car", zero=0,
+                npoints_s=[512, 256, 128], npoints_t=[256, 128, 64],
+                text="KITTI-Car shaped frames"),
+    "ped": dict(ref="BASELINE.json configs[2]", batch=48, ns=2048, nt=1024, K_s=60, K_t=40, kind="ped", zero=1,
+                npoints_s=[512, 256, 128], npoints_t=[256, 128, 64],
+                text="KITTI-Pedestrian shaped sparse frames (60 / 40 unique points resampled with replacement, one "
+                     "all-zero frame per 48)"),
+    "stress": dict(ref="BASELINE.json configs[4]", batch=32, ns=16384, nt=4096, K_s=16384, K_t=4096, kind="dense", zero=0,
+                   npoints_s=[8192, 4096, 2048], npoints_t=[2048, 1024, 512],
+                   text="roofline stress frames (no duplicate points)"),
+    "train": dict(ref="BASELINE.json configs[3]", batch=48, ns=1024, nt=512, K_s=200, K_t=100, kind="car", zero=0,
+                  npoints_s=[512, 256, 128], npoints_t=[256, 128, 64],
+                  text="nuScenes-Car shaped training batches (200 / 100 unique points)"),
+}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="car")
+    ap.add_argument("--batch", type=int, default=None, help="frames per GPU per step (default: the workload's)")
+    ap.add_argument("--ns", type=int, default=None, help="search points per frame (default: the workload's)")
+    ap.add_argument("--nt", type=int, default=None, help="template points per frame (default: the workload's)")
+    ap.add_argument("--sustain", type=float, default=2.0, help="seconds of extra replays for the sustained-clock figure (0: off)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--serial", action="store_true",
+                    help="eager, ONE stream, no pipelining: the form to put under rocprofv3 --kernel-trace (per-kernel "
+                         "durations then equal the HIP-event figures of the roofline object)")
+    ap.add_argument("--no-full-model", action="store_true", help="skip the secondary full PTT.forward measurement")
+    ap.add_argument("--no-latency", action="store_true", help="skip the B = 1 latency measurement")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="do not overlap the FPS of batch n+1 with the dense kernels of batch n")
+    ap.add_argument("--cpu-frames", type=int, default=8)
+    return ap.parse_args()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n):
+    """WORLD_SIZE unset and --gpus n > 1: run this very command line as n ranks under torch.distributed.run."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this host driver (RCCL needs it)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
 
 def pair_kernel_flops(B, N, k=16, D=512):
-    """Algorithmic FLOPs of one pt_attn_pair_kernel launch: per (point,neighbour) row
-    fc_delta[0] (3xD) + fc_delta[2] + fc_gamma[0] + fc_gamma[2] (DxD each), 2 FLOP per MAC
-    (softmax / weighted sum are not counted)."""
+    """Algorithmic FLOPs of one pt_attn_pair_kernel launch: per (point,neighbour) row fc_delta[0] (3xD) + fc_delta[2]
+    + fc_gamma[0] + fc_gamma[2] (DxD each), 2 FLOP per MAC (softmax / weighted sum not counted)."""
     return 2.0 * B * N * k * (3 * D + 3 * D * D)
 
 
@@ -51,55 +117,82 @@ def ball_query_bytes(B, N, M, ns):
     return B * (12.0 * N + 12.0 * M + 4.0 * M * ns)
 
 
+def timed_loop(step, steps, sync_all):
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync_all()
+    return time.perf_counter() - t0
+
+
+def cpu_baseline(model, cfg, s_np, t_np, frames, ns, nt):
+    """rank 0, N = 1 only: the oracle path on a bounded sample of the same workload (about 10-20 s of CPU work)."""
+    import torch
+    from oracle import frame_ref
+    from oracle import index_ops as oracle_index_ops
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncpu = os.cpu_count() or 1
+    nf = max(1, min(frames, s_np.shape[0]))
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    sc, tc = torch.from_numpy(s_np[:nf]), torch.from_numpy(t_np[:nf])
+
+    def run_cpu(threads, n):
+        torch.set_num_threads(threads)
+        oracle_index_ops.set_threads(threads)
+        t1 = time.perf_counter()
+        with torch.no_grad():
+            frame_ref.frame(sd, cfg, sc[:n], tc[:n])
+        return time.perf_counter() - t1
+
+    # the visible core count can exceed what the container may use: pick the fastest thread count
+    cands = sorted({c for c in (8, 16, 32, 64, 128, ncpu) if c <= ncpu})
+    run_cpu(cands[0], 1)                                   # warm-up (first-touch, library init)
+    trial = {c: run_cpu(c, min(2, nf)) for c in cands}
+    best = min(trial, key=trial.get)
+    reps, spent, times = 0, 0.0, []
+    while reps < 2 or (spent < 12.0 and reps < 20):
+        dt = run_cpu(best, nf)
+        times.append(dt)
+        spent += dt
+        reps += 1
+    dt = float(np.median(times))
+    return {"value": round(nf / dt, 3), "unit": "frames/s", "cores": best, "kind": "port",
+            "sample": "%d frames (%d+%d pts) x %d reps through oracle/frame_ref.py (C index ops with OpenMP + torch-CPU "
+                      "dense path); %d of %d visible cores used (fastest of %s)" % (nf, ns, nt, reps, best, ncpu, cands)}
+
+
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=48, help="frames per GPU per step")
-    ap.add_argument("--ns", type=int, default=2048, help="search points per frame")
-    ap.add_argument("--nt", type=int, default=1024, help="template points per frame")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
-    ap.add_argument("--no-full-model", action="store_true", help="skip the secondary full PTT.forward measurement")
-    ap.add_argument("--no-pipeline", action="store_true",
-                    help="do not overlap the FPS of batch n+1 with the dense kernels of batch n")
-    ap.add_argument("--cpu-frames", type=int, default=8)
-    args = ap.parse_args()
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus))
+
+    import torch
+    from ptt_amd import ops, synth
+    from ptt_amd.hot_path import (FrameHotPath, GraphedHotPath, PipelinedHotPath, TrackerThroughput, kitti_model_cfg,
+                                  randomize_)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback for the product path)")
+    if args.gpus != world and rank == 0:
+        print("warning: --gpus %d but WORLD_SIZE %d; the process group decides: %d ranks" % (args.gpus, world, world),
+              file=sys.stderr)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
+    ranks_seen = 1
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
-    if args.gpus != world:
-        if rank == 0:
-            print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
-
-    cfg = kitti_model_cfg()
-    model = randomize_(FrameHotPath(cfg), seed=0).to(dev).eval()
-    B = args.batch
-    s_np, t_np = synth.frames(1000 + rank, B, args.ns, args.nt, K_s=600, K_t=300, kind="car")
-    search = torch.from_numpy(s_np).to(dev)
-    template = torch.from_numpy(t_np).to(dev)
-
-    def eager_step():
-        with torch.no_grad():
-            return model(search, template)
-
-    graphed = None
-    if not args.no_graph:
-        graphed = (GraphedHotPath if args.no_pipeline else PipelinedHotPath)(model, search, template)
-    # pipelined: replay k runs the dense stage of batch k and the sampling stage of batch k+1; K replays
-    # therefore execute K full batches' worth of every kernel (the warm-up replays prime the pipeline)
-    step = eager_step if graphed is None else (lambda: graphed())
+        one = torch.ones(1, device=dev)
+        dist.all_reduce(one)                                # every rank adds 1 over RCCL
+        ranks_seen = int(one.item())
 
     def sync_all():
         torch.cuda.synchronize()
@@ -107,62 +200,106 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    W = WORKLOADS[args.workload]
+    B = args.batch or W["batch"]
+    NS, NT = args.ns or W["ns"], args.nt or W["nt"]
+    s_np, t_np = synth.frames(1000 + rank, B, NS, NT, K_s=min(W["K_s"], NS), K_t=min(W["K_t"], NT), kind=W["kind"],
+                              zero_clouds=W["zero"])
+
+    if args.workload == "train":
+        out = run_train(args, torch, dev, dist, world, rank, ranks_seen, sync_all, B, NS, NT, W)
+    else:
+        out = run_infer(args, torch, ops, dev, dist, world, rank, ranks_seen, sync_all, B, NS, NT, W, s_np, t_np,
+                        FrameHotPath, GraphedHotPath, PipelinedHotPath, TrackerThroughput, kitti_model_cfg, randomize_)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def reduce_max(torch, dist, dev, seconds):
+    if dist is None:
+        return seconds
+    t = torch.tensor([seconds], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def run_infer(args, torch, ops, dev, dist, world, rank, ranks_seen, sync_all, B, NS, NT, W, s_np, t_np,
+              FrameHotPath, GraphedHotPath, PipelinedHotPath, TrackerThroughput, kitti_model_cfg, randomize_):
+    cfg = kitti_model_cfg()
+    cfg.BACKBONE_3D.SA_CONFIG.NPOINTS_SEARCH = list(W["npoints_s"])
+    cfg.BACKBONE_3D.SA_CONFIG.NPOINTS_TEMPLATE = list(W["npoints_t"])
+    model = randomize_(FrameHotPath(cfg), seed=0).to(dev).eval()
+    search = torch.from_numpy(s_np).to(dev)
+    template = torch.from_numpy(t_np).to(dev)
+    eager = args.no_graph or args.serial
+    pipelined = not (args.no_pipeline or eager)
+    if args.serial:
+        model.overlap_branches = False
+
+    def eager_step():
+        with torch.no_grad():
+            return model(search, template)
+
+    graphed = None
+    if not eager:
+        graphed = (PipelinedHotPath if pipelined else GraphedHotPath)(model, search, template)
+    # pipelined: replay k runs the dense stage of batch k and the sampling stage of batch k+1; K replays
+    # therefore execute K full batches' worth of every kernel (the warm-up replays prime the pipeline)
+    step = eager_step if graphed is None else (lambda: graphed())
+
     for _ in range(args.warmup):
         step()
-    sync_all()
     timed = ["ptt_pt_attn_pair_f32", "ptt_fps_f32", "ptt_ball_query_f32", "ptt_sa_fused_fwd_f32", "ptt_linear_f32",
              "ptt_knn_f32"]
     if graphed is None:
         ops.start_kernel_timing(timed)          # HIP events around each launch, inside the timed region
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    if graphed is None:
-        ktimes = ops.stop_kernel_timing()
-    else:
-        # events cannot be recorded inside a replayed graph: the per-kernel durations come from the same
-        # kernels, same inputs, launched eagerly (single stream) right after the timed region
+    elapsed = timed_loop(step, args.steps, sync_all)
+    ktimes = ops.stop_kernel_timing() if graphed is None else None
+    elapsed = reduce_max(torch, dist, dev, elapsed)
+
+    # ---- the same step at sustained clocks: replay for >= --sustain seconds right after the timed region ----
+    sustained = None
+    if args.sustain > 0:
+        n_sus = max(args.steps, int(args.sustain / max(elapsed / args.steps, 1e-6)) + 1)
+        n_sus = min(n_sus, 200000)
+        dt = reduce_max(torch, dist, dev, timed_loop(step, n_sus, sync_all))
+        sustained = {"steps": n_sus, "seconds": round(dt, 3), "value": round(B * world * n_sus / dt, 2),
+                     "ms_per_step": round(dt / n_sus * 1e3, 4)}
+
+    if ktimes is None:
+        # events cannot be recorded inside a replayed graph: the per-kernel durations come from the same kernels, same
+        # inputs, launched eagerly on ONE stream right after the timed region (python bench.py --serial under
+        # rocprofv3 --kernel-trace reproduces them: profiles/)
         model.overlap_branches = False
+        for _ in range(2):
+            eager_step()
         ops.start_kernel_timing(timed)
         for _ in range(args.steps):
             eager_step()
         ktimes = ops.stop_kernel_timing()
         model.overlap_branches = True
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
 
     frames_total = float(B) * world * args.steps
     value = frames_total / elapsed
     ms_per_step = elapsed / args.steps * 1e3
 
     # ---- roofline of the dominant kernel (rank 0's launches) ----
+    n_seeds = W["npoints_s"][-1]
     pair_ms = ktimes["ptt_pt_attn_pair_f32"]
     n_launch = len(pair_ms)
-    flops_per_step = pair_kernel_flops(B, 128) + pair_kernel_flops(B, 64)     # seeds N=128, proposals N=64
+    flops_per_step = pair_kernel_flops(B, n_seeds) + pair_kernel_flops(B, 64)     # seeds, then the 64 proposals
     pair_avg_ms = sum(pair_ms) / max(n_launch, 1)
     flops_per_launch = flops_per_step / 2.0
     achieved = flops_per_launch / (pair_avg_ms * 1e-3) / 1e12 if n_launch else 0.0
-    # HBM-side traffic per launch: not measurable from inside this process; taken from the committed PMC passes
-    # (profiles/r01_pair_kernel_pmc.json: 2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction applied) when the
-    # workload matches the profiled one, else null.
-    traffic, traffic_src = None, None
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pair_kernel_pmc.json")))["launches"]
-        if B == 48 and "B48_N128" in pmc and "B48_N64" in pmc:
-            traffic = (pmc["B48_N128"]["traffic_bytes"] + pmc["B48_N64"]["traffic_bytes"]) / 2.0
-            traffic_src = "profiles/r01_pair_kernel_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, mean of the two launches; fabric-side, Infinity-Cache hits included)"
-    except Exception:
-        pass
     roofline = {"kernel": "pt_attn_pair_kernel<512>", "bound": "mfma", "achieved": round(achieved, 2),
                 "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
-                "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
+                "traffic": None,
+                "traffic_note": "HBM bytes need rocprofv3 --pmc passes (separate runs): see profiles/",
                 "avg_launch_ms": round(pair_avg_ms, 4), "launches": n_launch,
                 "timing": "HIP events on the launch stream" + ("" if graphed is None else
-                                                               ", eager pass of the same kernels after the graphed timed region"),
+                                                               ", eager single-stream pass of the same kernels right after the graphed timed region"),
                 "alg_flops_per_launch": flops_per_launch}
 
     # secondary: FPS + ball-query algorithmic HBM GB/s vs peak (BASELINE.json metric, second half)
@@ -170,101 +307,150 @@ def main():
         ms = sum(ktimes[name]) / args.steps
         return round(nbytes_per_step / (ms * 1e-3) / 1e9, 3) if ms > 0 else None, round(ms, 4)
 
-    fps_b = fps_bytes(B, args.ns, 512) + fps_bytes(B, args.nt, 256) + fps_bytes(B, 128, 64)
-    bq_b = (ball_query_bytes(B, args.ns, 512, 32) + ball_query_bytes(B, 512, 256, 32) + ball_query_bytes(B, 256, 128, 32)
-            + ball_query_bytes(B, args.nt, 256, 32) + ball_query_bytes(B, 256, 128, 32) + ball_query_bytes(B, 128, 64, 32)
-            + ball_query_bytes(B, 128, 64, 16))
+    ps, pt = W["npoints_s"], W["npoints_t"]
+    fps_b = fps_bytes(B, NS, ps[0]) + fps_bytes(B, NT, pt[0]) + fps_bytes(B, n_seeds, 64)
+    bq_b = (ball_query_bytes(B, NS, ps[0], 32) + ball_query_bytes(B, ps[0], ps[1], 32) + ball_query_bytes(B, ps[1], ps[2], 32)
+            + ball_query_bytes(B, NT, pt[0], 32) + ball_query_bytes(B, pt[0], pt[1], 32) + ball_query_bytes(B, pt[1], pt[2], 32)
+            + ball_query_bytes(B, n_seeds, 64, 16))
     fps_gbs, fps_ms = gbs("ptt_fps_f32", fps_b)
     bq_gbs, bq_ms = gbs("ptt_ball_query_f32", bq_b)
     kernel_ms = {k.replace("ptt_", "").replace("_f32", ""): round(sum(v) / args.steps, 4) for k, v in ktimes.items()}
     index_ops = {"fps": {"alg_GBps": fps_gbs, "ms_per_step": fps_ms, "frac_of_hbm_peak": (fps_gbs or 0) / PEAK_HBM_GBS},
                  "ball_query": {"alg_GBps": bq_gbs, "ms_per_step": bq_ms, "frac_of_hbm_peak": (bq_gbs or 0) / PEAK_HBM_GBS}}
 
+    solo = rank == 0 and world == 1
     # ---- secondary line: the FULL tracker forward (hot path + CosineSimAug + both heads), same batch, graph replay ----
     full = None
-    if rank == 0 and world == 1 and not args.no_full_model:
+    tracker = None
+    if solo and args.workload == "car" and not args.no_full_model and not eager:
         from ptt_amd.config import StubDataset, ptt_model_cfg
         from ptt_amd.models import build_network
         tracker = randomize_(build_network(ptt_model_cfg(), 1, StubDataset()), seed=0).to(dev).eval()
-        gfull = (GraphedHotPath if args.no_pipeline else PipelinedHotPath)(TrackerThroughput(tracker), search, template)
+        gfull = (PipelinedHotPath if pipelined else GraphedHotPath)(TrackerThroughput(tracker), search, template)
         for _ in range(3):
             gfull()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            gfull()
-        torch.cuda.synchronize()
-        dtf = time.perf_counter() - t1
+        dtf = timed_loop(gfull, args.steps, sync_all)
         full = {"metric": "full PTT.forward frames/sec (eval; backbone + CosineSimAug + centroid and box heads)",
                 "value": round(B * args.steps / dtf, 2), "ms_per_step": round(dtf / args.steps * 1e3, 4),
-                "launch": "hipGraph replay, two-stream branches" + ("" if args.no_pipeline else ", FPS of the next batch pipelined as in the headline")}
+                "launch": "hipGraph replay, two-stream branches" + (", FPS of the next batch pipelined as in the headline" if pipelined else "")}
+        del gfull
 
-    # ---- CPU baseline: rank 0, N=1 only, bounded sample ----
+    # ---- B = 1 latency: what one frame of a sequential tracklet costs (hipGraph replay of one frame) ----
+    latency = None
+    if solo and args.workload == "car" and not args.no_latency and not eager:
+        latency = latency_b1(torch, dev, model, tracker, search, template, GraphedHotPath, TrackerThroughput, sync_all)
+
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import frame_ref
-        from oracle import index_ops as oracle_index_ops
-        try:
-            ncpu = len(os.sched_getaffinity(0))
-        except AttributeError:
-            ncpu = os.cpu_count() or 1
-        nf = min(args.cpu_frames, B)
-        sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
-        sc, tc = torch.from_numpy(s_np[:nf]), torch.from_numpy(t_np[:nf])
+    if solo and not args.no_cpu_baseline:
+        cpu = cpu_baseline(model, cfg, s_np, t_np, args.cpu_frames if args.workload != "stress" else 1, NS, NT)
 
-        def run_cpu(threads, frames):
-            torch.set_num_threads(threads)
-            oracle_index_ops.set_threads(threads)
-            t1 = time.perf_counter()
-            with torch.no_grad():
-                frame_ref.frame(sd, cfg, sc[:frames], tc[:frames])
-            return time.perf_counter() - t1
+    out = {
+        "metric": "tracklet frames/sec (hot path: PointNet++ SA stack + Point-Track-Transformer blocks)",
+        "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%s: %s (%s): batch %d per GPU, %d search + %d template points, 3 SA levels x 2 "
+                               "branches (%s / %s centres) + vote-aggregation SA + 2 TransformerBlocks (d_model 512, "
+                               "k 16), random-init weights, eval mode"
+                               % (args.workload, W["text"], W["ref"], B, NS, NT, W["npoints_s"], W["npoints_t"]),
+                   "name": args.workload, "frames_per_gpu_per_step": B, "search_points": NS, "template_points": NT,
+                   "sharding": "frames across ranks, no data-path collective",
+                   "launch": ("eager, one stream" if args.serial else "eager" if graphed is None else
+                              "hipGraph replay, template branch on a second stream" +
+                              ("; software-pipelined across batches: FPS of batch n+1 runs on a side stream during the "
+                               "dense kernels of batch n (every batch still executes every kernel)" if pipelined else ""))},
+        "rccl_ranks_seen": ranks_seen,
+        "roofline": roofline,
+        "cpu_baseline": cpu,
+        "sustained": sustained,
+        "index_ops": index_ops,
+        "full_model": full,
+        "latency_b1": latency,
+        "kernel_ms_per_step": kernel_ms,
+    }
+    if cpu:
+        out["speedup_vs_cpu_baseline"] = round(value / cpu["value"], 1)
+    return out
 
-        # the visible core count can exceed what the container may use: pick the fastest thread count
-        cands = sorted({c for c in (8, 16, 32, 64, 128, ncpu) if c <= ncpu})
-        run_cpu(cands[0], 1)                                   # warm-up (first-touch, library init)
-        trial = {c: run_cpu(c, min(2, nf)) for c in cands}
-        best = min(trial, key=trial.get)
-        reps, spent, times = 0, 0.0, []
-        while reps < 2 or (spent < 12.0 and reps < 20):
-            dt = run_cpu(best, nf)
-            times.append(dt)
-            spent += dt
-            reps += 1
-        dt = float(np.median(times))
-        cpu = {"value": round(nf / dt, 3), "unit": "frames/s", "cores": best, "kind": "port",
-               "sample": "%d frames (%d+%d pts) x %d reps through oracle/frame_ref.py (C index ops with OpenMP + "
-                         "torch-CPU dense path); %d of %d visible cores used (fastest of %s)"
-                         % (nf, args.ns, args.nt, reps, best, ncpu, cands)}
 
-    if rank == 0:
-        out = {
-            "metric": "tracklet frames/sec (hot path: PointNet++ SA stack + Point-Track-Transformer blocks)",
-            "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "KITTI-Car shaped frames (BASELINE.json configs[1]): batch %d per GPU, %d search + "
-                                   "%d template points, 3 SA levels x 2 branches + vote-aggregation SA + 2 "
-                                   "TransformerBlocks (d_model 512, k 16), random-init weights, eval mode"
-                                   % (B, args.ns, args.nt),
-                       "frames_per_gpu_per_step": B, "search_points": args.ns, "template_points": args.nt,
-                       "sharding": "frames across ranks, no data-path collective",
-                       "launch": ("eager" if graphed is None else
-                                  "hipGraph replay, template branch on a second stream" +
-                                  ("" if args.no_pipeline else "; software-pipelined across batches: FPS of batch n+1 "
-                                   "runs on a side stream during the dense kernels of batch n (every batch still "
-                                   "executes every kernel)"))},
-            "roofline": roofline,
-            "cpu_baseline": cpu,
-            "index_ops": index_ops,
-            "full_model": full,
-            "kernel_ms_per_step": kernel_ms,
-        }
-        if cpu:
-            out["speedup_vs_cpu_baseline"] = round(value / cpu["value"], 1)
-        print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+def latency_b1(torch, dev, model, tracker, search, template, GraphedHotPath, TrackerThroughput, sync_all, n=300):
+    """One frame at a time (B = 1): hipGraph replay latency of the hot path and of the full tracker forward."""
+    s1, t1 = search[:1].contiguous(), template[:1].contiguous()
+    res = {"frames": n, "search_points": int(s1.shape[1]), "template_points": int(t1.shape[1]),
+           "launch": "hipGraph replay of one frame, template branch on a second stream; host waits for each frame"}
+
+    def per_frame(g):
+        for _ in range(20):
+            g()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            g()
+            torch.cuda.synchronize()            # a tracklet needs frame i's box before it can crop frame i+1
+        return (time.perf_counter() - t0) / n * 1e3
+
+    g = GraphedHotPath(model, s1, t1)
+    res["hot_path_ms_per_frame"] = round(per_frame(g), 4)
+    del g
+    if tracker is not None:
+        g = GraphedHotPath(TrackerThroughput(tracker), s1, t1)
+        ms = per_frame(g)
+        res["full_tracker_ms_per_frame"] = round(ms, 4)
+        res["full_tracker_frames_per_s"] = round(1e3 / ms, 1)
+    return res
+
+
+def run_train(args, torch, dev, dist, world, rank, ranks_seen, sync_all, B, NS, NT, W):
+    """configs[3]: forward + backward + clip + Adam of the full tracker, DDP gradient all-reduce when world > 1."""
+    from ptt_amd.config import StubDataset, ptt_model_cfg
+    from ptt_amd.models import build_network
+    from ptt_amd.train_step import GRAD_ELEMS, DataParallelTrainer, synthetic_train_batch
+    torch.manual_seed(1)                                    # tools/train_tracking.py:73-79
+    model = build_network(ptt_model_cfg(), 1, StubDataset(training=True)).to(dev).train()
+    trainer = DataParallelTrainer(model, dev)
+    batch = synthetic_train_batch(100 + rank, B, dev, NS, NT, K_s=W["K_s"], K_t=W["K_t"])
+    last = {}
+
+    def step():
+        last["loss"] = trainer.step(batch)
+
+    for _ in range(args.warmup):
+        step()
+    elapsed = reduce_max(torch, dist, dev, timed_loop(step, args.steps, sync_all))
+    sustained = None
+    if args.sustain > 0:
+        n_sus = max(args.steps, int(args.sustain / max(elapsed / args.steps, 1e-6)) + 1)
+        dt = reduce_max(torch, dist, dev, timed_loop(step, n_sus, sync_all))
+        sustained = {"steps": n_sus, "seconds": round(dt, 3), "value": round(B * world * n_sus / dt, 2),
+                     "ms_per_step": round(dt / n_sus * 1e3, 4)}
+    value = B * world * args.steps / elapsed
+    # dense FLOPs of one training step: forward 12.3 GFLOP per frame at 1024+512 (SURVEY.md §8a totals) x 3 (the
+    # backward of a linear layer is two GEMMs of the forward's size)
+    flops = 3.0 * 12.3e9 * B
+    achieved = flops / (elapsed / args.steps) / 1e12
+    return {
+        "metric": "training frames/sec (full tracker: forward + backward + clip_grad_norm + Adam)",
+        "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "train: %s (%s): batch %d per GPU, %d search + %d template points, full PTT tracker in "
+                               "train mode (batch-statistics BatchNorm), Adam lr 1e-3 betas .5/.999 eps 1e-6, clip 10"
+                               % (W["text"], W["ref"], B, NS, NT),
+                   "name": "train", "frames_per_gpu_per_step": B, "search_points": NS, "template_points": NT,
+                   "sharding": "batch across ranks; DistributedDataParallel, one %.1f MB gradient bucket all-reduced "
+                               "over RCCL per step" % (GRAD_ELEMS * 4 / 1e6) if world > 1 else "single rank, no collective",
+                   "launch": "eager"},
+        "rccl_ranks_seen": ranks_seen,
+        "roofline": {"kernel": "whole training step (no single dominant kernel)", "bound": "mfma",
+                     "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                     "alg_flops_per_step": flops,
+                     "timing": "wall clock of the timed steps (3 x 12.3 GFLOP per frame dense fp32)"},
+        "cpu_baseline": None,
+        "sustained": sustained,
+        "loss": float(last["loss"].detach()),
+        "grad_bytes_allreduced_per_step": GRAD_ELEMS * 4 if world > 1 else 0,
+    }
 
 
 if __name__ == "__main__":

@@ -1,0 +1,79 @@
+"""Data-parallel training step of the full tracker (BASELINE.json configs[3]): one process per GPU, the batch
+sharded across ranks, ONE gradient all-reduce per step (4 903 113 fp32 values = 19.6 MB, one DDP bucket) over
+RCCL/xGMI, overlapped with the backward pass by DistributedDataParallel.
+
+What it stands in for in the reference: tools/train_tracking.py:158-159 (the DistributedDataParallel wrap — dead
+code there because :63 forces dist_train=False, so the reference's `--launcher pytorch` runs N unsynchronised
+replicas) and tools/train_utils/train_utils.py:47-51 (model_func -> loss.backward() -> clip_grad_norm_(10) ->
+optimizer.step()), with the optimiser of tools/cfgs/kitti_models/ptt.yaml:129-133 (Adam, lr 1e-3, betas 0.5/0.999,
+eps 1e-6; ptt/optimization/__init__.py:12-14).
+
+The same class runs on `gloo` + CPU tensors in the tests (world_size 2) — there the HIP index ops are replaced by
+the tests' oracle, because the product ops refuse CPU tensors.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import synth
+
+GRAD_ELEMS = 4903113            # parameters of the shipped PTT model
+
+
+def synthetic_train_batch(seed, B, device, NS=1024, NT=512, K_s=200, K_t=100):
+    """A training batch shaped like KittiTrackingDataset.get_train_items' default-collated output
+    (ptt/datasets/kitti/kitti_dataset_tracking.py:60-107): search (B,NS,3), template (B,NT,3), cls_label (B,NS),
+    reg_label (B,4). K_s = 200 unique points: nuScenes-Car sparsity. Seeded numpy, so every box
+    and backend sees the same numbers."""
+    s, t = synth.frames(seed, B, NS, NT, K_s=K_s, K_t=K_t)
+    rs = np.random.RandomState(seed + 7919)
+    cls = (rs.random_sample((B, NS)) > 0.7).astype(np.float32)
+    reg = (rs.standard_normal((B, 4)) * 0.3).astype(np.float32)
+    to = lambda a: torch.from_numpy(a).to(device)
+    return {'search_points': to(s), 'template_points': to(t), 'batch_size': B, 'cls_label': to(cls), 'reg_label': to(reg)}
+
+
+class DataParallelTrainer(object):
+    """model (+ DDP when a process group with more than one rank is initialised) + Adam + gradient clipping.
+
+        trainer = DataParallelTrainer(build_network(...).to(dev).train(), dev)
+        loss = trainer.step(batch)          # forward, backward (all-reduce inside), clip, Adam
+    """
+
+    def __init__(self, model, device, lr=1e-3, betas=(0.5, 0.999), eps=1e-6, clip=10.0, bucket_cap_mb=25):
+        self.device = torch.device(device)
+        self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        self.tracker = model
+        if self.world > 1:
+            ids = [self.device.index] if self.device.type == 'cuda' else None
+            # bucket_cap_mb 25 > 19.6 MB: the whole gradient is one bucket, one all-reduce per step; for a message
+            # this small RCCL's direct algorithms over the 7 xGMI links beat a ring
+            self.model = torch.nn.parallel.DistributedDataParallel(model, device_ids=ids, bucket_cap_mb=bucket_cap_mb)
+        else:
+            self.model = model
+        self.optimizer = torch.optim.Adam(self.model.parameters(), lr=lr, betas=betas, eps=eps)
+        self.clip = clip
+
+    def forward_backward(self, batch):
+        """loss.mean() and its gradients (averaged over ranks by DDP); no optimiser step."""
+        ret, _, _ = self.model(dict(batch))
+        loss = ret['loss'].mean()
+        self.optimizer.zero_grad(set_to_none=True)
+        loss.backward()
+        return loss
+
+    def step(self, batch):
+        loss = self.forward_backward(batch)
+        if self.clip:
+            torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.clip)
+        self.optimizer.step()
+        self.tracker.update_global_step()
+        return loss
+
+    def ranks_seen(self):
+        """All-reduce of ones: how many ranks actually take part in the collective."""
+        if self.world == 1:
+            return 1
+        one = torch.ones(1, device=self.device)
+        dist.all_reduce(one)
+        return int(one.item())

@@ -23,6 +23,10 @@ Fixtures:
   G9 cosine_sim_aug.npz    CosineSimAug (N1): cosine map samples + cosine_feats
   G6 ptt_forward.npz       full PTT.forward (eval) through the reference's own heads (N2) + state_dict key/shape list
   G10 train_step.npz       one training forward + backward of the full tracker (N3): loss, gradient norms, 8 full gradients
+  G11 fps_reference.npz    the reference's OWN numpy farthest-point sampling (ptt/utils/common_utils.py:78-112,
+                           `fps_downsample`) on origin-free clouds incl. duplicated points and exact distance ties:
+                           the one reference-held statement of FPS (start point, min-update, np.argmax = lowest index
+                           among ties). It has no origin-ball skip (that is upstream CUDA behaviour), hence origin-free.
 """
 import os
 import sys
@@ -299,6 +303,44 @@ def main():
     kn = O.knn(c[:, :128], 16)
     save("G7_index_ops.npz", clouds=c, fps512=f, fps_full128=f_full, centres=centres, bq=bq, bq_far=bq_far, knn=kn)
     report.append("G7 index-op edge cases written (build-authored contract)")
+
+    # ---------------- G11: the reference's own numpy FPS ----------------
+    # fps_downsample draws its start point with np.random.randint and uses the removed alias np.long: the alias is
+    # restored HERE only, and the global numpy seed is chosen so that the draw is index 0 (upstream's fixed start).
+    import ptt.utils.common_utils as ref_cu
+    if not hasattr(np, "long"):
+        np.long = np.int64
+    rs11 = np.random.RandomState(1111)
+    clouds11 = []
+    for n, k_unique, kind in ((1024, 600, "car"), (512, 300, "car"), (2048, 600, "car"), (1024, 60, "ped"),
+                              (128, 128, "dense"), (256, 256, "grid")):
+        if kind == "grid":
+            pts = rs11.uniform(-1, 1, (n, 3)).round(1).astype(np.float32)           # exact distance ties
+        else:
+            sig = synth.PED_SIGMA if kind == "ped" else synth.CAR_SIGMA
+            pts = synth.cloud(rs11, n, k_unique, synth.SEARCH_BOX, sig, 1.0 if kind == "dense" else 0.7)
+        # origin-free: push every point outside the 1e-3 ball upstream skips (|p|^2 <= 1e-3), keeping duplicates equal
+        near = (pts * pts).sum(1) <= 2e-3
+        pts[near] += np.float32(0.25)
+        clouds11.append(np.ascontiguousarray(pts, np.float32))
+    g11 = {}
+    n_ok = 0
+    for ci, pts in enumerate(clouds11):
+        n = pts.shape[0]
+        for m in sorted({n // 2, 64, n}):
+            seed = next(sd for sd in range(100000) if np.random.RandomState(sd).randint(0, n, (1,))[0] == 0)
+            np.random.seed(seed)
+            ref_idx = np.asarray(ref_cu.fps_downsample(pts, m, id=True)).reshape(-1).astype(np.int32)
+            assert ref_idx[0] == 0
+            mine = O.fps(pts[None], m)[0]
+            assert np.array_equal(mine, ref_idx), ("oracle FPS != reference fps_downsample", ci, m,
+                                                   int(np.argmax(mine != ref_idx)))
+            g11["idx_%d_%d" % (ci, m)] = ref_idx
+            n_ok += 1
+        g11["cloud_%d" % ci] = pts
+    save("G11_fps_reference.npz", n_clouds=len(clouds11), **g11)
+    report.append("G11 reference numpy FPS (common_utils.fps_downsample, float32 input, start 0): oracle == reference "
+                  "on %d (cloud, npoint) cases incl. duplicates and exact ties" % n_ok)
 
     with open(os.path.join(HERE, "GOLDEN_REPORT.txt"), "w") as fh:
         fh.write("generated by tests/golden/make_golden.py against /root/reference (torch %s)\n" % torch.__version__)

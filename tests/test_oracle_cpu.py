@@ -97,6 +97,20 @@ def test_G7_index_op_edge_cases():
     assert (mag[g["fps512"][2][1:]] > 1e-3).all()
 
 
+def test_G11_oracle_fps_equals_the_references_own_numpy_fps():
+    """G11 = outputs of the reference's fps_downsample (ptt/utils/common_utils.py:78-112) on origin-free clouds with
+    duplicates and exact ties: the one reference-held pin of FPS semantics (start 0, min-update, lowest index wins)."""
+    g = np.load(os.path.join(GOLD, "G11_fps_reference.npz"))
+    n = 0
+    for ci in range(int(g["n_clouds"])):
+        pts = g["cloud_%d" % ci]
+        for key in [k for k in g.files if k.startswith("idx_%d_" % ci)]:
+            m = int(key.split("_")[2])
+            np.testing.assert_array_equal(O.fps(pts[None], m)[0], g[key], err_msg=key)
+            n += 1
+    assert n == 17
+
+
 def test_G8_knn_equals_reference_argsort():
     g = _g("G8_knn_argsort.npz")
     np.testing.assert_array_equal(O.knn(g["xyz"], 16), g["knn"])
