@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PTT_ABI_VERSION 4
+#define PTT_ABI_VERSION 5
 
 enum {
     PTT_OK = 0,
@@ -263,6 +263,65 @@ typedef struct ptt_attn_desc {
 } ptt_attn_desc;
 
 int ptt_pt_attn_pair_f32(const ptt_attn_desc* d, ptt_stream_t stream);
+
+/* ---------------------------------------------------------------------------------
+ * N4  device-side pre/post-processing of the sequential tracking loop
+ * (tools/eval_utils/eval_tracking_utils.py:140-229,266-274). A tracklet's clouds stay resident in HBM; per frame
+ * the host supplies the float64 box quantities of the previous result (a few dozen numbers) and receives one
+ * (x, y, z, theta, score) row.
+ *
+ * ptt_crop_compact_f32 — one job = crop_center_pc (ptt/datasets/kitti/kitti_tracking_utils.py:300-339):
+ *   keep points with lo1 < p < hi1 (crop_pc :281-298 in the cloud's frame; float32 point vs float64 bound, strict);
+ *   p <- float32(p + trans) per axis (PointCloud.translate :44-46); p <- float32(rot . p) (PointCloud.rotate :48-49,
+ *   float64 dot product); keep points with lo2 < p < hi2 (the second crop_pc, in the box frame). Survivors are
+ *   written to `out` as (count, 3) float32 rows IN THEIR ORIGINAL ORDER; *count receives their number (rows beyond
+ *   `capacity` are counted, not written). The job array lives in DEVICE memory (the caller uploads it).
+ * ------------------------------------------------------------------------------- */
+typedef struct ptt_crop_job {
+    const float* points;        /* (3, n_points) float32: row 0 = x, row 1 = y, row 2 = z (PointCloud.points) */
+    int64_t ld;                 /* elements between rows */
+    double lo1[3], hi1[3];
+    double trans[3];
+    double rot[9];              /* row-major 3x3 */
+    double lo2[3], hi2[3];
+    float* out;                 /* (capacity, 3) */
+    int32_t* count;
+    int32_t n_points;
+    int32_t capacity;
+} ptt_crop_job;
+
+int ptt_crop_compact_f32(const ptt_crop_job* jobs_device, int n_jobs, ptt_stream_t stream);
+
+/* ptt_regularize_f32 — one job = regularize_pc(pc, input_size, istrain=False) (kitti_tracking_utils.py:342-367) on the
+ * concatenation of up to PTT_MAX_SEGMENTS compacted crops (get_model :219-236 concatenates the crops of several
+ * frames): n = total rows; n <= 2 -> all-zero cloud; n == input_size -> copied through; otherwise row i of `out` is
+ * point idx[i], idx = np.random.randint(0, n, input_size) drawn right after set_manual_seed(1), i.e. the 32-bit
+ * outputs of MT19937(seed 1) masked to the smallest 2^k - 1 >= n - 1 and skipped while > n - 1. `draws` (DEVICE) holds
+ * the generator's first n_draws outputs: fill a host buffer with ptt_mt19937_fill(1, ...) and upload it once;
+ * n_draws >= 4 * input_size + 1024 always suffices (acceptance probability > 1/2). info (2 x int32, may be NULL)
+ * receives n and the number of generator outputs consumed (0 when nothing was drawn). */
+#define PTT_MAX_SEGMENTS 4
+typedef struct ptt_regularize_job {
+    const float* seg[PTT_MAX_SEGMENTS];          /* (seg_count, 3) float32 each */
+    const int32_t* seg_count[PTT_MAX_SEGMENTS];  /* device scalars written by ptt_crop_compact_f32 */
+    int32_t seg_capacity[PTT_MAX_SEGMENTS];
+    float* out;                                  /* (input_size, 3) */
+    int32_t* info;
+    int32_t n_seg;
+    int32_t input_size;
+} ptt_regularize_job;
+
+int ptt_regularize_f32(const ptt_regularize_job* jobs_device, int n_jobs, const uint32_t* draws, int n_draws,
+                       ptt_stream_t stream);
+
+/* First n outputs of MT19937 seeded with init_genrand(seed) (what np.random.seed(seed) followed by 32-bit draws
+ * yields) into a HOST buffer — the one entry point that takes a host pointer. */
+int ptt_mt19937_fill(uint32_t seed, uint32_t* out_host, int n);
+
+/* ptt_select_box_f32 — post_process (eval_tracking_utils.py:266-274): for every frame b the row of
+ * pred_box_data (B,P,5) with the largest score (column 4; first one among equals, as np.argmax) -> out (B,5);
+ * idx_out (B) receives its index, or NULL. */
+int ptt_select_box_f32(const float* pred_box_data, int B, int P, float* out, int32_t* idx_out, ptt_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -4,13 +4,13 @@ There is no fallback: if the shared library is missing or fails to load, every o
 """
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_uint32, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libptt_hip.so")
 
 PTT_SA_MAX_LAYERS = 4
-ABI_VERSION = 4            # PTT_ABI_VERSION of include/ptt_hip.h these structures mirror
+ABI_VERSION = 5            # PTT_ABI_VERSION of include/ptt_hip.h these structures mirror
 
 # every symbol include/ptt_hip.h declares (tests check the library exports all of them)
 EXPORTS = [
@@ -20,7 +20,25 @@ EXPORTS = [
     "ptt_knn_f32", "ptt_knn_rel_f32",
     "ptt_packed_weight_elems", "ptt_pack_weight_f32", "ptt_pack_weight_rot_f32", "ptt_linear_f32",
     "ptt_sa_fused_fwd_f32", "ptt_xcorr_fused_fwd_f32", "ptt_cosine_map_f32", "ptt_pt_attn_pair_f32",
+    "ptt_crop_compact_f32", "ptt_regularize_f32", "ptt_mt19937_fill", "ptt_select_box_f32",
 ]
+PTT_MAX_SEGMENTS = 4
+
+
+class CropJob(Structure):
+    """ptt_crop_job (include/ptt_hip.h): one crop_center_pc; arrays of these are uploaded to the device."""
+    _fields_ = [("points", c_void_p), ("ld", c_int64),
+                ("lo1", c_double * 3), ("hi1", c_double * 3), ("trans", c_double * 3), ("rot", c_double * 9),
+                ("lo2", c_double * 3), ("hi2", c_double * 3),
+                ("out", c_void_p), ("count", c_void_p), ("n_points", c_int32), ("capacity", c_int32)]
+
+
+class RegularizeJob(Structure):
+    """ptt_regularize_job: regularize_pc over the concatenation of up to 4 compacted crops."""
+    _fields_ = [("seg", c_void_p * PTT_MAX_SEGMENTS), ("seg_count", c_void_p * PTT_MAX_SEGMENTS),
+                ("seg_capacity", c_int32 * PTT_MAX_SEGMENTS), ("out", c_void_p), ("info", c_void_p),
+                ("n_seg", c_int32), ("input_size", c_int32)]
+
 
 
 class SaLayer(Structure):
@@ -83,6 +101,10 @@ def _declare(lib):
         "ptt_xcorr_fused_fwd_f32": [POINTER(XcorrDesc), vp],
         "ptt_cosine_map_f32": [vp, c_int64, c_int64, c_int64, vp, c_int64, c_int64, c_int64, i, i, i, i, f, vp, vp],
         "ptt_pt_attn_pair_f32": [POINTER(AttnDesc), vp],
+        "ptt_crop_compact_f32": [vp, i, vp],
+        "ptt_regularize_f32": [vp, i, vp, i, vp],
+        "ptt_mt19937_fill": [c_uint32, vp, i],
+        "ptt_select_box_f32": [vp, i, i, vp, vp, vp],
     }
     for name, args in sigs.items():
         fn = getattr(lib, name)

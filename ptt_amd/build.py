@@ -13,9 +13,9 @@ CSRC = os.path.join(ROOT, "ptt_amd", "csrc")
 LIBDIR = os.path.join(ROOT, "ptt_amd", "lib")
 LIB = os.path.join(LIBDIR, "libptt_hip.so")
 
-HIP_SOURCES = ["errors.hip", "point_ops.hip", "mfma_ops.hip"]
+HIP_SOURCES = ["errors.hip", "point_ops.hip", "mfma_ops.hip", "track_ops.hip"]
 # FPS / ball query / kNN index parity needs un-fused fp32 arithmetic (see point_ops.hip header)
-EXTRA_FLAGS = {"point_ops.hip": ["-ffp-contract=off"], "mfma_ops.hip": os.environ.get("PTT_MFMA_FLAGS", "").split()}
+EXTRA_FLAGS = {"point_ops.hip": ["-ffp-contract=off"], "track_ops.hip": ["-ffp-contract=off"], "mfma_ops.hip": os.environ.get("PTT_MFMA_FLAGS", "").split()}
 # build-time only: flags for every source, e.g. PTT_HIP_FLAGS="-DPTT_DEV" for a developer build that reads the PTT_*
 # A/B switches from the environment and keeps the kernels' cycle-stamp hooks (a release build has neither)
 COMMON_FLAGS = os.environ.get("PTT_HIP_FLAGS", "").split()
