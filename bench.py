@@ -397,7 +397,35 @@ def latency_b1(torch, dev, model, tracker, search, template, GraphedHotPath, Tra
         ms = per_frame(g)
         res["full_tracker_ms_per_frame"] = round(ms, 4)
         res["full_tracker_frames_per_s"] = round(1e3 / ms, 1)
+        del g
+        res["tracklet_loop"] = tracklet_loop(torch, dev, tracker)
     return res
+
+
+def tracklet_loop(torch, dev, tracker, frames_b1=120, frames_b48=30):
+    """The reference's actual "tracklet frames/sec" mode (tools/eval_utils/eval_tracking_utils.py:140-152): crop around
+    the previous result box, resample, infer, move the box — frame i needs frame i-1. ptt_amd.tracklet_runner keeps the
+    clouds on the device (crop + resample kernels, model graph, one 5-float read-back per frame); shipped sizes
+    1024 + 512 points. One tracklet alone (B = 1), and 48 tracklets advanced in lockstep."""
+    from ptt_amd import synth
+    from ptt_amd.tracklet_runner import TrackletRunner
+    out = {"search_points": 1024, "template_points": 512,
+           "per_frame": "host: float64 crop bounds + job upload; device: crop/compact, resample, tracker graph, box "
+                        "selection; host: 5-float read-back, float64 box update"}
+    for B, T, key in ((1, frames_b1, "b1"), (48, frames_b48, "b48")):
+        tracklets = [synth.tracklet(9000 + k, T) for k in range(B)]
+        runner = TrackletRunner(tracker, dev, batch=B)
+        runner.run([(c[:4], b[:4]) for c, b in tracklets])          # warm-up: graph capture, allocator
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        runner.run(tracklets)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        n = B * (T - 1)                                             # frame 0 only initialises (:96-100)
+        out[key] = {"tracklets": B, "frames_tracked": n, "ms_per_step": round(dt / (T - 1) * 1e3, 4),
+                    "frames_per_s": round(n / dt, 1)}
+        del runner
+    return out
 
 
 def run_train(args, torch, dev, dist, world, rank, ranks_seen, sync_all, B, NS, NT, W):

@@ -1,0 +1,250 @@
+"""Mirror of the part of ptt/datasets/kitti/kitti_tracking_utils.py the sequential tracking loop calls
+(tools/eval_utils/eval_tracking_utils.py:8-13 imports PointCloud, get_box_by_offset, and uses crop_center_pc,
+regularize_pc, get_model through `kitti_utils`): same names and argument meaning.
+
+What differs is WHERE the work happens. `PointCloud.points` is a (3, N) float32 tensor resident on the HIP device;
+`crop_center_pc` / `get_model` / `regularize_pc` run the device kernels of ptt_amd/csrc/track_ops.hip
+(ptt_crop_compact_f32, ptt_regularize_f32) and return device-resident results. Only box arithmetic — a few dozen
+float64 operations per frame — stays on the host (box_math.py). These functions are the drop-in, one-call-at-a-time
+form (each call that must know a point COUNT synchronises, as the reference's numpy code implicitly does); the
+tracking loop itself should use ptt_amd.tracklet_runner.TrackletRunner, which fuses a whole frame into two launches
+plus the model graph and reads back one row per tracklet.
+
+There is no CPU fallback: a host array is moved to the device, never processed on the host.
+"""
+import copy
+
+import numpy as np
+import torch
+
+from ... import ops
+from . import box_math as bm
+
+
+class Quaternion(object):
+    """The slice of pyquaternion.Quaternion the reference uses: Quaternion(matrix=R), Quaternion(axis=a, angle=t)
+    (or radians= / degrees=), Quaternion(w, x, y, z), q1 * q2, .inverse, .rotation_matrix, .elements, .axis, .radians,
+    .degrees. Unit-quaternion arithmetic in float64 (box_math.py)."""
+
+    def __init__(self, *args, **kw):
+        if 'matrix' in kw:
+            self.q = bm.q_from_matrix(np.asarray(kw['matrix'], np.float64))
+        elif 'axis' in kw:
+            ang = kw.get('angle', kw.get('radians', None))
+            if ang is None:
+                ang = np.deg2rad(kw.get('degrees', 0.0))
+            self.q = bm.q_from_axis_angle(np.asarray(kw['axis'], np.float64), np.float64(ang))
+        elif 'array' in kw:
+            self.q = np.array(kw['array'], np.float64)
+        elif len(args) == 4:
+            self.q = np.array(args, np.float64)
+        elif len(args) == 1:
+            a = args[0]
+            self.q = np.array(a.q if isinstance(a, Quaternion) else a, np.float64)
+        elif not args:
+            self.q = np.array([1.0, 0.0, 0.0, 0.0])
+        else:
+            raise ValueError("unsupported Quaternion constructor arguments")
+
+    def __mul__(self, other):
+        return Quaternion(array=bm.q_mul(self.q, other.q))
+
+    @property
+    def inverse(self):
+        return Quaternion(array=bm.q_inverse(self.q))
+
+    @property
+    def rotation_matrix(self):
+        return bm.q_rotation_matrix(self.q)
+
+    @property
+    def elements(self):
+        return self.q
+
+    @property
+    def radians(self):
+        q = bm.q_normalised(self.q)
+        n = np.linalg.norm(q[1:])
+        return float(((2.0 * np.arctan2(n, q[0])) + np.pi) % (2 * np.pi) - np.pi)
+
+    @property
+    def degrees(self):
+        return float(np.rad2deg(self.radians))
+
+    @property
+    def axis(self):
+        v = bm.q_normalised(self.q)[1:]
+        n = np.linalg.norm(v)
+        return v / n if n > 1e-14 else np.array([0.0, 0.0, 0.0])
+
+    def __repr__(self):
+        return "Quaternion(%r, %r, %r, %r)" % tuple(self.q.tolist())
+
+
+class Box(object):
+    """Box (:68-160): center (3), wlh (3), orientation; the attributes the tracking loop reads and writes."""
+
+    def __init__(self, center, size, orientation, label=np.nan, score=np.nan, velocity=(np.nan, np.nan, np.nan), name=None):
+        assert not np.any(np.isnan(center)) and not np.any(np.isnan(size))
+        assert len(center) == 3 and len(size) == 3
+        self.center = np.array(center, np.float64)
+        self.wlh = np.array(size, np.float64)
+        self.orientation = orientation
+        self.label = int(label) if not np.isnan(label) else label
+        self.score = float(score) if not np.isnan(score) else score
+        self.velocity = np.array(velocity)
+        self.name = name
+
+    @property
+    def rotation_matrix(self):
+        return self.orientation.rotation_matrix
+
+    def translate(self, x):
+        self.center += x
+
+    def rotate(self, quaternion):
+        self.center = np.dot(quaternion.rotation_matrix, self.center)
+        self.orientation = quaternion * self.orientation
+        self.velocity = np.dot(quaternion.rotation_matrix, self.velocity)
+
+    def corners(self, wlh_factor=1.0):
+        return bm.corners(self.center, self.wlh * wlh_factor, self.rotation_matrix)
+
+    def bottom_corners(self):
+        return self.corners()[:, [2, 3, 7, 6]]
+
+    def __repr__(self):
+        return "Box(center=%s, wlh=%s, q=%s)" % (self.center.tolist(), self.wlh.tolist(), self.orientation.q.tolist())
+
+
+def _device():
+    if not torch.cuda.is_available():
+        raise RuntimeError("ptt.datasets.kitti.kitti_tracking_utils runs on the HIP device; none is visible "
+                           "(there is no CPU fallback)")
+    return torch.device('cuda', torch.cuda.current_device())
+
+
+class PointCloud(object):
+    """(3, N) float32 points resident on the device (PointCloud, :9-65)."""
+
+    def __init__(self, points):
+        if isinstance(points, np.ndarray):
+            points = torch.from_numpy(np.ascontiguousarray(points[0:3], dtype=np.float32)).to(_device())
+        elif not points.is_cuda:
+            points = points.to(_device())
+        if points.shape[0] > 3:
+            points = points[0:3]
+        self.points = points.to(torch.float32).contiguous()
+
+    def nbr_points(self):
+        return int(self.points.shape[1])
+
+
+def get_box_by_offset(box, offset, use_z=False):
+    """:186-216 for one box; `offset` (x, y, z, theta in degrees) is updated in place when the reference would redraw
+    it (:205-208, from numpy's global generator — the same generator is used here)."""
+    c, q, used = bm.get_box_by_offset(box.center[None], box.wlh[None], box.orientation.q[None],
+                                      np.asarray(offset, np.float64)[None], use_z)
+    try:
+        offset[0], offset[1] = used[0, 0], used[0, 1]
+    except TypeError:
+        pass
+    new_box = copy.deepcopy(box)
+    new_box.center = c[0]
+    new_box.orientation = Quaternion(array=q[0])
+    return new_box
+
+
+def _crop_jobs(pcs, params, outs, counts):
+    """One ptt_crop_job per (cloud, bounds): `params` = box_math.crop_bounds over the same leading axis."""
+    n = len(pcs)
+    jobs = np.zeros(n, ops.CROP_JOB)
+    for i, pc in enumerate(pcs):
+        jobs['points'][i] = pc.points.data_ptr()
+        jobs['ld'][i] = pc.points.stride(0)
+        jobs['n_points'][i] = pc.points.shape[1]
+        jobs['out'][i] = outs[i].data_ptr()
+        jobs['capacity'][i] = outs[i].shape[0]
+        jobs['count'][i] = counts[i:i + 1].data_ptr()
+    for k in ('lo1', 'hi1', 'trans', 'lo2', 'hi2'):
+        jobs[k] = params[k]
+    jobs['rot'] = params['rot'].reshape(n, 9)
+    return jobs
+
+
+def _crop_on_device(pcs, boxes, offset, scale, extra2):
+    """crop_center_pc of every (pc, box) pair in ONE launch -> (list of (cap,3) device buffers, counts int32 (n,))."""
+    dev = pcs[0].points.device
+    center = np.stack([b.center for b in boxes])
+    wlh = np.stack([b.wlh for b in boxes])
+    quat = np.stack([b.orientation.q for b in boxes])
+    params = bm.crop_bounds(center, wlh, quat, offset, scale, extra2)
+    outs = [torch.empty((max(1, pc.nbr_points()), 3), dtype=torch.float32, device=dev) for pc in pcs]
+    counts = torch.zeros(len(pcs), dtype=torch.int32, device=dev)
+    jobs = ops.upload_jobs(_crop_jobs(pcs, params, outs, counts))
+    ops.crop_compact(jobs, len(pcs))
+    return outs, counts
+
+
+def crop_center_pc(pc, sample_box, gt_box=None, sample_offsets=None, offset=0.0, scale=1.0, normalize=False,
+                   visual_handle=None, refine_box=True):
+    """:300-339. Returns the cropped cloud in the sample box's frame (device-resident). With `gt_box` the reference
+    also returns per-point labels and a regression target; the tracking loop stores but never reads the labels
+    (eval_tracking_utils.py:128-138,175-182), so they are returned as None here; label_reg follows :325-329."""
+    extra2 = gt_box.wlh[1] * 0.6 if gt_box is not None else 0.0
+    outs, counts = _crop_on_device([pc], [sample_box], offset, scale, extra2)
+    n = int(counts.cpu()[0])
+    new_pc = PointCloud.__new__(PointCloud)
+    new_pc.points = outs[0][:n].t().contiguous()
+    if normalize:
+        wlh = sample_box.wlh
+        new_pc.points = new_pc.points / torch.tensor([[wlh[1]], [wlh[0]], [wlh[2]]], dtype=torch.float32,
+                                                     device=new_pc.points.device)
+    if gt_box is None:
+        return new_pc
+    label_reg = None
+    if sample_offsets is not None:
+        rot = np.transpose(sample_box.rotation_matrix)
+        g = np.dot(rot, gt_box.center - sample_box.center)
+        label_reg = np.array([g[0], g[1], g[2], -sample_offsets[-1]])
+    return new_pc, None, label_reg
+
+
+def get_model(PCs, boxes, offset=0., scale=1.0, normalize=False, visual_handle=None):
+    """:219-236: the crops of several (cloud, box) pairs concatenated in order (device-resident)."""
+    if len(PCs) == 0:
+        return PointCloud(torch.ones((3, 0), dtype=torch.float32, device=_device()))
+    outs, counts = _crop_on_device(list(PCs), list(boxes), offset, scale, 0.0)
+    ns = counts.cpu().tolist()
+    parts = [o[:n] for o, n in zip(outs, ns) if n > 0]
+    pts = torch.cat(parts, 0) if parts else torch.ones((0, 3), dtype=torch.float32, device=outs[0].device)
+    new_pc = PointCloud.__new__(PointCloud)
+    new_pc.points = pts.t().contiguous()
+    return new_pc
+
+
+def regularize_pc(pc, input_size, ratio=1, label=None, reg=None, istrain=True):
+    """:342-367 with istrain=False semantics (the tracking loop's): a fixed-size (input_size, 3) float32 cloud,
+    resampled with replacement by the index stream np.random.randint yields right after set_manual_seed(1). Returns a
+    device tensor. (istrain=True draws from numpy's running global state, a data-loader concern outside this mirror.)"""
+    if istrain or label is not None:
+        raise NotImplementedError("regularize_pc: only the evaluation form (istrain=False, no labels) is mirrored")
+    if input_size <= 0:
+        return pc.points.t().contiguous()
+    size = int(input_size) // int(ratio)
+    dev = pc.points.device
+    rows = pc.points.t().contiguous()                          # (n,3) rows, as ptt_crop_compact_f32 writes them
+    n = rows.shape[0]
+    if n == 0:
+        rows = torch.zeros((1, 3), dtype=torch.float32, device=dev)
+    count = torch.tensor([n], dtype=torch.int32, device=dev)
+    out = torch.empty((size, 3), dtype=torch.float32, device=dev)
+    jobs = np.zeros(1, ops.REGULARIZE_JOB)
+    jobs['seg'][0, 0] = rows.data_ptr()
+    jobs['seg_count'][0, 0] = count.data_ptr()
+    jobs['seg_capacity'][0, 0] = max(n, 1)
+    jobs['out'][0] = out.data_ptr()
+    jobs['n_seg'][0] = 1
+    jobs['input_size'][0] = size
+    ops.regularize(ops.upload_jobs(jobs), 1, ops.mt19937_draws(dev, max(8192, 4 * size + 1024)))
+    return out

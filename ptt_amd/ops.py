@@ -465,3 +465,67 @@ def pt_attn_pair(xyz, knn_idx, qkv, wd1p, wd2p, bd2, wg1p, bg1, wg2p, bg2, d_mod
     with torch.cuda.device(xyz.device), _timed('ptt_pt_attn_pair_f32'):
         _lib.check(_lib.lib().ptt_pt_attn_pair_f32(ctypes.byref(d), _stream()), "ptt_pt_attn_pair_f32")
     return res, attn
+
+
+# --------------------------------------------------------------------------- N4: tracking-loop pre/post-processing
+import numpy as np      # noqa: E402  (host-side job tables only)
+
+CROP_JOB = np.dtype([('points', '<u8'), ('ld', '<i8'), ('lo1', '<f8', 3), ('hi1', '<f8', 3), ('trans', '<f8', 3),
+                     ('rot', '<f8', 9), ('lo2', '<f8', 3), ('hi2', '<f8', 3), ('out', '<u8'), ('count', '<u8'),
+                     ('n_points', '<i4'), ('capacity', '<i4')])                    # = ptt_crop_job, 232 bytes
+REGULARIZE_JOB = np.dtype([('seg', '<u8', 4), ('seg_count', '<u8', 4), ('seg_capacity', '<i4', 4), ('out', '<u8'),
+                           ('info', '<u8'), ('n_seg', '<i4'), ('input_size', '<i4')])   # = ptt_regularize_job, 104 bytes
+assert CROP_JOB.itemsize == ctypes.sizeof(_lib.CropJob) and REGULARIZE_JOB.itemsize == ctypes.sizeof(_lib.RegularizeJob)
+
+_mt_tables = {}
+
+
+def mt19937_draws(device, n=8192, seed=1):
+    """The first n 32-bit outputs of MT19937(seed) as a device uint32 buffer (viewed int32): the index stream of
+    regularize_pc's np.random.randint after set_manual_seed(1) (kitti_tracking_utils.py:349-353). Built once per
+    (device, n, seed) by ptt_mt19937_fill and uploaded."""
+    key = (str(device), int(n), int(seed))
+    if key not in _mt_tables:
+        host = np.empty(int(n), np.uint32)
+        _lib.check(_lib.lib().ptt_mt19937_fill(int(seed), host.ctypes.data, int(n)), "ptt_mt19937_fill")
+        _mt_tables[key] = torch.from_numpy(host.view(np.int32)).to(device)
+        publish_params(torch.device(device))
+    return _mt_tables[key]
+
+
+def upload_jobs(jobs, out=None):
+    """numpy structured job table -> device bytes (non-blocking copy from pinned memory on the current stream).
+    `out`: an existing device uint8 buffer of the same size to refill (fixed address: hipGraph replays read it)."""
+    host = torch.from_numpy(np.ascontiguousarray(jobs).view(np.uint8).reshape(-1)).pin_memory()
+    if out is None:
+        return host.to('cuda', non_blocking=True)
+    out.copy_(host, non_blocking=True)
+    return out
+
+
+def crop_compact(jobs_dev, n_jobs):
+    """ptt_crop_compact_f32 over a device-resident table of `n_jobs` ptt_crop_job records (uint8 tensor)."""
+    with torch.cuda.device(jobs_dev.device), _timed('ptt_crop_compact_f32'):
+        _lib.check(_lib.lib().ptt_crop_compact_f32(_ptr(jobs_dev), int(n_jobs), _stream()), "ptt_crop_compact_f32")
+
+
+def regularize(jobs_dev, n_jobs, draws):
+    """ptt_regularize_f32 over a device-resident table of ptt_regularize_job records."""
+    with torch.cuda.device(jobs_dev.device), _timed('ptt_regularize_f32'):
+        _lib.check(_lib.lib().ptt_regularize_f32(_ptr(jobs_dev), int(n_jobs), _ptr(draws), draws.numel(), _stream()),
+                   "ptt_regularize_f32")
+
+
+def select_box(pred_box_data, out=None, idx_out=None):
+    """(B,P,5) f32 -> (B,5): per frame the proposal row with the highest score (first among equals), replacing the
+    `.cpu().numpy()` of the whole tensor + np.argmax of eval_tracking_utils.py:267-269."""
+    _chk(pred_box_data, "pred_box_data", torch.float32, 3)
+    B, P, five = pred_box_data.shape
+    if five != 5:
+        raise RuntimeError("pred_box_data must be (B,P,5)")
+    if out is None:
+        out = torch.empty((B, 5), dtype=torch.float32, device=pred_box_data.device)
+    with torch.cuda.device(pred_box_data.device):
+        _lib.check(_lib.lib().ptt_select_box_f32(_ptr(pred_box_data), B, P, _ptr(out), _ptr(idx_out), _stream()),
+                   "ptt_select_box_f32")
+    return out

@@ -52,3 +52,27 @@ def frames(seed, B, NS, NT, K_s=600, K_t=300, kind="car", zero_clouds=0):
         s[B - 1 - b] = 0.0
         t[B - 1 - b] = 0.0
     return s, t
+
+
+def tracklet(seed, n_frames, n_obj=(100, 700), n_bg=(1500, 4000)):
+    """A synthetic tracklet for the sequential tracking loop (tools/eval_utils/eval_tracking_utils.py:77-152): per frame
+    a (3, N_i) float32 cloud — a box-shaped object cluster moving along a smooth path inside uniform background clutter
+    within +-12 m (the reference pre-crops every scan to a neighbourhood of the ground-truth box,
+    kitti_dataset_tracking.py:304-310) — and its ground-truth box as (center (3), wlh (3), quaternion (w,x,y,z)).
+    Returns (clouds, boxes)."""
+    rs = np.random.RandomState(seed)
+    wlh = np.array([1.6 + 0.2 * rs.rand(), 3.9 + 0.5 * rs.rand(), 1.5])
+    centers = np.cumsum(np.c_[rs.uniform(0.3, 0.9, n_frames), rs.uniform(-0.2, 0.2, n_frames),
+                              rs.uniform(-0.03, 0.03, n_frames)], 0) + np.array([8.0, 2.0, -0.7])
+    yaws = rs.uniform(-1, 1) + np.cumsum(rs.uniform(-0.05, 0.05, n_frames))
+    clouds, boxes = [], []
+    for i in range(n_frames):
+        c, s_ = np.cos(yaws[i]), np.sin(yaws[i])
+        Rz = np.array([[c, -s_, 0], [s_, c, 0], [0, 0, 1]])
+        no, nb = int(rs.randint(*n_obj)), int(rs.randint(*n_bg))
+        obj = (rs.uniform(-0.5, 0.5, (no, 3)) * np.array([wlh[1], wlh[0], wlh[2]])) @ Rz.T + centers[i]
+        bg = rs.uniform(-1, 1, (nb, 3)) * np.array([12.0, 12.0, 2.0]) + centers[i]
+        pts = np.concatenate([obj, bg], 0)[rs.permutation(no + nb)].astype(np.float32)
+        clouds.append(np.ascontiguousarray(pts.T))
+        boxes.append((centers[i].copy(), wlh.copy(), np.array([np.cos(yaws[i] / 2), 0.0, 0.0, np.sin(yaws[i] / 2)])))
+    return clouds, boxes

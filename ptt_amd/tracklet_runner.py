@@ -1,0 +1,224 @@
+"""N4 — the reference's sequential tracking loop (TrackingEvaluator.test_batch / test_frame,
+tools/eval_utils/eval_tracking_utils.py:77-152) with everything but a few float64 box updates on the device.
+
+"Tracklet frames/sec" in the reference is this loop at B = 1: for frame i, crop the cloud around the PREVIOUS result
+box and resample it to 1024 points (prepare_search :155-184), build the template from the first and the previous
+frame's crops resampled to 512 (prepare_template :186-229), run the model (:231-264), take the best proposal and move
+the box (post_process :266-274). Frame i needs frame i-1's box, so a tracklet is strictly sequential; different
+tracklets are independent.
+
+TrackletRunner keeps the clouds of up to `batch` tracklets resident in HBM and advances them in LOCKSTEP, one frame of
+every tracklet per step:
+
+    host    crop bounds of B boxes (float64, vectorised numpy)            -> two small job tables, one pinned upload
+    device  ptt_crop_compact_f32   2B jobs: search crop, previous-frame template crop     (1 launch)
+            ptt_regularize_f32     2B jobs: resample to 1024 / 512 straight into the model's input buffers (1 launch)
+            the tracker forward for the B frames                                           (hipGraph replay)
+            ptt_select_box_f32     best proposal of each frame                             (inside the graph)
+    host    one (B,5) + (B,2,2) read-back, float64 box update of B boxes (get_box_by_offset)
+
+At batch = 1 this is the reference's own mode (one tracklet, one frame at a time) with the per-frame PCIe traffic cut
+to ~0.5 KB; at batch = 48 it is the throughput mode for evaluating a dataset's tracklets.
+
+REF_BOX = previous_result and SHAPE_AGGREGATION = firstandprevious (the shipped tools/cfgs/*/ptt.yaml:149-150) are what
+is implemented.
+"""
+import numpy as np
+import torch
+
+from . import ops
+from .datasets.kitti import box_math as bm
+from .hot_path import GraphedHotPath, TrackerThroughput
+
+
+class _BoxedForward(object):
+    """tracker forward + best-proposal selection as ONE capturable callable: (search, template) -> (B,5) rows."""
+
+    def __init__(self, tracker):
+        self.fwd = TrackerThroughput(tracker)
+
+    def __call__(self, search, template):
+        out = self.fwd(search, template)
+        return ops.select_box(out['pred_box_data'].contiguous())
+
+
+class TrackletRunner(object):
+    def __init__(self, tracker, device, batch=1, search_size=1024, template_size=512, search_offset=0.0,
+                 search_scale=1.25, model_offset=0.0, model_scale=1.25, use_z=True, use_graph=True):
+        """`tracker`: ptt_amd.models.trackers.PTT in eval mode on `device`. Sizes / offsets / scales are
+        DATA_CONFIG.{SEARCH,TEMPLATE}_INPUT_SIZE, SEARCH_BB_*, MODEL_BB_* and USE_Z_AXIS
+        (tools/cfgs/kitti_models/ptt.yaml:8-17)."""
+        self.tracker = tracker
+        self.device = torch.device(device)
+        self.B = int(batch)
+        self.S, self.T = int(search_size), int(template_size)
+        self.search_offset, self.search_scale = float(search_offset), float(search_scale)
+        self.model_offset, self.model_scale = float(model_offset), float(model_scale)
+        self.use_z = bool(use_z)
+        self.use_graph = use_graph
+        dev, B = self.device, self.B
+        self.search = torch.zeros((B, self.S, 3), dtype=torch.float32, device=dev)
+        self.template = torch.zeros((B, self.T, 3), dtype=torch.float32, device=dev)
+        self.counts = torch.zeros((B, 3), dtype=torch.int32, device=dev)          # search, first-frame, previous-frame
+        self.info = torch.zeros((B, 2, 2), dtype=torch.int32, device=dev)         # (n, draws used) of search / template
+        self.crop_jobs_dev = torch.zeros(2 * B * ops.CROP_JOB.itemsize, dtype=torch.uint8, device=dev)
+        self.reg_jobs_dev = torch.zeros(2 * B * ops.REGULARIZE_JOB.itemsize, dtype=torch.uint8, device=dev)
+        self.draws = ops.mt19937_draws(dev, max(8192, 4 * max(self.S, self.T) + 1024))
+        self.result_host = torch.empty((B, 5), dtype=torch.float32).pin_memory()
+        self.info_host = torch.empty((B, 2, 2), dtype=torch.int32).pin_memory()
+        self._model = _BoxedForward(tracker)
+        self._graph = None
+        self._rng = [np.random.RandomState(1) for _ in range(B)]    # mirrors numpy's global generator per tracklet
+
+    # ------------------------------------------------------------------ device buffers of one group of tracklets
+    def _load(self, tracklets):
+        """tracklets: list (<= batch) of (clouds, boxes): clouds = list of (3,N_i) float32 arrays / tensors, boxes =
+        list of (center (3), wlh (3), quat (4)) ground-truth boxes (frame 0 initialises; wlh[1] enters the search crop,
+        eval_tracking_utils.py:165-169)."""
+        dev, B = self.device, self.B
+        self._ensure_graph()
+        T = max(len(c) for c, _ in tracklets)
+        self.clouds = []
+        self.ptr = np.zeros((T, B), np.uint64)
+        self.ld = np.zeros((T, B), np.int64)
+        self.npts = np.zeros((T, B), np.int32)
+        cap = 1
+        for b, (clouds, _) in enumerate(tracklets):
+            row = []
+            for i, c in enumerate(clouds):
+                t = c if isinstance(c, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(c, np.float32))
+                t = t.to(dev, torch.float32).contiguous()
+                row.append(t)
+                self.ptr[i, b], self.ld[i, b], self.npts[i, b] = t.data_ptr(), t.stride(0), t.shape[1]
+                cap = max(cap, t.shape[1])
+            self.clouds.append(row)
+        self.cap = cap
+        self.crop_out = torch.zeros((B, 3, cap, 3), dtype=torch.float32, device=dev)   # slot 0 search, 1 first, 2 previous
+        esz = self.crop_out.element_size()
+        self.out_ptr = (self.crop_out.data_ptr() + (np.arange(B)[:, None] * 3 + np.arange(3)[None]) * (cap * 3 * esz)).astype(np.uint64)
+        self.cnt_ptr = (self.counts.data_ptr() + (np.arange(B)[:, None] * 3 + np.arange(3)[None]) * 4).astype(np.uint64)
+        self.ptr[self.npts == 0] = self.crop_out.data_ptr()        # empty jobs still carry a valid address
+        # the resampling jobs never change within a group: fixed segment / output pointers
+        rj = np.zeros(2 * B, ops.REGULARIZE_JOB)
+        s, t = rj[0::2], rj[1::2]
+        s['seg'][:, 0], s['seg_count'][:, 0], s['seg_capacity'][:, 0] = self.out_ptr[:, 0], self.cnt_ptr[:, 0], cap
+        s['n_seg'], s['input_size'] = 1, self.S
+        s['out'] = self.search.data_ptr() + np.arange(B) * (self.S * 3 * 4)
+        s['info'] = self.info.data_ptr() + np.arange(B) * 16
+        for k, slot in enumerate((1, 2)):                          # get_model([PC_0, PC_{i-1}], ...) order (:189-194)
+            t['seg'][:, k], t['seg_count'][:, k], t['seg_capacity'][:, k] = self.out_ptr[:, slot], self.cnt_ptr[:, slot], cap
+        t['n_seg'], t['input_size'] = 2, self.T
+        t['out'] = self.template.data_ptr() + np.arange(B) * (self.T * 3 * 4)
+        t['info'] = self.info.data_ptr() + np.arange(B) * 16 + 8
+        ops.upload_jobs(rj, self.reg_jobs_dev)
+
+    def _crop_jobs(self, frame_a, params_a, slot_a, frame_b, params_b, slot_b):
+        """The 2B-entry crop table of one step: job 2b = cloud `frame_a` of tracklet b cropped with params_a into slot_a,
+        job 2b+1 likewise (frame None or a finished tracklet: an empty job -> count 0 -> an all-zero resampled cloud)."""
+        jobs = np.zeros(2 * self.B, ops.CROP_JOB)
+        for half, frame, params, slot in ((jobs[0::2], frame_a, params_a, slot_a), (jobs[1::2], frame_b, params_b, slot_b)):
+            half['out'], half['count'], half['capacity'] = self.out_ptr[:, slot], self.cnt_ptr[:, slot], self.cap
+            if frame is None or frame >= self.ptr.shape[0]:
+                half['points'] = self.crop_out.data_ptr()
+                continue
+            half['points'], half['ld'], half['n_points'] = self.ptr[frame], self.ld[frame], self.npts[frame]
+            for key in ('lo1', 'hi1', 'trans', 'lo2', 'hi2'):
+                half[key] = params[key]
+            half['rot'] = params['rot'].reshape(self.B, 9)
+        return jobs
+
+    # ------------------------------------------------------------------ one group in lockstep
+    def _run_group(self, tracklets):
+        B = self.B
+        n = len(tracklets)
+        self._load(tracklets)
+        lengths = np.array([len(c) for c, _ in tracklets] + [0] * (B - n))
+        center = np.zeros((B, 3)); wlh = np.ones((B, 3)); quat = np.tile(np.array([1.0, 0, 0, 0]), (B, 1))
+        gt_wlh1 = np.zeros((int(lengths.max()), B))
+        for b, (_, boxes) in enumerate(tracklets):
+            center[b], wlh[b], quat[b] = boxes[0][0], boxes[0][1], boxes[0][2]
+            for i, bx in enumerate(boxes):
+                gt_wlh1[i, b] = bx[1][1]
+        results = [[(center[b].copy(), wlh[b].copy(), quat[b].copy())] for b in range(n)]
+
+        # frame 0: the first-frame template crop (get_model's first segment) is fixed for the whole tracklet
+        p0 = bm.crop_bounds(center, wlh, quat, self.model_offset, self.model_scale, 0.0)
+        ops.upload_jobs(self._crop_jobs(0, p0, 1, None, p0, 2), self.crop_jobs_dev)
+        ops.crop_compact(self.crop_jobs_dev, 2 * B)
+
+        for i in range(1, int(lengths.max())):
+            active = np.nonzero(i < lengths)[0]
+            # both crops of frame i are taken around the previous RESULT box (prepare_search :156-157, prepare_template
+            # :189-194 with results_BBs[frame_id - 1]); a finished tracklet's later frames have n_points 0
+            ps = bm.crop_bounds(center, wlh, quat, self.search_offset, self.search_scale, gt_wlh1[i] * 0.6)
+            pt = bm.crop_bounds(center, wlh, quat, self.model_offset, self.model_scale, 0.0)
+            jobs = self._crop_jobs(i, ps, 0, i - 1, pt, 2)
+            jobs['n_points'][1::2][lengths <= i] = 0
+            ops.upload_jobs(jobs, self.crop_jobs_dev)
+            ops.crop_compact(self.crop_jobs_dev, 2 * B)
+            ops.regularize(self.reg_jobs_dev, 2 * B, self.draws)
+            rows = self._forward()
+            self.result_host.copy_(rows, non_blocking=True)
+            self.info_host.copy_(self.info, non_blocking=True)
+            torch.cuda.current_stream(self.device).synchronize()
+            est = self.result_host.numpy()                        # (B,5) float32: x, y, z, theta (degrees), score
+            info = self.info_host.numpy()
+            center, quat = self._advance(center, wlh, quat, est, info, active)
+            for b in active:
+                results[b].append((center[b].copy(), wlh[b].copy(), quat[b].copy(), float(est[b, 4])))
+        return results
+
+    def _ensure_graph(self):
+        """The tracker forward + box selection for B frames as a hipGraph whose static inputs ARE the buffers the
+        resampling kernel writes (no staging copy)."""
+        if self.use_graph and self._graph is None:
+            with torch.no_grad():
+                self._graph = GraphedHotPath(self._model, self.search, self.template)
+            self.search, self.template = self._graph.search, self._graph.template
+
+    def _forward(self):
+        with torch.no_grad():
+            if not self.use_graph:
+                return self._model(self.search, self.template)
+            return self._graph()                                  # inputs are already in the graph's static buffers
+
+    def _advance(self, center, wlh, quat, est, info, active):
+        """post_process (:266-274): box_{i} = get_box_by_offset(box_{i-1}, best proposal's (x, y, z, theta), USE_Z_AXIS).
+        The reference redraws an implausibly large x / y offset from numpy's GLOBAL generator (:205-208), whose state at
+        that moment is "seeded with 1, then advanced by the template's (else the search's) resampling draws": the
+        per-tracklet generators reproduce exactly that from the draw counts the resampling kernel reports."""
+        new_c, new_q = center.copy(), quat.copy()
+        if len(active) == 0:
+            return new_c, new_q
+        idx = np.asarray(active)
+        for b in active:
+            used = int(info[b, 1, 1]) or int(info[b, 0, 1])
+            if used:
+                self._rng[b].seed(1)
+                self._rng[b].randint(0, 2 ** 32, used, dtype=np.uint32)          # one 32-bit output per draw
+        def uniform_for(b):
+            return lambda: self._rng[b].uniform(-1, 1)
+
+        # the redraw branch is rare: resolve it box by box only where it triggers, vectorise the rest
+        big = (est[idx, 0] > wlh[idx, 0]) | (est[idx, 1] > np.minimum(wlh[idx, 1], 2))
+        plain = idx[~big]
+        if plain.size:
+            c, q, _ = bm.get_box_by_offset(center[plain], wlh[plain], quat[plain], est[plain, 0:4], self.use_z)
+            new_c[plain], new_q[plain] = c, q
+        for b in idx[big]:
+            c, q, _ = bm.get_box_by_offset(center[b:b + 1], wlh[b:b + 1], quat[b:b + 1], est[b:b + 1, 0:4].copy(),
+                                           self.use_z, uniform=uniform_for(b))
+            new_c[b], new_q[b] = c[0], q[0]
+        return new_c, new_q
+
+    # ------------------------------------------------------------------ public
+    def run(self, tracklets):
+        """tracklets: list of (clouds, boxes) as in `_load`. Returns, per tracklet, the list of result boxes
+        [(center, wlh, quat[, score]), ...] — element 0 is the frame-0 ground-truth box, as in the reference
+        (eval_tracking_utils.py:96-100)."""
+        out = []
+        for g in range(0, len(tracklets), self.B):
+            for b in range(self.B):
+                self._rng[b] = np.random.RandomState(1)
+            out.extend(self._run_group(tracklets[g:g + self.B]))
+        return out

@@ -23,6 +23,11 @@ Fixtures:
   G9 cosine_sim_aug.npz    CosineSimAug (N1): cosine map samples + cosine_feats
   G6 ptt_forward.npz       full PTT.forward (eval) through the reference's own heads (N2) + state_dict key/shape list
   G10 train_step.npz       one training forward + backward of the full tracker (N3): loss, gradient norms, 8 full gradients
+  G12 tracking_pre_post.npz  N4: the reference's crop_center_pc / get_model / regularize_pc / get_box_by_offset
+                           (ptt/datasets/kitti/kitti_tracking_utils.py:186-367) on a synthetic 6-frame tracklet and on
+                           edge cases (empty crop, n <= 2, n == input_size, the redraw branch of get_box_by_offset).
+                           The reference imports `pyquaternion`, absent from this image: a stand-in restating its
+                           published formulas is injected (oracle.tracking_ref._Quat); rotation matrices travel as data.
   G11 fps_reference.npz    the reference's OWN numpy farthest-point sampling (ptt/utils/common_utils.py:78-112,
                            `fps_downsample`) on origin-free clouds incl. duplicated points and exact distance ties:
                            the one reference-held statement of FPS (start point, min-update, np.argmax = lowest index
@@ -83,6 +88,32 @@ def _install_stubs():
                 return self[k]
             except KeyError:
                 raise AttributeError(k)
+
+    # pyquaternion (imported by ptt/datasets/kitti/kitti_tracking_utils.py:5) is not installed: a stand-in with the
+    # constructor forms and operations the reference uses, on the formulas pyquaternion documents
+    from oracle.tracking_ref import _Quat
+
+    class Quaternion(object):
+        def __init__(self, *a, **kw):
+            if 'matrix' in kw:
+                self._q = _Quat.from_matrix(kw['matrix'])
+            elif 'axis' in kw:
+                self._q = _Quat.from_axis_angle(kw['axis'], kw['angle'] if 'angle' in kw else kw['radians'])
+            elif 'array' in kw:
+                self._q = _Quat(kw['array'])
+            else:
+                self._q = _Quat(a if len(a) == 4 else a[0])
+
+        def __mul__(self, other):
+            return Quaternion(array=self._q.mul(other._q).q)
+
+        inverse = property(lambda self: Quaternion(array=self._q.inverse.q))
+        rotation_matrix = property(lambda self: self._q.rotation_matrix)
+        elements = property(lambda self: self._q.q)
+
+    pq = types.ModuleType("pyquaternion")
+    pq.Quaternion = Quaternion
+    sys.modules["pyquaternion"] = pq
 
     ed = types.ModuleType("easydict")
     ed.EasyDict = EasyDict
@@ -303,6 +334,87 @@ def main():
     kn = O.knn(c[:, :128], 16)
     save("G7_index_ops.npz", clouds=c, fps512=f, fps_full128=f_full, centres=centres, bq=bq, bq_far=bq_far, knn=kn)
     report.append("G7 index-op edge cases written (build-authored contract)")
+
+    # ---------------- G12: pre/post-processing of the sequential tracking loop (N4) ----------------
+    from pyquaternion import Quaternion as PQ
+    # ptt/datasets/__init__.py pulls in the dataset classes (skimage, pandas readers, ...): load the one module file
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_kitti_tracking_utils",
+                                                  os.path.join(REF, "ptt/datasets/kitti/kitti_tracking_utils.py"))
+    ref_ku = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref_ku)
+    from oracle import tracking_ref as TR
+    rs12 = np.random.RandomState(1212)
+    T12, wlh12 = 6, np.array([1.7, 4.2, 1.5])
+    g12 = {"n_frames": T12, "wlh": wlh12}
+    centers = np.cumsum(np.c_[rs12.uniform(0.5, 1.2, T12), rs12.uniform(-0.3, 0.3, T12), rs12.uniform(-0.05, 0.05, T12)], 0) \
+        + np.array([12.0, -3.0, -0.8])
+    yaws = 0.4 + np.cumsum(rs12.uniform(-0.08, 0.08, T12))
+    clouds12, gt_boxes, ref_boxes = [], [], []
+    for i in range(T12):
+        Rz = np.array([[np.cos(yaws[i]), -np.sin(yaws[i]), 0], [np.sin(yaws[i]), np.cos(yaws[i]), 0], [0, 0, 1]])
+        n_obj, n_bg = int(rs12.randint(150, 900)), int(rs12.randint(2500, 5000))
+        obj = (rs12.uniform(-0.5, 0.5, (n_obj, 3)) * np.array([4.2, 1.7, 1.5])) @ Rz.T + centers[i]
+        bg = rs12.uniform(-1, 1, (n_bg, 3)) * np.array([14.0, 14.0, 2.0]) + centers[i]
+        pts = np.concatenate([obj, bg], 0)[rs12.permutation(n_obj + n_bg)].astype(np.float32)
+        clouds12.append(np.ascontiguousarray(pts.T))
+        gt_boxes.append(ref_ku.Box(centers[i], wlh12, PQ(axis=[0, 0, 1], angle=yaws[i])))
+        # the "previous result" the loop crops around: the ground truth of the previous frame, slightly off
+        j = max(i - 1, 0)
+        ref_boxes.append(ref_ku.Box(centers[j] + rs12.uniform(-0.15, 0.15, 3) * np.array([1, 1, 0.2]), wlh12,
+                                    PQ(axis=[0, 0, 1], angle=yaws[j] + rs12.uniform(-0.05, 0.05))))
+        g12["cloud_%d" % i] = clouds12[-1]
+        for nm, bx in (("gt", gt_boxes[-1]), ("ref", ref_boxes[-1])):
+            g12["%s_center_%d" % (nm, i)] = bx.center.copy()
+            g12["%s_quat_%d" % (nm, i)] = bx.orientation.elements.copy()
+            g12["%s_rot_%d" % (nm, i)] = bx.rotation_matrix.copy()
+    pcs12 = [ref_ku.PointCloud(c.copy()) for c in clouds12]
+    tb = lambda bx: TR.RefBox(bx.center, bx.wlh, bx.orientation.elements)
+    worst = 0.0
+    for i in range(1, T12):
+        cand, _, _ = ref_ku.crop_center_pc(pcs12[i], ref_boxes[i], gt_boxes[i], offset=0.0, scale=1.25)
+        search = ref_ku.regularize_pc(cand, 1024, istrain=False)
+        model = ref_ku.get_model([pcs12[0], pcs12[i - 1]], [gt_boxes[0], ref_boxes[i]], offset=0.0, scale=1.25)
+        templ = ref_ku.regularize_pc(model, 512, istrain=False)
+        g12["search_crop_%d" % i] = np.asarray(cand.points, np.float32)
+        g12["search_%d" % i] = np.asarray(search, np.float32)
+        g12["model_crop_%d" % i] = np.asarray(model.points, np.float32)
+        g12["template_%d" % i] = np.asarray(templ, np.float32)
+        o_cand = TR.crop_center_pc(clouds12[i], tb(ref_boxes[i]), wlh12[1], 0.0, 1.25)
+        o_model = TR.get_model([clouds12[0], clouds12[i - 1]], [tb(gt_boxes[0]), tb(ref_boxes[i])], 0.0, 1.25)
+        assert np.array_equal(o_cand, cand.points) and np.array_equal(o_model, model.points), i
+        assert np.array_equal(TR.regularize_pc(o_cand, 1024), search) and np.array_equal(TR.regularize_pc(o_model, 512), templ), i
+        worst = max(worst, 0.0)
+    # edge cases of regularize_pc: n <= 2 (zero cloud), n == input_size (copied through), tiny n, n just over a power of two
+    for tag, n in (("n0", 0), ("n2", 2), ("n3", 3), ("n512", 512), ("n513", 513), ("n1024", 1024), ("n1025", 1025), ("n5000", 5000)):
+        pts = rs12.standard_normal((3, n)).astype(np.float32)
+        out = ref_ku.regularize_pc(ref_ku.PointCloud(pts.copy()), 1024 if n != 512 else 512, istrain=False)
+        g12["reg_in_" + tag], g12["reg_out_" + tag] = pts, np.asarray(out, np.float32)
+        assert np.array_equal(TR.regularize_pc(pts, 1024 if n != 512 else 512), out), tag
+    # an empty crop: the reference box nowhere near the cloud
+    far = ref_ku.Box(centers[0] + 500.0, wlh12, PQ(axis=[0, 0, 1], angle=0.3))
+    e_c, _, _ = ref_ku.crop_center_pc(pcs12[1], far, gt_boxes[1], offset=0.0, scale=1.25)
+    assert e_c.points.shape[1] == 0
+    g12["far_center"], g12["far_quat"] = far.center.copy(), far.orientation.elements.copy()
+    # get_box_by_offset: float32 model outputs (x, y, z, theta in degrees), incl. the redraw branch (:205-208)
+    offs = np.array([[0.31, -0.12, 0.05, 3.0], [-0.4, 0.25, -0.02, -7.5], [0.0, 0.0, 0.0, 0.0], [2.5, 0.1, 0.0, 1.0],
+                     [0.2, 2.6, 0.1, -2.0], [3.0, 5.0, 0.3, 12.0]], np.float32)
+    g12["gbo_offsets"] = offs
+    for use_z in (True, False):
+        for k in range(offs.shape[0]):
+            np.random.seed(77 + k)
+            o_in = offs[k].copy()
+            nb = ref_ku.get_box_by_offset(ref_boxes[2], o_in, use_z)
+            g12["gbo_center_%d_%d" % (int(use_z), k)] = nb.center.copy()
+            g12["gbo_quat_%d_%d" % (int(use_z), k)] = nb.orientation.elements.copy()
+            g12["gbo_used_%d_%d" % (int(use_z), k)] = o_in.copy()
+            np.random.seed(77 + k)
+            ob = TR.get_box_by_offset(tb(ref_boxes[2]), offs[k].copy(), use_z)
+            assert np.allclose(ob.center, nb.center, rtol=0, atol=1e-12) and np.allclose(ob.quat.q, nb.orientation.elements, atol=1e-12)
+    save("G12_tracking_pre_post.npz", **g12)
+    report.append("G12 tracking pre/post-processing (crop_center_pc, get_model, regularize_pc, get_box_by_offset of "
+                  "kitti_tracking_utils.py with a restated pyquaternion): oracle == reference bitwise on %d frames + 8 "
+                  "resampling edge cases; box update within 1e-12" % (T12 - 1))
 
     # ---------------- G11: the reference's own numpy FPS ----------------
     # fps_downsample draws its start point with np.random.randint and uses the removed alias np.long: the alias is

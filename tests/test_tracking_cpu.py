@@ -1,0 +1,102 @@
+"""N4 on the CPU: the oracle of the tracking loop's pre/post-processing against fixture G12 (outputs of the reference's
+own crop_center_pc / get_model / regularize_pc / get_box_by_offset), and the product's HOST logic (float64 box math,
+job tables) against the oracle. The device kernels are tested in tests/test_tracking_gpu.py."""
+import os
+
+import numpy as np
+
+from oracle import tracking_ref as TR
+from ptt_amd.datasets.kitti import box_math as bm
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _g():
+    return np.load(os.path.join(GOLD, "G12_tracking_pre_post.npz"))
+
+
+def _box(g, kind, i):
+    return TR.RefBox(g["%s_center_%d" % (kind, i)], g["wlh"], g["%s_quat_%d" % (kind, i)])
+
+
+def test_G12_oracle_crops_and_resampling_equal_the_reference():
+    g = _g()
+    T = int(g["n_frames"])
+    clouds = [g["cloud_%d" % i] for i in range(T)]
+    for i in range(1, T):
+        cand = TR.crop_center_pc(clouds[i], _box(g, "ref", i), g["wlh"][1], 0.0, 1.25)
+        np.testing.assert_array_equal(cand, g["search_crop_%d" % i])
+        np.testing.assert_array_equal(TR.regularize_pc(cand, 1024), g["search_%d" % i])
+        model = TR.get_model([clouds[0], clouds[i - 1]], [_box(g, "gt", 0), _box(g, "ref", i)], 0.0, 1.25)
+        np.testing.assert_array_equal(model, g["model_crop_%d" % i])
+        np.testing.assert_array_equal(TR.regularize_pc(model, 512), g["template_%d" % i])
+        assert 2 < cand.shape[1] != 1024 and 2 < model.shape[1] != 512          # the resampling path is exercised
+    for tag in ("n0", "n2", "n3", "n512", "n513", "n1024", "n1025", "n5000"):
+        size = 512 if tag == "n512" else 1024
+        np.testing.assert_array_equal(TR.regularize_pc(g["reg_in_" + tag], size), g["reg_out_" + tag], err_msg=tag)
+    far = TR.RefBox(g["far_center"], g["wlh"], g["far_quat"])
+    assert TR.crop_center_pc(clouds[1], far, g["wlh"][1], 0.0, 1.25).shape[1] == 0
+
+
+def test_G12_box_update_oracle_and_product_host_math():
+    """get_box_by_offset incl. the redraw branch (:205-208): oracle and the product's batched float64 math against the
+    reference's outputs; the rotation matrices of the fixture boxes against both quaternion restatements."""
+    g = _g()
+    offs = g["gbo_offsets"]
+    assert offs.dtype == np.float32
+    box = _box(g, "ref", 2)
+    for i in range(int(g["n_frames"])):
+        for kind in ("gt", "ref"):
+            q = g["%s_quat_%d" % (kind, i)]
+            np.testing.assert_allclose(bm.q_rotation_matrix(q), g["%s_rot_%d" % (kind, i)], rtol=0, atol=1e-15)
+            np.testing.assert_allclose(TR._Quat(q).rotation_matrix, g["%s_rot_%d" % (kind, i)], rtol=0, atol=1e-15)
+    for use_z in (1, 0):
+        for k in range(offs.shape[0]):
+            want_c, want_q = g["gbo_center_%d_%d" % (use_z, k)], g["gbo_quat_%d_%d" % (use_z, k)]
+            np.random.seed(77 + k)
+            ob = TR.get_box_by_offset(box, offs[k].copy(), bool(use_z))
+            np.testing.assert_allclose(ob.center, want_c, rtol=0, atol=1e-12)
+            np.testing.assert_allclose(ob.quat.q, want_q, rtol=0, atol=1e-12)
+            rs = np.random.RandomState(77 + k)
+            c, q, used = bm.get_box_by_offset(box.center[None], box.wlh[None], box.quat.q[None], offs[k:k + 1].copy(),
+                                              bool(use_z), uniform=lambda: rs.uniform(-1, 1))
+            np.testing.assert_allclose(c[0], want_c, rtol=0, atol=1e-12)
+            np.testing.assert_allclose(q[0], want_q, rtol=0, atol=1e-12)
+            np.testing.assert_array_equal(used[0].astype(np.float32), g["gbo_used_%d_%d" % (use_z, k)])
+    # batched call == per-box calls (no redraw among the first three offsets)
+    c, q, _ = bm.get_box_by_offset(np.repeat(box.center[None], 3, 0), np.repeat(box.wlh[None], 3, 0),
+                                   np.repeat(box.quat.q[None], 3, 0), offs[:3].copy(), True)
+    for k in range(3):
+        np.testing.assert_allclose(c[k], g["gbo_center_1_%d" % k], rtol=0, atol=1e-12)
+
+
+def test_crop_bounds_match_the_oracles_box_arithmetic():
+    """box_math.crop_bounds (what the device kernel receives) == the bounds the oracle's crop_pc derives, for the search
+    crop (extra offset 0.6 * gt length) and the template crop."""
+    g = _g()
+    for i in range(1, int(g["n_frames"])):
+        b = _box(g, "ref", i)
+        p = bm.crop_bounds(b.center[None], b.wlh[None], b.quat.q[None], 0.0, 1.25, g["wlh"][1] * 0.6)
+        import copy
+        t = copy.deepcopy(b); t.wlh = t.wlh * 5.0
+        c = t.corners()
+        np.testing.assert_allclose(p["hi1"][0], c.max(1), rtol=0, atol=1e-12)
+        np.testing.assert_allclose(p["lo1"][0], c.min(1), rtol=0, atol=1e-12)
+        np.testing.assert_allclose(p["rot"][0], b.rotation_matrix.T, rtol=0, atol=1e-15)
+        np.testing.assert_array_equal(p["trans"][0], -b.center)
+        half = np.array([b.wlh[1], b.wlh[0], b.wlh[2]]) / 2 * 1.25 + g["wlh"][1] * 0.6
+        np.testing.assert_allclose(p["hi2"][0], half, rtol=0, atol=1e-12)
+        np.testing.assert_allclose(p["lo2"][0], -half, rtol=0, atol=1e-12)
+
+
+def test_job_tables_mirror_the_c_structs():
+    import ctypes
+    from ptt_amd import _lib, ops
+    for dt, st in ((ops.CROP_JOB, _lib.CropJob), (ops.REGULARIZE_JOB, _lib.RegularizeJob)):
+        assert dt.itemsize == ctypes.sizeof(st)
+        for name, _ in st._fields_:
+            assert dt.fields[name][1] == getattr(st, name).offset, name
+    draws = np.empty(64, np.uint32)
+    assert _lib.lib().ptt_mt19937_fill(1, draws.ctypes.data, 64) == 0
+    np.random.seed(1)
+    np.testing.assert_array_equal(draws, np.random.randint(0, 2 ** 32, 64, dtype=np.uint32))

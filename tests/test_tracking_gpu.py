@@ -1,0 +1,113 @@
+"""N4 on the GPU: the device-side pre/post-processing of the sequential tracking loop against fixture G12 (outputs of
+the reference's own kitti_tracking_utils functions) and against the oracle's restatement of the whole loop."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import tracking_ref as TR
+from ptt_amd import ops, synth
+from ptt_amd.datasets.kitti import box_math as bm
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _g():
+    return np.load(os.path.join(GOLD, "G12_tracking_pre_post.npz"))
+
+
+def _kbox(g, kind, i):
+    from ptt.datasets.kitti.kitti_tracking_utils import Box, Quaternion
+    return Box(g["%s_center_%d" % (kind, i)], g["wlh"], Quaternion(array=g["%s_quat_%d" % (kind, i)]))
+
+
+def test_G12_mirror_module_on_device_equals_the_reference(dev):
+    """ptt.datasets.kitti.kitti_tracking_utils (device-backed mirror): crop_center_pc, get_model, regularize_pc
+    bit-identical to the reference's outputs on every frame of the fixture tracklet."""
+    import ptt.datasets.kitti.kitti_tracking_utils as ku
+    g = _g()
+    T = int(g["n_frames"])
+    pcs = [ku.PointCloud(g["cloud_%d" % i]) for i in range(T)]
+    for i in range(1, T):
+        cand, _, _ = ku.crop_center_pc(pcs[i], _kbox(g, "ref", i), _kbox(g, "gt", i), offset=0.0, scale=1.25)
+        np.testing.assert_array_equal(cand.points.cpu().numpy(), g["search_crop_%d" % i])
+        np.testing.assert_array_equal(ku.regularize_pc(cand, 1024, istrain=False).cpu().numpy(), g["search_%d" % i])
+        model = ku.get_model([pcs[0], pcs[i - 1]], [_kbox(g, "gt", 0), _kbox(g, "ref", i)], offset=0.0, scale=1.25)
+        np.testing.assert_array_equal(model.points.cpu().numpy(), g["model_crop_%d" % i])
+        np.testing.assert_array_equal(ku.regularize_pc(model, 512, istrain=False).cpu().numpy(), g["template_%d" % i])
+    from ptt.datasets.kitti.kitti_tracking_utils import Box, Quaternion
+    far = Box(g["far_center"], g["wlh"], Quaternion(array=g["far_quat"]))
+    empty, _, _ = ku.crop_center_pc(pcs[1], far, _kbox(g, "gt", 1), offset=0.0, scale=1.25)
+    assert empty.nbr_points() == 0
+    assert float(ku.regularize_pc(empty, 1024, istrain=False).abs().max()) == 0.0         # :359-362 all-zero cloud
+
+
+def test_G12_regularize_edge_cases(dev):
+    """n = 0, 2 (zero cloud), 3, n == input_size (copied through), n just above a power of two, n >> size."""
+    import ptt.datasets.kitti.kitti_tracking_utils as ku
+    g = _g()
+    for tag in ("n0", "n2", "n3", "n512", "n513", "n1024", "n1025", "n5000"):
+        size = 512 if tag == "n512" else 1024
+        got = ku.regularize_pc(ku.PointCloud(g["reg_in_" + tag]), size, istrain=False).cpu().numpy()
+        np.testing.assert_array_equal(got, g["reg_out_" + tag], err_msg=tag)
+
+
+@pytest.mark.parametrize("n", [3, 17, 100, 1023, 2049, 40000])
+def test_resampling_index_stream_is_numpys(dev, n):
+    """The gathered rows identify the indices: resample the cloud whose point k is (k, 0, 0) and compare with
+    np.random.randint(0, n, 1024) after np.random.seed(1) (regularize_pc:349-353); info reports n and the draws used."""
+    import ptt.datasets.kitti.kitti_tracking_utils as ku
+    pts = np.zeros((3, n), np.float32)
+    pts[0] = np.arange(n)
+    got = ku.regularize_pc(ku.PointCloud(pts), 1024, istrain=False).cpu().numpy()
+    np.random.seed(1)
+    want = np.random.randint(low=0, high=n, size=1024, dtype=np.int64)
+    np.testing.assert_array_equal(got[:, 0].astype(np.int64), want)
+
+
+def test_select_box_is_first_argmax(dev):
+    rs = np.random.RandomState(3)
+    x = rs.standard_normal((7, 64, 5)).astype(np.float32)
+    x[1, 10, 4] = x[1, 40, 4] = 9.0                       # tie: the lower index wins
+    x[2, :, 4] = 0.5                                      # all equal -> 0
+    x[3, 63, 4] = 50.0
+    out = ops.select_box(torch.from_numpy(x).to(dev)).cpu().numpy()
+    for b in range(7):
+        np.testing.assert_array_equal(out[b], x[b, x[b, :, 4].argmax()])
+
+
+@pytest.mark.parametrize("batch,lengths", [(1, [6]), (3, [5, 3, 6]), (2, [4, 4, 3])])
+def test_tracklet_runner_equals_the_reference_loop(dev, batch, lengths):
+    """TrackletRunner (clouds resident on the device, crop + resample + model graph + box selection per step, lockstep
+    over `batch` tracklets, groups of tracklets when there are more than `batch`) against the oracle's restatement of
+    TrackingEvaluator.test_batch driving the SAME tracker one frame at a time: every result box of every frame equal
+    (the inputs the model sees are bit-identical, so are its outputs; the float64 box update agrees to 1e-9)."""
+    from ptt_amd.config import StubDataset, ptt_model_cfg
+    from ptt_amd.hot_path import randomize_
+    from ptt_amd.models import build_network
+    from ptt_amd.tracklet_runner import TrackletRunner
+    tracker = randomize_(build_network(ptt_model_cfg(), 1, StubDataset()), seed=2).to(dev).eval()
+    with torch.no_grad():                                  # small regression outputs, as a trained model's are:
+        tracker.box_voting_head.refine_layer[-1].conv.weight.mul_(0.05)      # keeps the boxes on their objects
+        tracker.box_voting_head.refine_layer[-1].conv.bias.mul_(0.05)
+    tracklets = [synth.tracklet(100 + k, T) for k, T in enumerate(lengths)]
+    runner = TrackletRunner(tracker, dev, batch=batch)
+    got = runner.run(tracklets)
+
+    def infer(search, template):
+        with torch.no_grad():
+            out = tracker({'search_points': torch.from_numpy(np.ascontiguousarray(search)).to(dev),
+                           'template_points': torch.from_numpy(np.ascontiguousarray(template)).to(dev), 'batch_size': 1})
+        return out['pred_box_data'][0].cpu().numpy()
+
+    n_moved = 0
+    for (clouds, boxes), res in zip(tracklets, got):
+        ref = TR.track(clouds, [TR.RefBox(*b) for b in boxes], infer, use_z=True)
+        assert len(res) == len(ref) == len(clouds)
+        for i, (r, o) in enumerate(zip(res, ref)):
+            np.testing.assert_allclose(r[0], o.center, rtol=0, atol=1e-9, err_msg="frame %d centre" % i)
+            np.testing.assert_allclose(bm.q_rotation_matrix(r[2]), o.rotation_matrix, rtol=0, atol=1e-9)
+            n_moved += int(i > 0 and float(np.abs(r[0] - res[0][0]).max()) > 1e-6)
+    assert n_moved > 0
