@@ -446,6 +446,7 @@ struct SaParams {
     const float* xyz; const float* new_xyz; const int32_t* idx; const float* feat; float* out;
     long long fsb, fsc, fsn, osb, osc, osm;
     int B, N, M, C, use_xyz, normalize, n_layers, ldk, K0, first_wave, stagger, vec_gather;
+    int tiles, chunk;     // sa_stream_kernel: 64-row tiles in the launch, consecutive tiles per (persistent) workgroup
     int hoist, l0_relu;   // layer 0 hoisted: feat = per-point term (B,N,C), wx = (3,C) weights of the relative coordinates
     const float* wx;
     float radius;
@@ -703,6 +704,182 @@ __global__ __launch_bounds__(256, PTT_SA_WAVES) void sa_fused_kernel(SaParams p)
         if (ctw <= 1) sa_layer<NS, 1, RT>(p, L, last, Xs, lane, w, centre0, ncentres, pre, Ln);
         else sa_layer<NS, 2, RT>(p, L, last, Xs, lane, w, centre0, ncentres, pre, Ln);
         PTT_STAMP(2 + l);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Streaming form of the fused set-abstraction level for the two levels that carry most of the SA work (SA1, SA2 of
+// both branches: hoisted layer 0 with 128 channels, then 128 -> 128 -> 256, 32 neighbours).
+//
+// Why: fp32 MFMA and the vector ALU are one SIMD resource, and a wave that issues vector-ALU / LDS instructions while
+// ANOTHER wave streams MFMAs on the same SIMD gets roughly one issue slot per MFMA (DESIGN.md lesson 8): the gather of
+// sa_fused_kernel (~150 instructions per wave) costs ~17k cycles beside the co-resident workgroup's GEMM although it
+// is ~1k cycles of work. Instructions of the SAME wave issue in order at full rate between its own MFMAs. So here a
+// workgroup is persistent (it walks `chunk` consecutive 64-row tiles), the LDS tile is double-buffered, and every wave
+// gathers ITS 16 rows of tile n+1 inside its own MFMA stream of tile n's last (longest) GEMM: per pair of K-blocks one
+// row pair — a broadcast ds_read of (row offset, rel), one buffer load, 12 FMAs + 4 max, one ds_write_b128.
+// ------------------------------------------------------------------------------------------
+constexpr int SAS_LDK = 132;                 // 128 channels + 4 (== 4 mod 8: conflict-free A reads)
+constexpr int SAS_TILE = 64 * SAS_LDK;
+
+// lanes 0..15 of wave w: neighbour index of the wave's row `lane` of `tile`, issued early (index -> coordinates is a
+// dependent chain of two L2 round trips)
+__device__ __forceinline__ void sas_meta_index(const SaParams& p, int tile, int w, int lane, int& c, int& n) {
+    const int r = 16 * w + (lane & 15);
+    c = tile * 2 + (r >> 5);
+    if (c >= p.B * p.M) c = p.B * p.M - 1;
+    n = p.idx[(size_t)c * 32 + (r & 31)];
+}
+// ... then the relative coordinates and the byte offset of the neighbour's per-point term row -> meta[w][row] (16 B)
+__device__ __forceinline__ void sas_meta_store(const SaParams& p, float* meta, int w, int lane, int c, int n) {
+    if (lane < 16) {
+        const int b = c / p.M;
+        const size_t flat = (size_t)b * p.N + n;
+        float dx = p.xyz[flat * 3 + 0] - p.new_xyz[(size_t)c * 3 + 0];
+        float dy = p.xyz[flat * 3 + 1] - p.new_xyz[(size_t)c * 3 + 1];
+        float dz = p.xyz[flat * 3 + 2] - p.new_xyz[(size_t)c * 3 + 2];
+        if (p.normalize) { dx /= p.radius; dy /= p.radius; dz /= p.radius; }
+        const int off = (int)(flat * 128 * sizeof(float));
+        *reinterpret_cast<f32x4*>(meta + (w * 16 + lane) * 4) = f32x4{__builtin_bit_cast(float, off), dx, dy, dz};
+    }
+}
+// one row pair of the wave's 16 rows: request (rows 2i, 2i+1 -> lanes 0-31 / 32-63, four channels per lane) ...
+__device__ __forceinline__ f32x4 sas_pair_load(const float* meta, __amdgpu_buffer_rsrc_t rf, int w, int i, int sub, int q,
+                                               f32x4& m) {
+    m = *reinterpret_cast<const f32x4*>(meta + (w * 16 + 2 * i + sub) * 4);
+    return weight_load(rf, __builtin_bit_cast(int, m[0]) + q * 16, 0);
+}
+// ... and finish: h0 = relu(term + Wx . rel) -> the tile (scalar FMAs: v_pk_fma_f32 beside MFMAs is an anti-lever,
+// MI355X_MICROARCH.md "price of one filler beside MFMAs")
+__device__ __forceinline__ void sas_pair_store(float* X, int w, int i, int sub, int q, f32x4 v, const f32x4& m, const f32x4& wx0,
+                                               const f32x4& wx1, const f32x4& wx2, int relu) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float y = __builtin_fmaf(wx0[j], m[1], v[j]);
+        y = __builtin_fmaf(wx1[j], m[2], y);
+        y = __builtin_fmaf(wx2[j], m[3], y);
+        v[j] = relu ? fmaxf(y, 0.f) : y;
+    }
+    *reinterpret_cast<f32x4*>(X + (16 * w + 2 * i + sub) * SAS_LDK + q * 4) = v;
+}
+
+template <int NS>
+__global__ __launch_bounds__(256, 2) void sa_stream_kernel(SaParams p) {
+    static_assert(NS == 32, "one centre per 32-row tile");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* meta = smem + 2 * SAS_TILE;                     // [4 waves][16 rows][off, dx, dy, dz]
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, half = lane >> 5, sub = half, q = lane & 31;
+    const int tile0 = logical_block() * p.chunk;
+    const int ntiles = min(p.chunk, p.tiles - tile0);
+    if (ntiles <= 0) return;
+    stagger_second_slot(p.first_wave, p.stagger);
+    const SaLayerDev& L1 = p.L[0];
+    const SaLayerDev& L2 = p.L[1];
+    const __amdgpu_buffer_rsrc_t rf = weight_rsrc(p.feat);
+    const f32x4 wx0 = *reinterpret_cast<const f32x4*>(p.wx + q * 4);
+    const f32x4 wx1 = *reinterpret_cast<const f32x4*>(p.wx + 128 + q * 4);
+    const f32x4 wx2 = *reinterpret_cast<const f32x4*>(p.wx + 256 + q * 4);
+    const int col = lane & 31;
+    const float sh1 = L1.shift ? L1.shift[w * 32 + col] : 0.f;
+    const float sh2a = L2.shift ? L2.shift[w * 32 + col] : 0.f;
+    const float sh2b = L2.shift ? L2.shift[(w + 4) * 32 + col] : 0.f;
+    const int total_centres = p.B * p.M;
+
+    // ---- prologue: the first tile is gathered in the open ----
+    {
+        int c, n;
+        sas_meta_index(p, tile0, w, lane, c, n);
+        sas_meta_store(p, meta, w, lane, c, n);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            f32x4 m;
+            const f32x4 v = sas_pair_load(meta, rf, w, i, sub, q, m);
+            sas_pair_store(smem, w, i, sub, q, v, m, wx0, wx1, wx2, p.l0_relu);
+        }
+    }
+
+    for (int it = 0; it < ntiles; ++it) {
+        const int tile = tile0 + it;
+        const int next = (it + 1 < ntiles) ? tile + 1 : tile;            // last tile: re-gathers itself (branch-free loop)
+        float* X = smem + (it & 1) * SAS_TILE;
+        float* Xn = smem + ((it & 1) ^ 1) * SAS_TILE;
+        lds_barrier();                                                   // A: tile `tile` is complete in X
+        int cn, nn;
+        sas_meta_index(p, next, w, lane, cn, nn);                        // index load in flight under the first GEMM
+
+        // ---- layer 1: 128 -> 128, this wave's column tile w, both row tiles ----
+        f32x16 acc1[2][1];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc1[rt][0][r] = sh1;
+        gemm_core<2, 1, 1, 4, 0>(X, SAS_LDK, 16, reinterpret_cast<const f32x4*>(L1.Wp), 4, w, lane, acc1);
+        f32x4 pre2[2];
+        prefetch_first_block_full<2>(L2.Wp, w, lane, pre2);              // layer 2's first weights ride across the epilogue
+        lds_barrier();                                                   // B: every wave has read X for layer 1
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                X[(rt * 32 + tile_row(r, half)) * SAS_LDK + w * 32 + col] = fmaxf(acc1[rt][0][r], 0.f);
+        sas_meta_store(p, meta, w, lane, cn, nn);                        // wave-private: same-wave LDS ops are ordered
+        lds_barrier();                                                   // C: h1 is complete
+
+        // ---- layer 2: 128 -> 256 (column tiles w, w+4), with the gather of tile `next` inside the MFMA stream ----
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[rt][0][r] = sh2a; acc[rt][1][r] = sh2b; }
+        {
+            const float* arow = X + (lane & 31) * SAS_LDK + 4 * half;
+            const __amdgpu_buffer_rsrc_t wr = weight_rsrc(L2.Wp);
+            const int wvoff = (w * 64 + lane) * 16;
+            constexpr int WK = 8 * 1024;                                 // bytes per K-block of L2's packed weights (NT = 8)
+            f32x4 a0[2], a1[2], b0[2], b1[2];
+#define SAS_LOAD(A, Bv, KB)                                                                     \
+            {                                                                                   \
+                Bv[0] = weight_load(wr, wvoff, (KB) * WK);                                      \
+                Bv[1] = weight_load(wr, wvoff, (KB) * WK + 4 * 1024);                           \
+                A[0] = *reinterpret_cast<const f32x4*>(arow + (KB) * 8);                        \
+                A[1] = *reinterpret_cast<const f32x4*>(arow + 32 * SAS_LDK + (KB) * 8);         \
+            }
+            b0[0] = pre2[0]; b0[1] = pre2[1];
+            a0[0] = *reinterpret_cast<const f32x4*>(arow);
+            a0[1] = *reinterpret_cast<const f32x4*>(arow + 32 * SAS_LDK);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {                                // K-blocks 2i, 2i+1 and row pair i of tile `next`
+                f32x4 m;
+                SAS_LOAD(a1, b1, 2 * i + 1)
+                const f32x4 v = sas_pair_load(meta, rf, w, i, sub, q, m);
+                __builtin_amdgcn_sched_barrier(0);
+                gemm_mfma_block<2, 2, 2>(a0, b0, acc);
+                __builtin_amdgcn_sched_barrier(0);
+                if (i < 7) SAS_LOAD(a0, b0, 2 * i + 2)
+                __builtin_amdgcn_sched_barrier(0);
+                gemm_mfma_block<2, 2, 2>(a1, b1, acc);
+                __builtin_amdgcn_sched_barrier(0);
+                sas_pair_store(Xn, w, i, sub, q, v, m, wx0, wx1, wx2, p.l0_relu);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#undef SAS_LOAD
+        }
+        // ---- max over the 32 neighbours (ReLU after the pool), one centre per row tile ----
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                float mx = acc[rt][u][0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[rt][u][r]);
+                mx = max_halves(mx);
+                if (L2.relu) mx = fmaxf(mx, 0.f);
+                const int c = tile * 2 + rt;
+                if (half == 0 && c < total_centres) {
+                    const int b = c / p.M, mm = c - b * p.M;
+                    p.out[b * p.osb + ((w + 4 * u) * 32 + col) * p.osc + mm * p.osm] = mx;
+                }
+            }
     }
 }
 
@@ -1270,6 +1447,20 @@ extern "C" int ptt_sa_fused_fwd_f32(const ptt_sa_desc* d, ptt_stream_t stream) {
             hipLaunchKernelGGL((sa_wave_kernel<16, 1>), grid, dim3(256), lds, s, p);
         }
         return check_launch("sa_wave_kernel");
+    }
+    // SA1 / SA2 shape (hoisted 128-channel layer 0, then 128 -> 128 -> 256 with the BatchNorm scale folded, 32
+    // neighbours): persistent double-buffered kernel that gathers the next tile inside its own MFMA stream
+    if (p.hoist == 2 && d->nsample == 32 && d->n_layers == 2 && p.L[0].Cin == 128 && p.L[0].Cout == 128 &&
+        p.L[1].Cout == 256 && !p.L[0].scale && !p.L[1].scale && p.L[0].relu && dev_switches().sa_stream) {
+        p.tiles = (total_centres + 1) / 2;
+        int wgs = p.tiles < 512 ? p.tiles : 512;                 // 2 workgroups per CU x 256 CUs stay resident
+        p.chunk = (p.tiles + wgs - 1) / wgs;
+        if (dev_switches().sa_chunk > 0 && p.chunk > dev_switches().sa_chunk) p.chunk = dev_switches().sa_chunk;
+        wgs = (p.tiles + p.chunk - 1) / p.chunk;
+        const int lds = (2 * SAS_TILE + 4 * 16 * 4) * (int)sizeof(float);
+        if ((rc = set_lds_limit(reinterpret_cast<const void*>(sa_stream_kernel<32>), lds))) return rc;
+        hipLaunchKernelGGL((sa_stream_kernel<32>), dim3(wgs), dim3(256), lds, s, p);
+        return check_launch("sa_stream_kernel");
     }
     int RT = dev_switches().sa_rt;                       // rows per workgroup = 32 * RT (2 unless a dev build says 1)
     if (d->nsample == 64) RT = 2;                        // one centre = two row tiles

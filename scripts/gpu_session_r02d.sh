@@ -1,0 +1,19 @@
+#!/bin/bash
+set -u
+O=gpurun_out/r02d
+mkdir -p $O
+PTT_HIP_FLAGS=-DPTT_DEV python -m ptt_amd.build --force > $O/build.log 2>&1
+run() { tag=$1; shift; env "$@" timeout 300 python bench.py --no-cpu-baseline --no-latency --no-full-model --sustain 1 $EXTRA > $O/b_$tag.json 2>/dev/null
+  python - <<PY
+import json
+d=json.loads(open("$O/b_$tag.json").read().strip().splitlines()[-1])
+print("$tag", d["value"], d["ms_per_step"], d["sustained"]["ms_per_step"], d["kernel_ms_per_step"]["sa_fused_fwd"], d["kernel_ms_per_step"]["pt_attn_pair"])
+PY
+}
+for mode in "" "--no-pipeline" "--serial"; do
+  EXTRA="$mode"
+  echo "== mode [$mode]"
+  run old$mode PTT_SA_STREAM=0
+  run stream$mode PTT_SA_STREAM=1
+  for c in 2 3 4 6; do run chunk$c$mode PTT_SA_STREAM=1 PTT_SA_CHUNK=$c; done
+done

@@ -85,11 +85,13 @@ def test_sa_fused(dev, N, M, C, spec, radius, ns, point_major, scale_in_weights)
     np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), **TOL)
 
 
+@pytest.mark.parametrize("B,scale_in_weights", [(3, False), (3, True), (26, True)])
 @pytest.mark.parametrize("N,M,C,spec,radius,ns", [c for c in SA_CASES if c[2] > 0])
-def test_sa_fused_hoisted_layer0(dev, N, M, C, spec, radius, ns):
+def test_sa_fused_hoisted_layer0(dev, N, M, C, spec, radius, ns, B, scale_in_weights):
     """ptt_sa_desc.l0_*: layer 0's feature half evaluated once per point on the linear kernel, the kernel adds the
-    three relative-coordinate terms — same oracle, same tolerance as the in-kernel layer 0."""
-    B = 3
+    three relative-coordinate terms — same oracle, same tolerance as the in-kernel layer 0. With the BatchNorm scale
+    folded into the weights (what the modules pass) the 128 -> 128 -> 256 levels run on the persistent
+    sa_stream_kernel; B = 26 gives its workgroups several tiles each (and a ragged last chunk), B = 3 one."""
     rs = np.random.RandomState(N + C)
     s, _ = synth.frames(N, B, N, 64, K_s=max(16, N // 2))
     s[2] = 0.0
@@ -104,6 +106,8 @@ def test_sa_fused_hoisted_layer0(dev, N, M, C, spec, radius, ns):
     folded = fold_layers(layers, dev, ops)
     w0 = layers[0]["conv_weight"].reshape(spec[1], spec[0]).to(dev)
     scale0, shift0 = folded[0][1], folded[0][2]
+    if scale_in_weights:
+        folded = fold_layers(layers, dev, ops, scale_in_weights=True)
     rows = feats.to(dev).transpose(1, 2).contiguous()                                   # (B,N,C)
     term = ops.linear(rows, ops.pack_weight(w0[:, 3:].contiguous()), spec[1], scale0, shift0, relu=False)
     wx = (w0[:, 0:3] * scale0[:, None]).t().contiguous()                                # (3,C0)
