@@ -318,6 +318,31 @@ int ptt_regularize_f32(const ptt_regularize_job* jobs_device, int n_jobs, const 
  * yields) into a HOST buffer — the one entry point that takes a host pointer. */
 int ptt_mt19937_fill(uint32_t seed, uint32_t* out_host, int n);
 
+/* Host-side float64 box arithmetic of the tracking loop (HOST pointers, no device work): what the reference does per
+ * frame through `Box` / pyquaternion (kitti_tracking_utils.py:68-160,186-216,300-339), batched over n tracklets so
+ * that a step of 48 interleaved tracklets costs microseconds of host time. Quaternions are (w, x, y, z).
+ *
+ * ptt_track_crop_bounds — the float64 quantities of crop_center_pc(pc, box, offset=offset, scale=scale) per box
+ *   (lo1/hi1: crop_pc with 2*offset, 4*scale in the cloud's frame; trans = -center; rot = R^T; lo2/hi2: crop_pc of the
+ *   carried-along box with offset + extra2[i] (extra2 NULL = 0; gt_box.wlh[1]*0.6 for the search crop, :321) and scale)
+ *   written into jobs_host[i * job_stride] (the other fields are left untouched).
+ * ptt_track_box_by_offset — boxes[i] <- get_box_by_offset(boxes[i], offsets[i*offset_stride .. +4), use_z) for every i
+ *   with active[i] != 0 (active NULL = all). offsets are the model's float32 outputs (x, y, z, theta in degrees); the
+ *   angle is formed as the float32 product the reference forms. An x / y offset larger than the box is redrawn from
+ *   U(-1, 1) (:205-208) using the two next 32-bit outputs of MT19937(seed 1) at position rng_pos[i] (the state numpy's
+ *   global generator has after regularize_pc's resampling consumed rng_pos[i] outputs); rng_pos[i] advances by 2 per
+ *   draw; offsets are updated in place with the values used. */
+typedef struct ptt_track_box {
+    double center[3];
+    double wlh[3];
+    double quat[4];
+} ptt_track_box;
+
+int ptt_track_crop_bounds(const ptt_track_box* boxes, int n, double offset, double scale, const double* extra2,
+                          ptt_crop_job* jobs_host, int job_stride);
+int ptt_track_box_by_offset(ptt_track_box* boxes, int n, float* offsets, int offset_stride, int use_z,
+                            const int32_t* active, int64_t* rng_pos);
+
 /* ptt_select_box_f32 — post_process (eval_tracking_utils.py:266-274): for every frame b the row of
  * pred_box_data (B,P,5) with the largest score (column 4; first one among equals, as np.argmax) -> out (B,5);
  * idx_out (B) receives its index, or NULL. */

@@ -21,6 +21,7 @@ EXPORTS = [
     "ptt_packed_weight_elems", "ptt_pack_weight_f32", "ptt_pack_weight_rot_f32", "ptt_linear_f32",
     "ptt_sa_fused_fwd_f32", "ptt_xcorr_fused_fwd_f32", "ptt_cosine_map_f32", "ptt_pt_attn_pair_f32",
     "ptt_crop_compact_f32", "ptt_regularize_f32", "ptt_mt19937_fill", "ptt_select_box_f32",
+    "ptt_track_crop_bounds", "ptt_track_box_by_offset",
 ]
 PTT_MAX_SEGMENTS = 4
 
@@ -105,6 +106,8 @@ def _declare(lib):
         "ptt_regularize_f32": [vp, i, vp, i, vp],
         "ptt_mt19937_fill": [c_uint32, vp, i],
         "ptt_select_box_f32": [vp, i, i, vp, vp, vp],
+        "ptt_track_crop_bounds": [vp, i, c_double, c_double, vp, vp, i],
+        "ptt_track_box_by_offset": [vp, i, vp, i, i, vp, vp],
     }
     for name, args in sigs.items():
         fn = getattr(lib, name)

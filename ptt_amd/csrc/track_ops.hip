@@ -12,6 +12,8 @@
 //   select_box_kernel    post_process (:266-274): first arg-max of the proposal scores, its 4-dof offset and score.
 // Arithmetic follows numpy's: points are float32, box quantities float64; `translate` rounds (double)p + t to float32,
 // `rotate` rounds the float64 dot product to float32; comparisons are float32 point against float64 bound, strict.
+#include <math.h>
+#include <stdlib.h>
 #include "common.h"
 
 namespace ptt {
@@ -208,6 +210,144 @@ extern "C" int ptt_regularize_f32(const ptt_regularize_job* jobs_device, int n_j
     if (!jobs_device || !draws) return fail(PTT_EINVAL, "ptt_regularize_f32: null pointer");
     hipLaunchKernelGGL((regularize_kernel<256>), dim3(n_jobs), dim3(256), 0, as_stream(stream), jobs_device, draws, n_draws);
     return check_launch("regularize_kernel");
+}
+
+// ---- host-side float64 box arithmetic (restates pyquaternion's documented formulas, as box_math.py does) ----
+namespace {
+struct Q { double w, x, y, z; };
+struct M3 { double m[3][3]; };
+
+inline Q q_mul(const Q& a, const Q& b) {
+    return Q{a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z, a.x * b.w + a.w * b.x - a.z * b.y + a.y * b.z,
+             a.y * b.w + a.z * b.x + a.w * b.y - a.x * b.z, a.z * b.w - a.y * b.x + a.x * b.y + a.w * b.z};
+}
+inline Q q_inverse(const Q& q) {
+    const double ss = q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z;
+    return Q{q.w / ss, -q.x / ss, -q.y / ss, -q.z / ss};
+}
+inline M3 q_rotation_matrix(Q q) {
+    const double n = sqrt(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
+    if (!(fabs(1.0 - n * n) < 1e-14) && n > 0) { q.w /= n; q.x /= n; q.y /= n; q.z /= n; }
+    const double w = q.w, x = q.x, y = q.y, z = q.z;
+    M3 r;
+    r.m[0][0] = x * x + w * w - z * z - y * y; r.m[0][1] = x * y - w * z - z * w + y * x; r.m[0][2] = x * z + w * y + z * x + y * w;
+    r.m[1][0] = y * x + z * w + w * z + x * y; r.m[1][1] = y * y - z * z + w * w - x * x; r.m[1][2] = y * z + z * y - w * x - x * w;
+    r.m[2][0] = z * x - y * w + x * z - w * y; r.m[2][1] = z * y + y * z + x * w + w * x; r.m[2][2] = z * z - y * y - x * x + w * w;
+    return r;
+}
+inline Q q_from_matrix(const M3& R) {           // branch on the diagonal of R^T, as pyquaternion's trace method does
+    double m[3][3];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) m[i][j] = R.m[j][i];
+    double t; Q q;
+    if (m[2][2] < 0) {
+        if (m[0][0] > m[1][1]) { t = 1 + m[0][0] - m[1][1] - m[2][2]; q = Q{m[1][2] - m[2][1], t, m[0][1] + m[1][0], m[2][0] + m[0][2]}; }
+        else { t = 1 - m[0][0] + m[1][1] - m[2][2]; q = Q{m[2][0] - m[0][2], m[0][1] + m[1][0], t, m[1][2] + m[2][1]}; }
+    } else {
+        if (m[0][0] < -m[1][1]) { t = 1 - m[0][0] - m[1][1] + m[2][2]; q = Q{m[0][1] - m[1][0], m[2][0] + m[0][2], m[1][2] + m[2][1], t}; }
+        else { t = 1 + m[0][0] + m[1][1] + m[2][2]; q = Q{t, m[1][2] - m[2][1], m[2][0] - m[0][2], m[0][1] - m[1][0]}; }
+    }
+    const double s = 0.5 / sqrt(t);
+    return Q{q.w * s, q.x * s, q.y * s, q.z * s};
+}
+inline void mat_vec(const M3& R, const double* v, double* out) {
+    for (int i = 0; i < 3; ++i) out[i] = R.m[i][0] * v[0] + R.m[i][1] * v[1] + R.m[i][2] * v[2];
+}
+// min / max over the 8 corners of Box.corners() (:140-158) for the box (center, wlh, R)
+inline void corner_extent(const double* center, const double* wlh, const M3& R, double* lo, double* hi) {
+    static const double sx[8] = {1, 1, 1, 1, -1, -1, -1, -1}, sy[8] = {1, -1, -1, 1, 1, -1, -1, 1}, sz[8] = {1, 1, -1, -1, 1, 1, -1, -1};
+    const double w = wlh[0], l = wlh[1], h = wlh[2];
+    for (int a = 0; a < 3; ++a) { lo[a] = 1e300; hi[a] = -1e300; }
+    for (int k = 0; k < 8; ++k) {
+        const double loc[3] = {l / 2 * sx[k], w / 2 * sy[k], h / 2 * sz[k]};
+        double c[3];
+        mat_vec(R, loc, c);
+        for (int a = 0; a < 3; ++a) {
+            const double v = c[a] + center[a];
+            if (v < lo[a]) lo[a] = v;
+            if (v > hi[a]) hi[a] = v;
+        }
+    }
+}
+inline void box_rotate(double* center, Q& quat, const Q& q) {      // Box.rotate (:127-130)
+    const M3 R = q_rotation_matrix(q);
+    double c[3];
+    mat_vec(R, center, c);
+    center[0] = c[0]; center[1] = c[1]; center[2] = c[2];
+    quat = q_mul(q, quat);
+}
+}  // namespace
+
+extern "C" int ptt_track_crop_bounds(const ptt_track_box* boxes, int n, double offset, double scale, const double* extra2,
+                                     ptt_crop_job* jobs_host, int job_stride) {
+    if (n < 0 || job_stride < 1) return fail(PTT_EINVAL, "ptt_track_crop_bounds: n=%d job_stride=%d", n, job_stride);
+    if (n == 0) return PTT_OK;
+    if (!boxes || !jobs_host) return fail(PTT_EINVAL, "ptt_track_crop_bounds: null pointer");
+    for (int i = 0; i < n; ++i) {
+        const ptt_track_box& b = boxes[i];
+        ptt_crop_job& j = jobs_host[(size_t)i * job_stride];
+        const Q q{b.quat[0], b.quat[1], b.quat[2], b.quat[3]};
+        const M3 R = q_rotation_matrix(q);
+        const double wlh1[3] = {b.wlh[0] * (4 * scale), b.wlh[1] * (4 * scale), b.wlh[2] * (4 * scale)};
+        corner_extent(b.center, wlh1, R, j.lo1, j.hi1);
+        for (int a = 0; a < 3; ++a) { j.lo1[a] -= 2 * offset; j.hi1[a] += 2 * offset; j.trans[a] = -b.center[a]; }
+        M3 Rt;
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { Rt.m[r][c] = R.m[c][r]; j.rot[r * 3 + c] = R.m[c][r]; }
+        double nc[3] = {b.center[0] + j.trans[0], b.center[1] + j.trans[1], b.center[2] + j.trans[2]};
+        Q nq = q;
+        box_rotate(nc, nq, q_from_matrix(Rt));
+        const double wlh2[3] = {b.wlh[0] * scale, b.wlh[1] * scale, b.wlh[2] * scale};
+        corner_extent(nc, wlh2, q_rotation_matrix(nq), j.lo2, j.hi2);
+        const double off2 = offset + (extra2 ? extra2[i] : 0.0);
+        for (int a = 0; a < 3; ++a) { j.lo2[a] -= off2; j.hi2[a] += off2; }
+    }
+    return PTT_OK;
+}
+
+extern "C" int ptt_track_box_by_offset(ptt_track_box* boxes, int n, float* offsets, int offset_stride, int use_z,
+                                       const int32_t* active, int64_t* rng_pos) {
+    if (n < 0 || offset_stride < 4) return fail(PTT_EINVAL, "ptt_track_box_by_offset: n=%d offset_stride=%d", n, offset_stride);
+    if (n == 0) return PTT_OK;
+    if (!boxes || !offsets) return fail(PTT_EINVAL, "ptt_track_box_by_offset: null pointer");
+    const double kPi = 3.141592653589793;
+    for (int i = 0; i < n; ++i) {
+        if (active && !active[i]) continue;
+        ptt_track_box& b = boxes[i];
+        float* off = offsets + (size_t)i * offset_stride;
+        Q quat{b.quat[0], b.quat[1], b.quat[2], b.quat[3]};
+        const Q rot_quat = q_from_matrix(q_rotation_matrix(quat));
+        const double trans[3] = {b.center[0], b.center[1], b.center[2]};
+        double c[3] = {b.center[0] - trans[0], b.center[1] - trans[1], b.center[2] - trans[2]};
+        box_rotate(c, quat, q_inverse(rot_quat));
+        // offset[-1] * np.pi / 180 on a float32 element: float32 product, then float32 quotient (numpy >= 2 promotion)
+        const float ang32 = (off[3] * (float)kPi) / 180.0f;     // python scalars are weak: pi and 180 enter as float32
+        const double theta = (double)ang32 / 2.0;
+        box_rotate(c, quat, Q{cos(theta), 0.0, 0.0, sin(theta)});
+        for (int a = 0; a < 2; ++a) {
+            const double lim = (a == 0) ? b.wlh[0] : (b.wlh[1] < 2.0 ? b.wlh[1] : 2.0);
+            if ((double)off[a] > lim) {
+                uint32_t d[2] = {0, 0};
+                if (rng_pos) {
+                    // outputs rng_pos[i], rng_pos[i] + 1 of MT19937(1): regenerate the prefix (a few thousand outputs, rare branch)
+                    const int64_t pos = rng_pos[i];
+                    const int cnt = (int)pos + 2;
+                    uint32_t* buf = (uint32_t*)malloc((size_t)cnt * sizeof(uint32_t));
+                    if (!buf) return fail(PTT_EINVAL, "ptt_track_box_by_offset: out of memory");
+                    mt19937_fill(1u, buf, cnt);
+                    d[0] = buf[pos]; d[1] = buf[pos + 1];
+                    free(buf);
+                    rng_pos[i] = pos + 2;
+                }
+                // RandomState.uniform(-1, 1) = -1 + 2 * random_sample(), random_sample from two 32-bit outputs (53 bits)
+                const double u = ((double)(d[0] >> 5) * 67108864.0 + (double)(d[1] >> 6)) / 9007199254740992.0;
+                off[a] = (float)(-1.0 + 2.0 * u);
+            }
+        }
+        c[0] += (double)off[0]; c[1] += (double)off[1]; c[2] += use_z ? (double)off[2] : 0.0;
+        box_rotate(c, quat, rot_quat);
+        b.center[0] = c[0] + trans[0]; b.center[1] = c[1] + trans[1]; b.center[2] = c[2] + trans[2];
+        b.quat[0] = quat.w; b.quat[1] = quat.x; b.quat[2] = quat.y; b.quat[3] = quat.z;
+    }
+    return PTT_OK;
 }
 
 extern "C" int ptt_select_box_f32(const float* pred_box_data, int B, int P, float* out, int32_t* idx_out,

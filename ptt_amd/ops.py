@@ -477,6 +477,28 @@ REGULARIZE_JOB = np.dtype([('seg', '<u8', 4), ('seg_count', '<u8', 4), ('seg_cap
                            ('info', '<u8'), ('n_seg', '<i4'), ('input_size', '<i4')])   # = ptt_regularize_job, 104 bytes
 assert CROP_JOB.itemsize == ctypes.sizeof(_lib.CropJob) and REGULARIZE_JOB.itemsize == ctypes.sizeof(_lib.RegularizeJob)
 
+TRACK_BOX = np.dtype([('center', '<f8', 3), ('wlh', '<f8', 3), ('quat', '<f8', 4)])     # = ptt_track_box, 80 bytes
+
+
+def track_crop_bounds(boxes, offset, scale, extra2, jobs, job_stride=1):
+    """ptt_track_crop_bounds: the float64 crop quantities of crop_center_pc for every box (TRACK_BOX array) into the
+    lo1/hi1/trans/rot/lo2/hi2 fields of jobs[i * job_stride] (a CROP_JOB array, typically a view of pinned memory)."""
+    ex = None if extra2 is None else np.ascontiguousarray(extra2, np.float64)
+    _lib.check(_lib.lib().ptt_track_crop_bounds(boxes.ctypes.data, len(boxes), float(offset), float(scale),
+                                                ex.ctypes.data if ex is not None else None, jobs.ctypes.data,
+                                                int(job_stride)), "ptt_track_crop_bounds")
+
+
+def track_box_by_offset(boxes, offsets, use_z, active=None, rng_pos=None):
+    """ptt_track_box_by_offset: boxes[i] <- get_box_by_offset(boxes[i], offsets[i, 0:4], use_z) in place (TRACK_BOX array,
+    float32 (n, >=4) C-contiguous offsets, optional int32 active mask and int64 generator positions)."""
+    assert offsets.dtype == np.float32 and offsets.flags['C_CONTIGUOUS'] and offsets.shape[1] >= 4
+    _lib.check(_lib.lib().ptt_track_box_by_offset(boxes.ctypes.data, len(boxes), offsets.ctypes.data, offsets.shape[1],
+                                                  int(bool(use_z)), active.ctypes.data if active is not None else None,
+                                                  rng_pos.ctypes.data if rng_pos is not None else None),
+               "ptt_track_box_by_offset")
+
+
 _mt_tables = {}
 
 

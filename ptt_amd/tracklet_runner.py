@@ -10,12 +10,12 @@ tracklets are independent.
 TrackletRunner keeps the clouds of up to `batch` tracklets resident in HBM and advances them in LOCKSTEP, one frame of
 every tracklet per step:
 
-    host    crop bounds of B boxes (float64, vectorised numpy)            -> two small job tables, one pinned upload
+    host    crop bounds of B boxes (float64, ptt_track_crop_bounds)       -> one job table in pinned memory, one upload
     device  ptt_crop_compact_f32   2B jobs: search crop, previous-frame template crop     (1 launch)
             ptt_regularize_f32     2B jobs: resample to 1024 / 512 straight into the model's input buffers (1 launch)
             the tracker forward for the B frames                                           (hipGraph replay)
             ptt_select_box_f32     best proposal of each frame                             (inside the graph)
-    host    one (B,5) + (B,2,2) read-back, float64 box update of B boxes (get_box_by_offset)
+    host    one (B,5) + (B,2,2) read-back, float64 box update of B boxes (ptt_track_box_by_offset)
 
 At batch = 1 this is the reference's own mode (one tracklet, one frame at a time) with the per-frame PCIe traffic cut
 to ~0.5 KB; at batch = 48 it is the throughput mode for evaluating a dataset's tracklets.
@@ -27,7 +27,6 @@ import numpy as np
 import torch
 
 from . import ops
-from .datasets.kitti import box_math as bm
 from .hot_path import GraphedHotPath, TrackerThroughput
 
 
@@ -62,13 +61,15 @@ class TrackletRunner(object):
         self.counts = torch.zeros((B, 3), dtype=torch.int32, device=dev)          # search, first-frame, previous-frame
         self.info = torch.zeros((B, 2, 2), dtype=torch.int32, device=dev)         # (n, draws used) of search / template
         self.crop_jobs_dev = torch.zeros(2 * B * ops.CROP_JOB.itemsize, dtype=torch.uint8, device=dev)
+        self.crop_jobs_host = torch.zeros(2 * B * ops.CROP_JOB.itemsize, dtype=torch.uint8).pin_memory()   # staging: the
+        self.crop_jobs_host_np = self.crop_jobs_host.numpy().view(ops.CROP_JOB)   # host waits for every step's result
+        #                                                                           before it rewrites the table
         self.reg_jobs_dev = torch.zeros(2 * B * ops.REGULARIZE_JOB.itemsize, dtype=torch.uint8, device=dev)
         self.draws = ops.mt19937_draws(dev, max(8192, 4 * max(self.S, self.T) + 1024))
         self.result_host = torch.empty((B, 5), dtype=torch.float32).pin_memory()
         self.info_host = torch.empty((B, 2, 2), dtype=torch.int32).pin_memory()
         self._model = _BoxedForward(tracker)
         self._graph = None
-        self._rng = [np.random.RandomState(1) for _ in range(B)]    # mirrors numpy's global generator per tracklet
 
     # ------------------------------------------------------------------ device buffers of one group of tracklets
     def _load(self, tracklets):
@@ -112,20 +113,21 @@ class TrackletRunner(object):
         t['info'] = self.info.data_ptr() + np.arange(B) * 16 + 8
         ops.upload_jobs(rj, self.reg_jobs_dev)
 
-    def _crop_jobs(self, frame_a, params_a, slot_a, frame_b, params_b, slot_b):
-        """The 2B-entry crop table of one step: job 2b = cloud `frame_a` of tracklet b cropped with params_a into slot_a,
-        job 2b+1 likewise (frame None or a finished tracklet: an empty job -> count 0 -> an all-zero resampled cloud)."""
-        jobs = np.zeros(2 * self.B, ops.CROP_JOB)
-        for half, frame, params, slot in ((jobs[0::2], frame_a, params_a, slot_a), (jobs[1::2], frame_b, params_b, slot_b)):
-            half['out'], half['count'], half['capacity'] = self.out_ptr[:, slot], self.cnt_ptr[:, slot], self.cap
+    def _crop_jobs(self, frame_a, slot_a, cfg_a, frame_b, slot_b, cfg_b):
+        """The 2B-entry crop table of one step, built in the pinned staging buffer and copied to the device: job 2b =
+        cloud `frame_a` of tracklet b cropped around the tracklet's current box into slot_a, job 2b+1 likewise (frame
+        None / past the tracklet's end: an empty job -> count 0 -> an all-zero resampled cloud). cfg = (offset, scale,
+        extra2 | None); the float64 bounds come from ptt_track_crop_bounds (microseconds for 48 boxes)."""
+        jobs = self.crop_jobs_host_np
+        for k, (frame, slot, cfg) in enumerate(((frame_a, slot_a, cfg_a), (frame_b, slot_b, cfg_b))):
+            half = jobs[k::2]
+            half['out'], half['count'] = self.out_ptr[:, slot], self.cnt_ptr[:, slot]
             if frame is None or frame >= self.ptr.shape[0]:
-                half['points'] = self.crop_out.data_ptr()
+                half['points'], half['n_points'] = self.crop_out.data_ptr(), 0
                 continue
             half['points'], half['ld'], half['n_points'] = self.ptr[frame], self.ld[frame], self.npts[frame]
-            for key in ('lo1', 'hi1', 'trans', 'lo2', 'hi2'):
-                half[key] = params[key]
-            half['rot'] = params['rot'].reshape(self.B, 9)
-        return jobs
+            ops.track_crop_bounds(self.boxes, cfg[0], cfg[1], cfg[2], half, job_stride=2)
+        self.crop_jobs_dev.copy_(self.crop_jobs_host, non_blocking=True)
 
     # ------------------------------------------------------------------ one group in lockstep
     def _run_group(self, tracklets):
@@ -133,28 +135,28 @@ class TrackletRunner(object):
         n = len(tracklets)
         self._load(tracklets)
         lengths = np.array([len(c) for c, _ in tracklets] + [0] * (B - n))
-        center = np.zeros((B, 3)); wlh = np.ones((B, 3)); quat = np.tile(np.array([1.0, 0, 0, 0]), (B, 1))
-        gt_wlh1 = np.zeros((int(lengths.max()), B))
-        for b, (_, boxes) in enumerate(tracklets):
-            center[b], wlh[b], quat[b] = boxes[0][0], boxes[0][1], boxes[0][2]
-            for i, bx in enumerate(boxes):
+        T = int(lengths.max())
+        boxes = self.boxes = np.zeros(B, ops.TRACK_BOX)
+        boxes['wlh'], boxes['quat'][:, 0] = 1.0, 1.0
+        gt_wlh1 = np.zeros((T, B))
+        for b, (_, gts) in enumerate(tracklets):
+            boxes['center'][b], boxes['wlh'][b], boxes['quat'][b] = gts[0][0], gts[0][1], gts[0][2]
+            for i, bx in enumerate(gts):
                 gt_wlh1[i, b] = bx[1][1]
-        results = [[(center[b].copy(), wlh[b].copy(), quat[b].copy())] for b in range(n)]
+        self.crop_jobs_host_np['capacity'] = self.cap
+        results = [[(boxes['center'][b].copy(), boxes['wlh'][b].copy(), boxes['quat'][b].copy())] for b in range(n)]
+        rng_pos = np.zeros(B, np.int64)            # where numpy's global generator stands for each tracklet
+        model_cfg = (self.model_offset, self.model_scale, None)
 
         # frame 0: the first-frame template crop (get_model's first segment) is fixed for the whole tracklet
-        p0 = bm.crop_bounds(center, wlh, quat, self.model_offset, self.model_scale, 0.0)
-        ops.upload_jobs(self._crop_jobs(0, p0, 1, None, p0, 2), self.crop_jobs_dev)
+        self._crop_jobs(0, 1, model_cfg, None, 2, model_cfg)
         ops.crop_compact(self.crop_jobs_dev, 2 * B)
 
-        for i in range(1, int(lengths.max())):
-            active = np.nonzero(i < lengths)[0]
+        for i in range(1, T):
+            active = (i < lengths).astype(np.int32)
             # both crops of frame i are taken around the previous RESULT box (prepare_search :156-157, prepare_template
             # :189-194 with results_BBs[frame_id - 1]); a finished tracklet's later frames have n_points 0
-            ps = bm.crop_bounds(center, wlh, quat, self.search_offset, self.search_scale, gt_wlh1[i] * 0.6)
-            pt = bm.crop_bounds(center, wlh, quat, self.model_offset, self.model_scale, 0.0)
-            jobs = self._crop_jobs(i, ps, 0, i - 1, pt, 2)
-            jobs['n_points'][1::2][lengths <= i] = 0
-            ops.upload_jobs(jobs, self.crop_jobs_dev)
+            self._crop_jobs(i, 0, (self.search_offset, self.search_scale, gt_wlh1[i] * 0.6), i - 1, 2, model_cfg)
             ops.crop_compact(self.crop_jobs_dev, 2 * B)
             ops.regularize(self.reg_jobs_dev, 2 * B, self.draws)
             rows = self._forward()
@@ -163,9 +165,14 @@ class TrackletRunner(object):
             torch.cuda.current_stream(self.device).synchronize()
             est = self.result_host.numpy()                        # (B,5) float32: x, y, z, theta (degrees), score
             info = self.info_host.numpy()
-            center, quat = self._advance(center, wlh, quat, est, info, active)
-            for b in active:
-                results[b].append((center[b].copy(), wlh[b].copy(), quat[b].copy(), float(est[b, 4])))
+            # post_process (:266-274): box_i = get_box_by_offset(box_{i-1}, best proposal, USE_Z_AXIS). An implausibly
+            # large x / y offset is redrawn from numpy's GLOBAL generator (:205-208), whose state then is "seeded with 1
+            # and advanced by the template's (else the search's) resampling draws" — the draw counts come back with the boxes
+            used = np.where(info[:, 1, 1] > 0, info[:, 1, 1], info[:, 0, 1])
+            rng_pos = np.where(used > 0, used, rng_pos).astype(np.int64)
+            ops.track_box_by_offset(boxes, est, self.use_z, active, rng_pos)
+            for b in np.nonzero(active)[0]:
+                results[b].append((boxes['center'][b].copy(), boxes['wlh'][b].copy(), boxes['quat'][b].copy(), float(est[b, 4])))
         return results
 
     def _ensure_graph(self):
@@ -182,35 +189,6 @@ class TrackletRunner(object):
                 return self._model(self.search, self.template)
             return self._graph()                                  # inputs are already in the graph's static buffers
 
-    def _advance(self, center, wlh, quat, est, info, active):
-        """post_process (:266-274): box_{i} = get_box_by_offset(box_{i-1}, best proposal's (x, y, z, theta), USE_Z_AXIS).
-        The reference redraws an implausibly large x / y offset from numpy's GLOBAL generator (:205-208), whose state at
-        that moment is "seeded with 1, then advanced by the template's (else the search's) resampling draws": the
-        per-tracklet generators reproduce exactly that from the draw counts the resampling kernel reports."""
-        new_c, new_q = center.copy(), quat.copy()
-        if len(active) == 0:
-            return new_c, new_q
-        idx = np.asarray(active)
-        for b in active:
-            used = int(info[b, 1, 1]) or int(info[b, 0, 1])
-            if used:
-                self._rng[b].seed(1)
-                self._rng[b].randint(0, 2 ** 32, used, dtype=np.uint32)          # one 32-bit output per draw
-        def uniform_for(b):
-            return lambda: self._rng[b].uniform(-1, 1)
-
-        # the redraw branch is rare: resolve it box by box only where it triggers, vectorise the rest
-        big = (est[idx, 0] > wlh[idx, 0]) | (est[idx, 1] > np.minimum(wlh[idx, 1], 2))
-        plain = idx[~big]
-        if plain.size:
-            c, q, _ = bm.get_box_by_offset(center[plain], wlh[plain], quat[plain], est[plain, 0:4], self.use_z)
-            new_c[plain], new_q[plain] = c, q
-        for b in idx[big]:
-            c, q, _ = bm.get_box_by_offset(center[b:b + 1], wlh[b:b + 1], quat[b:b + 1], est[b:b + 1, 0:4].copy(),
-                                           self.use_z, uniform=uniform_for(b))
-            new_c[b], new_q[b] = c[0], q[0]
-        return new_c, new_q
-
     # ------------------------------------------------------------------ public
     def run(self, tracklets):
         """tracklets: list of (clouds, boxes) as in `_load`. Returns, per tracklet, the list of result boxes
@@ -218,7 +196,5 @@ class TrackletRunner(object):
         (eval_tracking_utils.py:96-100)."""
         out = []
         for g in range(0, len(tracklets), self.B):
-            for b in range(self.B):
-                self._rng[b] = np.random.RandomState(1)
             out.extend(self._run_group(tracklets[g:g + self.B]))
         return out

@@ -100,3 +100,46 @@ def test_job_tables_mirror_the_c_structs():
     assert _lib.lib().ptt_mt19937_fill(1, draws.ctypes.data, 64) == 0
     np.random.seed(1)
     np.testing.assert_array_equal(draws, np.random.randint(0, 2 ** 32, 64, dtype=np.uint32))
+
+
+def test_c_host_box_math_equals_the_numpy_restatement():
+    """ptt_track_crop_bounds / ptt_track_box_by_offset (the per-step host helpers TrackletRunner calls) against
+    box_math.py on 48 random boxes, incl. the redraw branch with the generator position bookkeeping."""
+    from ptt_amd import ops
+    rs = np.random.RandomState(5)
+    B = 48
+    boxes = np.zeros(B, ops.TRACK_BOX)
+    boxes['center'] = rs.standard_normal((B, 3)) * 5
+    boxes['wlh'] = np.abs(rs.standard_normal((B, 3))) + 1
+    q = rs.standard_normal((B, 4))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    q[:24] = bm.q_from_axis_angle(np.tile([0, 0, 1.], (24, 1)), rs.uniform(-3, 3, 24))
+    boxes['quat'] = q
+    extra = np.abs(rs.standard_normal(B))
+    jobs = np.zeros(2 * B, ops.CROP_JOB)
+    ops.track_crop_bounds(boxes, 0.1, 1.25, extra, jobs[1::2], job_stride=2)
+    p = bm.crop_bounds(boxes['center'], boxes['wlh'], boxes['quat'], 0.1, 1.25, extra)
+    for k in ('lo1', 'hi1', 'trans', 'lo2', 'hi2'):
+        np.testing.assert_allclose(jobs[k][1::2], p[k], rtol=0, atol=1e-13, err_msg=k)
+        assert not jobs[k][0::2].any()
+    np.testing.assert_allclose(jobs['rot'][1::2], p['rot'].reshape(B, 9), rtol=0, atol=1e-15)
+
+    est = (rs.standard_normal((B, 5)) * 0.3).astype(np.float32)
+    est[3, 0], est[5, 1] = 9.0, 7.0
+    est[7, :2] = 5.0
+    active = np.ones(B, np.int32)
+    active[11] = 0
+    got, e2, pos = boxes.copy(), est.copy(), np.full(B, 1500, np.int64)
+    ops.track_box_by_offset(got, e2, True, active, pos)
+    for b in range(B):
+        if not active[b]:
+            assert got[b] == boxes[b]
+            continue
+        r = np.random.RandomState(1)
+        r.randint(0, 2 ** 32, 1500, dtype=np.uint32)            # numpy's generator after 1500 32-bit outputs
+        c, qq, used = bm.get_box_by_offset(boxes['center'][b:b + 1], boxes['wlh'][b:b + 1], boxes['quat'][b:b + 1],
+                                           est[b:b + 1, :4].copy(), True, uniform=lambda: r.uniform(-1, 1))
+        np.testing.assert_allclose(got['center'][b], c[0], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(got['quat'][b], qq[0], rtol=0, atol=1e-14)
+        np.testing.assert_array_equal(e2[b, :4], used[0].astype(np.float32))
+    assert pos[3] == pos[5] == 1502 and pos[7] == 1504 and pos[0] == 1500
