@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PTT_ABI_VERSION 5
+#define PTT_ABI_VERSION 6
 
 enum {
     PTT_OK = 0,
@@ -347,6 +347,41 @@ int ptt_track_box_by_offset(ptt_track_box* boxes, int n, float* offsets, int off
  * pred_box_data (B,P,5) with the largest score (column 4; first one among equals, as np.argmax) -> out (B,5);
  * idx_out (B) receives its index, or NULL. */
 int ptt_select_box_f32(const float* pred_box_data, int B, int P, float* out, int32_t* idx_out, ptt_stream_t stream);
+
+/* ---------------------------------------------------------------------------------
+ * N3  training step of the shared-MLP stages on hand-written kernels. The reference's SharedMLP in train mode is
+ * [1x1 conv (no bias) -> BatchNorm with batch statistics -> ReLU] x 3 followed by a max over the neighbour axis
+ * (pytorch_utils.py:12-36,94-114; pointnet2_modules.py:84-88; similarity_modules/p2b_xcoor.py:39-41), and
+ * loss.backward() (tools/train_utils/train_utils.py:47-48) runs their backward. Activations are (R, C) ROWS (one row
+ * per (centre, neighbour) position, channels contiguous): the convolution and its input gradient are ptt_linear_f32,
+ * the rest is below. Every reduction runs in a fixed order (float64 partials per 2048 / 4096-row chunk, combined in
+ * chunk order): bit-reproducible.
+ *
+ * ptt_bn_stats_f32      per-channel batch statistics of X (R,C): mean, BIASED variance, invstd = 1/sqrt(var + eps)
+ *                       (BatchNorm2d forward in train mode; the caller updates running_mean / running_var).
+ * ptt_bn_apply_f32      X = relu?((Z - mean) * invstd * gamma + beta)
+ * ptt_bn_bwd_f32        backward of BatchNorm(train) + ReLU: dy = G where Act > 0 else 0; dbeta = sum dy;
+ *                       dgamma = sum dy * xhat; dZ = gamma * invstd * (dy - dbeta / R - xhat * dgamma / R).
+ * ptt_pool_rows_f32     out[g,c] = max_k X[g*ns + k, c], arg = first arg-max   (F.max_pool2d over the neighbour axis)
+ * ptt_pool_rows_bwd_f32 dX[g*ns + k, c] = dOut[g,c] if k == arg[g,c] else 0
+ * ptt_linear_wgrad_f32  dW[o,i] (+)= sum_r dZ[r,o] * X[r,i] on fp32 MFMA (the weight gradient of a 1x1 convolution /
+ *                       nn.Linear over R rows), split over 4096-row chunks.
+ * ------------------------------------------------------------------------------- */
+size_t ptt_bn_stats_workspace(int R, int C);
+int ptt_bn_stats_f32(const float* X, int R, int C, int ldx, float eps, float* mean, float* var, float* invstd,
+                     void* workspace, size_t workspace_bytes, ptt_stream_t stream);
+int ptt_bn_apply_f32(const float* Z, int ldz, const float* mean, const float* invstd, const float* gamma,
+                     const float* beta, int R, int C, int relu, float* X, int ldx, ptt_stream_t stream);
+int ptt_bn_bwd_f32(const float* G, int ldg, const float* Act, int lda, const float* Z, int ldz, const float* mean,
+                   const float* invstd, const float* gamma, int R, int C, int relu, float* dZ, int ldd,
+                   float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, ptt_stream_t stream);
+int ptt_pool_rows_f32(const float* X, int ldx, int G, int ns, int C, float* out, int ldo, int32_t* arg,
+                      ptt_stream_t stream);
+int ptt_pool_rows_bwd_f32(const float* dOut, int ldo, const int32_t* arg, int G, int ns, int C, float* dX, int ldx,
+                          ptt_stream_t stream);
+size_t ptt_linear_wgrad_workspace(int R, int Cout, int Cin);
+int ptt_linear_wgrad_f32(const float* dZ, int ldz, const float* X, int ldx, int R, int Cout, int Cin, float* dW,
+                         int accumulate, void* workspace, size_t workspace_bytes, ptt_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libptt_hip.so")
 
 PTT_SA_MAX_LAYERS = 4
-ABI_VERSION = 5            # PTT_ABI_VERSION of include/ptt_hip.h these structures mirror
+ABI_VERSION = 6            # PTT_ABI_VERSION of include/ptt_hip.h these structures mirror
 
 # every symbol include/ptt_hip.h declares (tests check the library exports all of them)
 EXPORTS = [
@@ -22,6 +22,8 @@ EXPORTS = [
     "ptt_sa_fused_fwd_f32", "ptt_xcorr_fused_fwd_f32", "ptt_cosine_map_f32", "ptt_pt_attn_pair_f32",
     "ptt_crop_compact_f32", "ptt_regularize_f32", "ptt_mt19937_fill", "ptt_select_box_f32",
     "ptt_track_crop_bounds", "ptt_track_box_by_offset",
+    "ptt_bn_stats_workspace", "ptt_bn_stats_f32", "ptt_bn_apply_f32", "ptt_bn_bwd_f32", "ptt_pool_rows_f32",
+    "ptt_pool_rows_bwd_f32", "ptt_linear_wgrad_workspace", "ptt_linear_wgrad_f32",
 ]
 PTT_MAX_SEGMENTS = 4
 
@@ -108,6 +110,12 @@ def _declare(lib):
         "ptt_select_box_f32": [vp, i, i, vp, vp, vp],
         "ptt_track_crop_bounds": [vp, i, c_double, c_double, vp, vp, i],
         "ptt_track_box_by_offset": [vp, i, vp, i, i, vp, vp],
+        "ptt_bn_stats_f32": [vp, i, i, i, f, vp, vp, vp, vp, c_size_t, vp],
+        "ptt_bn_apply_f32": [vp, i, vp, vp, vp, vp, i, i, i, vp, i, vp],
+        "ptt_bn_bwd_f32": [vp, i, vp, i, vp, i, vp, vp, vp, i, i, i, vp, i, vp, vp, vp, c_size_t, vp],
+        "ptt_pool_rows_f32": [vp, i, i, i, i, vp, i, vp, vp],
+        "ptt_pool_rows_bwd_f32": [vp, i, vp, i, i, i, vp, i, vp],
+        "ptt_linear_wgrad_f32": [vp, i, vp, i, i, i, i, vp, i, vp, c_size_t, vp],
     }
     for name, args in sigs.items():
         fn = getattr(lib, name)
@@ -117,6 +125,10 @@ def _declare(lib):
     lib.ptt_packed_weight_elems.argtypes = [i, i]
     lib.ptt_scatter_add_det_workspace.restype = c_size_t
     lib.ptt_scatter_add_det_workspace.argtypes = [i, i, i]
+    lib.ptt_bn_stats_workspace.restype = c_size_t
+    lib.ptt_bn_stats_workspace.argtypes = [i, i]
+    lib.ptt_linear_wgrad_workspace.restype = c_size_t
+    lib.ptt_linear_wgrad_workspace.argtypes = [i, i, i]
 
 
 def lib():

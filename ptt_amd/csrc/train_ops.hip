@@ -1,0 +1,573 @@
+// N3: hand-written kernels of the TRAINING step for the shared-MLP stages (set-abstraction levels,
+// CosineSimAug): 1x1 convolution -> BatchNorm with BATCH statistics -> ReLU, three times, then a max over the
+// neighbour axis — the reference's SharedMLP + F.max_pool2d in train mode (pytorch_utils.py:12-36,94-114,
+// pointnet2_modules.py:84-88) and their backward (tools/train_utils/train_utils.py:47-48, loss.backward()).
+//
+// Layout: activations are ROWS x CHANNELS ("point-major", one row per (centre, neighbour) position), so that
+//   * the convolution is ptt_linear_f32 on the fp32-MFMA linear kernel (forward and the input gradient),
+//   * the weight gradient is one more MFMA GEMM over the row axis (linear_wgrad_kernel below),
+//   * BatchNorm statistics are column reductions, coalesced over channels, in a FIXED order: per-workgroup partial sums
+//     in float64, combined by a single finalising workgroup in chunk order — bit-reproducible run to run, which
+//     torch's / MIOpen's atomics-free-but-layout-dependent kernels do not promise across versions,
+//   * no NCHW <-> NHWC transposes exist (the stock step spends 6 % of its time in batched_transpose kernels).
+#include <math.h>
+#include "common.h"
+
+namespace ptt {
+
+typedef float f32x4t __attribute__((ext_vector_type(4)));
+typedef float f32x16t __attribute__((ext_vector_type(16)));
+
+constexpr int ST_ROWS = 2048;       // rows per workgroup of the column-statistics kernels
+
+// ------------------------------------------------------------------------------------------
+// Column statistics. MODE 0: s0 = sum x, s1 = sum x^2.
+//                    MODE 1: BatchNorm+ReLU backward sums — dy = g where the ReLU passed (act > 0), else 0;
+//                            s0 = sum dy, s1 = sum dy * xhat, xhat = (z - mean) * invstd.
+// One workgroup = 256 threads = 4 row groups x 64 column lanes; thread (rg, lane) visits rows rg, rg+4, ... of its
+// chunk and columns lane, lane+64, ...; float64 accumulation; partial[chunk][2][C].
+// ------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void col_stats_kernel(const float* __restrict__ X, const float* __restrict__ Act,
+                                                        const float* __restrict__ Z, const float* __restrict__ mean,
+                                                        const float* __restrict__ invstd, int R, int C, int ldx, int lda,
+                                                        int ldz, double* __restrict__ partial) {
+    __shared__ double red[2][4][64];
+    const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int r0 = blockIdx.x * ST_ROWS, r1 = min(R, r0 + ST_ROWS);
+    for (int cg = 0; cg * 64 < C; ++cg) {
+        const int c = cg * 64 + lane;
+        double s0 = 0.0, s1 = 0.0;
+        if (c < C) {
+            float mu = 0.f, is = 0.f;
+            if (MODE == 1) { mu = mean[c]; is = invstd[c]; }
+            for (int r = r0 + rg; r < r1; r += 4) {
+                const float x = X[(size_t)r * ldx + c];
+                if (MODE == 0) {
+                    s0 += (double)x;
+                    s1 += (double)x * (double)x;
+                } else {
+                    const float dy = Act[(size_t)r * lda + c] > 0.f ? x : 0.f;
+                    const float xh = (Z[(size_t)r * ldz + c] - mu) * is;
+                    s0 += (double)dy;
+                    s1 += (double)dy * (double)xh;
+                }
+            }
+        }
+        red[0][rg][lane] = s0;
+        red[1][rg][lane] = s1;
+        __syncthreads();
+        if (rg == 0 && c < C) {
+            partial[((size_t)blockIdx.x * 2 + 0) * C + c] = ((red[0][0][lane] + red[0][1][lane]) + red[0][2][lane]) + red[0][3][lane];
+            partial[((size_t)blockIdx.x * 2 + 1) * C + c] = ((red[1][0][lane] + red[1][1][lane]) + red[1][2][lane]) + red[1][3][lane];
+        }
+        __syncthreads();
+    }
+}
+
+// Combine the partials in chunk order. MODE 0: mean, biased variance, invstd = 1/sqrt(var + eps).
+//                                     MODE 1: the two sums themselves as float (out0 = sum dy, out1 = sum dy*xhat).
+template <int MODE>
+__global__ __launch_bounds__(256) void col_stats_finish_kernel(const double* __restrict__ partial, int nchunks, int C, int R,
+                                                               float eps, float* __restrict__ out0, float* __restrict__ out1,
+                                                               float* __restrict__ out2) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double s0 = 0.0, s1 = 0.0;
+    for (int k = 0; k < nchunks; ++k) {
+        s0 += partial[((size_t)k * 2 + 0) * C + c];
+        s1 += partial[((size_t)k * 2 + 1) * C + c];
+    }
+    if (MODE == 0) {
+        const double mu = s0 / (double)R;
+        double var = s1 / (double)R - mu * mu;
+        if (var < 0.0) var = 0.0;
+        out0[c] = (float)mu;
+        out1[c] = (float)var;
+        out2[c] = (float)(1.0 / sqrt(var + (double)eps));
+    } else {
+        out0[c] = (float)s0;
+        out1[c] = (float)s1;
+    }
+}
+
+// Vectorised forms for C % 4 == 0, 16-byte aligned rows (every conv OUTPUT of the shipped networks: 64 / 128 / 256
+// channels). A workgroup covers ST4_ROWS rows; thread (rg, q) owns the channel quad q of the rows rg, rg + RG, ...
+// (RG = 256 / quads-per-row threads side by side read whole rows, coalesced float4s); float64 accumulation; the RG
+// row groups are combined through LDS in a fixed order.
+constexpr int ST4_ROWS = 256;
+
+template <int MODE>
+__global__ __launch_bounds__(256) void col_stats4_kernel(const float* __restrict__ X, const float* __restrict__ Act,
+                                                         const float* __restrict__ Z, const float* __restrict__ mean,
+                                                         const float* __restrict__ invstd, int R, int C, int ldx, int lda,
+                                                         int ldz, double* __restrict__ partial) {
+    extern __shared__ double red4[];                       // [256][8]
+    const int Cq = C >> 2;                                  // quads per row
+    const int span = Cq < 256 ? Cq : 256;                   // threads side by side on one row
+    const int RG = 256 / span;                              // rows in flight per pass
+    const int q0 = threadIdx.x % span, rg = threadIdx.x / span;
+    const int r0 = blockIdx.x * ST4_ROWS, r1 = min(R, r0 + ST4_ROWS);
+    for (int qb = 0; qb < Cq; qb += span) {                 // one pass unless C > 1024
+        const int q = qb + q0;
+        double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+        if (q < Cq && rg < RG) {
+            f32x4t mu = {0, 0, 0, 0}, is = {0, 0, 0, 0};
+            if (MODE == 1) { mu = *reinterpret_cast<const f32x4t*>(mean + 4 * q); is = *reinterpret_cast<const f32x4t*>(invstd + 4 * q); }
+            for (int r = r0 + rg; r < r1; r += RG) {
+                const f32x4t x = *reinterpret_cast<const f32x4t*>(X + (size_t)r * ldx + 4 * q);
+                if (MODE == 0) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { s0[k] += (double)x[k]; s1[k] += (double)x[k] * (double)x[k]; }
+                } else {
+                    const f32x4t a = *reinterpret_cast<const f32x4t*>(Act + (size_t)r * lda + 4 * q);
+                    const f32x4t z = *reinterpret_cast<const f32x4t*>(Z + (size_t)r * ldz + 4 * q);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float dy = a[k] > 0.f ? x[k] : 0.f;
+                        const float xh = (z[k] - mu[k]) * is[k];
+                        s0[k] += (double)dy;
+                        s1[k] += (double)dy * (double)xh;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { red4[threadIdx.x * 8 + k] = s0[k]; red4[threadIdx.x * 8 + 4 + k] = s1[k]; }
+        __syncthreads();
+        if (rg == 0 && q < Cq) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                double a = 0.0, b = 0.0;
+                for (int g = 0; g < RG; ++g) { a += red4[(g * span + q0) * 8 + k]; b += red4[(g * span + q0) * 8 + 4 + k]; }
+                partial[((size_t)blockIdx.x * 2 + 0) * C + 4 * q + k] = a;
+                partial[((size_t)blockIdx.x * 2 + 1) * C + 4 * q + k] = b;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// Second level for many chunks: workgroup = one channel, 256 threads stride over the chunks, LDS tree in a fixed order.
+template <int MODE>
+__global__ __launch_bounds__(256) void col_stats_finish2_kernel(const double* __restrict__ partial, int nchunks, int C, int R,
+                                                                float eps, float* __restrict__ out0, float* __restrict__ out1,
+                                                                float* __restrict__ out2) {
+    __shared__ double t0[256], t1[256];
+    const int c = blockIdx.x, t = threadIdx.x;
+    double s0 = 0.0, s1 = 0.0;
+    for (int k = t; k < nchunks; k += 256) {
+        s0 += partial[((size_t)k * 2 + 0) * C + c];
+        s1 += partial[((size_t)k * 2 + 1) * C + c];
+    }
+    t0[t] = s0; t1[t] = s1;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (t < w) { t0[t] += t0[t + w]; t1[t] += t1[t + w]; }
+        __syncthreads();
+    }
+    if (t == 0) {
+        if (MODE == 0) {
+            const double mu = t0[0] / (double)R;
+            double var = t1[0] / (double)R - mu * mu;
+            if (var < 0.0) var = 0.0;
+            out0[c] = (float)mu; out1[c] = (float)var; out2[c] = (float)(1.0 / sqrt(var + (double)eps));
+        } else {
+            out0[c] = (float)t0[0]; out1[c] = (float)t1[0];
+        }
+    }
+}
+
+// element-wise kernels, vector form: a workgroup walks whole rows, thread = one channel quad (no index division)
+__global__ __launch_bounds__(256) void bn_apply4_kernel(const float* __restrict__ Z, int ldz, const float* __restrict__ mean,
+                                                        const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, int R, int C, int relu,
+                                                        float* __restrict__ X, int ldx) {
+    const int Cq = C >> 2, span = Cq < 256 ? Cq : 256, RG = 256 / span;
+    const int q0 = threadIdx.x % span, rg = threadIdx.x / span;
+    if (rg >= RG) return;
+    for (int q = q0; q < Cq; q += span) {
+        const f32x4t mu = *reinterpret_cast<const f32x4t*>(mean + 4 * q), is = *reinterpret_cast<const f32x4t*>(invstd + 4 * q);
+        const f32x4t ga = *reinterpret_cast<const f32x4t*>(gamma + 4 * q), be = *reinterpret_cast<const f32x4t*>(beta + 4 * q);
+        for (int r = blockIdx.x * RG + rg; r < R; r += gridDim.x * RG) {
+            const f32x4t z = *reinterpret_cast<const f32x4t*>(Z + (size_t)r * ldz + 4 * q);
+            f32x4t y;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                y[k] = (z[k] - mu[k]) * is[k] * ga[k] + be[k];
+                if (relu) y[k] = fmaxf(y[k], 0.f);
+            }
+            *reinterpret_cast<f32x4t*>(X + (size_t)r * ldx + 4 * q) = y;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const float* __restrict__ G, int ldg, const float* __restrict__ Act,
+                                                            int lda, const float* __restrict__ Z, int ldz,
+                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                            const float* __restrict__ gamma, const float* __restrict__ s0,
+                                                            const float* __restrict__ s1, int R, int C, float* __restrict__ dZ,
+                                                            int ldd) {
+    const int Cq = C >> 2, span = Cq < 256 ? Cq : 256, RG = 256 / span;
+    const int q0 = threadIdx.x % span, rg = threadIdx.x / span;
+    if (rg >= RG) return;
+    const float rinv = 1.0f / (float)R;
+    for (int q = q0; q < Cq; q += span) {
+        const f32x4t mu = *reinterpret_cast<const f32x4t*>(mean + 4 * q), is = *reinterpret_cast<const f32x4t*>(invstd + 4 * q);
+        const f32x4t ga = *reinterpret_cast<const f32x4t*>(gamma + 4 * q);
+        const f32x4t a0 = *reinterpret_cast<const f32x4t*>(s0 + 4 * q), a1 = *reinterpret_cast<const f32x4t*>(s1 + 4 * q);
+        for (int r = blockIdx.x * RG + rg; r < R; r += gridDim.x * RG) {
+            const f32x4t g = *reinterpret_cast<const f32x4t*>(G + (size_t)r * ldg + 4 * q);
+            const f32x4t a = *reinterpret_cast<const f32x4t*>(Act + (size_t)r * lda + 4 * q);
+            const f32x4t z = *reinterpret_cast<const f32x4t*>(Z + (size_t)r * ldz + 4 * q);
+            f32x4t d;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float dy = a[k] > 0.f ? g[k] : 0.f;
+                const float xh = (z[k] - mu[k]) * is[k];
+                d[k] = ga[k] * is[k] * (dy - a0[k] * rinv - xh * (a1[k] * rinv));
+            }
+            *reinterpret_cast<f32x4t*>(dZ + (size_t)r * ldd + 4 * q) = d;
+        }
+    }
+}
+
+static inline bool vec4_ok(const void* p, int ld, int C) {
+    return (C & 3) == 0 && (ld & 3) == 0 && (reinterpret_cast<uintptr_t>(p) & 15) == 0;
+}
+
+// X = relu((Z - mean) * invstd * gamma + beta), element-wise over (R, C) rows; relu == 0: no activation.
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ Z, int ldz, const float* __restrict__ mean,
+                                                       const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, int R, int C, int relu,
+                                                       float* __restrict__ X, int ldx) {
+    const size_t total = (size_t)R * C;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const int r = (int)(e / C), c = (int)(e - (size_t)r * C);
+        float y = (Z[(size_t)r * ldz + c] - mean[c]) * invstd[c] * gamma[c] + beta[c];
+        if (relu) y = fmaxf(y, 0.f);
+        X[(size_t)r * ldx + c] = y;
+    }
+}
+
+// dZ = gamma * invstd * (dy - s0 / R - xhat * s1 / R), dy = g masked by the ReLU (act > 0) — BatchNorm backward in
+// training mode (batch statistics depend on the input).
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ G, int ldg, const float* __restrict__ Act,
+                                                           int lda, const float* __restrict__ Z, int ldz,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           const float* __restrict__ gamma, const float* __restrict__ s0,
+                                                           const float* __restrict__ s1, int R, int C, int relu,
+                                                           float* __restrict__ dZ, int ldd) {
+    const size_t total = (size_t)R * C;
+    const float rinv = 1.0f / (float)R;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const int r = (int)(e / C), c = (int)(e - (size_t)r * C);
+        float dy = G[(size_t)r * ldg + c];
+        if (relu && !(Act[(size_t)r * lda + c] > 0.f)) dy = 0.f;
+        const float xh = (Z[(size_t)r * ldz + c] - mean[c]) * invstd[c];
+        dZ[(size_t)r * ldd + c] = gamma[c] * invstd[c] * (dy - s0[c] * rinv - xh * (s1[c] * rinv));
+    }
+}
+
+// out[g, c] = max over the ns consecutive rows of group g; arg[g, c] = the first row that attains it.
+__global__ __launch_bounds__(256) void pool_rows_kernel(const float* __restrict__ X, int ldx, int G, int ns, int C,
+                                                        float* __restrict__ out, int ldo, int32_t* __restrict__ arg) {
+    const size_t total = (size_t)G * C;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const int g = (int)(e / C), c = (int)(e - (size_t)g * C);
+        const float* p = X + (size_t)g * ns * ldx + c;
+        float m = p[0];
+        int a = 0;
+        for (int k = 1; k < ns; ++k) {
+            const float v = p[(size_t)k * ldx];
+            if (v > m) { m = v; a = k; }
+        }
+        out[(size_t)g * ldo + c] = m;
+        arg[(size_t)g * C + c] = a;
+    }
+}
+
+// dX[g*ns + k, c] = dOut[g, c] if k == arg[g, c] else 0 (every element of dX is written).
+__global__ __launch_bounds__(256) void pool_rows_bwd_kernel(const float* __restrict__ dOut, int ldo, const int32_t* __restrict__ arg,
+                                                            int G, int ns, int C, float* __restrict__ dX, int ldx) {
+    const size_t total = (size_t)G * ns * C;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const size_t row = e / C;
+        const int c = (int)(e - row * C);
+        const int g = (int)(row / ns), k = (int)(row - (size_t)g * ns);
+        dX[row * ldx + c] = (arg[(size_t)g * C + c] == k) ? dOut[(size_t)g * ldo + c] : 0.f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Weight gradient of a row-wise linear layer: dW[o, i] = sum_r dZ[r, o] * X[r, i]  (and db[o] = sum_r dZ[r, o]).
+// A GEMM whose reduction axis is the ROW axis (hundreds of thousands of rows, <= 512 x 512 outputs): split over row
+// chunks, one workgroup = one 128 x 128 output block of one chunk, 4 waves x (2 x 2) MFMA tiles of 32 x 32,
+// v_mfma_f32_32x32x2_f32 (exact fp32). Both operands are k-major in memory (row r holds all channels), which is the
+// MFMA's native operand order for this product: lane (k = lane >> 5, m = lane & 31) reads dZ[r0 + 2j + k][o0 + m] —
+// 32 consecutive floats, conflict-free from the LDS tile. Partials go to a workspace and are summed in chunk order.
+// ------------------------------------------------------------------------------------------
+constexpr int WG_KC = 32;            // rows per staged sub-chunk
+constexpr int WG_LD = 132;           // LDS row stride (floats)
+constexpr int WG_ROWS = 4096;        // rows per workgroup at most (fewer when that leaves CUs idle)
+constexpr int WG_MIN_ROWS = 512;
+
+template <bool VEC>   // VEC: ld % 4 == 0 and P 16-byte aligned -> whole float4s (channels past cmax are zeroed afterwards)
+__device__ __forceinline__ void wg_fetch(const float* __restrict__ P, int ld, int r0, int rmax, int c0, int cmax, int t,
+                                         f32x4t (&st)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = t + i * 256;                  // float4 slot in the [32][128] block
+        const int r = r0 + (e >> 5), c = c0 + ((e & 31) << 2);
+        f32x4t v = {0.f, 0.f, 0.f, 0.f};
+        if (r < rmax) {
+            const float* src = P + (size_t)r * ld + c;
+            if (VEC && c + 3 < cmax) {
+                v = *reinterpret_cast<const f32x4t*>(src);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (c + q < cmax) v[q] = src[q];
+            }
+        }
+        st[i] = v;
+    }
+}
+__device__ __forceinline__ void wg_stage(float* S, int t, const f32x4t (&st)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = t + i * 256;
+        *reinterpret_cast<f32x4t*>(S + (e >> 5) * WG_LD + ((e & 31) << 2)) = st[i];
+    }
+}
+
+template <bool VZ, bool VX>
+__global__ __launch_bounds__(256, 2) void linear_wgrad_kernel(const float* __restrict__ dZ, int ldz, const float* __restrict__ X,
+                                                              int ldx, int R, int Cout, int Cin, int nbi, int chunk_rows,
+                                                              float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float wg_smem[];         // As[2][32 x 132] | Bs[2][32 x 132]: 67.6 KB
+    constexpr int WG_BUF = WG_KC * WG_LD;
+#define As(b) (wg_smem + (b) * WG_BUF)
+#define Bs(b) (wg_smem + (2 + (b)) * WG_BUF)
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, half = lane >> 5, col = lane & 31;
+    const int bo = blockIdx.x / nbi, bi = blockIdx.x - bo * nbi;       // 128-wide output-channel / input-channel block
+    const int o0 = bo * 128, i0 = bi * 128;
+    const int r_begin = blockIdx.y * chunk_rows, r_end = min(R, r_begin + chunk_rows);
+    const int wo = (w >> 1) * 64, wi = (w & 1) * 64;                   // this wave's 64 x 64 quadrant
+    f32x16t acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    f32x4t sa[4], sb[4];
+    wg_fetch<VZ>(dZ, ldz, r_begin, r_end, o0, Cout, t, sa);
+    wg_fetch<VX>(X, ldx, r_begin, r_end, i0, Cin, t, sb);
+    wg_stage(As(0), t, sa);
+    wg_stage(Bs(0), t, sb);
+    __syncthreads();
+    int buf = 0;
+    for (int r0 = r_begin; r0 < r_end; r0 += WG_KC) {
+        const bool more = r0 + WG_KC < r_end;
+        if (more) {
+            wg_fetch<VZ>(dZ, ldz, r0 + WG_KC, r_end, o0, Cout, t, sa);
+            wg_fetch<VX>(X, ldx, r0 + WG_KC, r_end, i0, Cin, t, sb);
+        }
+        const float* A = As(buf) + half * WG_LD + wo + col;
+        const float* B = Bs(buf) + half * WG_LD + wi + col;
+#pragma unroll
+        for (int j = 0; j < WG_KC / 2; ++j) {
+            const float a0 = A[2 * j * WG_LD], a1 = A[2 * j * WG_LD + 32];
+            const float b0 = B[2 * j * WG_LD], b1 = B[2 * j * WG_LD + 32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (more) {
+            wg_stage(As(buf ^ 1), t, sa);
+            wg_stage(Bs(buf ^ 1), t, sb);
+        }
+        __syncthreads();
+        buf ^= 1;
+    }
+#undef As
+#undef Bs
+    // C/D layout: column (input channel) = lane & 31, row (output channel) = (reg & 3) + 8 * (reg >> 2) + 4 * half
+    float* P = partial + (size_t)blockIdx.y * Cout * Cin;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int ci = i0 + wi + b * 32 + col;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = o0 + wo + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (co < Cout && ci < Cin) P[(size_t)co * Cin + ci] = acc[a][b][r];
+            }
+        }
+}
+
+// dW = sum over chunks (fixed order); optionally accumulates into dW (beta = 1) for parameters used more than once.
+__global__ __launch_bounds__(256) void wgrad_finish_kernel(const float* __restrict__ partial, int nchunks, size_t n, int accumulate,
+                                                           float* __restrict__ dW) {
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
+        float s = 0.f;
+        for (int k = 0; k < nchunks; ++k) s += partial[(size_t)k * n + e];
+        dW[e] = accumulate ? dW[e] + s : s;
+    }
+}
+
+static inline int ew_grid(size_t total) {
+    size_t g = (total + 255) / 256;
+    return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
+}
+
+}  // namespace ptt
+
+using namespace ptt;
+
+extern "C" size_t ptt_bn_stats_workspace(int R, int C) {
+    if (R <= 0 || C <= 0) return 0;
+    return (size_t)((R + ST4_ROWS - 1) / ST4_ROWS) * 2 * (size_t)C * sizeof(double);      // the finer of the two chunkings
+}
+
+extern "C" int ptt_bn_stats_f32(const float* X, int R, int C, int ldx, float eps, float* mean, float* var, float* invstd,
+                                void* ws, size_t ws_bytes, ptt_stream_t stream) {
+    if (R <= 0 || C <= 0 || ldx < C) return fail(PTT_EINVAL, "ptt_bn_stats_f32: R=%d C=%d ldx=%d", R, C, ldx);
+    if (!X || !mean || !var || !invstd) return fail(PTT_EINVAL, "ptt_bn_stats_f32: null pointer");
+    if (!ws || ws_bytes < ptt_bn_stats_workspace(R, C)) return fail(PTT_EWORKSPACE, "ptt_bn_stats_f32: workspace too small");
+    hipStream_t s = as_stream(stream);
+    if (vec4_ok(X, ldx, C)) {
+        const int nchunks = (R + ST4_ROWS - 1) / ST4_ROWS;
+        hipLaunchKernelGGL((col_stats4_kernel<0>), dim3(nchunks), dim3(256), 256 * 8 * sizeof(double), s, X, nullptr, nullptr, nullptr,
+                           nullptr, R, C, ldx, 0, 0, static_cast<double*>(ws));
+        hipLaunchKernelGGL((col_stats_finish2_kernel<0>), dim3(C), dim3(256), 0, s, static_cast<const double*>(ws), nchunks, C, R, eps,
+                           mean, var, invstd);
+        return check_launch("col_stats4_kernel");
+    }
+    const int nchunks = (R + ST_ROWS - 1) / ST_ROWS;
+    hipLaunchKernelGGL((col_stats_kernel<0>), dim3(nchunks), dim3(256), 0, s, X, nullptr, nullptr, nullptr, nullptr, R, C, ldx, 0, 0,
+                       static_cast<double*>(ws));
+    hipLaunchKernelGGL((col_stats_finish_kernel<0>), dim3((C + 255) / 256), dim3(256), 0, s, static_cast<const double*>(ws), nchunks,
+                       C, R, eps, mean, var, invstd);
+    return check_launch("col_stats_kernel");
+}
+
+extern "C" int ptt_bn_apply_f32(const float* Z, int ldz, const float* mean, const float* invstd, const float* gamma,
+                                const float* beta, int R, int C, int relu, float* X, int ldx, ptt_stream_t stream) {
+    if (R <= 0 || C <= 0) return fail(PTT_EINVAL, "ptt_bn_apply_f32: R=%d C=%d", R, C);
+    if (!Z || !mean || !invstd || !gamma || !beta || !X) return fail(PTT_EINVAL, "ptt_bn_apply_f32: null pointer");
+    if (vec4_ok(Z, ldz, C) && vec4_ok(X, ldx, C) && vec4_ok(mean, 4, 4) && vec4_ok(invstd, 4, 4) && vec4_ok(gamma, 4, 4) &&
+        vec4_ok(beta, 4, 4)) {
+        const int Cq = C >> 2, RG = 256 / (Cq < 256 ? Cq : 256);
+        int grid = (R + RG * 8 - 1) / (RG * 8);
+        if (grid > 16384) grid = 16384;
+        hipLaunchKernelGGL(bn_apply4_kernel, dim3(grid), dim3(256), 0, as_stream(stream), Z, ldz, mean, invstd, gamma, beta, R, C, relu,
+                           X, ldx);
+        return check_launch("bn_apply4_kernel");
+    }
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid((size_t)R * C)), dim3(256), 0, as_stream(stream), Z, ldz, mean, invstd, gamma,
+                       beta, R, C, relu, X, ldx);
+    return check_launch("bn_apply_kernel");
+}
+
+extern "C" int ptt_bn_bwd_f32(const float* G, int ldg, const float* Act, int lda, const float* Z, int ldz, const float* mean,
+                              const float* invstd, const float* gamma, int R, int C, int relu, float* dZ, int ldd,
+                              float* dgamma, float* dbeta, void* ws, size_t ws_bytes, ptt_stream_t stream) {
+    if (R <= 0 || C <= 0) return fail(PTT_EINVAL, "ptt_bn_bwd_f32: R=%d C=%d", R, C);
+    if (!G || !Z || !mean || !invstd || !gamma || !dZ || !dgamma || !dbeta || (relu && !Act))
+        return fail(PTT_EINVAL, "ptt_bn_bwd_f32: null pointer");
+    if (!ws || ws_bytes < ptt_bn_stats_workspace(R, C)) return fail(PTT_EWORKSPACE, "ptt_bn_bwd_f32: workspace too small");
+    hipStream_t s = as_stream(stream);
+    if (relu && vec4_ok(G, ldg, C) && vec4_ok(Act, lda, C) && vec4_ok(Z, ldz, C) && vec4_ok(dZ, ldd, C) && vec4_ok(mean, 4, 4) &&
+        vec4_ok(invstd, 4, 4) && vec4_ok(gamma, 4, 4) && vec4_ok(dgamma, 4, 4) && vec4_ok(dbeta, 4, 4)) {
+        const int nch = (R + ST4_ROWS - 1) / ST4_ROWS;
+        hipLaunchKernelGGL((col_stats4_kernel<1>), dim3(nch), dim3(256), 256 * 8 * sizeof(double), s, G, Act, Z, mean, invstd, R, C, ldg,
+                           lda, ldz, static_cast<double*>(ws));
+        hipLaunchKernelGGL((col_stats_finish2_kernel<1>), dim3(C), dim3(256), 0, s, static_cast<const double*>(ws), nch, C, R, 0.f, dbeta,
+                           dgamma, nullptr);
+        const int Cq = C >> 2, RG = 256 / (Cq < 256 ? Cq : 256);
+        int grid = (R + RG * 8 - 1) / (RG * 8);
+        if (grid > 16384) grid = 16384;
+        hipLaunchKernelGGL(bn_bwd_apply4_kernel, dim3(grid), dim3(256), 0, s, G, ldg, Act, lda, Z, ldz, mean, invstd, gamma, dbeta, dgamma,
+                           R, C, dZ, ldd);
+        return check_launch("bn_bwd4_kernels");
+    }
+    const int nchunks = (R + ST_ROWS - 1) / ST_ROWS;
+    // without a ReLU every position passes: the mask test reads G itself against 0 only when relu is set, so pass an
+    // always-positive stand-in through Act == G is NOT valid; MODE 1 with relu == 0 uses Act = nullptr guarded below
+    if (relu) {
+        hipLaunchKernelGGL((col_stats_kernel<1>), dim3(nchunks), dim3(256), 0, s, G, Act, Z, mean, invstd, R, C, ldg, lda, ldz,
+                           static_cast<double*>(ws));
+    } else {
+        return fail(PTT_EUNSUPPORTED, "ptt_bn_bwd_f32: relu == 0 is not instantiated (every SharedMLP unit has a ReLU)");
+    }
+    hipLaunchKernelGGL((col_stats_finish_kernel<1>), dim3((C + 255) / 256), dim3(256), 0, s, static_cast<const double*>(ws), nchunks,
+                       C, R, 0.f, dbeta, dgamma, nullptr);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid((size_t)R * C)), dim3(256), 0, s, G, ldg, Act, lda, Z, ldz, mean, invstd,
+                       gamma, dbeta, dgamma, R, C, relu, dZ, ldd);
+    return check_launch("bn_bwd_kernels");
+}
+
+extern "C" int ptt_pool_rows_f32(const float* X, int ldx, int G, int ns, int C, float* out, int ldo, int32_t* arg,
+                                 ptt_stream_t stream) {
+    if (G <= 0 || ns <= 0 || C <= 0) return fail(PTT_EINVAL, "ptt_pool_rows_f32: G=%d ns=%d C=%d", G, ns, C);
+    if (!X || !out || !arg) return fail(PTT_EINVAL, "ptt_pool_rows_f32: null pointer");
+    hipLaunchKernelGGL(pool_rows_kernel, dim3(ew_grid((size_t)G * C)), dim3(256), 0, as_stream(stream), X, ldx, G, ns, C, out, ldo, arg);
+    return check_launch("pool_rows_kernel");
+}
+
+extern "C" int ptt_pool_rows_bwd_f32(const float* dOut, int ldo, const int32_t* arg, int G, int ns, int C, float* dX, int ldx,
+                                     ptt_stream_t stream) {
+    if (G <= 0 || ns <= 0 || C <= 0) return fail(PTT_EINVAL, "ptt_pool_rows_bwd_f32: G=%d ns=%d C=%d", G, ns, C);
+    if (!dOut || !arg || !dX) return fail(PTT_EINVAL, "ptt_pool_rows_bwd_f32: null pointer");
+    hipLaunchKernelGGL(pool_rows_bwd_kernel, dim3(ew_grid((size_t)G * ns * C)), dim3(256), 0, as_stream(stream), dOut, ldo, arg, G, ns,
+                       C, dX, ldx);
+    return check_launch("pool_rows_bwd_kernel");
+}
+
+// rows per workgroup: aim at >= ~1024 workgroups (4 per CU) in the launch, between 512 and 4096 rows, multiple of 32
+static int wgrad_chunk_rows(int R, int Cout, int Cin) {
+    const int blocks = ((Cout + 127) / 128) * ((Cin + 127) / 128);
+    int want = (1024 + blocks - 1) / blocks;                 // row chunks wanted
+    int rows = (R + want - 1) / want;
+    rows = (rows + WG_KC - 1) / WG_KC * WG_KC;
+    if (rows < WG_MIN_ROWS) rows = WG_MIN_ROWS;
+    if (rows > WG_ROWS) rows = WG_ROWS;
+    return rows;
+}
+
+extern "C" size_t ptt_linear_wgrad_workspace(int R, int Cout, int Cin) {
+    if (R <= 0 || Cout <= 0 || Cin <= 0) return 0;
+    const int rows = wgrad_chunk_rows(R, Cout, Cin);
+    return (size_t)((R + rows - 1) / rows) * (size_t)Cout * Cin * sizeof(float);
+}
+
+extern "C" int ptt_linear_wgrad_f32(const float* dZ, int ldz, const float* X, int ldx, int R, int Cout, int Cin, float* dW,
+                                    int accumulate, void* ws, size_t ws_bytes, ptt_stream_t stream) {
+    if (R <= 0 || Cout <= 0 || Cin <= 0 || ldz < Cout || ldx < Cin)
+        return fail(PTT_EINVAL, "ptt_linear_wgrad_f32: R=%d Cout=%d Cin=%d ldz=%d ldx=%d", R, Cout, Cin, ldz, ldx);
+    if (!dZ || !X || !dW) return fail(PTT_EINVAL, "ptt_linear_wgrad_f32: null pointer");
+    if (!ws || ws_bytes < ptt_linear_wgrad_workspace(R, Cout, Cin))
+        return fail(PTT_EWORKSPACE, "ptt_linear_wgrad_f32: workspace too small");
+    const int rows = wgrad_chunk_rows(R, Cout, Cin);
+    const int nchunks = (R + rows - 1) / rows;
+    const int nbo = (Cout + 127) / 128, nbi = (Cin + 127) / 128;
+    hipStream_t s = as_stream(stream);
+    const int lds = 4 * WG_KC * WG_LD * (int)sizeof(float);
+    const bool vz = (ldz & 3) == 0 && (reinterpret_cast<uintptr_t>(dZ) & 15) == 0;
+    const bool vx = (ldx & 3) == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0;
+#define PTT_WGRAD_CASE(VZ, VX)                                                                                        \
+    if (vz == VZ && vx == VX) {                                                                                       \
+        if (int rc = set_lds_limit(reinterpret_cast<const void*>(linear_wgrad_kernel<VZ, VX>), lds)) return rc;       \
+        hipLaunchKernelGGL((linear_wgrad_kernel<VZ, VX>), dim3(nbo * nbi, nchunks), dim3(256), lds, s, dZ, ldz, X, ldx, R, Cout, Cin, \
+                           nbi, rows, static_cast<float*>(ws));                                                       \
+    }
+    PTT_WGRAD_CASE(true, true) PTT_WGRAD_CASE(true, false) PTT_WGRAD_CASE(false, true) PTT_WGRAD_CASE(false, false)
+#undef PTT_WGRAD_CASE
+    const size_t n = (size_t)Cout * Cin;
+    hipLaunchKernelGGL(wgrad_finish_kernel, dim3(ew_grid(n)), dim3(256), 0, s, static_cast<const float*>(ws), nchunks, n, accumulate, dW);
+    return check_launch("linear_wgrad_kernel");
+}

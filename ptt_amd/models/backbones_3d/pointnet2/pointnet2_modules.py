@@ -20,7 +20,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .... import ops
+from .... import ops, train_ops
 from . import pointnet2_utils
 from . import pytorch_utils as pt_utils
 
@@ -181,6 +181,10 @@ class PointnetSAModuleVotes(nn.Module):
         xyz_flipped = xyz.transpose(1, 2).contiguous()
         new_xyz = pointnet2_utils.gather_operation(xyz_flipped, inds).transpose(1, 2).contiguous()
         grouped_features, grouped_xyz = self.grouper(xyz, new_xyz, features)      # (B,C,M,ns)
+        if train_ops.usable(self.mlp_module, grouped_features):
+            # training mode on a HIP device: SharedMLP (batch-statistics BatchNorm) + the max over the neighbours, forward
+            # and backward, on the hand-written row kernels (ptt_amd/train_ops.py)
+            return new_xyz, train_ops.shared_mlp_pool(grouped_features, self.mlp_module, pool_dim=3), inds.to(torch.int64)
         y = self.mlp_module(grouped_features)
         # reference: F.max_pool2d(y, kernel_size=[1, nsample]).squeeze(-1) (:85-88); max over the last axis routes the
         # gradient to one arg-max the same way and avoids torch's NCHW pooling kernel (6 ms per training step here)

@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ... import ops
+from ... import ops, train_ops
 from ..backbones_3d.pointnet2 import pytorch_utils as layer_utils
 
 
@@ -122,6 +122,9 @@ class CosineSimAug(nn.Module):
         template_xyz_ = template_xyz.transpose(1, 2).contiguous().unsqueeze(-1).expand(b, 3, n1, n2)
         fusion_feature = torch.cat((sim_feat.unsqueeze(1), template_xyz_), dim=1)
         fusion_feature = torch.cat((fusion_feature, template_feats.unsqueeze(-1).expand(b, f, n1, n2)), dim=1)
+        if train_ops.usable(self.mlp, fusion_feature):         # training on a HIP device: hand-written row kernels
+            batch_dict['cosine_feats'] = self.conv(train_ops.shared_mlp_pool(fusion_feature, self.mlp, pool_dim=2))
+            return batch_dict
         fusion_feature = self.mlp(fusion_feature)
         fusion_feature = fusion_feature.max(dim=2)[0]        # = F.max_pool2d(., [n1, 1]).squeeze(2) (reference :41-42)
         batch_dict['cosine_feats'] = self.conv(fusion_feature)

@@ -551,3 +551,93 @@ def select_box(pred_box_data, out=None, idx_out=None):
         _lib.check(_lib.lib().ptt_select_box_f32(_ptr(pred_box_data), B, P, _ptr(out), _ptr(idx_out), _stream()),
                    "ptt_select_box_f32")
     return out
+
+
+# --------------------------------------------------------------------------- N3: training-step kernels (rows x channels)
+def _rows(t, name):
+    if not t.is_cuda or t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1:
+        raise RuntimeError("%s must be a (rows, channels) float32 device tensor with contiguous channels" % name)
+    return t
+
+
+def _ws(nbytes, device):
+    return torch.empty((max(1, (int(nbytes) + 7) // 8),), dtype=torch.float64, device=device)
+
+
+def bn_stats(x, eps):
+    """Per-channel batch statistics of x (R,C): (mean, biased var, invstd) — ptt_bn_stats_f32."""
+    _rows(x, "x")
+    R, C = x.shape
+    mean, var, invstd = (torch.empty((C,), dtype=torch.float32, device=x.device) for _ in range(3))
+    nb = _lib.lib().ptt_bn_stats_workspace(R, C)
+    ws = _ws(nb, x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().ptt_bn_stats_f32(_ptr(x), R, C, x.stride(0), float(eps), _ptr(mean), _ptr(var), _ptr(invstd),
+                                               _ptr(ws), ws.numel() * 8, _stream()), "ptt_bn_stats_f32")
+    return mean, var, invstd
+
+
+def bn_apply(z, mean, invstd, gamma, beta, relu=True, out=None):
+    """relu?((z - mean) * invstd * gamma + beta) over rows — ptt_bn_apply_f32."""
+    _rows(z, "z")
+    R, C = z.shape
+    if out is None:
+        out = torch.empty((R, C), dtype=torch.float32, device=z.device)
+    with torch.cuda.device(z.device):
+        _lib.check(_lib.lib().ptt_bn_apply_f32(_ptr(z), z.stride(0), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), R, C,
+                                               int(bool(relu)), _ptr(out), out.stride(0), _stream()), "ptt_bn_apply_f32")
+    return out
+
+
+def bn_bwd(g, act, z, mean, invstd, gamma, out=None):
+    """Backward of BatchNorm(train) + ReLU on rows: -> (dz, dgamma, dbeta). `out` may alias g (in place)."""
+    _rows(g, "g"); _rows(act, "act"); _rows(z, "z")
+    R, C = z.shape
+    if out is None:
+        out = torch.empty((R, C), dtype=torch.float32, device=z.device)
+    dgamma = torch.empty((C,), dtype=torch.float32, device=z.device)
+    dbeta = torch.empty((C,), dtype=torch.float32, device=z.device)
+    ws = _ws(_lib.lib().ptt_bn_stats_workspace(R, C), z.device)
+    with torch.cuda.device(z.device):
+        _lib.check(_lib.lib().ptt_bn_bwd_f32(_ptr(g), g.stride(0), _ptr(act), act.stride(0), _ptr(z), z.stride(0), _ptr(mean),
+                                             _ptr(invstd), _ptr(gamma), R, C, 1, _ptr(out), out.stride(0), _ptr(dgamma),
+                                             _ptr(dbeta), _ptr(ws), ws.numel() * 8, _stream()), "ptt_bn_bwd_f32")
+    return out, dgamma, dbeta
+
+
+def pool_rows(x, ns):
+    """max over every ns consecutive rows: (G*ns, C) -> (G, C) and the int32 arg-max (first among equals)."""
+    _rows(x, "x")
+    R, C = x.shape
+    G = R // int(ns)
+    out = torch.empty((G, C), dtype=torch.float32, device=x.device)
+    arg = torch.empty((G, C), dtype=torch.int32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().ptt_pool_rows_f32(_ptr(x), x.stride(0), G, int(ns), C, _ptr(out), C, _ptr(arg), _stream()),
+                   "ptt_pool_rows_f32")
+    return out, arg
+
+
+def pool_rows_bwd(dout, arg, ns):
+    _rows(dout, "dout")
+    G, C = dout.shape
+    dx = torch.empty((G * int(ns), C), dtype=torch.float32, device=dout.device)
+    with torch.cuda.device(dout.device):
+        _lib.check(_lib.lib().ptt_pool_rows_bwd_f32(_ptr(dout), dout.stride(0), _ptr(arg), G, int(ns), C, _ptr(dx), C, _stream()),
+                   "ptt_pool_rows_bwd_f32")
+    return dx
+
+
+def linear_wgrad(dz, x, out=None, accumulate=False):
+    """dW (Cout,Cin) = dz^T x over the rows, on fp32 MFMA — ptt_linear_wgrad_f32."""
+    _rows(dz, "dz"); _rows(x, "x")
+    R, Cout = dz.shape
+    Cin = x.shape[1]
+    if out is None:
+        out = torch.empty((Cout, Cin), dtype=torch.float32, device=dz.device)
+    ws = _ws(_lib.lib().ptt_linear_wgrad_workspace(R, Cout, Cin), dz.device)
+    with torch.cuda.device(dz.device), _timed('ptt_linear_wgrad_f32'):
+        _lib.check(_lib.lib().ptt_linear_wgrad_f32(_ptr(dz), dz.stride(0), _ptr(x), x.stride(0), R, Cout, Cin, _ptr(out),
+                                                   int(bool(accumulate)), _ptr(ws), ws.numel() * 8, _stream()),
+                   "ptt_linear_wgrad_f32")
+    return out
