@@ -410,12 +410,26 @@ __global__ __launch_bounds__(256, 2) void linear_wgrad_kernel(const float* __res
 }
 
 // dW = sum over chunks (fixed order); optionally accumulates into dW (beta = 1) for parameters used more than once.
+// Workgroup = 32 consecutive outputs x 8 chunk groups: group g adds the chunks g, g + 8, ... in order, the 8 group sums are
+// then added in order — a fixed summation tree, and 8x the loads in flight of a one-thread-per-output loop.
 __global__ __launch_bounds__(256) void wgrad_finish_kernel(const float* __restrict__ partial, int nchunks, size_t n, int accumulate,
                                                            float* __restrict__ dW) {
-    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
+    __shared__ float part[8][32];
+    const int lane = threadIdx.x & 31, g = threadIdx.x >> 5;
+    for (size_t base = (size_t)blockIdx.x * 32; base < n; base += (size_t)gridDim.x * 32) {
+        const size_t e = base + lane;
         float s = 0.f;
-        for (int k = 0; k < nchunks; ++k) s += partial[(size_t)k * n + e];
-        dW[e] = accumulate ? dW[e] + s : s;
+        if (e < n)
+            for (int k = g; k < nchunks; k += 8) s += partial[(size_t)k * n + e];
+        part[g][lane] = s;
+        __syncthreads();
+        if (g == 0 && e < n) {
+            float tot = part[0][lane];
+#pragma unroll
+            for (int q = 1; q < 8; ++q) tot += part[q][lane];
+            dW[e] = accumulate ? dW[e] + tot : tot;
+        }
+        __syncthreads();
     }
 }
 
@@ -528,10 +542,10 @@ extern "C" int ptt_pool_rows_bwd_f32(const float* dOut, int ldo, const int32_t* 
     return check_launch("pool_rows_bwd_kernel");
 }
 
-// rows per workgroup: aim at >= ~1024 workgroups (4 per CU) in the launch, between 512 and 4096 rows, multiple of 32
+// rows per workgroup: aim at ~768 workgroups (3 per CU; 2 are resident) in the launch, between 512 and 4096 rows, multiple of 32
 static int wgrad_chunk_rows(int R, int Cout, int Cin) {
     const int blocks = ((Cout + 127) / 128) * ((Cin + 127) / 128);
-    int want = (1024 + blocks - 1) / blocks;                 // row chunks wanted
+    int want = (768 + blocks - 1) / blocks;                  // row chunks wanted
     int rows = (R + want - 1) / want;
     rows = (rows + WG_KC - 1) / WG_KC * WG_KC;
     if (rows < WG_MIN_ROWS) rows = WG_MIN_ROWS;
@@ -568,6 +582,8 @@ extern "C" int ptt_linear_wgrad_f32(const float* dZ, int ldz, const float* X, in
     PTT_WGRAD_CASE(true, true) PTT_WGRAD_CASE(true, false) PTT_WGRAD_CASE(false, true) PTT_WGRAD_CASE(false, false)
 #undef PTT_WGRAD_CASE
     const size_t n = (size_t)Cout * Cin;
-    hipLaunchKernelGGL(wgrad_finish_kernel, dim3(ew_grid(n)), dim3(256), 0, s, static_cast<const float*>(ws), nchunks, n, accumulate, dW);
+    int fgrid = (int)((n + 31) / 32);
+    if (fgrid > 4096) fgrid = 4096;
+    hipLaunchKernelGGL(wgrad_finish_kernel, dim3(fgrid), dim3(256), 0, s, static_cast<const float*>(ws), nchunks, n, accumulate, dW);
     return check_launch("linear_wgrad_kernel");
 }
