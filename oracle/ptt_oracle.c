@@ -13,11 +13,17 @@
  * :112/:118 (gather, gather grad), :237/:257 (group, group grad), :287 (ball query), and
  * does kNN as square_distance(...).argsort()[:, :, :k] (transformer_block/variants.py:150-151,
  * model_utils/layer_utils.py:12-26). The reference has no tests, golden vectors or CPU
- * implementation for the four extension ops, so for those ops:  PARITY UNPINNED  — this
- * file restates the upstream package's published algorithm as specified in SURVEY.md §8c
- * and is the contract both the HIP kernels and the tests follow. kNN, gather and group
- * semantics ARE pinned: tests/golden/make_golden.py checks them against the imported
- * reference (torch argsort / the reference's own QueryAndGroup glue run on these ops).
+ * implementation of the extension ops themselves; this file restates the upstream package's
+ * published algorithm as specified in SURVEY.md §8c and is the contract both the HIP kernels
+ * and the tests follow. Pinning status:
+ *   FPS         PINNED by the reference's own numpy farthest-point sampling,
+ *               ptt/utils/common_utils.py:78-112 (fps_downsample): fixture tests/golden/G11 holds its
+ *               outputs on float32 clouds with duplicated points and exact distance ties (start index 0);
+ *               oracle_fps equals them bit for bit (tests/test_oracle_cpu.py::test_G11_...). Not covered by
+ *               that pin: the skip of points with |p|^2 <= 1e-3 (upstream CUDA behaviour; G11 is origin-free).
+ *   ball query  PARITY UNPINNED (no reference-held source or vector).
+ *   kNN, gather, group   pinned: tests/golden/make_golden.py checks them against the imported reference
+ *               (torch argsort / the reference's own QueryAndGroup glue run on these ops).
  *
  * Arithmetic: fp32 throughout, squared distance = (dx*dx + dy*dy) + dz*dz with no fused
  * multiply-add (build with -ffp-contract=off; see ptt_amd/build.py:build_oracle).
