@@ -26,6 +26,7 @@ struct DevSwitches {
     int sa_stagger = 2;                  // PTT_SA_STAGGER
     int sa_wave = 1;                     // PTT_SA_WAVE=0: column-split kernel for small-weight levels
     int sa_rt = 2;                       // PTT_SA_RT=1: 32-row workgroups
+    int sa_lds = 1;                      // PTT_SA_LDS=0: SA0 on sa_wave_kernel instead of sa_lds_kernel
     int sa_stream = 1;                   // PTT_SA_STREAM=0: SA1 / SA2 on sa_fused_kernel instead of sa_stream_kernel
     int sa_chunk = 2;                    // PTT_SA_CHUNK=n: at most n tiles per sa_stream workgroup (0: 512 workgroups).
                                          // Measured (profiles/r02d): 2, 3, 4, 6 and 12 tiles per workgroup run the

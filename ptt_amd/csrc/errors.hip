@@ -34,6 +34,7 @@ static DevSwitches read_switches() {
     if (const char* e = getenv("PTT_SA_WAVE")) d.sa_wave = atoi(e) != 0;
     if (const char* e = getenv("PTT_SA_RT")) d.sa_rt = (atoi(e) == 1) ? 1 : 2;
     if (const char* e = getenv("PTT_SA_STREAM")) d.sa_stream = atoi(e) != 0;
+    if (const char* e = getenv("PTT_SA_LDS")) d.sa_lds = atoi(e) != 0;
     if (const char* e = getenv("PTT_SA_CHUNK")) d.sa_chunk = atoi(e);
     if (const char* e = getenv("PTT_PAIR_STAGGER")) d.pair_stagger = atoi(e);
     if (const char* e = getenv("PTT_PAIR_LDS_PAD")) d.pair_lds_pad = atoi(e);

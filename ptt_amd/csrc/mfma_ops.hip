@@ -1097,6 +1097,144 @@ __device__ __forceinline__ void sa_wave_layer(const SaParams& p, const SaLayerDe
     __builtin_amdgcn_wave_barrier();
 }
 
+// ------------------------------------------------------------------------------------------
+// SA0 (no point features: rows are [rel.x rel.y rel.z], 3 -> 64 -> 64 -> 128, 32 neighbours): the whole packed weight
+// set is 50 KB, so it lives in LDS for the life of a PERSISTENT workgroup of 8 waves (one per CU, two waves per SIMD):
+//   * B fragments come from LDS (one conflict-free 1 KiB ds_read_b128 per fragment) instead of the L2 -> CU path
+//     that sa_wave_kernel's twelve waves per CU saturate (50 KB of weights per 32-row tile per wave);
+//   * every wave owns 32-row tiles (one centre) in a private LDS tile: no workgroup barrier after the weight load;
+//   * the neighbour indices and coordinates of the NEXT tile are requested while the current tile is in its GEMMs;
+//   * 2 waves per SIMD leave 256 VGPRs: nothing spills (sa_wave_kernel<32,1>: 22 VGPRs, 92 B per lane of scratch).
+// ------------------------------------------------------------------------------------------
+constexpr int SAL_LDK = 68;                      // 64 channels + 4
+
+template <int CT, int NKB>
+__device__ __forceinline__ void gemm_lds_weights(const float* Xw, const float* Wl, int NT, int lane, f32x16 (&acc)[CT]) {
+    const float* arow = Xw + (lane & 31) * SAL_LDK + 4 * (lane >> 5);
+    const float* brow = Wl + lane * 4;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(arow + kb * 8);
+        f32x4 b[CT];
+#pragma unroll
+        for (int u = 0; u < CT; ++u) b[u] = *reinterpret_cast<const f32x4*>(brow + (kb * NT + u) * 256);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int u = 0; u < CT; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[u][j], acc[u], 0, 0, 0);
+    }
+}
+
+__global__ __launch_bounds__(512, 1) void sa_lds_kernel(SaParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* W0 = smem;                                        // [1][2][256]   3 (-> 8) x 64
+    float* W1 = smem + 512;                                  // [8][2][256]   64 x 64
+    float* W2 = smem + 512 + 4096;                           // [8][4][256]   64 x 128
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, half = lane >> 5, col = lane & 31;
+    float* Xw = smem + 512 + 4096 + 8192 + w * 32 * SAL_LDK; // this wave's private [32][68] tile
+    {
+        const f32x4* g0 = reinterpret_cast<const f32x4*>(p.L[0].Wp);
+        const f32x4* g1 = reinterpret_cast<const f32x4*>(p.L[1].Wp);
+        const f32x4* g2 = reinterpret_cast<const f32x4*>(p.L[2].Wp);
+        f32x4* s0 = reinterpret_cast<f32x4*>(W0);
+        f32x4* s1 = reinterpret_cast<f32x4*>(W1);
+        f32x4* s2 = reinterpret_cast<f32x4*>(W2);
+        for (int i = t; i < 128; i += 512) s0[i] = g0[i];
+        for (int i = t; i < 1024; i += 512) s1[i] = g1[i];
+        for (int i = t; i < 2048; i += 512) s2[i] = g2[i];
+    }
+    __syncthreads();
+    const int total = p.B * p.M;                             // one tile per centre
+    const int gw = logical_block() * 8 + w;
+    const int c0 = gw * p.chunk, c1 = min(total, c0 + p.chunk);
+    if (c0 >= c1) return;
+    float sh0[2], sh1[2], sh2[4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        sh0[u] = p.L[0].shift ? p.L[0].shift[u * 32 + col] : 0.f;
+        sh1[u] = p.L[1].shift ? p.L[1].shift[u * 32 + col] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) sh2[u] = p.L[2].shift ? p.L[2].shift[u * 32 + col] : 0.f;
+
+    // lanes 0..31: one grouped row each. Request the first tile's neighbour and centre coordinates.
+    int n_cur = p.idx[(size_t)c0 * 32 + col];
+    float px, py, pz, cx, cy, cz;
+    {
+        const size_t flat = (size_t)(c0 / p.M) * p.N + n_cur;
+        px = p.xyz[flat * 3]; py = p.xyz[flat * 3 + 1]; pz = p.xyz[flat * 3 + 2];
+        cx = p.new_xyz[(size_t)c0 * 3]; cy = p.new_xyz[(size_t)c0 * 3 + 1]; cz = p.new_xyz[(size_t)c0 * 3 + 2];
+    }
+    for (int c = c0; c < c1; ++c) {
+        const int cn = (c + 1 < c1) ? c + 1 : c;              // the last tile re-requests itself (branch-free loop body)
+        // ---- rows [rel | 0] of this tile ----
+        if (half == 0) {
+            float dx = px - cx, dy = py - cy, dz = pz - cz;
+            if (p.normalize) { dx /= p.radius; dy /= p.radius; dz /= p.radius; }
+            *reinterpret_cast<f32x4*>(Xw + col * SAL_LDK) = f32x4{dx, dy, dz, 0.f};
+            *reinterpret_cast<f32x4*>(Xw + col * SAL_LDK + 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        const int n_next = p.idx[(size_t)cn * 32 + col];      // in flight under layers 0 and 1
+        __builtin_amdgcn_wave_barrier();
+        // ---- layer 0: 3 (padded to 8) -> 64 ----
+        {
+            f32x16 acc[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[u][r] = sh0[u];
+            gemm_lds_weights<2, 1>(Xw, W0, 2, lane, acc);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) Xw[tile_row(r, half) * SAL_LDK + u * 32 + col] = fmaxf(acc[u][r], 0.f);
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- layer 1: 64 -> 64 ----
+        {
+            f32x16 acc[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[u][r] = sh1[u];
+            gemm_lds_weights<2, 8>(Xw, W1, 2, lane, acc);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) Xw[tile_row(r, half) * SAL_LDK + u * 32 + col] = fmaxf(acc[u][r], 0.f);
+        }
+        // the next tile's coordinates: in flight under layer 2
+        {
+            const size_t flat = (size_t)(cn / p.M) * p.N + n_next;
+            px = p.xyz[flat * 3]; py = p.xyz[flat * 3 + 1]; pz = p.xyz[flat * 3 + 2];
+            cx = p.new_xyz[(size_t)cn * 3]; cy = p.new_xyz[(size_t)cn * 3 + 1]; cz = p.new_xyz[(size_t)cn * 3 + 2];
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- layer 2: 64 -> 128, max over the 32 neighbours, ReLU after the pool ----
+        {
+            f32x16 acc[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[u][r] = sh2[u];
+            gemm_lds_weights<4, 8>(Xw, W2, 4, lane, acc);
+            const int b = c / p.M, mm = c - b * p.M;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float mx = acc[u][0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[u][r]);
+                mx = max_halves(mx);
+                if (p.L[2].relu) mx = fmaxf(mx, 0.f);
+                if (half == 0) p.out[b * p.osb + (u * 32 + col) * p.osc + mm * p.osm] = mx;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // RT row tiles (32 * RT grouped rows) per wave; only RT = 1 is launched (see the host entry point).
 template <int NS, int RT>
 __global__ __launch_bounds__(256, RT == 1 ? 3 : 2) void sa_wave_kernel(SaParams p) {
@@ -1424,6 +1562,19 @@ extern "C" int ptt_sa_fused_fwd_f32(const ptt_sa_desc* d, ptt_stream_t stream) {
     const int total_centres = d->B * d->M;
     hipStream_t s = as_stream(stream);
     int rc;
+    // SA0 shape (no point features, 3 -> 64 -> 64 -> 128, 32 neighbours, BatchNorm scale folded): persistent workgroups
+    // with the 50 KB of packed weights resident in LDS
+    if (d->C == 0 && d->use_xyz && !hoist && d->nsample == 32 && d->n_layers == 3 && p.L[0].Cout == 64 && p.L[1].Cout == 64 &&
+        p.L[2].Cout == 128 && !p.L[0].scale && !p.L[1].scale && !p.L[2].scale && p.L[0].relu && p.L[1].relu &&
+        dev_switches().sa_lds) {
+        const int waves = 256 * 8;                           // one 8-wave workgroup per CU
+        p.chunk = (total_centres + waves - 1) / waves;
+        int wgs = (total_centres + p.chunk * 8 - 1) / (p.chunk * 8);
+        const int lds = (512 + 4096 + 8192 + 8 * 32 * SAL_LDK) * (int)sizeof(float);
+        if ((rc = set_lds_limit(reinterpret_cast<const void*>(sa_lds_kernel), lds))) return rc;
+        hipLaunchKernelGGL(sa_lds_kernel, dim3(wgs), dim3(512), lds, s, p);
+        return check_launch("sa_lds_kernel");
+    }
     // small weight set (fits L1/L2 comfortably) and <= 4 column tiles everywhere: barrier-free wave-private kernel
     size_t wbytes = 0;
     bool wave_ok = true;

@@ -397,8 +397,22 @@ extern "C" int ptt_fps_f32(const float* xyz, int B, int N, int npoint, int32_t* 
     if (N <= 64) return launch_fps<64, 1>(xyz, B, N, npoint, idx_out, s);
     if (N <= 128) return launch_fps<64, 2>(xyz, B, N, npoint, idx_out, s);
     if (N <= 256) return launch_fps<64, 4>(xyz, B, N, npoint, idx_out, s);
-    if (N <= 512) return launch_fps<256, 2>(xyz, B, N, npoint, idx_out, s);
-    if (N <= 1024) return launch_fps<256, 4>(xyz, B, N, npoint, idx_out, s);
+    if (N <= 512) {
+        if (const int T = dev_switches().fps_t) {       // dev: workgroup-size sweep
+            if (T == 256) return launch_fps<256, 2>(xyz, B, N, npoint, idx_out, s);
+            if (T == 128) return launch_fps<128, 4>(xyz, B, N, npoint, idx_out, s);
+            if (T == 512) return launch_fps<512, 1>(xyz, B, N, npoint, idx_out, s);
+        }
+        return launch_fps<64, 8>(xyz, B, N, npoint, idx_out, s);     // one wave, no barrier: 0.36 us / iteration (256 threads: 0.42)
+    }
+    if (N <= 1024) {
+        if (const int T = dev_switches().fps_t) {
+            if (T == 64) return launch_fps<64, 16>(xyz, B, N, npoint, idx_out, s);
+            if (T == 128) return launch_fps<128, 8>(xyz, B, N, npoint, idx_out, s);
+            if (T == 256) return launch_fps<256, 4>(xyz, B, N, npoint, idx_out, s);
+        }
+        return launch_fps<512, 2>(xyz, B, N, npoint, idx_out, s);    // 0.43 us / iteration (256 threads: 0.47; scripts/fps_sweep.py)
+    }
     if (N <= 2048) {
         if (const int T = dev_switches().fps_t) {       // dev: workgroup-size sweep
             if (T == 256) return launch_fps<256, 8>(xyz, B, N, npoint, idx_out, s);
