@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PTT_ABI_VERSION 6
+#define PTT_ABI_VERSION 7
 
 enum {
     PTT_OK = 0,
@@ -382,6 +382,24 @@ int ptt_pool_rows_bwd_f32(const float* dOut, int ldo, const int32_t* arg, int G,
 size_t ptt_linear_wgrad_workspace(int R, int Cout, int Cin);
 int ptt_linear_wgrad_f32(const float* dZ, int ldz, const float* X, int ldx, int R, int Cout, int Cin, float* dW,
                          int accumulate, void* workspace, size_t workspace_bytes, ptt_stream_t stream);
+
+/* ---------------------------------------------------------------------------------
+ * T-opt  the dense scaled-dot-product variant TransformerBlockSTD (transformer_block/variants.py:29-40): the only
+ * literal Q.K^T / attn.V of the reference, as batched fp32-MFMA GEMMs.
+ *   ptt_pack_weight_strided_f32  packs `batch` matrices given by strides into MFMA B-fragment order: element
+ *                                (output o, input k) of batch b at W[b*stride_batch + o*stride_out + k*stride_k].
+ *                                K of a batch (rows of the q|k|v buffer) -> the B operand of Q.K^T; V + delta read
+ *                                transposed (stride_out 1, stride_k = row stride) -> the B operand of attn.V.
+ *   ptt_linear_batched_f32       ptt_linear_f32 over `batch` independent (X, Wpacked, out[, residual]) sets.
+ *   ptt_softmax_rows_f32         in-place softmax(scale * x) along the rows of a (rows, n) matrix (`attn / sqrt(d)`, :35).
+ * ------------------------------------------------------------------------------- */
+int ptt_pack_weight_strided_f32(const float* W, int Cout, int K, int64_t stride_out, int64_t stride_k, int batch,
+                                int64_t stride_batch, float* packed, ptt_stream_t stream);
+int ptt_linear_batched_f32(const float* X, int rows, int K, int ldx, int64_t x_batch_stride, const float* Wpacked,
+                           int64_t w_batch_stride, int Cout, const float* scale, const float* shift, int relu,
+                           const float* residual, int ldr, int64_t r_batch_stride, float* out, int ldo,
+                           int64_t o_batch_stride, int batch, ptt_stream_t stream);
+int ptt_softmax_rows_f32(float* X, int64_t rows, int n, int ld, float scale, ptt_stream_t stream);
 
 #ifdef __cplusplus
 }

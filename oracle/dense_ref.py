@@ -119,6 +119,21 @@ def transformer_block(xyz, features, P, k, knn_idx=None):
     return res, attn
 
 
+def transformer_block_std(xyz, features, P):
+    """TransformerBlockSTD.forward — transformer_block/variants.py:29-40 (the dense Q.K^T / attn.V variant).
+    P: fc1.*, fc2.*, fc_delta.0.*, fc_delta.2.*, w_qs.weight, w_ks.weight, w_vs.weight."""
+    pre = features
+    x = F.linear(features, P["fc1.weight"], P["fc1.bias"])                                  # :31
+    q, k, v = F.linear(x, P["w_qs.weight"]), F.linear(x, P["w_ks.weight"]), F.linear(x, P["w_vs.weight"])   # :32
+    attn = q @ k.transpose(1, 2)                                                            # :34
+    attn = F.softmax(attn / np.sqrt(k.size(-1)), dim=-1)                                    # :35
+    pos_enc = F.linear(F.relu(F.linear(xyz, P["fc_delta.0.weight"], P["fc_delta.0.bias"])),
+                       P["fc_delta.2.weight"], P["fc_delta.2.bias"])                        # :37
+    res = attn @ (v + pos_enc)                                                              # :38
+    res = F.linear(res, P["fc2.weight"], P["fc2.bias"]) + pre                               # :39
+    return res, attn
+
+
 def cosine_sim_aug(search_feats, template_feats, template_xyz, mlp_layers, conv):
     """CosineSimAug.forward — similarity_modules/p2b_xcoor.py:25-46.
     search_feats (B,f,n2), template_feats (B,f,n1), template_xyz (B,n1,3); mlp_layers as shared_mlp_eval;

@@ -107,8 +107,13 @@ __device__ __forceinline__ int logical_block() {
 // ------------------------------------------------------------------------------------------
 // weight packing
 // ------------------------------------------------------------------------------------------
+// W element (output col, input k) of batch b lives at W[b * sb + col * so + k * sk]: a plain (Cout,K) weight is
+// so = K, sk = 1; a weight given TRANSPOSED in memory ((K,Cout) rows, e.g. the values of an attention block used as the
+// B operand of P.V) is so = 1, sk = row stride. blockIdx.y = batch.
 __global__ void pack_weight_kernel(const float* __restrict__ W, int Cout, int K, int NT, int rot, size_t total,
-                                   float* __restrict__ P) {
+                                   float* __restrict__ P, long long so, long long sk, long long sb) {
+    const float* Wb = W + (size_t)blockIdx.y * sb;
+    float* Pb = P + (size_t)blockIdx.y * total;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
         const int j = (int)(e & 3);
         const int lane = (int)((e >> 2) & 63);
@@ -118,7 +123,7 @@ __global__ void pack_weight_kernel(const float* __restrict__ W, int Cout, int K,
         const int col = ct * 32 + (lane & 31);
         const int k = kb * 8 + 4 * (lane >> 5) + j;
         // packed position k holds original input channel (k + rot) mod K
-        P[e] = (col < Cout && k < K) ? W[(size_t)col * K + (k + rot) % K] : 0.0f;
+        Pb[e] = (col < Cout && k < K) ? Wb[(size_t)col * so + (size_t)((k + rot) % K) * sk] : 0.0f;
     }
 }
 
@@ -347,6 +352,7 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[RT][CT]) {
 struct LinearParams {
     const float* X; const float* Wp; const float* scale; const float* shift; const float* residual; float* out;
     int rows, K, ldx, Cout, relu, ldr, ldo, nkb, NT, vec_ok;
+    long long xb, wb, ob, rb;       // per-batch element strides (blockIdx.z = batch; all 0 for a plain launch)
 };
 
 constexpr int LIN_KC = 128;          // channels per staged chunk
@@ -384,6 +390,10 @@ __device__ __forceinline__ void lin_stage(float* Xs, int t, const f32x4 (&st)[RT
 
 template <int RT, bool VEC, int CT>   // a workgroup owns RT*32 rows x CT*128 columns
 __global__ __launch_bounds__(256, 2) void linear_kernel(LinearParams p) {
+    if (blockIdx.z) {               // batched launch: this workgroup's operands
+        p.X += (size_t)blockIdx.z * p.xb; p.Wp += (size_t)blockIdx.z * p.wb; p.out += (size_t)blockIdx.z * p.ob;
+        if (p.residual) p.residual += (size_t)blockIdx.z * p.rb;
+    }
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Xs = smem;                                    // 2 x [RT*32][LIN_LDK]
     constexpr int BUF = RT * 32 * LIN_LDK;
@@ -1442,9 +1452,40 @@ __global__ __launch_bounds__(256, 2) void pt_attn_pair_kernel(AttnParams p) {
     PTT_STAMP(7);
 }
 
+// softmax(scale * x) along each row of a (rows, n) matrix, in place: one wave per row (the N x N scores of the dense
+// attention variant, n <= a few thousand). Row maximum and sum over the wave with DPP reductions.
+__global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ X, long long rows, int n, int ld, float scale) {
+    const int lane = threadIdx.x & 63;
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    float* x = X + r * ld;
+    float m = -3.0e38f;
+    for (int c = lane; c < n; c += 64) m = fmaxf(m, x[c] * scale);
+    m = wave_max_f32(m);
+    float sum = 0.f;
+    for (int c = lane; c < n; c += 64) {
+        const float e = __expf(x[c] * scale - m);
+        x[c] = e;
+        sum += e;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    const float inv = 1.0f / sum;
+    for (int c = lane; c < n; c += 64) x[c] *= inv;
+}
+
 }  // namespace ptt
 
 using namespace ptt;
+
+extern "C" int ptt_softmax_rows_f32(float* X, int64_t rows, int n, int ld, float scale, ptt_stream_t stream) {
+    if (rows < 0 || n <= 0 || ld < n) return fail(PTT_EINVAL, "ptt_softmax_rows_f32: rows=%lld n=%d ld=%d", (long long)rows, n, ld);
+    if (rows == 0) return PTT_OK;
+    if (!X) return fail(PTT_EINVAL, "ptt_softmax_rows_f32: null pointer");
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, as_stream(stream), X, (long long)rows, n, ld,
+                       scale);
+    return check_launch("softmax_rows_kernel");
+}
 
 extern "C" size_t ptt_packed_weight_elems(int Cout, int K) {
     if (Cout <= 0 || K <= 0) return 0;
@@ -1461,7 +1502,21 @@ extern "C" int ptt_pack_weight_rot_f32(const float* W, int Cout, int K, int rot,
     size_t g = (total + 255) / 256;
     if (g > 4096) g = 4096;
     hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)g), dim3(256), 0, as_stream(stream), W, Cout, K, NT, rot, total,
-                       packed);
+                       packed, (long long)K, 1LL, 0LL);
+    return check_launch("pack_weight_kernel");
+}
+
+extern "C" int ptt_pack_weight_strided_f32(const float* W, int Cout, int K, int64_t stride_out, int64_t stride_k, int batch,
+                                           int64_t stride_batch, float* packed, ptt_stream_t stream) {
+    if (Cout <= 0 || K <= 0 || batch < 0) return fail(PTT_EINVAL, "ptt_pack_weight_strided_f32: Cout=%d K=%d batch=%d", Cout, K, batch);
+    if (batch == 0) return PTT_OK;
+    if (!W || !packed) return fail(PTT_EINVAL, "ptt_pack_weight_strided_f32: null pointer");
+    const size_t total = ptt_packed_weight_elems(Cout, K);
+    const int NT = (Cout + 31) / 32;
+    size_t g = (total + 255) / 256;
+    if (g > 1024) g = 1024;
+    hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)g, (unsigned)batch), dim3(256), 0, as_stream(stream), W, Cout, K, NT, 0,
+                       total, packed, (long long)stride_out, (long long)stride_k, (long long)stride_batch);
     return check_launch("pack_weight_kernel");
 }
 
@@ -1469,9 +1524,29 @@ extern "C" int ptt_pack_weight_f32(const float* W, int Cout, int K, float* packe
     return ptt_pack_weight_rot_f32(W, Cout, K, 0, packed, stream);
 }
 
+static int linear_launch(const float* X, int rows, int K, int ldx, const float* Wpacked, int Cout, const float* scale,
+                         const float* shift, int relu, const float* residual, int ldr, float* out, int ldo, int batch,
+                         long long xb, long long wb, long long ob, long long rb, ptt_stream_t stream);
+
 extern "C" int ptt_linear_f32(const float* X, int rows, int K, int ldx, const float* Wpacked, int Cout,
                               const float* scale, const float* shift, int relu, const float* residual, int ldr,
                               float* out, int ldo, ptt_stream_t stream) {
+    return linear_launch(X, rows, K, ldx, Wpacked, Cout, scale, shift, relu, residual, ldr, out, ldo, 1, 0, 0, 0, 0, stream);
+}
+
+extern "C" int ptt_linear_batched_f32(const float* X, int rows, int K, int ldx, int64_t x_batch_stride, const float* Wpacked,
+                                      int64_t w_batch_stride, int Cout, const float* scale, const float* shift, int relu,
+                                      const float* residual, int ldr, int64_t r_batch_stride, float* out, int ldo,
+                                      int64_t o_batch_stride, int batch, ptt_stream_t stream) {
+    if (batch < 0 || batch > 65535) return fail(PTT_EINVAL, "ptt_linear_batched_f32: batch=%d", batch);
+    if (batch == 0) return PTT_OK;
+    return linear_launch(X, rows, K, ldx, Wpacked, Cout, scale, shift, relu, residual, ldr, out, ldo, batch, x_batch_stride,
+                         w_batch_stride, o_batch_stride, r_batch_stride, stream);
+}
+
+static int linear_launch(const float* X, int rows, int K, int ldx, const float* Wpacked, int Cout, const float* scale,
+                         const float* shift, int relu, const float* residual, int ldr, float* out, int ldo, int batch,
+                         long long xb, long long wb, long long ob, long long rb, ptt_stream_t stream) {
     if (rows < 0 || K <= 0 || Cout <= 0 || ldx < K || ldo < Cout || (residual && ldr < Cout))
         return fail(PTT_EINVAL, "ptt_linear_f32: rows=%d K=%d Cout=%d ldx=%d ldo=%d ldr=%d", rows, K, Cout, ldx, ldo,
                     ldr);
@@ -1481,7 +1556,8 @@ extern "C" int ptt_linear_f32(const float* X, int rows, int K, int ldx, const fl
     p.X = X; p.Wp = Wpacked; p.scale = scale; p.shift = shift; p.residual = residual; p.out = out;
     p.rows = rows; p.K = K; p.ldx = ldx; p.Cout = Cout; p.relu = relu; p.ldr = ldr; p.ldo = ldo;
     p.nkb = (K + 7) / 8; p.NT = (Cout + 31) / 32;
-    p.vec_ok = ((ldx & 3) == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0) ? 1 : 0;
+    p.vec_ok = ((ldx & 3) == 0 && (xb & 3) == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0) ? 1 : 0;
+    p.xb = xb; p.wb = wb; p.ob = ob; p.rb = rb;
     // Tile choice (measured on all six GEMM shapes of the path, scripts/kernel_bench.py SWEEP_LINEAR=1): the smallest
     // tile, 32 rows x 128 columns, wins everywhere (qkv 93 vs 75 TFLOP/s for 64x256): these launches are only
     // 1-10 GFLOP, so workgroup count (>= 4 per CU, fine-grained tails) matters more than weight reuse per workgroup.
@@ -1489,7 +1565,7 @@ extern "C" int ptt_linear_f32(const float* X, int rows, int K, int ldx, const fl
     const int rt64 = (rows + 63) / 64, rt32 = (rows + 31) / 32, cg256 = (p.NT + 7) / 8, cg128 = (p.NT + 3) / 4;
     const int RT = dev_switches().linear_rt, CT = dev_switches().linear_ct;
     const int lds = 2 * (RT * 32) * LIN_LDK * (int)sizeof(float);
-    const dim3 grid(RT == 2 ? rt64 : rt32, CT == 2 ? cg256 : cg128);
+    const dim3 grid(RT == 2 ? rt64 : rt32, CT == 2 ? cg256 : cg128, batch);
     hipStream_t s = as_stream(stream);
     int rc = PTT_OK;
 #define PTT_LIN_CASE(R, V, C)                                                                                  \

@@ -641,3 +641,44 @@ def linear_wgrad(dz, x, out=None, accumulate=False):
                                                    int(bool(accumulate)), _ptr(ws), ws.numel() * 8, _stream()),
                    "ptt_linear_wgrad_f32")
     return out
+
+
+# --------------------------------------------------------------------------- T-opt: dense attention as batched MFMA GEMMs
+def pack_weight_strided(src, cout, k, stride_out, stride_k, batch, stride_batch):
+    """`batch` (cout x k) matrices addressed by element strides inside the float32 device tensor `src` -> packed
+    MFMA B-fragment buffers, (batch, ptt_packed_weight_elems(cout, k)) — ptt_pack_weight_strided_f32."""
+    if not src.is_cuda or src.dtype != torch.float32:
+        raise RuntimeError("src must be a float32 device tensor")
+    n = _lib.lib().ptt_packed_weight_elems(int(cout), int(k))
+    out = torch.empty((int(batch), n), dtype=torch.float32, device=src.device)
+    with torch.cuda.device(src.device):
+        _lib.check(_lib.lib().ptt_pack_weight_strided_f32(_ptr(src), int(cout), int(k), int(stride_out), int(stride_k), int(batch),
+                                                          int(stride_batch), _ptr(out), _stream()), "ptt_pack_weight_strided_f32")
+    return out
+
+
+def linear_batched(x, wpacked, cout, residual=None):
+    """out[b] = x[b] @ W[b]^T (+ residual[b]) for b < batch: x (batch, rows, K) with contiguous last dim (any row /
+    batch strides, e.g. a column slice of a wider buffer), wpacked (batch, packed elems) -> (batch, rows, cout)."""
+    if not x.is_cuda or x.dtype != torch.float32 or x.dim() != 3 or x.stride(2) != 1:
+        raise RuntimeError("x must be a (batch, rows, K) float32 device tensor with contiguous channels")
+    Bt, rows, K = x.shape
+    out = torch.empty((Bt, rows, int(cout)), dtype=torch.float32, device=x.device)
+    r = residual
+    if r is not None and (r.dim() != 3 or r.stride(2) != 1):
+        raise RuntimeError("residual must be (batch, rows, cout) with contiguous channels")
+    with torch.cuda.device(x.device), _timed('ptt_linear_f32'):
+        _lib.check(_lib.lib().ptt_linear_batched_f32(
+            _ptr(x), rows, K, x.stride(1), x.stride(0), _ptr(wpacked), wpacked.stride(0), int(cout), None, None, 0,
+            _ptr(r), r.stride(1) if r is not None else int(cout), r.stride(0) if r is not None else 0,
+            _ptr(out), int(cout), rows * int(cout), Bt, _stream()), "ptt_linear_batched_f32")
+    return out
+
+
+def softmax_rows_(x, scale):
+    """In-place softmax(scale * x) along the last dim of a contiguous float32 device tensor."""
+    _chk(x, "x", torch.float32)
+    n = x.shape[-1]
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().ptt_softmax_rows_f32(_ptr(x), x.numel() // n, n, n, float(scale), _stream()), "ptt_softmax_rows_f32")
+    return x

@@ -23,6 +23,7 @@ Fixtures:
   G9 cosine_sim_aug.npz    CosineSimAug (N1): cosine map samples + cosine_feats
   G6 ptt_forward.npz       full PTT.forward (eval) through the reference's own heads (N2) + state_dict key/shape list
   G10 train_step.npz       one training forward + backward of the full tracker (N3): loss, gradient norms, 8 full gradients
+  G13 transformer_std.npz  TransformerBlockSTD (the dense Q.K^T / attn.V variant no shipped config selects), N = 128 / 64 / 50
   G12 tracking_pre_post.npz  N4: the reference's crop_center_pc / get_model / regularize_pc / get_box_by_offset
                            (ptt/datasets/kitti/kitti_tracking_utils.py:186-367) on a synthetic 6-frame tracklet and on
                            edge cases (empty crop, n <= 2, n == input_size, the redraw branch of get_box_by_offset).
@@ -243,6 +244,24 @@ def main():
         report.append("G5 TransformerBlock N=%d: oracle vs reference max |res diff| = %.2e (incl. duplicated points)"
                       % (N, d_res))
     save("G5_transformer.npz", **g5)
+
+    # ---------------- G13 TransformerBlockSTD (T-opt: the dense Q.K^T / attn.V variant, variants.py:12-40) ----------------
+    from ptt.models.transformer_block.variants import TransformerBlockSTD as RefSTD
+    g13 = {}
+    for N in (128, 64, 50):
+        P = {k: v for k, v in transformer_params(1300 + N).items() if not k.startswith("fc_gamma")}
+        tb = RefSTD(256, 512, 16).eval()
+        tb.load_state_dict(P)
+        s13, _ = synth.frames(1300 + N, 2, N, 64, K_s=N)
+        f13 = np.random.RandomState(13 + N).standard_normal((2, N, 256)).astype(np.float32)
+        with torch.no_grad():
+            res, attn = tb(torch.from_numpy(s13), torch.from_numpy(f13))
+        mres, mattn = R.transformer_block_std(torch.from_numpy(s13), torch.from_numpy(f13), P)
+        d13 = max(float((res - mres).abs().max()), float((attn - mattn).abs().max()))
+        assert d13 == 0.0, d13
+        g13.update({"xyz%d" % N: s13, "feat%d" % N: f13, "res%d" % N: res.numpy(), "attn%d" % N: attn.numpy()})
+    save("G13_transformer_std.npz", **g13)
+    report.append("G13 TransformerBlockSTD N=128/64/50: oracle == reference bitwise (res and the N x N attention)")
 
     # ---------------- G8 kNN vs reference square_distance + argsort (tie-free) ----------------
     rs8 = np.random.RandomState(808)

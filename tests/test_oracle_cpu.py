@@ -111,6 +111,26 @@ def test_G11_oracle_fps_equals_the_references_own_numpy_fps():
     assert n == 17
 
 
+def test_G13_transformer_block_std_oracle_and_mirror():
+    """Fixture G13 (the reference's TransformerBlockSTD): the oracle restatement and the mirror module's stock-torch
+    path (CPU) both reproduce it."""
+    from ptt_amd.models.transformer_block.variants import TransformerBlockSTD
+    from tests.util import transformer_params
+    g = np.load(os.path.join(GOLD, "G13_transformer_std.npz"))
+    for N in (128, 64, 50):
+        P = {k: v for k, v in transformer_params(1300 + N).items() if not k.startswith("fc_gamma")}
+        xyz, feat = torch.from_numpy(g["xyz%d" % N]), torch.from_numpy(g["feat%d" % N])
+        res, attn = R.transformer_block_std(xyz, feat, P)
+        np.testing.assert_array_equal(res.numpy(), g["res%d" % N])
+        np.testing.assert_array_equal(attn.numpy(), g["attn%d" % N])
+        tb = TransformerBlockSTD(256, 512, 16).eval()
+        tb.load_state_dict(P)
+        with torch.no_grad():
+            r2, a2 = tb(xyz, feat)
+        np.testing.assert_allclose(r2.numpy(), g["res%d" % N], atol=1e-6, rtol=1e-6)
+        np.testing.assert_allclose(a2.numpy(), g["attn%d" % N], atol=1e-7, rtol=1e-6)
+
+
 def test_G8_knn_equals_reference_argsort():
     g = _g("G8_knn_argsort.npz")
     np.testing.assert_array_equal(O.knn(g["xyz"], 16), g["knn"])
