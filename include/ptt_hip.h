@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PTT_ABI_VERSION 7
+#define PTT_ABI_VERSION 8
 
 enum {
     PTT_OK = 0,
@@ -379,6 +379,15 @@ int ptt_pool_rows_f32(const float* X, int ldx, int G, int ns, int C, float* out,
                       ptt_stream_t stream);
 int ptt_pool_rows_bwd_f32(const float* dOut, int ldo, const int32_t* arg, int G, int ns, int C, float* dX, int ldx,
                           ptt_stream_t stream);
+/* Grouping of point-major rows and its deterministic backward (the training-mode layer-0 hoist: the first MLP layer's
+ * feature half is evaluated once per point, then gathered per (centre, neighbour) row):
+ *   ptt_gather_rows_f32       out[b,e,:] = src[b, idx[b,e], :]        src (B,N,C), idx (B,E) -> out (B,E,C); C % 4 == 0
+ *   ptt_scatter_csr_i32       order (B,E) / start (B,N+1): the entries of every cloud sorted by (idx, e)
+ *   ptt_scatter_rows_csr_f32  out[b,n,:] = sum of g[b,e,:] over idx[b,e] == n in ascending e (fixed order) */
+int ptt_gather_rows_f32(const float* src, const int32_t* idx, int B, int N, int E, int C, float* out, ptt_stream_t stream);
+int ptt_scatter_csr_i32(const int32_t* idx, int B, int N, int E, int32_t* order, int32_t* start, ptt_stream_t stream);
+int ptt_scatter_rows_csr_f32(const float* g, const int32_t* order, const int32_t* start, int B, int N, int E, int C,
+                             float* out, ptt_stream_t stream);
 size_t ptt_linear_wgrad_workspace(int R, int Cout, int Cin);
 int ptt_linear_wgrad_f32(const float* dZ, int ldz, const float* X, int ldx, int R, int Cout, int Cin, float* dW,
                          int accumulate, void* workspace, size_t workspace_bytes, ptt_stream_t stream);

@@ -553,6 +553,19 @@ extern "C" int ptt_scatter_add_det_f32(const float* src, const int32_t* idx, int
     return check_launch("scatter_add_det_kernel");
 }
 
+extern "C" int ptt_scatter_csr_i32(const int32_t* idx, int B, int N, int E, int32_t* order, int32_t* start, ptt_stream_t stream) {
+    if (B < 0 || N <= 0 || E <= 0) return fail(PTT_EINVAL, "ptt_scatter_csr_i32: B=%d N=%d E=%d", B, N, E);
+    if (B == 0) return PTT_OK;
+    if (!idx || !order || !start) return fail(PTT_EINVAL, "ptt_scatter_csr_i32: null pointer");
+    if (E > 16384 || (unsigned long long)N * 16384ull > 0xffffffffull)
+        return fail(PTT_EUNSUPPORTED, "ptt_scatter_csr_i32: E=%d N=%d (at most 16384 entries per cloud)", E, N);
+    int Epad = 2;
+    while (Epad < E) Epad <<= 1;
+    hipLaunchKernelGGL(scatter_csr_kernel, dim3(B), dim3(1024), (size_t)Epad * sizeof(unsigned), as_stream(stream), idx, N, E, Epad,
+                       order, start);
+    return check_launch("scatter_csr_kernel");
+}
+
 extern "C" int ptt_knn_rel_f32(const float* xyz, int B, int N, int k, int32_t* idx_out, float* rel_out,
                                ptt_stream_t stream);
 

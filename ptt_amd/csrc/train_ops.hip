@@ -433,6 +433,49 @@ __global__ __launch_bounds__(256) void wgrad_finish_kernel(const float* __restri
     }
 }
 
+// out[b, e, :] = src[b, idx[b, e], :] over point-major rows (float4 quads; C % 4 == 0): the forward of grouping once the
+// first MLP layer has been evaluated per POINT (the training-mode layer-0 hoist, ptt_amd/train_ops.py).
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, const int32_t* __restrict__ idx, int N,
+                                                          int E, int C, float* __restrict__ out) {
+    const int Cq = C >> 2, span = Cq < 256 ? Cq : 256, RG = 256 / span;
+    const int q0 = threadIdx.x % span, rg = threadIdx.x / span;
+    if (rg >= RG) return;
+    const int b = blockIdx.y;
+    const float* sb = src + (size_t)b * N * C;
+    float* ob = out + (size_t)b * E * C;
+    const int32_t* ib = idx + (size_t)b * E;
+    for (int e = blockIdx.x * RG + rg; e < E; e += gridDim.x * RG) {
+        const int n = ib[e];
+        for (int q = q0; q < Cq; q += span)
+            *reinterpret_cast<f32x4t*>(ob + (size_t)e * C + 4 * q) = *reinterpret_cast<const f32x4t*>(sb + (size_t)n * C + 4 * q);
+    }
+}
+
+// Its backward, deterministic: out[b, n, :] = sum of g[b, e, :] over the entries e with idx[b, e] == n, in ASCENDING e
+// (order / start = the CSR scatter_csr_kernel builds). Thread = (point n, channel quad): coalesced row reads.
+__global__ __launch_bounds__(256) void scatter_rows_det_kernel(const float* __restrict__ g, const int32_t* __restrict__ order,
+                                                               const int32_t* __restrict__ start, int N, int E, int C,
+                                                               float* __restrict__ out) {
+    const int Cq = C >> 2, span = Cq < 256 ? Cq : 256, RG = 256 / span;
+    const int q0 = threadIdx.x % span, rg = threadIdx.x / span;
+    if (rg >= RG) return;
+    const int b = blockIdx.y;
+    const float* gb = g + (size_t)b * E * C;
+    const int32_t* ob = order + (size_t)b * E;
+    const int32_t* st = start + (size_t)b * (N + 1);
+    for (int n = blockIdx.x * RG + rg; n < N; n += gridDim.x * RG) {
+        const int k0 = st[n], k1 = st[n + 1];
+        for (int q = q0; q < Cq; q += span) {
+            f32x4t acc = {0.f, 0.f, 0.f, 0.f};
+            for (int k = k0; k < k1; ++k) {
+                const f32x4t v = *reinterpret_cast<const f32x4t*>(gb + (size_t)ob[k] * C + 4 * q);
+                acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
+            }
+            *reinterpret_cast<f32x4t*>(out + ((size_t)b * N + n) * C + 4 * q) = acc;
+        }
+    }
+}
+
 static inline int ew_grid(size_t total) {
     size_t g = (total + 255) / 256;
     return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
@@ -551,6 +594,32 @@ static int wgrad_chunk_rows(int R, int Cout, int Cin) {
     if (rows < WG_MIN_ROWS) rows = WG_MIN_ROWS;
     if (rows > WG_ROWS) rows = WG_ROWS;
     return rows;
+}
+
+extern "C" int ptt_gather_rows_f32(const float* src, const int32_t* idx, int B, int N, int E, int C, float* out,
+                                   ptt_stream_t stream) {
+    if (B < 0 || N <= 0 || E < 0 || C <= 0 || (C & 3)) return fail(PTT_EINVAL, "ptt_gather_rows_f32: B=%d N=%d E=%d C=%d (C %% 4)", B, N, E, C);
+    if (B == 0 || E == 0) return PTT_OK;
+    if (!src || !idx || !out || ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(out)) & 15))
+        return fail(PTT_EINVAL, "ptt_gather_rows_f32: null or unaligned pointer");
+    const int Cq = C >> 2, RG = 256 / (Cq < 256 ? Cq : 256);
+    int gx = (E + RG * 4 - 1) / (RG * 4);
+    if (gx > 4096) gx = 4096;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(gx, B), dim3(256), 0, as_stream(stream), src, idx, N, E, C, out);
+    return check_launch("gather_rows_kernel");
+}
+
+extern "C" int ptt_scatter_rows_csr_f32(const float* g, const int32_t* order, const int32_t* start, int B, int N, int E, int C,
+                                        float* out, ptt_stream_t stream) {
+    if (B < 0 || N <= 0 || E < 0 || C <= 0 || (C & 3)) return fail(PTT_EINVAL, "ptt_scatter_rows_csr_f32: B=%d N=%d E=%d C=%d", B, N, E, C);
+    if (B == 0) return PTT_OK;
+    if (!g || !order || !start || !out || ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(out)) & 15))
+        return fail(PTT_EINVAL, "ptt_scatter_rows_csr_f32: null or unaligned pointer");
+    const int Cq = C >> 2, RG = 256 / (Cq < 256 ? Cq : 256);
+    int gx = (N + RG - 1) / RG;
+    if (gx > 4096) gx = 4096;
+    hipLaunchKernelGGL(scatter_rows_det_kernel, dim3(gx, B), dim3(256), 0, as_stream(stream), g, order, start, N, E, C, out);
+    return check_launch("scatter_rows_det_kernel");
 }
 
 extern "C" size_t ptt_linear_wgrad_workspace(int R, int Cout, int Cin) {

@@ -180,6 +180,14 @@ class PointnetSAModuleVotes(nn.Module):
 
         xyz_flipped = xyz.transpose(1, 2).contiguous()
         new_xyz = pointnet2_utils.gather_operation(xyz_flipped, inds).transpose(1, 2).contiguous()
+        if (features is not None and self.use_xyz and not self.sample_uniformly
+                and self.nsample * npoint <= 16384 and train_ops.usable(self.mlp_module, features)
+                and self.mlp_module[0].conv.weight.shape[0] % 4 == 0):
+            # training mode on a HIP device, a level with point features: layer 0 hoisted to one row per POINT
+            # (ptt_amd/train_ops.py: sa_level_hoisted), the rest of the SharedMLP + max-pool on the row kernels
+            idx = pointnet2_utils.ball_query(self.radius, self.nsample, xyz, new_xyz)
+            y = train_ops.sa_level_hoisted(xyz, new_xyz, features, idx, self.mlp_module, self.radius, self.normalize_xyz)
+            return new_xyz, y, inds.to(torch.int64)
         grouped_features, grouped_xyz = self.grouper(xyz, new_xyz, features)      # (B,C,M,ns)
         if train_ops.usable(self.mlp_module, grouped_features):
             # training mode on a HIP device: SharedMLP (batch-statistics BatchNorm) + the max over the neighbours, forward

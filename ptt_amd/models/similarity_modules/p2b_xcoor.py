@@ -117,6 +117,13 @@ class CosineSimAug(nn.Module):
             batch_dict['cosine_feats'] = y.transpose(1, 2)                                    # (B,c,n2) view
             return batch_dict
 
+        if (train_ops.usable(self.mlp, search_feats) and self.mlp[0].conv.weight.shape[1] == f + 4
+                and self.mlp[0].conv.weight.shape[0] % 4 == 0):
+            # training on a HIP device: layer 0 split per template point + similarity term (train_ops.xcorr_hoisted),
+            # the remaining SharedMLP layers and the max over the template axis on the row kernels
+            batch_dict['cosine_feats'] = self.conv(train_ops.xcorr_hoisted(search_feats, template_feats, template_xyz,
+                                                                           self.mlp, self.cosine.eps))
+            return batch_dict
         sim_feat = self.cosine(template_feats.unsqueeze(-1).expand(b, f, n1, n2),
                                search_feats.unsqueeze(2).expand(b, f, n1, n2))
         template_xyz_ = template_xyz.transpose(1, 2).contiguous().unsqueeze(-1).expand(b, 3, n1, n2)

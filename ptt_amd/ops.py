@@ -682,3 +682,30 @@ def softmax_rows_(x, scale):
     with torch.cuda.device(x.device):
         _lib.check(_lib.lib().ptt_softmax_rows_f32(_ptr(x), x.numel() // n, n, n, float(scale), _stream()), "ptt_softmax_rows_f32")
     return x
+
+
+def gather_rows(src, idx):
+    """src (B,N,C) point-major rows, idx (B,E) int32 -> (B,E,C): out[b,e] = src[b, idx[b,e]] — ptt_gather_rows_f32."""
+    _chk(src, "src", torch.float32, 3)
+    _chk(idx, "idx", torch.int32, 2)
+    B, N, C = src.shape
+    E = idx.shape[1]
+    out = torch.empty((B, E, C), dtype=torch.float32, device=src.device)
+    with torch.cuda.device(src.device):
+        _lib.check(_lib.lib().ptt_gather_rows_f32(_ptr(src), _ptr(idx), B, N, E, C, _ptr(out), _stream()), "ptt_gather_rows_f32")
+    return out
+
+
+def scatter_rows_det(g, idx, N):
+    """The adjoint of gather_rows in a fixed summation order: g (B,E,C), idx (B,E) -> (B,N,C)."""
+    _chk(g, "g", torch.float32, 3)
+    _chk(idx, "idx", torch.int32, 2)
+    B, E, C = g.shape
+    order = torch.empty((B, E), dtype=torch.int32, device=g.device)
+    start = torch.empty((B, int(N) + 1), dtype=torch.int32, device=g.device)
+    out = torch.empty((B, int(N), C), dtype=torch.float32, device=g.device)
+    with torch.cuda.device(g.device):
+        _lib.check(_lib.lib().ptt_scatter_csr_i32(_ptr(idx), B, int(N), E, _ptr(order), _ptr(start), _stream()), "ptt_scatter_csr_i32")
+        _lib.check(_lib.lib().ptt_scatter_rows_csr_f32(_ptr(g), _ptr(order), _ptr(start), B, int(N), E, C, _ptr(out), _stream()),
+                   "ptt_scatter_rows_csr_f32")
+    return out

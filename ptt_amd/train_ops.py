@@ -35,18 +35,39 @@ def usable(mlp, x):
     return True
 
 
-class _SharedMlpPool(torch.autograd.Function):
-    """(rows (R,C0), ns, eps per layer, [W, gamma, beta] per layer) -> (pooled (R/ns, C_L), [mean, var] per layer)."""
+class _GatherRows(torch.autograd.Function):
+    """rows (B,N,C), idx (B,E) -> (B,E,C); backward = the deterministic row scatter-add."""
 
     @staticmethod
-    def forward(ctx, x, ns, eps, *params):
+    def forward(ctx, rows, idx):
+        ctx.save_for_backward(idx)
+        ctx.N = rows.shape[1]
+        return ops.gather_rows(rows.contiguous(), idx)
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        return ops.scatter_rows_det(g.contiguous(), idx, ctx.N), None
+
+
+def gather_rows(rows, idx):
+    return _GatherRows.apply(rows, idx)
+
+
+class _SharedMlpPool(torch.autograd.Function):
+    """(rows (R,C0), ns, eps per layer, preact, [W, gamma, beta] per layer) -> (pooled (R/ns, C_L), [mean, var] per layer).
+    preact: `rows` already IS layer 0's convolution output (the caller hoisted that layer: train_ops.sa_level_hoisted /
+    xcorr_hoisted), so layer 0 is BatchNorm + ReLU only and its W entry is a placeholder that gets no gradient."""
+
+    @staticmethod
+    def forward(ctx, x, ns, eps, preact, *params):
         L = len(params) // 3
         saved, stats = [], []
         cur = x.contiguous()
         for l in range(L):
             W, gamma, beta = params[3 * l], params[3 * l + 1], params[3 * l + 2]
-            cout = W.shape[0]
-            z = ops.linear(cur, ops.pack_weight(W), cout)
+            cout = gamma.shape[0]
+            z = cur if (preact and l == 0) else ops.linear(cur, ops.pack_weight(W), cout)
             mean, var, invstd = ops.bn_stats(z, eps[l])
             nxt = ops.bn_apply(z, mean, invstd, gamma.detach(), beta.detach(), relu=True)
             saved += [cur, z, nxt, mean, invstd]
@@ -54,7 +75,7 @@ class _SharedMlpPool(torch.autograd.Function):
             cur = nxt
         pooled, arg = ops.pool_rows(cur, ns)
         ctx.save_for_backward(arg, *saved, *[p.detach() for p in params])
-        ctx.L, ctx.ns = L, int(ns)
+        ctx.L, ctx.ns, ctx.preact = L, int(ns), bool(preact)
         ctx.mark_non_differentiable(*stats)
         return (pooled,) + tuple(stats)
 
@@ -69,14 +90,17 @@ class _SharedMlpPool(torch.autograd.Function):
             x_in, z, act, mean, invstd = saved[5 * l:5 * l + 5]
             W, gamma = params[3 * l], params[3 * l + 1]
             dz, dgamma, dbeta = ops.bn_bwd(g, act, z, mean, invstd, gamma, out=g)      # in place over the incoming gradient
+            grads[3 * l + 1], grads[3 * l + 2] = dgamma, dbeta
+            if ctx.preact and l == 0:
+                g = dz                                                                  # d(loss)/d(layer-0 pre-activation)
+                break
             w2 = W.reshape(W.shape[0], -1)
             grads[3 * l] = ops.linear_wgrad(dz, x_in).view_as(W)
-            grads[3 * l + 1], grads[3 * l + 2] = dgamma, dbeta
             if l > 0 or ctx.needs_input_grad[0]:
                 g = ops.linear(dz, ops.pack_weight(w2.t().contiguous()), w2.shape[1])
             else:
                 g = None
-        return (g, None, None) + tuple(grads)
+        return (g, None, None, None) + tuple(grads)
 
 
 def shared_mlp_pool(grouped, mlp, pool_dim):
@@ -89,12 +113,18 @@ def shared_mlp_pool(grouped, mlp, pool_dim):
     else:
         rows = grouped.permute(0, 3, 2, 1).reshape(B * W * H, C)             # (b, w, h) rows, max over h
         ns, keep = H, W
+    return rows_mlp_pool(rows, mlp, ns, B, keep, preact=False)
+
+
+def rows_mlp_pool(rows, mlp, ns, B, keep, preact):
+    """The row form: rows (B * keep * ns, C) ordered (frame, kept position, pooled position) -> (B, C_L, keep).
+    preact: rows are layer 0's convolution output already (hoisted by the caller)."""
     params, eps = [], []
     for unit in mlp:
         bn = unit.normlayer.bn
         params += [unit.conv.weight, bn.weight, bn.bias]
         eps.append(float(bn.eps))
-    out = _SharedMlpPool.apply(rows, ns, tuple(eps), *params)
+    out = _SharedMlpPool.apply(rows, ns, tuple(eps), bool(preact), *params)
     pooled, stats = out[0], out[1:]
     R = rows.shape[0]
     with torch.no_grad():                                   # nn.BatchNorm2d's bookkeeping in training mode
@@ -105,3 +135,42 @@ def shared_mlp_pool(grouped, mlp, pool_dim):
             bn.running_var.mul_(1 - m).add_(stats[2 * l + 1], alpha=m * R / max(R - 1, 1))
             bn.num_batches_tracked.add_(1)
     return pooled.view(B, keep, -1).transpose(1, 2)         # (B, C_L, keep)
+
+
+def sa_level_hoisted(xyz, new_xyz, features, idx, mlp, radius, normalize_xyz):
+    """One set-abstraction level in TRAINING mode with layer 0 hoisted, as the fused inference kernels do it (DESIGN.md
+    lesson 9): the first 1x1 convolution is linear in [rel ; f_n], so its feature half is evaluated once per POINT
+    (B*N rows) instead of once per (centre, neighbour) row (16-32x more), gathered per row (ptt_gather_rows_f32, with the
+    deterministic row scatter-add as its backward), and the three relative-coordinate terms are added:
+        z0[b,m,k,:] = (W0[:,3:] f)[b, idx[b,m,k]] + W0[:,:3] (xyz[b, idx[b,m,k]] - new_xyz[b,m]) / radius
+    The grouped (B, 3+C, M, ns) tensor of QueryAndGroup (pointnet2_utils.py:350-361) and the K = 3+C convolution over all
+    rows never exist. xyz (B,N,3), new_xyz (B,M,3), features (B,C,N), idx (B,M,ns) int32 -> (B, C_L, M)."""
+    from .models.backbones_3d.pointnet2 import pointnet2_utils as pu
+    B, M, ns = idx.shape
+    w0 = mlp[0].conv.weight.reshape(mlp[0].conv.weight.shape[0], -1)                    # (C0, 3 + C): xyz first (:359-361)
+    rel = pu.grouping_operation(xyz.transpose(1, 2).contiguous(), idx) - new_xyz.transpose(1, 2).unsqueeze(-1)   # (B,3,M,ns)
+    if normalize_xyz:
+        rel = rel / radius
+    rel_rows = rel.permute(0, 2, 3, 1).reshape(B * M * ns, 3)
+    term = torch.nn.functional.linear(features.transpose(1, 2), w0[:, 3:])              # (B,N,C0), once per point
+    z0 = torch.addmm(gather_rows(term, idx.view(B, M * ns)).view(B * M * ns, -1), rel_rows, w0[:, 0:3].t())
+    return rows_mlp_pool(z0, mlp, ns, B, M, preact=True)
+
+
+def xcorr_hoisted(search_feats, template_feats, template_xyz, mlp, eps):
+    """CosineSimAug's fusion + SharedMLP + max over the template axis (p2b_xcoor.py:35-42) in TRAINING mode with layer 0
+    split as the fused inference kernel splits it: only the similarity channel depends on the search point, so
+        z0[b,j,i,:] = w_sim * cos(t_i, s_j) + (W0[:,1:] [xyz_i ; feat_i])        (j search, i template point)
+    and neither the (B,260,n1,n2) fusion tensor nor the expanded operands of nn.CosineSimilarity are ever built: the
+    cosine map is a (B,n1,n2) matrix product of the normalised features (x1.x2 / (max(|x1|,eps) max(|x2|,eps)), as
+    torch.nn.functional.cosine_similarity defines it). -> (B, C_L, n2)."""
+    B, C, n2 = search_feats.shape
+    n1 = template_feats.shape[-1]
+    w0 = mlp[0].conv.weight.reshape(mlp[0].conv.weight.shape[0], -1)                    # (C0, 1 + 3 + C)
+    tn = template_feats / template_feats.norm(dim=1, keepdim=True).clamp_min(eps)       # (B,C,n1)
+    sn = search_feats / search_feats.norm(dim=1, keepdim=True).clamp_min(eps)           # (B,C,n2)
+    cos = torch.bmm(sn.transpose(1, 2), tn)                                             # (B,n2,n1)
+    rows_i = torch.cat((template_xyz, template_feats.transpose(1, 2)), dim=2)           # (B,n1,3+C)
+    P = torch.nn.functional.linear(rows_i, w0[:, 1:])                                   # (B,n1,C0)
+    z0 = P.unsqueeze(1) + cos.unsqueeze(-1) * w0[:, 0]                                  # (B,n2,n1,C0)
+    return rows_mlp_pool(z0.reshape(B * n2 * n1, -1), mlp, n1, B, n2, preact=True)
