@@ -54,6 +54,25 @@ def gather_rows(rows, idx):
     return _GatherRows.apply(rows, idx)
 
 
+class _AddRelTerm(torch.autograd.Function):
+    """z0 = gathered + rel @ Wx^T : the three relative-coordinate terms of a hoisted layer 0, on the linear kernel (K = 3,
+    `gathered` as the residual) — stock BLAS picks badly shaped kernels for K = 3 and for the 3 x R x C0 weight
+    gradient. rel (R,3), gathered (R,C0), Wx (C0,3)."""
+
+    @staticmethod
+    def forward(ctx, gathered, rel, wx):
+        ctx.save_for_backward(rel, wx)
+        return ops.linear(rel.contiguous(), ops.pack_weight(wx.detach().contiguous()), wx.shape[0], residual=gathered.contiguous())
+
+    @staticmethod
+    def backward(ctx, g):
+        rel, wx = ctx.saved_tensors
+        g = g.contiguous()
+        d_rel = ops.linear(g, ops.pack_weight(wx.detach().t().contiguous()), 3) if ctx.needs_input_grad[1] else None
+        d_wx = ops.linear_wgrad(g, rel.contiguous()) if ctx.needs_input_grad[2] else None
+        return g, d_rel, d_wx
+
+
 class _SharedMlpPool(torch.autograd.Function):
     """(rows (R,C0), ns, eps per layer, preact, [W, gamma, beta] per layer) -> (pooled (R/ns, C_L), [mean, var] per layer).
     preact: `rows` already IS layer 0's convolution output (the caller hoisted that layer: train_ops.sa_level_hoisted /
@@ -153,7 +172,7 @@ def sa_level_hoisted(xyz, new_xyz, features, idx, mlp, radius, normalize_xyz):
         rel = rel / radius
     rel_rows = rel.permute(0, 2, 3, 1).reshape(B * M * ns, 3)
     term = torch.nn.functional.linear(features.transpose(1, 2), w0[:, 3:])              # (B,N,C0), once per point
-    z0 = torch.addmm(gather_rows(term, idx.view(B, M * ns)).view(B * M * ns, -1), rel_rows, w0[:, 0:3].t())
+    z0 = _AddRelTerm.apply(gather_rows(term, idx.view(B, M * ns)).view(B * M * ns, -1), rel_rows, w0[:, 0:3])
     return rows_mlp_pool(z0, mlp, ns, B, M, preact=True)
 
 
