@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PTT_ABI_VERSION 8
+#define PTT_ABI_VERSION 9
 
 enum {
     PTT_OK = 0,
@@ -379,6 +379,20 @@ int ptt_pool_rows_f32(const float* X, int ldx, int G, int ns, int C, float* out,
                       ptt_stream_t stream);
 int ptt_pool_rows_bwd_f32(const float* dOut, int ldo, const int32_t* arg, int G, int ns, int C, float* dX, int ldx,
                           ptt_stream_t stream);
+/* Point-Transformer block in training mode (transformer_block/variants.py:156-163): the element-wise chains around its
+ * GEMMs over the (B,N,k,D) per-(point, neighbour) tensors, one pass each (k = 16, D % 4 == 0; q / kf / vf are (B,N,D)
+ * point rows, knn (B,N,k) int32, pos / a / t / attn / da / dvp (B,N,k,D)):
+ *   ptt_pt_pair_input_f32      t = q_i - kf[knn_ij] + pos_ij                                  (argument of fc_gamma, :160)
+ *   ptt_pt_attn_train_fwd_f32  attn = softmax_j(a * scale); res_i = sum_j attn_ij * (vf[knn_ij] + pos_ij)      (:161-163)
+ *   ptt_pt_attn_train_bwd_f32  from dres: dvp_ij = attn_ij * dres_i (gradient of v[knn] and of pos),
+ *                              da_ij = attn_ij * (dres_i.vp_ij - sum_j' attn_ij' dres_i.vp_ij') * scale          */
+int ptt_pt_pair_input_f32(const float* q, const float* kf, const int32_t* knn, const float* pos, int B, int N, int k, int D,
+                          float* t, ptt_stream_t stream);
+int ptt_pt_attn_train_fwd_f32(const float* a, const float* vf, const int32_t* knn, const float* pos, int B, int N, int k, int D,
+                              float scale, float* attn, float* res, ptt_stream_t stream);
+int ptt_pt_attn_train_bwd_f32(const float* attn, const float* vf, const int32_t* knn, const float* pos, const float* dres, int B,
+                              int N, int k, int D, float scale, float* da, float* dvp, ptt_stream_t stream);
+
 /* Grouping of point-major rows and its deterministic backward (the training-mode layer-0 hoist: the first MLP layer's
  * feature half is evaluated once per point, then gathered per (centre, neighbour) row):
  *   ptt_gather_rows_f32       out[b,e,:] = src[b, idx[b,e], :]        src (B,N,C), idx (B,E) -> out (B,E,C); C % 4 == 0

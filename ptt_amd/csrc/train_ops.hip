@@ -476,6 +476,111 @@ __global__ __launch_bounds__(256) void scatter_rows_det_kernel(const float* __re
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Point-Transformer block in TRAINING mode: the element-wise chains around its GEMMs over the per-(point, neighbour)
+// tensors (B,N,k,D) (transformer_block/variants.py:156-163), each as ONE pass. Thread = (point, channel quad); the k
+// neighbours are a loop in registers, so the softmax over neighbours needs no cross-thread traffic.
+//   pair_input:   t[b,i,j,:]  = q[b,i,:] - kf[b, knn[b,i,j], :] + pos[b,i,j,:]                          (:160 argument)
+//   attn_fwd:     attn[b,i,j,:] = softmax_j(a[b,i,j,:] * scale);  res[b,i,:] = sum_j attn * (vf[b,knn] + pos)   (:161-163)
+//   attn_bwd:     given dres: dvp[b,i,j,:] = attn * dres;  da = attn * (dres.vp_j - sum_j' attn_j' dres.vp_j') * scale
+// ------------------------------------------------------------------------------------------
+template <int KN>
+__global__ __launch_bounds__(256) void pair_input_kernel(const float* __restrict__ q, const float* __restrict__ kf,
+                                                         const int32_t* __restrict__ knn, const float* __restrict__ pos, int N,
+                                                         int D, long long total_pts, float* __restrict__ t) {
+    const int Dq = D >> 2;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total_pts * Dq; e += (long long)gridDim.x * 256) {
+        const long long pt = e / Dq;
+        const int c = (int)(e - pt * Dq) * 4;
+        const long long b = pt / N;
+        const f32x4t qv = *reinterpret_cast<const f32x4t*>(q + pt * D + c);
+#pragma unroll 4
+        for (int j = 0; j < KN; ++j) {
+            const int n = knn[pt * KN + j];
+            const f32x4t kv = *reinterpret_cast<const f32x4t*>(kf + (b * N + n) * D + c);
+            const f32x4t pv = *reinterpret_cast<const f32x4t*>(pos + (pt * KN + j) * D + c);
+            f32x4t o;
+#pragma unroll
+            for (int x = 0; x < 4; ++x) o[x] = (qv[x] - kv[x]) + pv[x];
+            *reinterpret_cast<f32x4t*>(t + (pt * KN + j) * D + c) = o;
+        }
+    }
+}
+
+template <int KN>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ a, const float* __restrict__ vf,
+                                                       const int32_t* __restrict__ knn, const float* __restrict__ pos, int N, int D,
+                                                       long long total_pts, float scale, float* __restrict__ attn,
+                                                       float* __restrict__ res) {
+    const int Dq = D >> 2;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total_pts * Dq; e += (long long)gridDim.x * 256) {
+        const long long pt = e / Dq;
+        const int c = (int)(e - pt * Dq) * 4;
+        const long long b = pt / N;
+        f32x4t av[KN];
+        f32x4t m = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+#pragma unroll
+        for (int j = 0; j < KN; ++j) {
+            av[j] = *reinterpret_cast<const f32x4t*>(a + (pt * KN + j) * D + c);
+#pragma unroll
+            for (int x = 0; x < 4; ++x) { av[j][x] *= scale; m[x] = fmaxf(m[x], av[j][x]); }
+        }
+        f32x4t sum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < KN; ++j)
+#pragma unroll
+            for (int x = 0; x < 4; ++x) { av[j][x] = __expf(av[j][x] - m[x]); sum[x] += av[j][x]; }
+        f32x4t inv, acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int x = 0; x < 4; ++x) inv[x] = 1.0f / sum[x];
+#pragma unroll
+        for (int j = 0; j < KN; ++j) {
+            const int n = knn[pt * KN + j];
+            const f32x4t vv = *reinterpret_cast<const f32x4t*>(vf + (b * N + n) * D + c);
+            const f32x4t pv = *reinterpret_cast<const f32x4t*>(pos + (pt * KN + j) * D + c);
+            f32x4t w;
+#pragma unroll
+            for (int x = 0; x < 4; ++x) { w[x] = av[j][x] * inv[x]; acc[x] += w[x] * (vv[x] + pv[x]); }
+            *reinterpret_cast<f32x4t*>(attn + (pt * KN + j) * D + c) = w;
+        }
+        *reinterpret_cast<f32x4t*>(res + pt * D + c) = acc;
+    }
+}
+
+template <int KN>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__ attn, const float* __restrict__ vf,
+                                                       const int32_t* __restrict__ knn, const float* __restrict__ pos,
+                                                       const float* __restrict__ dres, int N, int D, long long total_pts, float scale,
+                                                       float* __restrict__ da, float* __restrict__ dvp) {
+    const int Dq = D >> 2;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total_pts * Dq; e += (long long)gridDim.x * 256) {
+        const long long pt = e / Dq;
+        const int c = (int)(e - pt * Dq) * 4;
+        const long long b = pt / N;
+        const f32x4t g = *reinterpret_cast<const f32x4t*>(dres + pt * D + c);
+        f32x4t w[KN], dat[KN];
+        f32x4t s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < KN; ++j) {
+            const int n = knn[pt * KN + j];
+            w[j] = *reinterpret_cast<const f32x4t*>(attn + (pt * KN + j) * D + c);
+            const f32x4t vv = *reinterpret_cast<const f32x4t*>(vf + (b * N + n) * D + c);
+            const f32x4t pv = *reinterpret_cast<const f32x4t*>(pos + (pt * KN + j) * D + c);
+            f32x4t o;
+#pragma unroll
+            for (int x = 0; x < 4; ++x) { dat[j][x] = g[x] * (vv[x] + pv[x]); s[x] += w[j][x] * dat[j][x]; o[x] = w[j][x] * g[x]; }
+            *reinterpret_cast<f32x4t*>(dvp + (pt * KN + j) * D + c) = o;
+        }
+#pragma unroll
+        for (int j = 0; j < KN; ++j) {
+            f32x4t o;
+#pragma unroll
+            for (int x = 0; x < 4; ++x) o[x] = w[j][x] * (dat[j][x] - s[x]) * scale;
+            *reinterpret_cast<f32x4t*>(da + (pt * KN + j) * D + c) = o;
+        }
+    }
+}
+
 static inline int ew_grid(size_t total) {
     size_t g = (total + 255) / 256;
     return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
@@ -620,6 +725,46 @@ extern "C" int ptt_scatter_rows_csr_f32(const float* g, const int32_t* order, co
     if (gx > 4096) gx = 4096;
     hipLaunchKernelGGL(scatter_rows_det_kernel, dim3(gx, B), dim3(256), 0, as_stream(stream), g, order, start, N, E, C, out);
     return check_launch("scatter_rows_det_kernel");
+}
+
+static int pt_train_check(const char* what, int B, int N, int k, int D, const void* p0, const void* p1, const void* p2, const void* p3) {
+    if (B < 0 || N <= 0 || D <= 0 || (D & 3)) return fail(PTT_EINVAL, "%s: B=%d N=%d D=%d (D %% 4)", what, B, N, D);
+    if (k != 16) return fail(PTT_EUNSUPPORTED, "%s: k=%d (16 neighbours is instantiated)", what, k);
+    if (B > 0 && (!p0 || !p1 || !p2 || !p3)) return fail(PTT_EINVAL, "%s: null pointer", what);
+    return PTT_OK;
+}
+
+extern "C" int ptt_pt_pair_input_f32(const float* q, const float* kf, const int32_t* knn, const float* pos, int B, int N, int k,
+                                     int D, float* t, ptt_stream_t stream) {
+    if (int rc = pt_train_check("ptt_pt_pair_input_f32", B, N, k, D, q, kf, knn, pos)) return rc;
+    if (B == 0) return PTT_OK;
+    if (!t) return fail(PTT_EINVAL, "ptt_pt_pair_input_f32: null pointer");
+    const long long pts = (long long)B * N;
+    hipLaunchKernelGGL((pair_input_kernel<16>), dim3(ew_grid((size_t)pts * (D >> 2))), dim3(256), 0, as_stream(stream), q, kf, knn, pos, N,
+                       D, pts, t);
+    return check_launch("pair_input_kernel");
+}
+
+extern "C" int ptt_pt_attn_train_fwd_f32(const float* a, const float* vf, const int32_t* knn, const float* pos, int B, int N, int k,
+                                         int D, float scale, float* attn, float* res, ptt_stream_t stream) {
+    if (int rc = pt_train_check("ptt_pt_attn_train_fwd_f32", B, N, k, D, a, vf, knn, pos)) return rc;
+    if (B == 0) return PTT_OK;
+    if (!attn || !res) return fail(PTT_EINVAL, "ptt_pt_attn_train_fwd_f32: null pointer");
+    const long long pts = (long long)B * N;
+    hipLaunchKernelGGL((attn_fwd_kernel<16>), dim3(ew_grid((size_t)pts * (D >> 2))), dim3(256), 0, as_stream(stream), a, vf, knn, pos, N, D,
+                       pts, scale, attn, res);
+    return check_launch("attn_fwd_kernel");
+}
+
+extern "C" int ptt_pt_attn_train_bwd_f32(const float* attn, const float* vf, const int32_t* knn, const float* pos, const float* dres,
+                                         int B, int N, int k, int D, float scale, float* da, float* dvp, ptt_stream_t stream) {
+    if (int rc = pt_train_check("ptt_pt_attn_train_bwd_f32", B, N, k, D, attn, vf, knn, pos)) return rc;
+    if (B == 0) return PTT_OK;
+    if (!dres || !da || !dvp) return fail(PTT_EINVAL, "ptt_pt_attn_train_bwd_f32: null pointer");
+    const long long pts = (long long)B * N;
+    hipLaunchKernelGGL((attn_bwd_kernel<16>), dim3(ew_grid((size_t)pts * (D >> 2))), dim3(256), 0, as_stream(stream), attn, vf, knn, pos,
+                       dres, N, D, pts, scale, da, dvp);
+    return check_launch("attn_bwd_kernel");
 }
 
 extern "C" size_t ptt_linear_wgrad_workspace(int R, int Cout, int Cin) {

@@ -20,7 +20,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ... import ops
+from ... import ops, train_ops
 from ..model_utils import index_points, square_distance
 
 
@@ -102,7 +102,27 @@ class TransformerBlock(nn.Module):
             res = ops.linear(res, P['fc2'], self.d_points, None, P['fc2_b'], False, features)
             return res, attn
 
-        # training / CPU: the reference's op sequence in stock torch (variants.py:149-165)
+        if train_ops.pt_block_usable(self, xyz, features):
+            # training mode on a HIP device: the GEMMs stay nn.Linear (autograd), the element-wise chains over the
+            # (B,N,k,D) tensors run as one hand-written pass each (ptt_amd/train_ops.py: _PairInput, _AttnAggregate); the
+            # neighbour gathers of k and v happen inside those passes and their gradients come back through the
+            # deterministic row scatter-add. kNN: the HIP kernel (ascending (distance, index), a stable refinement of the
+            # reference's argsort).
+            knn_idx, rel = ops.knn(xyz.contiguous(), self.k, want_rel=True)          # rel = xyz_i - xyz_j (:158)
+            if xyz.requires_grad:                                                     # the box head's proposals carry grad
+                knn_xyz = index_points(xyz, knn_idx.long())
+                rel = xyz[:, :, None] - knn_xyz
+            pre = features
+            x = self.fc1(features)
+            q, kf, vf = self.w_qs(x), self.w_ks(x), self.w_vs(x)
+            pos_enc = _rows2d(self.fc_delta, rel)
+            t = train_ops._PairInput.apply(q, kf, knn_idx, pos_enc)
+            a = _rows2d(self.fc_gamma, t)
+            res, attn = train_ops._AttnAggregate.apply(a, vf, knn_idx, pos_enc, 1.0 / np.sqrt(self.d_model))
+            res = self.fc2(res) + pre
+            return res, attn
+
+        # CPU: the reference's op sequence in stock torch (variants.py:149-165)
         dists = square_distance(xyz, xyz)
         knn_idx = dists.argsort()[:, :, :self.k]
         knn_xyz = index_points(xyz, knn_idx)

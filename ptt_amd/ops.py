@@ -709,3 +709,36 @@ def scatter_rows_det(g, idx, N):
         _lib.check(_lib.lib().ptt_scatter_rows_csr_f32(_ptr(g), _ptr(order), _ptr(start), B, int(N), E, C, _ptr(out), _stream()),
                    "ptt_scatter_rows_csr_f32")
     return out
+
+
+# --------------------------------------------------------------------------- Point-Transformer block, training mode
+def pt_pair_input(q, kf, knn, pos):
+    """t = q_i - kf[knn_ij] + pos_ij : (B,N,D), (B,N,D), (B,N,k) i32, (B,N,k,D) -> (B,N,k,D)."""
+    B, N, D = q.shape
+    k = knn.shape[2]
+    t = torch.empty((B, N, k, D), dtype=torch.float32, device=q.device)
+    with torch.cuda.device(q.device):
+        _lib.check(_lib.lib().ptt_pt_pair_input_f32(_ptr(q), _ptr(kf), _ptr(knn), _ptr(pos), B, N, k, D, _ptr(t), _stream()),
+                   "ptt_pt_pair_input_f32")
+    return t
+
+
+def pt_attn_train_fwd(a, vf, knn, pos, scale):
+    """attn = softmax_j(a * scale), res = sum_j attn * (vf[knn] + pos) -> (attn (B,N,k,D), res (B,N,D))."""
+    B, N, k, D = a.shape
+    attn = torch.empty_like(a)
+    res = torch.empty((B, N, D), dtype=torch.float32, device=a.device)
+    with torch.cuda.device(a.device):
+        _lib.check(_lib.lib().ptt_pt_attn_train_fwd_f32(_ptr(a), _ptr(vf), _ptr(knn), _ptr(pos), B, N, k, D, float(scale), _ptr(attn),
+                                                        _ptr(res), _stream()), "ptt_pt_attn_train_fwd_f32")
+    return attn, res
+
+
+def pt_attn_train_bwd(attn, vf, knn, pos, dres, scale):
+    """-> (da, dvp), both (B,N,k,D)."""
+    B, N, k, D = attn.shape
+    da, dvp = torch.empty_like(attn), torch.empty_like(attn)
+    with torch.cuda.device(attn.device):
+        _lib.check(_lib.lib().ptt_pt_attn_train_bwd_f32(_ptr(attn), _ptr(vf), _ptr(knn), _ptr(pos), _ptr(dres), B, N, k, D, float(scale),
+                                                        _ptr(da), _ptr(dvp), _stream()), "ptt_pt_attn_train_bwd_f32")
+    return da, dvp

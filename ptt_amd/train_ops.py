@@ -193,3 +193,49 @@ def xcorr_hoisted(search_feats, template_feats, template_xyz, mlp, eps):
     P = torch.nn.functional.linear(rows_i, w0[:, 1:])                                   # (B,n1,C0)
     z0 = P.unsqueeze(1) + cos.unsqueeze(-1) * w0[:, 0]                                  # (B,n2,n1,C0)
     return rows_mlp_pool(z0.reshape(B * n2 * n1, -1), mlp, n1, B, n2, preact=True)
+
+
+class _PairInput(torch.autograd.Function):
+    """t = q_i - kf[knn_ij] + pos_ij in one pass (variants.py:160's argument); backward: dq = sum_j dt, dpos = dt,
+    dkf = -(deterministic row scatter-add of dt over knn)."""
+
+    @staticmethod
+    def forward(ctx, q, kf, knn, pos):
+        ctx.save_for_backward(knn)
+        return ops.pt_pair_input(q.contiguous(), kf.contiguous(), knn, pos.contiguous())
+
+    @staticmethod
+    def backward(ctx, dt):
+        (knn,) = ctx.saved_tensors
+        B, N, k, D = dt.shape
+        dt = dt.contiguous()
+        dq = dt.sum(dim=2) if ctx.needs_input_grad[0] else None
+        dkf = ops.scatter_rows_det(dt.view(B, N * k, D), knn.view(B, N * k), N).neg_() if ctx.needs_input_grad[1] else None
+        return dq, dkf, None, dt
+
+
+class _AttnAggregate(torch.autograd.Function):
+    """attn = softmax_j(a / sqrt(d)); res = sum_j attn * (vf[knn] + pos) (variants.py:161-163) in one pass each way.
+    Returns (res, attn); attn is returned for the caller's benefit only (both heads drop it) and carries no gradient."""
+
+    @staticmethod
+    def forward(ctx, a, vf, knn, pos, scale):
+        a, vf, pos = a.contiguous(), vf.contiguous(), pos.contiguous()
+        attn, res = ops.pt_attn_train_fwd(a, vf, knn, pos, scale)
+        ctx.save_for_backward(attn, vf, knn, pos)
+        ctx.scale = float(scale)
+        ctx.mark_non_differentiable(attn)
+        return res, attn
+
+    @staticmethod
+    def backward(ctx, dres, _dattn):
+        attn, vf, knn, pos = ctx.saved_tensors
+        B, N, k, D = attn.shape
+        da, dvp = ops.pt_attn_train_bwd(attn, vf, knn, pos, dres.contiguous(), ctx.scale)
+        dvf = ops.scatter_rows_det(dvp.view(B, N * k, D), knn.view(B, N * k), N) if ctx.needs_input_grad[1] else None
+        return da, dvf, None, dvp, None
+
+
+def pt_block_usable(block, xyz, features):
+    return (block.training and xyz.is_cuda and features.dtype == torch.float32 and block.k == 16 and block.d_model % 4 == 0
+            and xyz.shape[1] * block.k <= 16384)

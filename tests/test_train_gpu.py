@@ -246,3 +246,45 @@ def test_gather_rows_and_its_deterministic_adjoint(dev, B, N, E, C):
         (torch.arange(B, device=dev)[:, None].expand(B, E), idx.long()), up.double(), accumulate=True)
     assert float((adj.double() - ref).abs().max()) <= 1e-5 * (float(ref.abs().max()) + 1)
     assert torch.equal(adj, ops.scatter_rows_det(up, idx, N))
+
+
+@pytest.mark.parametrize("N,xyz_grad", [(128, False), (64, True)])
+def test_transformer_block_training_path_equals_the_reference_op_sequence(dev, N, xyz_grad):
+    """TransformerBlock in train mode: the hand-written element-wise passes (pair input, softmax-over-neighbours +
+    weighted sum, their backward with deterministic neighbour scatter-adds) against the reference's op sequence in stock
+    torch (variants.py:149-165): res, attn, the gradients of the features, of the coordinates (the box head's proposal
+    centres carry gradient) and of every parameter."""
+    import copy
+    from ptt_amd.models.transformer_block.variants import TransformerBlock
+    torch.manual_seed(N)
+    a = TransformerBlock(256, 512, 16).to(dev).train()
+    b = copy.deepcopy(a)
+    B = 3
+    xyz1 = (torch.rand(B, N, 3, device=dev) * 4 - 2).requires_grad_(xyz_grad)
+    f1 = torch.randn(B, N, 256, device=dev, requires_grad=True)
+    xyz2, f2 = xyz1.detach().clone().requires_grad_(xyz_grad), f1.detach().clone().requires_grad_(True)
+    assert train_ops.pt_block_usable(a, xyz1, f1)
+    r1, at1 = a(xyz1, f1)
+    orig = train_ops.pt_block_usable
+    train_ops.pt_block_usable = lambda *k: False
+    try:
+        r2, at2 = b(xyz2, f2)
+    finally:
+        train_ops.pt_block_usable = orig
+    torch.testing.assert_close(r1, r2, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(at1, at2, rtol=1e-4, atol=1e-5)
+    up = torch.randn_like(r2)
+    (r1 * up).sum().backward()
+    (r2 * up).sum().backward()
+
+    def close(p, q, name, tol=1e-3):
+        err = float((p - q).abs().max()) / max(float(q.abs().max()), 1e-6)
+        assert err < tol, (name, err)
+
+    close(f1.grad, f2.grad, "feature grad")
+    if xyz_grad:
+        close(xyz1.grad, xyz2.grad, "xyz grad")
+    gmax = max(float(p.grad.abs().max()) for p in b.parameters())
+    for (n1, p1), (_, p2) in zip(a.named_parameters(), b.named_parameters()):
+        err = float((p1.grad - p2.grad).abs().max()) / max(float(p2.grad.abs().max()), 1e-3 * gmax)   # fc_gamma.2.bias: exactly 0
+        assert err < 1e-3, (n1, err)
