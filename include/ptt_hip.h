@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PTT_ABI_VERSION 9
+#define PTT_ABI_VERSION 10
 
 enum {
     PTT_OK = 0,
@@ -374,9 +374,10 @@ int ptt_bn_apply_f32(const float* Z, int ldz, const float* mean, const float* in
                      const float* beta, int R, int C, int relu, float* X, int ldx, ptt_stream_t stream);
 int ptt_bn_bwd_f32(const float* G, int ldg, const float* Act, int lda, const float* Z, int ldz, const float* mean,
                    const float* invstd, const float* gamma, int R, int C, int relu, float* dZ, int ldd,
-                   float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, ptt_stream_t stream);
+                   float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, const float* act_scale,
+                   const float* act_shift, ptt_stream_t stream);
 int ptt_pool_rows_f32(const float* X, int ldx, int G, int ns, int C, float* out, int ldo, int32_t* arg,
-                      ptt_stream_t stream);
+                      const float* act_scale, const float* act_shift, ptt_stream_t stream);
 int ptt_pool_rows_bwd_f32(const float* dOut, int ldo, const int32_t* arg, int G, int ns, int C, float* dX, int ldx,
                           ptt_stream_t stream);
 /* Point-Transformer block in training mode (transformer_block/variants.py:156-163): the element-wise chains around its
@@ -404,7 +405,14 @@ int ptt_scatter_rows_csr_f32(const float* g, const int32_t* order, const int32_t
                              float* out, ptt_stream_t stream);
 size_t ptt_linear_wgrad_workspace(int R, int Cout, int Cin);
 int ptt_linear_wgrad_f32(const float* dZ, int ldz, const float* X, int ldx, int R, int Cout, int Cin, float* dW,
-                         int accumulate, void* workspace, size_t workspace_bytes, ptt_stream_t stream);
+                         int accumulate, void* workspace, size_t workspace_bytes, const float* x_scale, const float* x_shift,
+                         ptt_stream_t stream);
+/* Deferred activation (training): a layer's output relu(z * a[c] + b[c]) (a = gamma * invstd, b = beta - mean * a) is
+ * never written; its consumers apply it while they load z — ptt_linear_act_in_f32 (the next convolution),
+ * ptt_linear_wgrad_f32's x_scale / x_shift (that convolution's weight gradient), ptt_pool_rows_f32's act_scale /
+ * act_shift (the max-pool), ptt_bn_bwd_f32 with Act == NULL (the ReLU mask is z * a + b > 0). NULL scales = no transform. */
+int ptt_linear_act_in_f32(const float* X, int rows, int K, int ldx, const float* in_scale, const float* in_shift,
+                          const float* Wpacked, int Cout, float* out, int ldo, ptt_stream_t stream);
 
 /* ---------------------------------------------------------------------------------
  * T-opt  the dense scaled-dot-product variant TransformerBlockSTD (transformer_block/variants.py:29-40): the only

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libptt_hip.so")
 
 PTT_SA_MAX_LAYERS = 4
-ABI_VERSION = 9            # PTT_ABI_VERSION of include/ptt_hip.h these structures mirror
+ABI_VERSION = 10            # PTT_ABI_VERSION of include/ptt_hip.h these structures mirror
 
 # every symbol include/ptt_hip.h declares (tests check the library exports all of them)
 EXPORTS = [
@@ -26,7 +26,7 @@ EXPORTS = [
     "ptt_pool_rows_bwd_f32", "ptt_linear_wgrad_workspace", "ptt_linear_wgrad_f32",
     "ptt_pack_weight_strided_f32", "ptt_linear_batched_f32", "ptt_softmax_rows_f32",
     "ptt_gather_rows_f32", "ptt_scatter_csr_i32", "ptt_scatter_rows_csr_f32",
-    "ptt_pt_pair_input_f32", "ptt_pt_attn_train_fwd_f32", "ptt_pt_attn_train_bwd_f32",
+    "ptt_pt_pair_input_f32", "ptt_pt_attn_train_fwd_f32", "ptt_pt_attn_train_bwd_f32", "ptt_linear_act_in_f32",
 ]
 PTT_MAX_SEGMENTS = 4
 
@@ -115,10 +115,11 @@ def _declare(lib):
         "ptt_track_box_by_offset": [vp, i, vp, i, i, vp, vp],
         "ptt_bn_stats_f32": [vp, i, i, i, f, vp, vp, vp, vp, c_size_t, vp],
         "ptt_bn_apply_f32": [vp, i, vp, vp, vp, vp, i, i, i, vp, i, vp],
-        "ptt_bn_bwd_f32": [vp, i, vp, i, vp, i, vp, vp, vp, i, i, i, vp, i, vp, vp, vp, c_size_t, vp],
-        "ptt_pool_rows_f32": [vp, i, i, i, i, vp, i, vp, vp],
+        "ptt_bn_bwd_f32": [vp, i, vp, i, vp, i, vp, vp, vp, i, i, i, vp, i, vp, vp, vp, c_size_t, vp, vp, vp],
+        "ptt_pool_rows_f32": [vp, i, i, i, i, vp, i, vp, vp, vp, vp],
+        "ptt_linear_act_in_f32": [vp, i, i, i, vp, vp, vp, i, vp, i, vp],
         "ptt_pool_rows_bwd_f32": [vp, i, vp, i, i, i, vp, i, vp],
-        "ptt_linear_wgrad_f32": [vp, i, vp, i, i, i, i, vp, i, vp, c_size_t, vp],
+        "ptt_linear_wgrad_f32": [vp, i, vp, i, i, i, i, vp, i, vp, c_size_t, vp, vp, vp],
         "ptt_pack_weight_strided_f32": [vp, i, i, c_int64, c_int64, i, c_int64, vp, vp],
         "ptt_linear_batched_f32": [vp, i, i, i, c_int64, vp, c_int64, i, vp, vp, i, vp, i, c_int64, vp, i, c_int64, i, vp],
         "ptt_softmax_rows_f32": [vp, c_int64, i, i, f, vp],

@@ -353,6 +353,8 @@ struct LinearParams {
     const float* X; const float* Wp; const float* scale; const float* shift; const float* residual; float* out;
     int rows, K, ldx, Cout, relu, ldr, ldo, nkb, NT, vec_ok;
     long long xb, wb, ob, rb;       // per-batch element strides (blockIdx.z = batch; all 0 for a plain launch)
+    const float* in_a; const float* in_b;   // optional input transform x <- relu(x * in_a[k] + in_b[k]) applied while the A
+                                            // operand is staged (training: the previous layer's BatchNorm + ReLU, never materialised)
 };
 
 constexpr int LIN_KC = 128;          // channels per staged chunk
@@ -376,6 +378,16 @@ __device__ __forceinline__ void lin_fetch(const LinearParams& p, int row0, int k
                 if (c + q < p.K) v[q] = src[q];
         }
         st[i] = v;
+    }
+    if (p.in_a) {                                // same channel quad for every slot of this thread (e & 31 == t & 31)
+        const int c = k0 + ((t & 31) << 2);
+        if (c < p.K) {
+            const f32x4 a4 = *reinterpret_cast<const f32x4*>(p.in_a + c), b4 = *reinterpret_cast<const f32x4*>(p.in_b + c);
+#pragma unroll
+            for (int i = 0; i < RT * 4; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) st[i][q] = fmaxf(__builtin_fmaf(st[i][q], a4[q], b4[q]), 0.f);
+        }
     }
 }
 
@@ -1526,7 +1538,17 @@ extern "C" int ptt_pack_weight_f32(const float* W, int Cout, int K, float* packe
 
 static int linear_launch(const float* X, int rows, int K, int ldx, const float* Wpacked, int Cout, const float* scale,
                          const float* shift, int relu, const float* residual, int ldr, float* out, int ldo, int batch,
-                         long long xb, long long wb, long long ob, long long rb, ptt_stream_t stream);
+                         long long xb, long long wb, long long ob, long long rb, ptt_stream_t stream,
+                         const float* in_a = nullptr, const float* in_b = nullptr);
+
+extern "C" int ptt_linear_act_in_f32(const float* X, int rows, int K, int ldx, const float* in_scale, const float* in_shift,
+                                     const float* Wpacked, int Cout, float* out, int ldo, ptt_stream_t stream) {
+    if (!in_scale || !in_shift || (K & 3) || (ldx & 3) || ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(in_scale) |
+                                                             reinterpret_cast<uintptr_t>(in_shift)) & 15))
+        return fail(PTT_EINVAL, "ptt_linear_act_in_f32: needs K %% 4 == 0, ldx %% 4 == 0 and 16-byte aligned X / in_scale / in_shift");
+    return linear_launch(X, rows, K, ldx, Wpacked, Cout, nullptr, nullptr, 0, nullptr, 0, out, ldo, 1, 0, 0, 0, 0, stream, in_scale,
+                         in_shift);
+}
 
 extern "C" int ptt_linear_f32(const float* X, int rows, int K, int ldx, const float* Wpacked, int Cout,
                               const float* scale, const float* shift, int relu, const float* residual, int ldr,
@@ -1546,7 +1568,8 @@ extern "C" int ptt_linear_batched_f32(const float* X, int rows, int K, int ldx, 
 
 static int linear_launch(const float* X, int rows, int K, int ldx, const float* Wpacked, int Cout, const float* scale,
                          const float* shift, int relu, const float* residual, int ldr, float* out, int ldo, int batch,
-                         long long xb, long long wb, long long ob, long long rb, ptt_stream_t stream) {
+                         long long xb, long long wb, long long ob, long long rb, ptt_stream_t stream, const float* in_a,
+                         const float* in_b) {
     if (rows < 0 || K <= 0 || Cout <= 0 || ldx < K || ldo < Cout || (residual && ldr < Cout))
         return fail(PTT_EINVAL, "ptt_linear_f32: rows=%d K=%d Cout=%d ldx=%d ldo=%d ldr=%d", rows, K, Cout, ldx, ldo,
                     ldr);
@@ -1558,6 +1581,7 @@ static int linear_launch(const float* X, int rows, int K, int ldx, const float* 
     p.nkb = (K + 7) / 8; p.NT = (Cout + 31) / 32;
     p.vec_ok = ((ldx & 3) == 0 && (xb & 3) == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0) ? 1 : 0;
     p.xb = xb; p.wb = wb; p.ob = ob; p.rb = rb;
+    p.in_a = in_a; p.in_b = in_b;
     // Tile choice (measured on all six GEMM shapes of the path, scripts/kernel_bench.py SWEEP_LINEAR=1): the smallest
     // tile, 32 rows x 128 columns, wins everywhere (qkv 93 vs 75 TFLOP/s for 64x256): these launches are only
     // 1-10 GFLOP, so workgroup count (>= 4 per CU, fine-grained tails) matters more than weight reuse per workgroup.

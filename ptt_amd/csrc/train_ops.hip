@@ -101,7 +101,8 @@ template <int MODE>
 __global__ __launch_bounds__(256) void col_stats4_kernel(const float* __restrict__ X, const float* __restrict__ Act,
                                                          const float* __restrict__ Z, const float* __restrict__ mean,
                                                          const float* __restrict__ invstd, int R, int C, int ldx, int lda,
-                                                         int ldz, double* __restrict__ partial) {
+                                                         int ldz, double* __restrict__ partial, const float* __restrict__ act_a,
+                                                         const float* __restrict__ act_b) {
     extern __shared__ double red4[];                       // [256][8]
     const int Cq = C >> 2;                                  // quads per row
     const int span = Cq < 256 ? Cq : 256;                   // threads side by side on one row
@@ -113,15 +114,22 @@ __global__ __launch_bounds__(256) void col_stats4_kernel(const float* __restrict
         double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
         if (q < Cq && rg < RG) {
             f32x4t mu = {0, 0, 0, 0}, is = {0, 0, 0, 0};
+            f32x4t ga = {0, 0, 0, 0}, gb = {0, 0, 0, 0};
             if (MODE == 1) { mu = *reinterpret_cast<const f32x4t*>(mean + 4 * q); is = *reinterpret_cast<const f32x4t*>(invstd + 4 * q); }
+            if (MODE == 1 && !Act) { ga = *reinterpret_cast<const f32x4t*>(act_a + 4 * q); gb = *reinterpret_cast<const f32x4t*>(act_b + 4 * q); }
             for (int r = r0 + rg; r < r1; r += RG) {
                 const f32x4t x = *reinterpret_cast<const f32x4t*>(X + (size_t)r * ldx + 4 * q);
                 if (MODE == 0) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) { s0[k] += (double)x[k]; s1[k] += (double)x[k] * (double)x[k]; }
                 } else {
-                    const f32x4t a = *reinterpret_cast<const f32x4t*>(Act + (size_t)r * lda + 4 * q);
                     const f32x4t z = *reinterpret_cast<const f32x4t*>(Z + (size_t)r * ldz + 4 * q);
+                    f32x4t a;
+                    if (Act) a = *reinterpret_cast<const f32x4t*>(Act + (size_t)r * lda + 4 * q);
+                    else {                           // the activation was never materialised: relu(z * ga + gb) > 0
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) a[k] = __builtin_fmaf(z[k], ga[k], gb[k]);
+                    }
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const float dy = a[k] > 0.f ? x[k] : 0.f;
@@ -207,7 +215,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const float* __restr
                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
                                                             const float* __restrict__ gamma, const float* __restrict__ s0,
                                                             const float* __restrict__ s1, int R, int C, float* __restrict__ dZ,
-                                                            int ldd) {
+                                                            int ldd, const float* __restrict__ act_a, const float* __restrict__ act_b) {
     const int Cq = C >> 2, span = Cq < 256 ? Cq : 256, RG = 256 / span;
     const int q0 = threadIdx.x % span, rg = threadIdx.x / span;
     if (rg >= RG) return;
@@ -216,10 +224,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const float* __restr
         const f32x4t mu = *reinterpret_cast<const f32x4t*>(mean + 4 * q), is = *reinterpret_cast<const f32x4t*>(invstd + 4 * q);
         const f32x4t ga = *reinterpret_cast<const f32x4t*>(gamma + 4 * q);
         const f32x4t a0 = *reinterpret_cast<const f32x4t*>(s0 + 4 * q), a1 = *reinterpret_cast<const f32x4t*>(s1 + 4 * q);
+        f32x4t ca = {0, 0, 0, 0}, cb = {0, 0, 0, 0};
+        if (!Act) { ca = *reinterpret_cast<const f32x4t*>(act_a + 4 * q); cb = *reinterpret_cast<const f32x4t*>(act_b + 4 * q); }
         for (int r = blockIdx.x * RG + rg; r < R; r += gridDim.x * RG) {
             const f32x4t g = *reinterpret_cast<const f32x4t*>(G + (size_t)r * ldg + 4 * q);
-            const f32x4t a = *reinterpret_cast<const f32x4t*>(Act + (size_t)r * lda + 4 * q);
             const f32x4t z = *reinterpret_cast<const f32x4t*>(Z + (size_t)r * ldz + 4 * q);
+            f32x4t a;
+            if (Act) a = *reinterpret_cast<const f32x4t*>(Act + (size_t)r * lda + 4 * q);
+            else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) a[k] = __builtin_fmaf(z[k], ca[k], cb[k]);
+            }
             f32x4t d;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -271,15 +286,18 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 
 // out[g, c] = max over the ns consecutive rows of group g; arg[g, c] = the first row that attains it.
 __global__ __launch_bounds__(256) void pool_rows_kernel(const float* __restrict__ X, int ldx, int G, int ns, int C,
-                                                        float* __restrict__ out, int ldo, int32_t* __restrict__ arg) {
+                                                        float* __restrict__ out, int ldo, int32_t* __restrict__ arg,
+                                                        const float* __restrict__ act_a, const float* __restrict__ act_b) {
     const size_t total = (size_t)G * C;
     for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
         const int g = (int)(e / C), c = (int)(e - (size_t)g * C);
         const float* p = X + (size_t)g * ns * ldx + c;
-        float m = p[0];
+        const float sa = act_a ? act_a[c] : 1.f, sb = act_a ? act_b[c] : 0.f;     // optional relu(x * a + b) on the fly
+        float m = act_a ? fmaxf(__builtin_fmaf(p[0], sa, sb), 0.f) : p[0];
         int a = 0;
         for (int k = 1; k < ns; ++k) {
-            const float v = p[(size_t)k * ldx];
+            float v = p[(size_t)k * ldx];
+            if (act_a) v = fmaxf(__builtin_fmaf(v, sa, sb), 0.f);
             if (v > m) { m = v; a = k; }
         }
         out[(size_t)g * ldo + c] = m;
@@ -341,10 +359,24 @@ __device__ __forceinline__ void wg_stage(float* S, int t, const f32x4t (&st)[4])
     }
 }
 
+// relu(x * a + b) on the staged X block (training: the layer input = previous layer's BatchNorm + ReLU, never materialised)
+__device__ __forceinline__ void wg_act(f32x4t (&st)[4], const float* __restrict__ xa, const float* __restrict__ xb, int c0, int cmax,
+                                       int t) {
+    const int c = c0 + ((t & 31) << 2);
+    if (c + 3 < cmax) {
+        const f32x4t a4 = *reinterpret_cast<const f32x4t*>(xa + c), b4 = *reinterpret_cast<const f32x4t*>(xb + c);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) st[i][q] = fmaxf(__builtin_fmaf(st[i][q], a4[q], b4[q]), 0.f);
+    }
+}
+
 template <bool VZ, bool VX>
 __global__ __launch_bounds__(256, 2) void linear_wgrad_kernel(const float* __restrict__ dZ, int ldz, const float* __restrict__ X,
                                                               int ldx, int R, int Cout, int Cin, int nbi, int chunk_rows,
-                                                              float* __restrict__ partial) {
+                                                              float* __restrict__ partial, const float* __restrict__ xa,
+                                                              const float* __restrict__ xb) {
     extern __shared__ __attribute__((aligned(16))) float wg_smem[];         // As[2][32 x 132] | Bs[2][32 x 132]: 67.6 KB
     constexpr int WG_BUF = WG_KC * WG_LD;
 #define As(b) (wg_smem + (b) * WG_BUF)
@@ -364,6 +396,7 @@ __global__ __launch_bounds__(256, 2) void linear_wgrad_kernel(const float* __res
     f32x4t sa[4], sb[4];
     wg_fetch<VZ>(dZ, ldz, r_begin, r_end, o0, Cout, t, sa);
     wg_fetch<VX>(X, ldx, r_begin, r_end, i0, Cin, t, sb);
+    if (xa) wg_act(sb, xa, xb, i0, Cin, t);
     wg_stage(As(0), t, sa);
     wg_stage(Bs(0), t, sb);
     __syncthreads();
@@ -373,6 +406,7 @@ __global__ __launch_bounds__(256, 2) void linear_wgrad_kernel(const float* __res
         if (more) {
             wg_fetch<VZ>(dZ, ldz, r0 + WG_KC, r_end, o0, Cout, t, sa);
             wg_fetch<VX>(X, ldx, r0 + WG_KC, r_end, i0, Cin, t, sb);
+            if (xa) wg_act(sb, xa, xb, i0, Cin, t);
         }
         const float* A = As(buf) + half * WG_LD + wo + col;
         const float* B = Bs(buf) + half * WG_LD + wi + col;
@@ -604,7 +638,7 @@ extern "C" int ptt_bn_stats_f32(const float* X, int R, int C, int ldx, float eps
     if (vec4_ok(X, ldx, C)) {
         const int nchunks = (R + ST4_ROWS - 1) / ST4_ROWS;
         hipLaunchKernelGGL((col_stats4_kernel<0>), dim3(nchunks), dim3(256), 256 * 8 * sizeof(double), s, X, nullptr, nullptr, nullptr,
-                           nullptr, R, C, ldx, 0, 0, static_cast<double*>(ws));
+                           nullptr, R, C, ldx, 0, 0, static_cast<double*>(ws), nullptr, nullptr);
         hipLaunchKernelGGL((col_stats_finish2_kernel<0>), dim3(C), dim3(256), 0, s, static_cast<const double*>(ws), nchunks, C, R, eps,
                            mean, var, invstd);
         return check_launch("col_stats4_kernel");
@@ -637,26 +671,29 @@ extern "C" int ptt_bn_apply_f32(const float* Z, int ldz, const float* mean, cons
 
 extern "C" int ptt_bn_bwd_f32(const float* G, int ldg, const float* Act, int lda, const float* Z, int ldz, const float* mean,
                               const float* invstd, const float* gamma, int R, int C, int relu, float* dZ, int ldd,
-                              float* dgamma, float* dbeta, void* ws, size_t ws_bytes, ptt_stream_t stream) {
+                              float* dgamma, float* dbeta, void* ws, size_t ws_bytes, const float* act_scale,
+                              const float* act_shift, ptt_stream_t stream) {
     if (R <= 0 || C <= 0) return fail(PTT_EINVAL, "ptt_bn_bwd_f32: R=%d C=%d", R, C);
-    if (!G || !Z || !mean || !invstd || !gamma || !dZ || !dgamma || !dbeta || (relu && !Act))
+    if (!G || !Z || !mean || !invstd || !gamma || !dZ || !dgamma || !dbeta || (relu && !Act && !(act_scale && act_shift)))
         return fail(PTT_EINVAL, "ptt_bn_bwd_f32: null pointer");
     if (!ws || ws_bytes < ptt_bn_stats_workspace(R, C)) return fail(PTT_EWORKSPACE, "ptt_bn_bwd_f32: workspace too small");
     hipStream_t s = as_stream(stream);
-    if (relu && vec4_ok(G, ldg, C) && vec4_ok(Act, lda, C) && vec4_ok(Z, ldz, C) && vec4_ok(dZ, ldd, C) && vec4_ok(mean, 4, 4) &&
+    if (relu && vec4_ok(G, ldg, C) && (Act ? vec4_ok(Act, lda, C) : (vec4_ok(act_scale, 4, 4) && vec4_ok(act_shift, 4, 4))) &&
+        vec4_ok(Z, ldz, C) && vec4_ok(dZ, ldd, C) && vec4_ok(mean, 4, 4) &&
         vec4_ok(invstd, 4, 4) && vec4_ok(gamma, 4, 4) && vec4_ok(dgamma, 4, 4) && vec4_ok(dbeta, 4, 4)) {
         const int nch = (R + ST4_ROWS - 1) / ST4_ROWS;
         hipLaunchKernelGGL((col_stats4_kernel<1>), dim3(nch), dim3(256), 256 * 8 * sizeof(double), s, G, Act, Z, mean, invstd, R, C, ldg,
-                           lda, ldz, static_cast<double*>(ws));
+                           lda, ldz, static_cast<double*>(ws), act_scale, act_shift);
         hipLaunchKernelGGL((col_stats_finish2_kernel<1>), dim3(C), dim3(256), 0, s, static_cast<const double*>(ws), nch, C, R, 0.f, dbeta,
                            dgamma, nullptr);
         const int Cq = C >> 2, RG = 256 / (Cq < 256 ? Cq : 256);
         int grid = (R + RG * 8 - 1) / (RG * 8);
         if (grid > 16384) grid = 16384;
         hipLaunchKernelGGL(bn_bwd_apply4_kernel, dim3(grid), dim3(256), 0, s, G, ldg, Act, lda, Z, ldz, mean, invstd, gamma, dbeta, dgamma,
-                           R, C, dZ, ldd);
+                           R, C, dZ, ldd, act_scale, act_shift);
         return check_launch("bn_bwd4_kernels");
     }
+    if (!Act) return fail(PTT_EUNSUPPORTED, "ptt_bn_bwd_f32: the mask-from-z form needs C %% 4 == 0 and 16-byte aligned rows");
     const int nchunks = (R + ST_ROWS - 1) / ST_ROWS;
     // without a ReLU every position passes: the mask test reads G itself against 0 only when relu is set, so pass an
     // always-positive stand-in through Act == G is NOT valid; MODE 1 with relu == 0 uses Act = nullptr guarded below
@@ -674,10 +711,11 @@ extern "C" int ptt_bn_bwd_f32(const float* G, int ldg, const float* Act, int lda
 }
 
 extern "C" int ptt_pool_rows_f32(const float* X, int ldx, int G, int ns, int C, float* out, int ldo, int32_t* arg,
-                                 ptt_stream_t stream) {
+                                 const float* act_scale, const float* act_shift, ptt_stream_t stream) {
     if (G <= 0 || ns <= 0 || C <= 0) return fail(PTT_EINVAL, "ptt_pool_rows_f32: G=%d ns=%d C=%d", G, ns, C);
     if (!X || !out || !arg) return fail(PTT_EINVAL, "ptt_pool_rows_f32: null pointer");
-    hipLaunchKernelGGL(pool_rows_kernel, dim3(ew_grid((size_t)G * C)), dim3(256), 0, as_stream(stream), X, ldx, G, ns, C, out, ldo, arg);
+    hipLaunchKernelGGL(pool_rows_kernel, dim3(ew_grid((size_t)G * C)), dim3(256), 0, as_stream(stream), X, ldx, G, ns, C, out, ldo, arg,
+                       act_scale, act_scale ? act_shift : nullptr);
     return check_launch("pool_rows_kernel");
 }
 
@@ -774,7 +812,10 @@ extern "C" size_t ptt_linear_wgrad_workspace(int R, int Cout, int Cin) {
 }
 
 extern "C" int ptt_linear_wgrad_f32(const float* dZ, int ldz, const float* X, int ldx, int R, int Cout, int Cin, float* dW,
-                                    int accumulate, void* ws, size_t ws_bytes, ptt_stream_t stream) {
+                                    int accumulate, void* ws, size_t ws_bytes, const float* x_scale, const float* x_shift,
+                                    ptt_stream_t stream) {
+    if (x_scale && (!x_shift || (Cin & 3) || ((reinterpret_cast<uintptr_t>(x_scale) | reinterpret_cast<uintptr_t>(x_shift)) & 15)))
+        return fail(PTT_EINVAL, "ptt_linear_wgrad_f32: the input transform needs Cin %% 4 == 0 and 16-byte aligned scale / shift");
     if (R <= 0 || Cout <= 0 || Cin <= 0 || ldz < Cout || ldx < Cin)
         return fail(PTT_EINVAL, "ptt_linear_wgrad_f32: R=%d Cout=%d Cin=%d ldz=%d ldx=%d", R, Cout, Cin, ldz, ldx);
     if (!dZ || !X || !dW) return fail(PTT_EINVAL, "ptt_linear_wgrad_f32: null pointer");
@@ -791,7 +832,7 @@ extern "C" int ptt_linear_wgrad_f32(const float* dZ, int ldz, const float* X, in
     if (vz == VZ && vx == VX) {                                                                                       \
         if (int rc = set_lds_limit(reinterpret_cast<const void*>(linear_wgrad_kernel<VZ, VX>), lds)) return rc;       \
         hipLaunchKernelGGL((linear_wgrad_kernel<VZ, VX>), dim3(nbo * nbi, nchunks), dim3(256), lds, s, dZ, ldz, X, ldx, R, Cout, Cin, \
-                           nbi, rows, static_cast<float*>(ws));                                                       \
+                           nbi, rows, static_cast<float*>(ws), x_scale, x_shift);                                     \
     }
     PTT_WGRAD_CASE(true, true) PTT_WGRAD_CASE(true, false) PTT_WGRAD_CASE(false, true) PTT_WGRAD_CASE(false, false)
 #undef PTT_WGRAD_CASE

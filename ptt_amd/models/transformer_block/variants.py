@@ -115,7 +115,10 @@ class TransformerBlock(nn.Module):
             pre = features
             x = self.fc1(features)
             q, kf, vf = self.w_qs(x), self.w_ks(x), self.w_vs(x)
-            pos_enc = _rows2d(self.fc_delta, rel)
+            # fc_delta: Linear(3 -> d) -> ReLU -> Linear(d -> d); the K = 3 layer runs on the hand-written linear / weight-
+            # gradient kernels (stock BLAS spends 0.45 ms per call on its skinny GEMMs), the d x d layer stays on hipBLASLt
+            h = torch.relu(train_ops.rows_linear(self.fc_delta[0], rel.reshape(-1, 3)))
+            pos_enc = self.fc_delta[2](h).view(*rel.shape[:-1], self.d_model)
             t = train_ops._PairInput.apply(q, kf, knn_idx, pos_enc)
             a = _rows2d(self.fc_gamma, t)
             res, attn = train_ops._AttnAggregate.apply(a, vf, knn_idx, pos_enc, 1.0 / np.sqrt(self.d_model))

@@ -589,9 +589,12 @@ def bn_apply(z, mean, invstd, gamma, beta, relu=True, out=None):
     return out
 
 
-def bn_bwd(g, act, z, mean, invstd, gamma, out=None):
-    """Backward of BatchNorm(train) + ReLU on rows: -> (dz, dgamma, dbeta). `out` may alias g (in place)."""
-    _rows(g, "g"); _rows(act, "act"); _rows(z, "z")
+def bn_bwd(g, act, z, mean, invstd, gamma, out=None, act_scale=None, act_shift=None):
+    """Backward of BatchNorm(train) + ReLU on rows: -> (dz, dgamma, dbeta). `out` may alias g (in place). act = the
+    layer's output, or None with act_scale / act_shift: the ReLU mask is then z * act_scale + act_shift > 0."""
+    _rows(g, "g"); _rows(z, "z")
+    if act is not None:
+        _rows(act, "act")
     R, C = z.shape
     if out is None:
         out = torch.empty((R, C), dtype=torch.float32, device=z.device)
@@ -599,22 +602,24 @@ def bn_bwd(g, act, z, mean, invstd, gamma, out=None):
     dbeta = torch.empty((C,), dtype=torch.float32, device=z.device)
     ws = _ws(_lib.lib().ptt_bn_stats_workspace(R, C), z.device)
     with torch.cuda.device(z.device):
-        _lib.check(_lib.lib().ptt_bn_bwd_f32(_ptr(g), g.stride(0), _ptr(act), act.stride(0), _ptr(z), z.stride(0), _ptr(mean),
-                                             _ptr(invstd), _ptr(gamma), R, C, 1, _ptr(out), out.stride(0), _ptr(dgamma),
-                                             _ptr(dbeta), _ptr(ws), ws.numel() * 8, _stream()), "ptt_bn_bwd_f32")
+        _lib.check(_lib.lib().ptt_bn_bwd_f32(_ptr(g), g.stride(0), _ptr(act), act.stride(0) if act is not None else 0, _ptr(z),
+                                             z.stride(0), _ptr(mean), _ptr(invstd), _ptr(gamma), R, C, 1, _ptr(out),
+                                             out.stride(0), _ptr(dgamma), _ptr(dbeta), _ptr(ws), ws.numel() * 8,
+                                             _ptr(act_scale), _ptr(act_shift), _stream()), "ptt_bn_bwd_f32")
     return out, dgamma, dbeta
 
 
-def pool_rows(x, ns):
-    """max over every ns consecutive rows: (G*ns, C) -> (G, C) and the int32 arg-max (first among equals)."""
+def pool_rows(x, ns, act_scale=None, act_shift=None):
+    """max over every ns consecutive rows: (G*ns, C) -> (G, C) and the int32 arg-max (first among equals); with
+    act_scale / act_shift the rows are relu(x * scale + shift), applied on the fly."""
     _rows(x, "x")
     R, C = x.shape
     G = R // int(ns)
     out = torch.empty((G, C), dtype=torch.float32, device=x.device)
     arg = torch.empty((G, C), dtype=torch.int32, device=x.device)
     with torch.cuda.device(x.device):
-        _lib.check(_lib.lib().ptt_pool_rows_f32(_ptr(x), x.stride(0), G, int(ns), C, _ptr(out), C, _ptr(arg), _stream()),
-                   "ptt_pool_rows_f32")
+        _lib.check(_lib.lib().ptt_pool_rows_f32(_ptr(x), x.stride(0), G, int(ns), C, _ptr(out), C, _ptr(arg), _ptr(act_scale),
+                                                _ptr(act_shift), _stream()), "ptt_pool_rows_f32")
     return out, arg
 
 
@@ -628,8 +633,20 @@ def pool_rows_bwd(dout, arg, ns):
     return dx
 
 
-def linear_wgrad(dz, x, out=None, accumulate=False):
-    """dW (Cout,Cin) = dz^T x over the rows, on fp32 MFMA — ptt_linear_wgrad_f32."""
+def linear_act_in(x, in_scale, in_shift, wpacked, cout):
+    """relu(x * in_scale + in_shift) @ W^T with the transform applied while x is staged — ptt_linear_act_in_f32."""
+    _rows(x, "x")
+    rows, K = x.shape
+    out = torch.empty((rows, int(cout)), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device), _timed('ptt_linear_f32'):
+        _lib.check(_lib.lib().ptt_linear_act_in_f32(_ptr(x), rows, K, x.stride(0), _ptr(in_scale), _ptr(in_shift), _ptr(wpacked),
+                                                    int(cout), _ptr(out), int(cout), _stream()), "ptt_linear_act_in_f32")
+    return out
+
+
+def linear_wgrad(dz, x, out=None, accumulate=False, x_scale=None, x_shift=None):
+    """dW (Cout,Cin) = dz^T x over the rows, on fp32 MFMA — ptt_linear_wgrad_f32; with x_scale / x_shift the rows of x
+    are relu(x * scale + shift), applied while they are staged."""
     _rows(dz, "dz"); _rows(x, "x")
     R, Cout = dz.shape
     Cin = x.shape[1]
@@ -638,8 +655,8 @@ def linear_wgrad(dz, x, out=None, accumulate=False):
     ws = _ws(_lib.lib().ptt_linear_wgrad_workspace(R, Cout, Cin), dz.device)
     with torch.cuda.device(dz.device), _timed('ptt_linear_wgrad_f32'):
         _lib.check(_lib.lib().ptt_linear_wgrad_f32(_ptr(dz), dz.stride(0), _ptr(x), x.stride(0), R, Cout, Cin, _ptr(out),
-                                                   int(bool(accumulate)), _ptr(ws), ws.numel() * 8, _stream()),
-                   "ptt_linear_wgrad_f32")
+                                                   int(bool(accumulate)), _ptr(ws), ws.numel() * 8, _ptr(x_scale), _ptr(x_shift),
+                                                   _stream()), "ptt_linear_wgrad_f32")
     return out
 
 

@@ -24,7 +24,7 @@ def usable(mlp, x):
     for unit in mlp:
         conv = getattr(unit, 'conv', None)
         bn = getattr(getattr(unit, 'normlayer', None), 'bn', None)
-        if not isinstance(conv, nn.Conv2d) or conv.kernel_size != (1, 1) or conv.bias is not None:
+        if not isinstance(conv, nn.Conv2d) or conv.kernel_size != (1, 1) or conv.bias is not None or conv.weight.shape[0] % 4:
             return False
         if not isinstance(bn, nn.BatchNorm2d) or not bn.affine or not bn.track_running_stats or bn.momentum is None:
             return False
@@ -80,19 +80,28 @@ class _SharedMlpPool(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, ns, eps, preact, *params):
+        """Deferred activation: a layer's output relu(BatchNorm(z)) = relu(z * a + b) is never written — the next
+        convolution, its weight gradient, the max-pool and the BatchNorm backward apply it while they load z."""
         L = len(params) // 3
         saved, stats = [], []
-        cur = x.contiguous()
+        cur, cur_a, cur_b = x.contiguous(), None, None
         for l in range(L):
             W, gamma, beta = params[3 * l], params[3 * l + 1], params[3 * l + 2]
             cout = gamma.shape[0]
-            z = cur if (preact and l == 0) else ops.linear(cur, ops.pack_weight(W), cout)
+            if preact and l == 0:
+                z = cur
+            elif cur_a is not None:
+                z = ops.linear_act_in(cur, cur_a, cur_b, ops.pack_weight(W), cout)
+            else:
+                z = ops.linear(cur, ops.pack_weight(W), cout)
             mean, var, invstd = ops.bn_stats(z, eps[l])
-            nxt = ops.bn_apply(z, mean, invstd, gamma.detach(), beta.detach(), relu=True)
-            saved += [cur, z, nxt, mean, invstd]
+            a = (gamma.detach() * invstd).contiguous()
+            b = (beta.detach() - mean * a).contiguous()
+            saved += [cur, cur_a if cur_a is not None else mean.new_empty(0), cur_b if cur_b is not None else mean.new_empty(0),
+                      z, mean, invstd, a, b]
             stats += [mean, var]
-            cur = nxt
-        pooled, arg = ops.pool_rows(cur, ns)
+            cur, cur_a, cur_b = z, a, b
+        pooled, arg = ops.pool_rows(cur, ns, cur_a, cur_b)
         ctx.save_for_backward(arg, *saved, *[p.detach() for p in params])
         ctx.L, ctx.ns, ctx.preact = L, int(ns), bool(preact)
         ctx.mark_non_differentiable(*stats)
@@ -102,21 +111,22 @@ class _SharedMlpPool(torch.autograd.Function):
     def backward(ctx, dpooled, *unused):
         L, ns = ctx.L, ctx.ns
         t = ctx.saved_tensors
-        arg, saved, params = t[0], t[1:1 + 5 * L], t[1 + 5 * L:]
+        arg, saved, params = t[0], t[1:1 + 8 * L], t[1 + 8 * L:]
         g = ops.pool_rows_bwd(dpooled.contiguous(), arg, ns)
         grads = [None] * (3 * L)
         for l in range(L - 1, -1, -1):
-            x_in, z, act, mean, invstd = saved[5 * l:5 * l + 5]
+            x_in, in_a, in_b, z, mean, invstd, a, b = saved[8 * l:8 * l + 8]
             W, gamma = params[3 * l], params[3 * l + 1]
-            dz, dgamma, dbeta = ops.bn_bwd(g, act, z, mean, invstd, gamma, out=g)      # in place over the incoming gradient
+            dz, dgamma, dbeta = ops.bn_bwd(g, None, z, mean, invstd, gamma, out=g, act_scale=a, act_shift=b)   # in place over g
             grads[3 * l + 1], grads[3 * l + 2] = dgamma, dbeta
             if ctx.preact and l == 0:
                 g = dz                                                                  # d(loss)/d(layer-0 pre-activation)
                 break
             w2 = W.reshape(W.shape[0], -1)
-            grads[3 * l] = ops.linear_wgrad(dz, x_in).view_as(W)
+            has_t = in_a.numel() > 0
+            grads[3 * l] = ops.linear_wgrad(dz, x_in, x_scale=in_a if has_t else None, x_shift=in_b if has_t else None).view_as(W)
             if l > 0 or ctx.needs_input_grad[0]:
-                g = ops.linear(dz, ops.pack_weight(w2.t().contiguous()), w2.shape[1])
+                g = ops.linear(dz, ops.pack_weight(w2.t().contiguous()), w2.shape[1])   # w.r.t. the activated input of layer l
             else:
                 g = None
         return (g, None, None, None) + tuple(grads)
@@ -239,3 +249,33 @@ class _AttnAggregate(torch.autograd.Function):
 def pt_block_usable(block, xyz, features):
     return (block.training and xyz.is_cuda and features.dtype == torch.float32 and block.k == 16 and block.d_model % 4 == 0
             and xyz.shape[1] * block.k <= 16384)
+
+
+class _RowsLinear(torch.autograd.Function):
+    """y = x W^T + b over (rows, K) on the hand-written kernels: forward and input gradient on ptt_linear_f32, weight
+    gradient on ptt_linear_wgrad_f32, bias gradient = column sums. Used where stock BLAS picks badly shaped kernels —
+    the K = 3 layer fc_delta[0] over ~10^5 (point, neighbour) rows and its 512 x 3 weight gradient."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        ctx.save_for_backward(x2, W)
+        ctx.shape = x.shape
+        y = ops.linear(x2, ops.pack_weight(W.detach().contiguous()), W.shape[0], None, b.detach() if b is not None else None)
+        return y.view(*x.shape[:-1], W.shape[0])
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, W = ctx.saved_tensors
+        g2 = g.reshape(-1, g.shape[-1]).contiguous()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.linear(g2, ops.pack_weight(W.detach().t().contiguous()), W.shape[1]).view(ctx.shape)
+        dW = ops.linear_wgrad(g2, x2) if ctx.needs_input_grad[1] else None
+        db = g2.sum(0) if ctx.needs_input_grad[2] else None
+        return dx, dW, db
+
+
+def rows_linear(layer, x):
+    """nn.Linear `layer` applied to x (..., K) through _RowsLinear."""
+    return _RowsLinear.apply(x, layer.weight, layer.bias)
