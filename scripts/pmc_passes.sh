@@ -16,7 +16,7 @@ pass() {
         python "$REPO/scripts/kernel_bench.py" --only "$ONLY" --iters 4 > /tmp/pmc_$name.log 2>&1
     f=$(find /tmp/pmc_$name -name "*counter_collection.csv" | head -1)
     if [ -n "$f" ]; then
-        grep -E "Counter_Name|pt_attn_pair|sa_fused_kernel|sa_wave_kernel|linear_kernel|xcorr_fused" "$f" > "$REPO/$OUT/pmc_$name.csv"
+        grep -E "Counter_Name|pt_attn_pair|sa_fused_kernel|sa_wave_kernel|sa_stream_kernel|sa_lds_kernel|linear_kernel|xcorr_fused" "$f" > "$REPO/$OUT/pmc_$name.csv"
     else
         tail -5 /tmp/pmc_$name.log > "$REPO/$OUT/pmc_$name.err"
     fi
