@@ -966,84 +966,126 @@ __global__ __launch_bounds__(256, 2) void xcorr_fused_kernel(XcorrParams q) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const SaParams& p = q.sa;
     float* Xs = smem;                        // [64][ldk]
-    float* simv = smem + 64 * p.ldk;         // [64] cosine of each template point with this search point
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    float* simv = smem + 64 * p.ldk;         // [64] cosine of the current 64 template points with this search point
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, half = lane >> 5;
     const int j = logical_block();           // flat search point b*Ns + jj
     const int b = j / p.M, jj = j - b * p.M;
     stagger_second_slot(p.first_wave, p.stagger);
     SaPre pre;
     pre.w[0] = pre.w[1] = f32x4{0.f, 0.f, 0.f, 0.f};
-    prefetch_first_block(p.L[0].Wp, p.L[0].scale, p.L[0].shift, p.L[0].NT, w, lane, pre);
+    // running max over the template axis of this wave's (up to 2) column tiles: the template points are walked in
+    // chunks of 64 rows (Nt = 64: one chunk; 512 template seeds of the stress configuration: eight)
+    float run[2] = {-__builtin_inff(), -__builtin_inff()};
+    const int nlast = p.n_layers - 1;
+    const SaLayerDev& LL = p.L[nlast];
 
-    if (q.cos_t) {
-        // the cosine map of the whole batch was computed once by cos_map_kernel: 64 values to fetch instead of ~340
-        // vector-ALU / load instructions per wave in a phase that runs beside another workgroup's MFMA stream
-        if (t < 64) {
-            const float cs = q.cos_t[((long long)b * p.M + jj) * q.Nt + t];
-            simv[t] = cs;
-            if (q.sim_out) q.sim_out[((long long)b * q.Nt + t) * p.M + jj] = cs;
+    for (int i0 = 0; i0 < q.Nt; i0 += 64) {
+        prefetch_first_block(p.L[0].Wp, p.L[0].scale, p.L[0].shift, p.L[0].NT, w, lane, pre);
+        if (i0) __syncthreads();             // the previous chunk's last GEMM has read Xs / simv
+        if (q.cos_t) {
+            // the cosine map of the whole batch was computed once by cos_map_kernel: 64 values to fetch instead of ~340
+            // vector-ALU / load instructions per wave in a phase that runs beside another workgroup's MFMA stream
+            if (t < 64) {
+                const float cs = q.cos_t[((long long)b * p.M + jj) * q.Nt + i0 + t];
+                simv[t] = cs;
+                if (q.sim_out) q.sim_out[((long long)b * q.Nt + i0 + t) * p.M + jj] = cs;
+            }
+        } else {
+            // ---- 64 cosines: thread (i = t>>2, quarter = t&3) covers channels quarter, quarter+4, ... ----
+            const int i = t >> 2, qd = t & 3;
+            const float* a = q.tfeat + (long long)b * q.t_sb + (long long)(i0 + i) * q.t_sn;
+            const float* sp = q.sfeat + (long long)b * q.s_sb + (long long)jj * q.s_sn;
+            float dot = 0.f, na = 0.f, ns = 0.f;
+            for (int c = qd; c < q.C; c += 4) {
+                const float av = a[(long long)c * q.t_sc], sv = sp[(long long)c * q.s_sc];
+                dot += av * sv; na += av * av; ns += sv * sv;
+            }
+            dot += __shfl_xor(dot, 1, 64); dot += __shfl_xor(dot, 2, 64);
+            na += __shfl_xor(na, 1, 64);   na += __shfl_xor(na, 2, 64);
+            ns += __shfl_xor(ns, 1, 64);   ns += __shfl_xor(ns, 2, 64);
+            // torch.nn.functional.cosine_similarity: x1.x2 / (max(|x1|, eps) * max(|x2|, eps))
+            const float cs = dot / (fmaxf(sqrtf(na), q.eps) * fmaxf(sqrtf(ns), q.eps));
+            if (qd == 0) {
+                simv[i] = cs;
+                if (q.sim_out) q.sim_out[((long long)b * q.Nt + i0 + i) * p.M + jj] = cs;
+            }
         }
-    } else {
-    // ---- 64 cosines: thread (i = t>>2, quarter = t&3) covers channels quarter, quarter+4, ... ----
-    {
-        const int i = t >> 2, qd = t & 3;
-        const float* a = q.tfeat + (long long)b * q.t_sb + (long long)i * q.t_sn;
-        const float* s = q.sfeat + (long long)b * q.s_sb + (long long)jj * q.s_sn;
-        float dot = 0.f, na = 0.f, ns = 0.f;
-        for (int c = qd; c < q.C; c += 4) {
-            const float av = a[(long long)c * q.t_sc], sv = s[(long long)c * q.s_sc];
-            dot += av * sv; na += av * av; ns += sv * sv;
-        }
-        dot += __shfl_xor(dot, 1, 64); dot += __shfl_xor(dot, 2, 64);
-        na += __shfl_xor(na, 1, 64);   na += __shfl_xor(na, 2, 64);
-        ns += __shfl_xor(ns, 1, 64);   ns += __shfl_xor(ns, 2, 64);
-        // torch.nn.functional.cosine_similarity: x1.x2 / (max(|x1|, eps) * max(|x2|, eps))
-        const float cs = dot / (fmaxf(sqrtf(na), q.eps) * fmaxf(sqrtf(ns), q.eps));
-        if (qd == 0) {
-            simv[i] = cs;
-            if (q.sim_out) q.sim_out[((long long)b * q.Nt + i) * p.M + jj] = cs;
-        }
-    }
-    }
-    __syncthreads();
+        __syncthreads();
 
-    // ---- layer 0: relu(bn0(w_sim * cos_i + P[b,i,:])) -> X ----
-    if (!q.scale0 && !q.shift0 && (q.C0 & 3) == 0) {
-        // BatchNorm already folded into P and w_sim by the caller: relu(P'_i + w' * cos_i), four channels per lane
-        // (one 16-byte load, two packed FMAs, four max, one 16-byte LDS write) — 8 instructions per 4 values
-        typedef float f32x2 __attribute__((ext_vector_type(2)));
-        const int nq = q.C0 >> 2;
-        for (int e = t; e < 64 * nq; e += 256) {
-            const int i = e / nq, c4 = e - i * nq;
-            const f32x4 pv = *reinterpret_cast<const f32x4*>(q.P + ((long long)b * q.Nt + i) * q.C0 + c4 * 4);
-            const f32x4 w4 = *reinterpret_cast<const f32x4*>(q.wsim + c4 * 4);
-            const float cs = simv[i];
-            const f32x2 c2 = {cs, cs};
-            f32x2 lo = __builtin_elementwise_fma(f32x2{w4[0], w4[1]}, c2, f32x2{pv[0], pv[1]});
-            f32x2 hi = __builtin_elementwise_fma(f32x2{w4[2], w4[3]}, c2, f32x2{pv[2], pv[3]});
-            *reinterpret_cast<f32x4*>(Xs + i * p.ldk + c4 * 4) =
-                f32x4{fmaxf(lo[0], 0.f), fmaxf(lo[1], 0.f), fmaxf(hi[0], 0.f), fmaxf(hi[1], 0.f)};
-        }
-    } else {
-    for (int c = t; c < q.C0; c += 256) {
-        const float wsim = q.wsim[c], sc = q.scale0 ? q.scale0[c] : 1.f, sh = q.shift0 ? q.shift0[c] : 0.f;
-        const float* pr = q.P + (long long)b * q.Nt * q.C0 + c;
+        // ---- layer 0: relu(bn0(w_sim * cos_i + P[b,i,:])) -> X ----
+        if (!q.scale0 && !q.shift0 && (q.C0 & 3) == 0) {
+            // BatchNorm already folded into P and w_sim by the caller: relu(P'_i + w' * cos_i), four channels per lane
+            // (one 16-byte load, two packed FMAs, four max, one 16-byte LDS write) — 8 instructions per 4 values
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            const int nq = q.C0 >> 2;
+            for (int e = t; e < 64 * nq; e += 256) {
+                const int i = e / nq, c4 = e - i * nq;
+                const f32x4 pv = *reinterpret_cast<const f32x4*>(q.P + ((long long)b * q.Nt + i0 + i) * q.C0 + c4 * 4);
+                const f32x4 w4 = *reinterpret_cast<const f32x4*>(q.wsim + c4 * 4);
+                const float cs = simv[i];
+                const f32x2 c2 = {cs, cs};
+                f32x2 lo = __builtin_elementwise_fma(f32x2{w4[0], w4[1]}, c2, f32x2{pv[0], pv[1]});
+                f32x2 hi = __builtin_elementwise_fma(f32x2{w4[2], w4[3]}, c2, f32x2{pv[2], pv[3]});
+                *reinterpret_cast<f32x4*>(Xs + i * p.ldk + c4 * 4) =
+                    f32x4{fmaxf(lo[0], 0.f), fmaxf(lo[1], 0.f), fmaxf(hi[0], 0.f), fmaxf(hi[1], 0.f)};
+            }
+        } else {
+            for (int c = t; c < q.C0; c += 256) {
+                const float wsim = q.wsim[c], sc = q.scale0 ? q.scale0[c] : 1.f, sh = q.shift0 ? q.shift0[c] : 0.f;
+                const float* pr = q.P + ((long long)b * q.Nt + i0) * q.C0 + c;
 #pragma unroll 8
-        for (int i = 0; i < 64; ++i) {
-            const float v = (pr[(long long)i * q.C0] + wsim * simv[i]) * sc + sh;
-            Xs[i * p.ldk + c] = fmaxf(v, 0.f);
+                for (int i = 0; i < 64; ++i) {
+                    const float v = (pr[(long long)i * q.C0] + wsim * simv[i]) * sc + sh;
+                    Xs[i * p.ldk + c] = fmaxf(v, 0.f);
+                }
+            }
+        }
+        __syncthreads();
+
+        for (int l = 0; l < nlast; ++l) {
+            const SaLayerDev& L = p.L[l];
+            const int ctw = (L.NT + 3) >> 2;
+            if (ctw <= 1) sa_layer<64, 1>(p, L, false, Xs, lane, w, j, 1, pre, &p.L[l + 1]);
+            else sa_layer<64, 2>(p, L, false, Xs, lane, w, j, 1, pre, &p.L[l + 1]);
+        }
+        // ---- last layer: GEMM, then the max over this chunk's 64 template rows into the running max ----
+        {
+            const bool affine = LL.scale != nullptr;
+            f32x16 acc[2][2];
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[rt][u][r] = pre.sh[u];
+            int nvalid = 0;
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                if (w + 4 * u < LL.NT) nvalid = u + 1;
+            gemm_tiles<2, 2, 0>(Xs, p.ldk, LL.nkb, reinterpret_cast<const f32x4*>(LL.Wp), LL.NT, w, nvalid, lane, acc, pre.w);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (u >= nvalid) break;
+                const int col = (w + 4 * u) * 32 + (lane & 31);
+                float sc = 1.f, sh = 0.f;
+                if (affine) { sc = LL.scale[col]; sh = LL.shift ? LL.shift[col] : 0.f; }
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) {
+                    float m = affine ? acc[rt][u][0] * sc + sh : acc[rt][u][0];
+#pragma unroll
+                    for (int r = 1; r < 16; ++r) m = fmaxf(m, affine ? acc[rt][u][r] * sc + sh : acc[rt][u][r]);
+                    run[u] = fmaxf(run[u], max_halves(m));
+                }
+            }
         }
     }
-    }
-    __syncthreads();
-
-    for (int l = 0; l < p.n_layers; ++l) {
-        const SaLayerDev& L = p.L[l];
-        const bool last = (l == p.n_layers - 1);
-        const int ctw = (L.NT + 3) >> 2;
-        const SaLayerDev* Ln = last ? nullptr : &p.L[l + 1];
-        if (ctw <= 1) sa_layer<64, 1>(p, L, last, Xs, lane, w, j, 1, pre, Ln);
-        else sa_layer<64, 2>(p, L, last, Xs, lane, w, j, 1, pre, Ln);
+    if (half == 0) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (w + 4 * u >= LL.NT) break;
+            const int col = (w + 4 * u) * 32 + (lane & 31);
+            p.out[b * p.osb + col * p.osc + jj * p.osm] = LL.relu ? fmaxf(run[u], 0.f) : run[u];
+        }
     }
 }
 
@@ -1734,7 +1776,9 @@ extern "C" int ptt_xcorr_fused_fwd_f32(const ptt_xcorr_desc* d, ptt_stream_t str
     if (d->B < 0 || d->Ns <= 0 || d->C <= 0 || d->C0 <= 0 || d->n_layers < 1 || d->n_layers > PTT_SA_MAX_LAYERS)
         return fail(PTT_EINVAL, "ptt_xcorr_fused_fwd_f32: B=%d Ns=%d C=%d C0=%d layers=%d", d->B, d->Ns, d->C, d->C0,
                     d->n_layers);
-    if (d->Nt != 64) return fail(PTT_EUNSUPPORTED, "ptt_xcorr_fused_fwd_f32: Nt=%d (64 template seeds is instantiated)", d->Nt);
+    if (d->Nt <= 0 || (d->Nt % 64) != 0)
+        return fail(PTT_EUNSUPPORTED, "ptt_xcorr_fused_fwd_f32: Nt=%d (the template seeds are walked in chunks of 64)", d->Nt);
+    if (d->n_layers < 2) return fail(PTT_EUNSUPPORTED, "ptt_xcorr_fused_fwd_f32: needs at least two MFMA layers after layer 0");
     if ((d->C0 % 8) != 0 || d->C0 > 256) return fail(PTT_EUNSUPPORTED, "ptt_xcorr_fused_fwd_f32: C0=%d", d->C0);
     if (d->B == 0) return PTT_OK;
     if ((!d->cos_t && (!d->search_feat || !d->templ_feat)) || !d->P || !d->w_sim || !d->out)

@@ -42,11 +42,11 @@ class CosineSimAug(nn.Module):
             return ops.note_unfused(name, 'autograd is recording (wrap inference in torch.no_grad())')
         if search_feats.dtype != torch.float32 or template_feats.dtype != torch.float32:
             return ops.note_unfused(name, 'features must be float32')
-        if template_feats.shape[-1] != 64:
-            return ops.note_unfused(name, 'ptt_xcorr_fused_fwd_f32 instantiates 64 template seeds (got %d)'
+        if template_feats.shape[-1] % 64 != 0:
+            return ops.note_unfused(name, 'ptt_xcorr_fused_fwd_f32 walks the template seeds in chunks of 64 (got %d)'
                                     % template_feats.shape[-1])
         units = list(self.mlp)
-        if len(units) < 2 or len(units) > 5:
+        if len(units) < 3 or len(units) > 5:
             return ops.note_unfused(name, 'SharedMLP depth %d' % len(units))
         for u in units:
             if not hasattr(u, 'normlayer') or u.conv.weight.shape[0] % 32 or u.conv.weight.shape[0] > 256:

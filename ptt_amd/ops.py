@@ -401,8 +401,8 @@ def xcorr_fused(search_feats, templ_feats, P, w_sim, scale0, shift0, layers, eps
     B, C, Ns = search_feats.shape
     Nt = templ_feats.shape[2]
     C0 = P.shape[2]
-    if Nt != 64:
-        raise RuntimeError("xcorr_fused: Nt=%d (ptt_xcorr_fused_fwd_f32 instantiates 64 template seeds)" % Nt)
+    if Nt <= 0 or Nt % 64:
+        raise RuntimeError("xcorr_fused: Nt=%d (ptt_xcorr_fused_fwd_f32 walks the template seeds in chunks of 64)" % Nt)
     if P.shape[0] != B or P.shape[1] != Nt or w_sim.shape[0] != C0 or templ_feats.shape[:2] != search_feats.shape[:2]:
         raise RuntimeError("xcorr_fused: inconsistent shapes")
     if cos_t is not None:

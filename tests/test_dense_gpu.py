@@ -147,3 +147,27 @@ def test_transformer_pair_kernel(dev, N):
                                   ops.pack_weight(d("fc_gamma.2.weight")), d("fc_gamma.2.bias"), D, False)
     assert none is None
     np.testing.assert_array_equal(res2.cpu().numpy(), res.cpu().numpy())
+
+
+@pytest.mark.parametrize("n1,n2", [(128, 96), (192, 64), (512, 40)])
+def test_cosine_sim_aug_fused_for_other_template_sizes(dev, n1, n2):
+    """The fused CosineSimAug kernel walks the template seeds in chunks of 64 (BASELINE configs[4] leaves 512 of them):
+    module output against the oracle restatement of the reference op sequence, and the fused path must be the one that
+    ran (no 'unfused' note)."""
+    from ptt_amd.hot_path import AttrDict
+    from ptt_amd.models.similarity_modules import CosineSimAug
+    from tests.util import cosine_sim_params, load_cosine_sim
+    mlp, conv = cosine_sim_params(77 + n1)
+    m = CosineSimAug(AttrDict.wrap(dict(DEBUG=False, MLP=dict(CHANNELS=[260, 256, 256, 256], BN=True),
+                                        CONV=dict(CHANNELS=[256, 256, 256], BN=True)))).eval()
+    load_cosine_sim(m, mlp, conv)
+    rs = np.random.RandomState(n1 + n2)
+    sf = torch.from_numpy(rs.standard_normal((2, 256, n2)).astype(np.float32))
+    tf = torch.from_numpy(rs.standard_normal((2, 256, n1)).astype(np.float32))
+    txyz = torch.from_numpy(rs.uniform(-2, 2, (2, n1, 3)).astype(np.float32))
+    ref, _ = R.cosine_sim_aug(sf, tf, txyz, mlp, conv)
+    before = dict(ops.unfused_calls)
+    with torch.no_grad():
+        got = m.to(dev)({'search_feats': sf.to(dev), 'template_feats': tf.to(dev), 'template_seeds': txyz.to(dev)})['cosine_feats']
+    assert dict(ops.unfused_calls) == before
+    np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), **TOL)
