@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PTT_ABI_VERSION 10
+#define PTT_ABI_VERSION 11
 
 enum {
     PTT_OK = 0,
@@ -83,6 +83,11 @@ int ptt_select_centres_f32(const float* xyz, const int32_t* idx, int B, int N, i
  * ------------------------------------------------------------------------------- */
 int ptt_ball_query_f32(const float* new_xyz, const float* xyz, int B, int M, int N,
                        float radius, int nsample, int32_t* idx_out, ptt_stream_t stream);
+
+/* ptt_select_centres_f32 + ptt_ball_query_f32 of one SA level in one launch (same results): new_xyz (B,M,3), idx64_out
+ * (B,M) or NULL, idx_out (B,M,nsample); sel (B,M) int32 sample indices or NULL for the first M points. */
+int ptt_centres_ball_query_f32(const float* xyz, const int32_t* sel, int B, int N, int M, float radius, int nsample,
+                               float* new_xyz, int64_t* idx64_out, int32_t* idx_out, ptt_stream_t stream);
 
 /* ---------------------------------------------------------------------------------
  * F4  grouping

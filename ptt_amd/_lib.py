@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libptt_hip.so")
 
 PTT_SA_MAX_LAYERS = 4
-ABI_VERSION = 10            # PTT_ABI_VERSION of include/ptt_hip.h these structures mirror
+ABI_VERSION = 11            # PTT_ABI_VERSION of include/ptt_hip.h these structures mirror
 
 # every symbol include/ptt_hip.h declares (tests check the library exports all of them)
 EXPORTS = [
@@ -27,6 +27,7 @@ EXPORTS = [
     "ptt_pack_weight_strided_f32", "ptt_linear_batched_f32", "ptt_softmax_rows_f32",
     "ptt_gather_rows_f32", "ptt_scatter_csr_i32", "ptt_scatter_rows_csr_f32",
     "ptt_pt_pair_input_f32", "ptt_pt_attn_train_fwd_f32", "ptt_pt_attn_train_bwd_f32", "ptt_linear_act_in_f32",
+    "ptt_centres_ball_query_f32",
 ]
 PTT_MAX_SEGMENTS = 4
 
@@ -95,6 +96,7 @@ def _declare(lib):
         "ptt_gather_grad_f32": [vp, vp, i, i, i, i, vp, vp],
         "ptt_select_centres_f32": [vp, vp, i, i, i, vp, vp, vp],
         "ptt_ball_query_f32": [vp, vp, i, i, i, f, i, vp, vp],
+        "ptt_centres_ball_query_f32": [vp, vp, i, i, i, f, i, vp, vp, vp, vp],
         "ptt_group_f32": [vp, vp, i, i, i, i, i, vp, vp],
         "ptt_group_grad_f32": [vp, vp, i, i, i, i, i, vp, vp],
         "ptt_scatter_add_det_f32": [vp, vp, i, i, i, i, vp, vp, c_size_t, vp],

@@ -185,6 +185,48 @@ __global__ __launch_bounds__(256) void ball_query_kernel(const float* __restrict
     for (int s = cnt + lane; s < ns; s += 64) out[s] = fill;
 }
 
+// Centre selection and ball query of one SA level in ONE launch (pointnet2_modules.py:79-83,90): the wave that owns
+// centre c reads its coordinates through the sample index (sel == NULL: the first M points, 'sequence' sampling),
+// writes them to new_xyz and the index as int64, then sweeps the cloud as ball_query_kernel does. Same results as
+// select_centres_kernel + ball_query_kernel; one launch and one dependent round trip less per level, which is what a
+// B = 1 tracklet frame is made of.
+__global__ __launch_bounds__(256) void centres_ball_query_kernel(const float* __restrict__ xyz, const int32_t* __restrict__ sel,
+                                                                 int BM, int M, int N, float r2, int ns,
+                                                                 float* __restrict__ new_xyz, long long* __restrict__ idx64,
+                                                                 int32_t* __restrict__ idx_out) {
+    const int centre = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (centre >= BM) return;
+    const int lane = threadIdx.x & 63;
+    const int b = centre / M;
+    const float* __restrict__ pts = xyz + (size_t)b * N * 3;
+    int32_t* __restrict__ out = idx_out + (size_t)centre * ns;
+    const int n = sel ? sel[centre] : centre - b * M;
+    const float cx = pts[3 * n + 0], cy = pts[3 * n + 1], cz = pts[3 * n + 2];
+    if (lane == 0) {
+        new_xyz[(size_t)centre * 3 + 0] = cx; new_xyz[(size_t)centre * 3 + 1] = cy; new_xyz[(size_t)centre * 3 + 2] = cz;
+        if (idx64) idx64[centre] = n;
+    }
+    int cnt = 0, first = 0;
+    for (int base = 0; base < N; base += 64) {
+        const int k = base + lane;
+        bool hit = false;
+        if (k < N) {
+            const float d = sqdist3(cx, cy, cz, pts[3 * k + 0], pts[3 * k + 1], pts[3 * k + 2]);
+            hit = d < r2;
+        }
+        const unsigned long long mask = __ballot(hit);
+        if (mask != 0ull) {
+            if (cnt == 0) first = base + (__ffsll((long long)mask) - 1);
+            const int pos = cnt + __popcll(mask & ((1ull << lane) - 1ull));
+            if (hit && pos < ns) out[pos] = k;
+            cnt += __popcll(mask);
+            if (cnt >= ns) break;
+        }
+    }
+    const int fill = (cnt > 0) ? first : 0;
+    for (int s = cnt + lane; s < ns; s += 64) out[s] = fill;
+}
+
 // ------------------------------------------------------------------------------------------
 // gather / group and their scatter-add backward passes (channel-major features, as the
 // reference hands them over).
@@ -488,6 +530,18 @@ extern "C" int ptt_group_f32(const float* feat, const int32_t* idx, int B, int C
     hipLaunchKernelGGL(group_kernel, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), feat, idx, C, N, M,
                        ns, out, total);
     return check_launch("group_kernel");
+}
+
+extern "C" int ptt_centres_ball_query_f32(const float* xyz, const int32_t* sel, int B, int N, int M, float radius, int nsample,
+                                          float* new_xyz, int64_t* idx64_out, int32_t* idx_out, ptt_stream_t stream) {
+    if (B < 0 || M < 0 || N <= 0 || nsample <= 0 || (!sel && M > N))
+        return fail(PTT_EINVAL, "ptt_centres_ball_query_f32: B=%d M=%d N=%d nsample=%d", B, M, N, nsample);
+    if (B == 0 || M == 0) return PTT_OK;
+    if (!xyz || !new_xyz || !idx_out) return fail(PTT_EINVAL, "ptt_centres_ball_query_f32: null pointer");
+    const int BM = B * M;
+    hipLaunchKernelGGL(centres_ball_query_kernel, dim3((BM + 3) / 4), dim3(256), 0, as_stream(stream), xyz, sel, BM, M, N,
+                       radius * radius, nsample, new_xyz, reinterpret_cast<long long*>(idx64_out), idx_out);
+    return check_launch("centres_ball_query_kernel");
 }
 
 extern "C" int ptt_group_grad_f32(const float* grad_out, const int32_t* idx, int B, int C, int N, int M, int ns,

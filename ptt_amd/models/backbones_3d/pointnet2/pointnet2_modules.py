@@ -160,11 +160,10 @@ class PointnetSAModuleVotes(nn.Module):
 
         if fused:
             xyz = xyz.contiguous()
-            if prefix:
-                new_xyz, _ = ops.select_centres(xyz, None, npoint)
+            if prefix:                                   # centres + ball query in one launch
+                new_xyz, _, idx = ops.centres_ball_query(xyz, None, npoint, self.radius, self.nsample)
             else:
-                new_xyz, inds64 = ops.select_centres(xyz, inds.contiguous(), npoint)
-            idx = ops.ball_query(new_xyz, xyz, self.radius, self.nsample)
+                new_xyz, inds64, idx = ops.centres_ball_query(xyz, inds.contiguous(), npoint, self.radius, self.nsample)
             layers, hoist = self._fused_params(xyz.device)
             if hoist is not None and features is not None:
                 wf_packed, wx, c0, relu0 = hoist

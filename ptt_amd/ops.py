@@ -214,6 +214,23 @@ def ball_query(new_xyz, xyz, radius, nsample):
     return out
 
 
+def centres_ball_query(xyz, sel, npoint, radius, nsample, want_idx64=True):
+    """select_centres + ball_query of one SA level in one launch: -> (new_xyz (B,npoint,3), idx64 (B,npoint) | None,
+    idx (B,npoint,nsample) i32). sel: (B,npoint) i32 sample indices, or None for the first npoint points."""
+    _chk(xyz, "xyz", torch.float32, 3)
+    B, N, _ = xyz.shape
+    if sel is not None:
+        _chk(sel, "sel", torch.int32, 2)
+    M = int(npoint)
+    new_xyz = torch.empty((B, M, 3), dtype=torch.float32, device=xyz.device)
+    idx64 = torch.empty((B, M), dtype=torch.int64, device=xyz.device) if (want_idx64 and sel is not None) else None
+    idx = torch.empty((B, M, int(nsample)), dtype=torch.int32, device=xyz.device)
+    with torch.cuda.device(xyz.device), _timed('ptt_ball_query_f32'):
+        _lib.check(_lib.lib().ptt_centres_ball_query_f32(_ptr(xyz), _ptr(sel), B, N, M, float(radius), int(nsample), _ptr(new_xyz),
+                                                         _ptr(idx64), _ptr(idx), _stream()), "ptt_centres_ball_query_f32")
+    return new_xyz, idx64, idx
+
+
 def group_points(features, idx):
     """(B,C,N) f32, (B,M,ns) i32 -> (B,C,M,ns).  Replaces _ext.group_points (pointnet2_utils.py:237)."""
     _chk(features, "features", torch.float32, 3)

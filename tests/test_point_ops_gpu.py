@@ -182,3 +182,19 @@ def test_argument_errors_are_loud(dev):
         ops.furthest_point_sampling(t.transpose(1, 2), 4)   # non-contiguous
     with pytest.raises(RuntimeError):
         ops.group_points(torch.zeros(1, 4, 8, device=dev), torch.zeros(1, 2, 3, device=dev), )   # idx dtype
+
+
+@pytest.mark.parametrize("N,M,ns,with_sel", [(1024, 512, 32, True), (512, 256, 32, False), (128, 64, 16, True), (100, 7, 5, False)])
+def test_centres_ball_query_equals_the_two_kernels(dev, N, M, ns, with_sel):
+    """ptt_centres_ball_query_f32 (one launch per SA level) == ptt_select_centres_f32 followed by ptt_ball_query_f32, and
+    through them the oracle."""
+    xyz = _clouds(N + M, 4, N, kind="car", K=max(8, N // 3))
+    xyz[3] = 0.0
+    xd = _dev(xyz, dev)
+    sel = ops.furthest_point_sampling(xd, M) if with_sel else None
+    new_a, i64_a = ops.select_centres(xd, sel, M)
+    idx_a = ops.ball_query(new_a, xd, 0.4, ns)
+    new_b, i64_b, idx_b = ops.centres_ball_query(xd, sel, M, 0.4, ns)
+    assert torch.equal(new_a, new_b) and torch.equal(idx_a, idx_b)
+    assert (i64_a is None and i64_b is None) or torch.equal(i64_a, i64_b)
+    np.testing.assert_array_equal(idx_b.cpu().numpy(), O.ball_query(new_b.cpu().numpy(), xyz, 0.4, ns))
