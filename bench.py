@@ -82,6 +82,10 @@ def parse_args():
     ap.add_argument("--no-latency", action="store_true", help="skip the B = 1 latency measurement")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="do not overlap the FPS of batch n+1 with the dense kernels of batch n")
+    ap.add_argument("--ways", type=int, default=0,
+                    help="independent batches in flight (InterleavedHotPath: that many pipelined graphs on their own "
+                         "streams, replayed round-robin); 1 = a single pipelined graph; 0 = 2 for clouds up to 4096 points, "
+                         "1 above (the long FPS chains of two 16384-point batches compete: measured 1147 vs 1177 frames/s)")
     ap.add_argument("--cpu-frames", type=int, default=8)
     return ap.parse_args()
 
@@ -171,8 +175,8 @@ def main():
 
     import torch
     from ptt_amd import ops, synth
-    from ptt_amd.hot_path import (FrameHotPath, GraphedHotPath, PipelinedHotPath, TrackerThroughput, kitti_model_cfg,
-                                  randomize_)
+    from ptt_amd.hot_path import (FrameHotPath, GraphedHotPath, InterleavedHotPath, PipelinedHotPath, TrackerThroughput,
+                                  kitti_model_cfg, randomize_)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -203,14 +207,18 @@ def main():
     W = WORKLOADS[args.workload]
     B = args.batch or W["batch"]
     NS, NT = args.ns or W["ns"], args.nt or W["nt"]
+    if args.ways <= 0:
+        args.ways = 2 if NS <= 4096 else 1
     s_np, t_np = synth.frames(1000 + rank, B, NS, NT, K_s=min(W["K_s"], NS), K_t=min(W["K_t"], NT), kind=W["kind"],
                               zero_clouds=W["zero"])
 
     if args.workload == "train":
         out = run_train(args, torch, dev, dist, world, rank, ranks_seen, sync_all, B, NS, NT, W)
     else:
+        def throughput_graph(m, a, b):             # the pipelined form: one graph, or `--ways` of them round-robin
+            return PipelinedHotPath(m, a, b) if args.ways <= 1 else InterleavedHotPath(m, a, b, ways=args.ways)
         out = run_infer(args, torch, ops, dev, dist, world, rank, ranks_seen, sync_all, B, NS, NT, W, s_np, t_np,
-                        FrameHotPath, GraphedHotPath, PipelinedHotPath, TrackerThroughput, kitti_model_cfg, randomize_)
+                        FrameHotPath, GraphedHotPath, throughput_graph, TrackerThroughput, kitti_model_cfg, randomize_)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
@@ -358,7 +366,9 @@ def run_infer(args, torch, ops, dev, dist, world, rank, ranks_seen, sync_all, B,
                    "launch": ("eager, one stream" if args.serial else "eager" if graphed is None else
                               "hipGraph replay, template branch on a second stream" +
                               ("; software-pipelined across batches: FPS of batch n+1 runs on a side stream during the "
-                               "dense kernels of batch n (every batch still executes every kernel)" if pipelined else ""))},
+                               "dense kernels of batch n (every batch still executes every kernel)" +
+                               ("; %d such pipelines on their own streams replayed round-robin (%d independent batches in "
+                                "flight)" % (args.ways, args.ways) if args.ways > 1 else "") if pipelined else ""))},
         "rccl_ranks_seen": ranks_seen,
         "roofline": roofline,
         "cpu_baseline": cpu,

@@ -202,6 +202,42 @@ class PipelinedHotPath(object):
         return self.__call__()
 
 
+class InterleavedHotPath(object):
+    """Throughput mode with `ways` independent batches in flight: `ways` PipelinedHotPath graphs, each on its own HIP
+    stream, replayed round-robin. The tail of one batch's kernels (the last workgroups of a launch, the launch gaps
+    between ~55 dependent kernels) is filled by the other batch's kernels; every batch still executes every kernel.
+    Measured on the KITTI-Car workload (scripts/dual_pipeline_probe.py): 3.18 -> 3.11 ms per 48-frame step with two
+    ways, nothing more with three or four.
+
+        pipe = InterleavedHotPath(model, search0, template0)        # ways = 2
+        out = pipe(search_k, template_k)     # enqueues batch k; returns the outputs of batch k - ways (None at first)
+
+    The outputs belong to the stream in `pipe.last_stream`; make the consuming stream wait on it (or synchronise)."""
+
+    def __init__(self, model, search_points, template_points, ways=2, warmup=3):
+        dev = search_points.device
+        self.ways = int(ways)
+        self.streams = [torch.cuda.Stream(device=dev) for _ in range(self.ways)]
+        self.pipes = []
+        for st in self.streams:
+            st.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(st):
+                self.pipes.append(PipelinedHotPath(model, search_points, template_points, warmup=warmup))
+        torch.cuda.synchronize(dev)
+        self.calls = 0
+        self.last_stream = self.streams[0]
+
+    def __call__(self, next_search=None, next_template=None):
+        k = self.calls % self.ways
+        self.calls += 1
+        self.last_stream = self.streams[k]
+        with torch.cuda.stream(self.streams[k]):
+            return self.pipes[k](next_search, next_template)
+
+    def flush(self):
+        return [self.__call__() for _ in range(self.ways)]
+
+
 def randomize_(module, seed=0):
     """Random-init weights incl. non-trivial BatchNorm running statistics (no checkpoints offline)."""
     g = torch.Generator().manual_seed(seed)
