@@ -100,6 +100,30 @@ def test_graphed_and_pipelined_drivers_match_eager(dev):
             assert torch.equal(out[k], ref[k]), k
 
 
+def test_interleaved_driver_returns_every_batch_in_order(dev):
+    """InterleavedHotPath (two pipelined graphs on their own streams, two batches in flight): every batch comes back
+    bit-identical to an eager call, `ways` calls after it was enqueued."""
+    from ptt_amd.hot_path import InterleavedHotPath
+    model = randomize_(FrameHotPath(kitti_model_cfg()), seed=9).to(dev).eval()
+    batches = [tuple(torch.from_numpy(a).to(dev) for a in synth.frames(300 + i, 2, 1024, 512)) for i in range(5)]
+    with torch.no_grad():
+        eager = [{k: v.clone() for k, v in model(s, t).items()} for s, t in batches]
+    p = InterleavedHotPath(model, *batches[0], ways=2)        # both pipelines primed with batch 0
+    got = []
+    for s, t in batches[1:]:
+        out = p(s, t)
+        p.last_stream.synchronize()
+        got.append({k: v.clone() for k, v in out.items()})
+    for out in p.flush():
+        torch.cuda.synchronize()
+        got.append({k: v.clone() for k, v in out.items()})
+    expect = [0, 0, 1, 2, 3, 4]                               # which batch each returned result belongs to
+    assert len(got) == len(expect)
+    for out, b in zip(got, expect):
+        for k in ("search_inds", "template_inds", "search_feats", "box_feats", "pred_box_center"):
+            assert torch.equal(out[k], eager[b][k]), (k, b)
+
+
 def test_pipelined_driver_on_the_full_tracker(dev):
     """TrackerThroughput + PipelinedHotPath: the whole tracker (two-stream backbone, 'fps_inds' handed in by the driver)
     replayed as a graph returns what an eager call on the same batch returns."""
