@@ -1629,7 +1629,11 @@ static int linear_launch(const float* X, int rows, int K, int ldx, const float* 
     // 1-10 GFLOP, so workgroup count (>= 4 per CU, fine-grained tails) matters more than weight reuse per workgroup.
     const bool vec = p.vec_ok && (K & 3) == 0;
     const int rt64 = (rows + 63) / 64, rt32 = (rows + 31) / 32, cg256 = (p.NT + 7) / 8, cg128 = (p.NT + 3) / 4;
-    const int RT = dev_switches().linear_rt, CT = dev_switches().linear_ct;
+    int RT = dev_switches().linear_rt, CT = dev_switches().linear_ct;
+    // the row GEMMs of the training step (10^5-10^6 rows): 32 x 256 tiles reuse every A tile for twice the columns —
+    // 93 vs 85 TFLOP/s at 393k x 128 -> 256, 106 vs 95 at 256 -> 256 (scripts/rows_gemm_bench.py); inference launches
+    // (<= 24576 rows) keep the 32 x 128 tile that wins there
+    if (rows >= 32768 && Cout >= 256 && RT == 1 && CT == 1) CT = 2;
     const int lds = 2 * (RT * 32) * LIN_LDK * (int)sizeof(float);
     const dim3 grid(RT == 2 ? rt64 : rt32, CT == 2 ? cg256 : cg128, batch);
     hipStream_t s = as_stream(stream);
