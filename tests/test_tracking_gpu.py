@@ -111,3 +111,22 @@ def test_tracklet_runner_equals_the_reference_loop(dev, batch, lengths):
             np.testing.assert_allclose(bm.q_rotation_matrix(r[2]), o.rotation_matrix, rtol=0, atol=1e-9)
             n_moved += int(i > 0 and float(np.abs(r[0] - res[0][0]).max()) > 1e-6)
     assert n_moved > 0
+
+
+def test_overlapped_runners_give_the_same_boxes(dev):
+    """run_overlapped (two runners on two streams, their lockstep groups advancing alternately) == one runner, box for
+    box: tracklets are independent, and a frame's result does not depend on which other frames share its batch."""
+    from ptt_amd.config import StubDataset, ptt_model_cfg
+    from ptt_amd.hot_path import randomize_
+    from ptt_amd.models import build_network
+    from ptt_amd.tracklet_runner import TrackletRunner, run_overlapped
+    tracker = randomize_(build_network(ptt_model_cfg(), 1, StubDataset()), seed=4).to(dev).eval()
+    tracklets = [synth.tracklet(500 + k, T) for k, T in enumerate([5, 3, 6, 4, 2, 5, 1])]
+    single = TrackletRunner(tracker, dev, batch=3).run(tracklets)
+    both = run_overlapped([TrackletRunner(tracker, dev, batch=2), TrackletRunner(tracker, dev, batch=2)], tracklets)
+    assert len(both) == len(single) == len(tracklets)
+    for a, b, (clouds, _) in zip(single, both, tracklets):
+        assert len(a) == len(b) == len(clouds)
+        for x, y in zip(a, b):
+            np.testing.assert_array_equal(x[0], y[0])
+            np.testing.assert_array_equal(x[2], y[2])
