@@ -14,6 +14,7 @@
 // `rotate` rounds the float64 dot product to float32; comparisons are float32 point against float64 bound, strict.
 #include <math.h>
 #include <stdlib.h>
+#include <mutex>
 #include "common.h"
 
 namespace ptt {
@@ -327,14 +328,23 @@ extern "C" int ptt_track_box_by_offset(ptt_track_box* boxes, int n, float* offse
             if ((double)off[a] > lim) {
                 uint32_t d[2] = {0, 0};
                 if (rng_pos) {
-                    // outputs rng_pos[i], rng_pos[i] + 1 of MT19937(1): regenerate the prefix (a few thousand outputs, rare branch)
+                    // outputs rng_pos[i], rng_pos[i] + 1 of MT19937(1): from a table built once per process (the
+                    // resampling consumes a few thousand outputs at most); beyond it, regenerate the prefix
+                    static uint32_t table[32768];
+                    static std::once_flag once;
+                    std::call_once(once, [] { mt19937_fill(1u, table, 32768); });
                     const int64_t pos = rng_pos[i];
-                    const int cnt = (int)pos + 2;
-                    uint32_t* buf = (uint32_t*)malloc((size_t)cnt * sizeof(uint32_t));
-                    if (!buf) return fail(PTT_EINVAL, "ptt_track_box_by_offset: out of memory");
-                    mt19937_fill(1u, buf, cnt);
-                    d[0] = buf[pos]; d[1] = buf[pos + 1];
-                    free(buf);
+                    if (pos < 0) return fail(PTT_EINVAL, "ptt_track_box_by_offset: negative generator position");
+                    if (pos + 2 <= 32768) {
+                        d[0] = table[pos]; d[1] = table[pos + 1];
+                    } else {
+                        const int cnt = (int)pos + 2;
+                        uint32_t* buf = (uint32_t*)malloc((size_t)cnt * sizeof(uint32_t));
+                        if (!buf) return fail(PTT_EINVAL, "ptt_track_box_by_offset: out of memory");
+                        mt19937_fill(1u, buf, cnt);
+                        d[0] = buf[pos]; d[1] = buf[pos + 1];
+                        free(buf);
+                    }
                     rng_pos[i] = pos + 2;
                 }
                 // RandomState.uniform(-1, 1) = -1 + 2 * random_sample(), random_sample from two 32-bit outputs (53 bits)

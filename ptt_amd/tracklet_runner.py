@@ -87,11 +87,19 @@ class TrackletRunner(object):
         self.npts = np.zeros((T, B), np.int32)
         cap = 1
         for b, (clouds, _) in enumerate(tracklets):
-            row = []
-            for i, c in enumerate(clouds):
-                t = c if isinstance(c, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(c, np.float32))
-                t = t.to(dev, torch.float32).contiguous()
-                row.append(t)
+            if all(isinstance(c, np.ndarray) for c in clouds) and len(clouds) > 0:
+                # host arrays: ONE upload per tracklet — the frames side by side in a (3, sum N_i) buffer, every frame a
+                # column range of it (the crop kernel takes the row stride) — instead of one small copy per frame
+                sizes = [c.shape[1] for c in clouds]
+                packed = torch.from_numpy(np.ascontiguousarray(np.concatenate([c[0:3] for c in clouds], axis=1), np.float32))
+                packed = packed.to(dev)                  # pageable copy: pinning a fresh buffer per tracklet costs more than it saves
+                offs = np.concatenate([[0], np.cumsum(sizes)])
+                row = [packed[:, offs[i]:offs[i + 1]] for i in range(len(clouds))]
+            else:
+                row = [(c if isinstance(c, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(c, np.float32)))
+                       .to(dev, torch.float32) for c in clouds]
+                row = [t if t.stride(1) == 1 else t.contiguous() for t in row]
+            for i, t in enumerate(row):
                 self.ptr[i, b], self.ld[i, b], self.npts[i, b] = t.data_ptr(), t.stride(0), t.shape[1]
                 cap = max(cap, t.shape[1])
             self.clouds.append(row)
@@ -149,7 +157,8 @@ class TrackletRunner(object):
             for i, bx in enumerate(gts):
                 gt_wlh1[i, b] = bx[1][1]
         self.crop_jobs_host_np['capacity'] = self.cap
-        results = [[(boxes['center'][b].copy(), boxes['wlh'][b].copy(), boxes['quat'][b].copy())] for b in range(n)]
+        wlh0 = boxes['wlh'].copy()
+        history = [(np.ones(B, np.int32), boxes['center'].copy(), boxes['quat'].copy(), None)]   # per step: whole-batch copies
         rng_pos = np.zeros(B, np.int64)            # where numpy's global generator stands for each tracklet
         model_cfg = (self.model_offset, self.model_scale, None)
 
@@ -182,8 +191,15 @@ class TrackletRunner(object):
             used = np.where(info[:, 1, 1] > 0, info[:, 1, 1], info[:, 0, 1])
             rng_pos = np.where(used > 0, used, rng_pos).astype(np.int64)
             ops.track_box_by_offset(boxes, est, self.use_z, active, rng_pos)
-            for b in np.nonzero(active)[0]:
-                results[b].append((boxes['center'][b].copy(), boxes['wlh'][b].copy(), boxes['quat'][b].copy(), float(est[b, 4])))
+            history.append((active, boxes['center'].copy(), boxes['quat'].copy(), est[:, 4].copy()))
+        # per-tracklet result lists, assembled once (three array copies per step instead of 3 x B small ones)
+        results = []
+        for b in range(n):
+            rows = []
+            for act, c, q, sc in history:
+                if act[b]:
+                    rows.append((c[b], wlh0[b], q[b]) if sc is None else (c[b], wlh0[b], q[b], float(sc[b])))
+            results.append(rows)
         return results
 
     def _run_group(self, tracklets):
