@@ -744,27 +744,6 @@ __global__ __launch_bounds__(256, PTT_SA_WAVES) void sa_fused_kernel(SaParams p)
 constexpr int SAS_LDK = 132;                 // 128 channels + 4 (== 4 mod 8: conflict-free A reads)
 constexpr int SAS_TILE = 64 * SAS_LDK;
 
-// lanes 0..15 of wave w: neighbour index of the wave's row `lane` of `tile`, issued early (index -> coordinates is a
-// dependent chain of two L2 round trips)
-__device__ __forceinline__ void sas_meta_index(const SaParams& p, int tile, int w, int lane, int& c, int& n) {
-    const int r = 16 * w + (lane & 15);
-    c = tile * 2 + (r >> 5);
-    if (c >= p.B * p.M) c = p.B * p.M - 1;
-    n = p.idx[(size_t)c * 32 + (r & 31)];
-}
-// ... then the relative coordinates and the byte offset of the neighbour's per-point term row -> meta[w][row] (16 B)
-__device__ __forceinline__ void sas_meta_store(const SaParams& p, float* meta, int w, int lane, int c, int n) {
-    if (lane < 16) {
-        const int b = c / p.M;
-        const size_t flat = (size_t)b * p.N + n;
-        float dx = p.xyz[flat * 3 + 0] - p.new_xyz[(size_t)c * 3 + 0];
-        float dy = p.xyz[flat * 3 + 1] - p.new_xyz[(size_t)c * 3 + 1];
-        float dz = p.xyz[flat * 3 + 2] - p.new_xyz[(size_t)c * 3 + 2];
-        if (p.normalize) { dx /= p.radius; dy /= p.radius; dz /= p.radius; }
-        const int off = (int)(flat * 128 * sizeof(float));
-        *reinterpret_cast<f32x4*>(meta + (w * 16 + lane) * 4) = f32x4{__builtin_bit_cast(float, off), dx, dy, dz};
-    }
-}
 // one row pair of the wave's 16 rows: request (rows 2i, 2i+1 -> lanes 0-31 / 32-63, four channels per lane) ...
 __device__ __forceinline__ f32x4 sas_pair_load(const float* meta, __amdgpu_buffer_rsrc_t rf, int w, int i, int sub, int q,
                                                f32x4& m) {
@@ -774,23 +753,50 @@ __device__ __forceinline__ f32x4 sas_pair_load(const float* meta, __amdgpu_buffe
 // ... and finish: h0 = relu(term + Wx . rel) -> the tile (scalar FMAs: v_pk_fma_f32 beside MFMAs is an anti-lever,
 // MI355X_MICROARCH.md "price of one filler beside MFMAs")
 __device__ __forceinline__ void sas_pair_store(float* X, int w, int i, int sub, int q, f32x4 v, const f32x4& m, const f32x4& wx0,
-                                               const f32x4& wx1, const f32x4& wx2, int relu) {
+                                               const f32x4& wx1, const f32x4& wx2, float floor) {   // floor: 0 = ReLU, -inf = none
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         float y = __builtin_fmaf(wx0[j], m[1], v[j]);
         y = __builtin_fmaf(wx1[j], m[2], y);
         y = __builtin_fmaf(wx2[j], m[3], y);
-        v[j] = relu ? fmaxf(y, 0.f) : y;
+        v[j] = fmaxf(y, floor);
     }
     *reinterpret_cast<f32x4*>(X + (16 * w + 2 * i + sub) * SAS_LDK + q * 4) = v;
 }
 
+// a centre index with its (cloud, index inside the cloud), advanced without divisions: wave-uniform, scalar ALU only
+struct SasCentre {
+    int c, b, m;
+    __device__ __forceinline__ void advance(int k, int M) {
+        c += k; m += k;
+        while (m >= M) { m -= M; ++b; }
+    }
+};
+
+// max over the 32 neighbour rows of one 32 x 32 accumulator tile (16 registers x 2 half-waves), + shift, ReLU
+__device__ __forceinline__ float sas_pool(const f32x16& a, float sh, int relu) {
+    float mx = a[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, a[r]);
+    mx = max_halves(mx) + sh;
+    return relu ? fmaxf(mx, 0.f) : mx;
+}
+
+#ifndef PTT_SAS_INTERLEAVE
+#define PTT_SAS_INTERLEAVE 0    // 1: one gather instruction behind each MFMA (measured 3.5 % SLOWER than the block behind the last MFMA)
+#endif
+#ifndef PTT_SAS_EXP
+#define PTT_SAS_EXP 0    // timing experiments only (wrong results): 1 no barriers, 2 no gather, 4 no h1 writes, 8 no pool, 16 no meta
+#endif
 template <int NS>
 __global__ __launch_bounds__(256, 2) void sa_stream_kernel(SaParams p) {
     static_assert(NS == 32, "one centre per 32-row tile");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* meta = smem + 2 * SAS_TILE;                     // [4 waves][16 rows][off, dx, dy, dz]
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6, half = lane >> 5, sub = half, q = lane & 31;
+    float* const P = smem;                                 // h0 of the current tile (gathered during the previous tile's layer 2)
+    float* const Q = smem + SAS_TILE;                      // h1 of the current tile
+    float* const meta = smem + 2 * SAS_TILE;               // [4 waves][16 rows][off, dx, dy, dz]
+    const int t = threadIdx.x, lane = t & 63, half = lane >> 5, sub = half, q = lane & 31;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int tile0 = logical_block() * p.chunk;
     const int ntiles = min(p.chunk, p.tiles - tile0);
     if (ntiles <= 0) return;
@@ -798,6 +804,9 @@ __global__ __launch_bounds__(256, 2) void sa_stream_kernel(SaParams p) {
     const SaLayerDev& L1 = p.L[0];
     const SaLayerDev& L2 = p.L[1];
     const __amdgpu_buffer_rsrc_t rf = weight_rsrc(p.feat);
+    const __amdgpu_buffer_rsrc_t wr1 = weight_rsrc(L1.Wp), wr2 = weight_rsrc(L2.Wp);
+    const int wvoff = (w * 64 + lane) * 16;                // this lane's byte offset inside a K-block row of fragments
+    constexpr int WK1 = 4 * 1024, WK2 = 8 * 1024;          // bytes per K-block of the packed weights (NT = 4 / 8)
     const f32x4 wx0 = *reinterpret_cast<const f32x4*>(p.wx + q * 4);
     const f32x4 wx1 = *reinterpret_cast<const f32x4*>(p.wx + 128 + q * 4);
     const f32x4 wx2 = *reinterpret_cast<const f32x4*>(p.wx + 256 + q * 4);
@@ -805,104 +814,237 @@ __global__ __launch_bounds__(256, 2) void sa_stream_kernel(SaParams p) {
     const float sh1 = L1.shift ? L1.shift[w * 32 + col] : 0.f;
     const float sh2a = L2.shift ? L2.shift[w * 32 + col] : 0.f;
     const float sh2b = L2.shift ? L2.shift[(w + 4) * 32 + col] : 0.f;
+    f32x16 sh1v;                                           // layer 1's shift as the C operand of its first MFMAs
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sh1v[r] = sh1;
     const int total_centres = p.B * p.M;
+    const float floor0 = p.l0_relu ? 0.f : -__builtin_inff();
+    const float rdiv = p.normalize ? p.radius : 1.0f;      // x / 1 is exact: one code path, no branch in the MFMA stream
+    const int M = p.M, N = p.N;
+    const int osb = (int)p.osb, osm = (int)p.osm;
+    const int ocol0 = (w * 32 + col) * (int)p.osc, ocol1 = ((w + 4) * 32 + col) * (int)p.osc;
+
+    // the wave's own centre of a tile (rows 16w .. 16w+15 belong to centre 2*tile + (w >> 1)) and the tile's first centre
+    SasCentre own, first;
+    {
+        const int c0 = tile0 * 2;
+        first.c = c0; first.b = c0 / M; first.m = c0 - first.b * M;
+        own = first;
+        own.advance(w >> 1, M);
+    }
+    // index -> (relative coordinates, byte offset of the neighbour's per-point term row) of the wave's 16 rows, all
+    // 64 lanes redundantly (lane & 15): no exec-mask change, so the pieces can sit inside an MFMA stream
+    auto meta_index = [&](const SasCentre& ce) -> int {
+        const int c = ce.c < total_centres ? ce.c : total_centres - 1;
+        return p.idx[(size_t)c * 32 + 16 * (w & 1) + (lane & 15)];
+    };
+    struct MetaXyz { float x, y, z, cx, cy, cz; int flat; };
+    auto meta_fetch = [&](const SasCentre& ce, int n) -> MetaXyz {
+        const bool in = ce.c < total_centres;
+        const int c = in ? ce.c : total_centres - 1;
+        const int b = in ? ce.b : p.B - 1;
+        MetaXyz r;
+        r.flat = b * N + n;
+        r.x = p.xyz[(size_t)r.flat * 3 + 0]; r.y = p.xyz[(size_t)r.flat * 3 + 1]; r.z = p.xyz[(size_t)r.flat * 3 + 2];
+        r.cx = p.new_xyz[(size_t)c * 3 + 0]; r.cy = p.new_xyz[(size_t)c * 3 + 1]; r.cz = p.new_xyz[(size_t)c * 3 + 2];
+        return r;
+    };
+    auto meta_store = [&](const MetaXyz& r) {
+        const float dx = (r.x - r.cx) / rdiv, dy = (r.y - r.cy) / rdiv, dz = (r.z - r.cz) / rdiv;
+        const int off = r.flat * (128 * (int)sizeof(float));
+        *reinterpret_cast<f32x4*>(meta + (w * 16 + (lane & 15)) * 4) = f32x4{__builtin_bit_cast(float, off), dx, dy, dz};
+    };
 
     // ---- prologue: the first tile is gathered in the open ----
+    f32x4 pre1[2] = {weight_load(wr1, wvoff, 0), weight_load(wr1, wvoff, WK1)};   // layer 1's first two weight blocks
     {
-        int c, n;
-        sas_meta_index(p, tile0, w, lane, c, n);
-        sas_meta_store(p, meta, w, lane, c, n);
+        const int n = meta_index(own);
+        meta_store(meta_fetch(own, n));
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             f32x4 m;
             const f32x4 v = sas_pair_load(meta, rf, w, i, sub, q, m);
-            sas_pair_store(smem, w, i, sub, q, v, m, wx0, wx1, wx2, p.l0_relu);
+            sas_pair_store(P, w, i, sub, q, v, m, wx0, wx1, wx2, floor0);
         }
     }
 
-    for (int it = 0; it < ntiles; ++it) {
-        const int tile = tile0 + it;
-        const int next = (it + 1 < ntiles) ? tile + 1 : tile;            // last tile: re-gathers itself (branch-free loop)
-        float* X = smem + (it & 1) * SAS_TILE;
-        float* Xn = smem + ((it & 1) ^ 1) * SAS_TILE;
-        lds_barrier();                                                   // A: tile `tile` is complete in X
-        int cn, nn;
-        sas_meta_index(p, next, w, lane, cn, nn);                        // index load in flight under the first GEMM
-
-        // ---- layer 1: 128 -> 128, this wave's column tile w, both row tiles ----
-        f32x16 acc1[2][1];
+    f32x16 acc[2][2];                                      // layer 2's accumulators: pooled inside the NEXT tile's layer 1
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc1[rt][0][r] = sh1;
-        gemm_core<2, 1, 1, 4, 0>(X, SAS_LDK, 16, reinterpret_cast<const f32x4*>(L1.Wp), 4, w, lane, acc1);
-        f32x4 pre2[2];
-        prefetch_first_block_full<2>(L2.Wp, w, lane, pre2);              // layer 2's first weights ride across the epilogue
-        lds_barrier();                                                   // B: every wave has read X for layer 1
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                X[(rt * 32 + tile_row(r, half)) * SAS_LDK + w * 32 + col] = fmaxf(acc1[rt][0][r], 0.f);
-        sas_meta_store(p, meta, w, lane, cn, nn);                        // wave-private: same-wave LDS ops are ordered
-        lds_barrier();                                                   // C: h1 is complete
-
-        // ---- layer 2: 128 -> 256 (column tiles w, w+4), with the gather of tile `next` inside the MFMA stream ----
-        f32x16 acc[2][2];
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { acc[rt][0][r] = sh2a; acc[rt][1][r] = sh2b; }
-        {
-            const float* arow = X + (lane & 31) * SAS_LDK + 4 * half;
-            const __amdgpu_buffer_rsrc_t wr = weight_rsrc(L2.Wp);
-            const int wvoff = (w * 64 + lane) * 16;
-            constexpr int WK = 8 * 1024;                                 // bytes per K-block of L2's packed weights (NT = 8)
-            f32x4 a0[2], a1[2], b0[2], b1[2];
-#define SAS_LOAD(A, Bv, KB)                                                                     \
-            {                                                                                   \
-                Bv[0] = weight_load(wr, wvoff, (KB) * WK);                                      \
-                Bv[1] = weight_load(wr, wvoff, (KB) * WK + 4 * 1024);                           \
-                A[0] = *reinterpret_cast<const f32x4*>(arow + (KB) * 8);                        \
-                A[1] = *reinterpret_cast<const f32x4*>(arow + 32 * SAS_LDK + (KB) * 8);         \
-            }
-            b0[0] = pre2[0]; b0[1] = pre2[1];
-            a0[0] = *reinterpret_cast<const f32x4*>(arow);
-            a0[1] = *reinterpret_cast<const f32x4*>(arow + 32 * SAS_LDK);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {                                // K-blocks 2i, 2i+1 and row pair i of tile `next`
-                f32x4 m;
-                SAS_LOAD(a1, b1, 2 * i + 1)
-                const f32x4 v = sas_pair_load(meta, rf, w, i, sub, q, m);
-                __builtin_amdgcn_sched_barrier(0);
-                gemm_mfma_block<2, 2, 2>(a0, b0, acc);
-                __builtin_amdgcn_sched_barrier(0);
-                if (i < 7) SAS_LOAD(a0, b0, 2 * i + 2)
-                __builtin_amdgcn_sched_barrier(0);
-                gemm_mfma_block<2, 2, 2>(a1, b1, acc);
-                __builtin_amdgcn_sched_barrier(0);
-                sas_pair_store(Xn, w, i, sub, q, v, m, wx0, wx1, wx2, p.l0_relu);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#undef SAS_LOAD
-        }
-        // ---- max over the 32 neighbours (ReLU after the pool), one centre per row tile ----
+    for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt) {
-                float mx = acc[rt][u][0];
-#pragma unroll
-                for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[rt][u][r]);
-                mx = max_halves(mx);
-                if (L2.relu) mx = fmaxf(mx, 0.f);
-                const int c = tile * 2 + rt;
-                if (half == 0 && c < total_centres) {
-                    const int b = c / p.M, mm = c - b * p.M;
-                    p.out[b * p.osb + ((w + 4 * u) * 32 + col) * p.osc + mm * p.osm] = mx;
-                }
+            for (int r = 0; r < 16; ++r) acc[rt][u][r] = 0.f;
+    float pv[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    SasCentre prev = first;                                // first centre of the tile whose accumulators are pending
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+    auto store_pooled = [&](const SasCentre& f) {          // the two centres of a tile: scalar index arithmetic
+        SasCentre c1 = f;
+        c1.advance(1, M);
+        if (half == 0) {
+            if (f.c < total_centres) {
+                float* o = p.out + (f.b * osb + f.m * osm);
+                o[ocol0] = pv[0][0]; o[ocol1] = pv[0][1];
             }
+            if (c1.c < total_centres) {
+                float* o = p.out + (c1.b * osb + c1.m * osm);
+                o[ocol0] = pv[1][0]; o[ocol1] = pv[1][1];
+            }
+        }
+    };
+
+    for (int it = 0; it < ntiles; ++it) {
+        const bool more = it + 1 < ntiles;                               // last tile: re-gathers itself (branch-free loop)
+        SasCentre own_next = own;
+        if (more) own_next.advance(2, M);
+        if (!(PTT_SAS_EXP & 1)) lds_barrier();                           // A: P is complete; every wave is done with Q
+        const int nn = meta_index(own_next);                             // index load in flight under the first K-blocks
+        MetaXyz mx;
+
+        // ---- layer 1: 128 -> 128, this wave's column tile w, both row tiles; inside its MFMA stream the max-pool of
+        // the PREVIOUS tile's layer-2 accumulators and the (index -> coordinates -> meta) chain of the NEXT tile ----
+        f32x16 acc1[2];
+        {
+            const float* arow = P + (lane & 31) * SAS_LDK + 4 * half;
+            // weight fragments two K-blocks ahead (an L2 round trip is longer than the 8 MFMAs of one K-block), A one ahead
+            f32x4 a0[2], a1[2], bc[2], bn[2];
+#define SAS_A1(A, KB)                                                                           \
+            {                                                                                   \
+                A[0] = *reinterpret_cast<const f32x4*>(arow + (KB) * 8);                        \
+                A[1] = *reinterpret_cast<const f32x4*>(arow + 32 * SAS_LDK + (KB) * 8);         \
+            }
+            bc[0] = pre1[0]; bc[1] = pre1[1];
+            SAS_A1(a0, 0)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (i < 7) { bn[0] = weight_load(wr1, wvoff, (2 * i + 2) * WK1); bn[1] = weight_load(wr1, wvoff, (2 * i + 3) * WK1); }
+                SAS_A1(a1, 2 * i + 1)
+                if (i == 4 && !(PTT_SAS_EXP & 16)) mx = meta_fetch(own_next, nn);
+                __builtin_amdgcn_sched_barrier(0);
+                if (i == 0) {
+#pragma unroll
+                    for (int rt = 0; rt < 2; ++rt) acc1[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[rt][0], bc[0][0], sh1v, 0, 0, 0);
+#pragma unroll
+                    for (int j = 1; j < 4; ++j)
+#pragma unroll
+                        for (int rt = 0; rt < 2; ++rt)
+                            acc1[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[rt][j], bc[0][j], acc1[rt], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int rt = 0; rt < 2; ++rt)
+                            acc1[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[rt][j], bc[0][j], acc1[rt], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (i < 7) SAS_A1(a0, 2 * i + 2)
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int rt = 0; rt < 2; ++rt)
+                        acc1[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[rt][j], bc[1][j], acc1[rt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (i < 4 && !(PTT_SAS_EXP & 8)) pv[i >> 1][i & 1] = sas_pool(acc[i >> 1][i & 1], (i & 1) ? sh2b : sh2a, L2.relu);
+                if (i == 6 && !(PTT_SAS_EXP & 16)) meta_store(mx);
+                __builtin_amdgcn_sched_barrier(0);
+                bc[0] = bn[0]; bc[1] = bn[1];
+            }
+#undef SAS_A1
+        }
+        f32x4 pre2[2][2];                                                // layer 2's first two K-blocks ride across the epilogue
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            pre2[k][0] = weight_load(wr2, wvoff, k * WK2);
+            pre2[k][1] = weight_load(wr2, wvoff, k * WK2 + 4 * 1024);
+        }
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int r = (PTT_SAS_EXP & 4) ? 15 : 0; r < 16; ++r)
+                Q[(rt * 32 + tile_row(r, half)) * SAS_LDK + w * 32 + col] = fmaxf(acc1[rt][r], 0.f);
+        if (it > 0) store_pooled(prev);
+        if (!(PTT_SAS_EXP & 1)) lds_barrier();                           // C: h1 is complete; every wave is done with P
+
+        // ---- layer 2: 128 -> 256 (column tiles w, w+4), with the gather of the next tile inside the MFMA stream ----
+        {
+            const float* arow = Q + (lane & 31) * SAS_LDK + 4 * half;
+            f32x4 a0[2], a1[2], bc[2][2], bn[2][2];
+#define SAS_A2(A, KB)                                                                           \
+            {                                                                                   \
+                A[0] = *reinterpret_cast<const f32x4*>(arow + (KB) * 8);                        \
+                A[1] = *reinterpret_cast<const f32x4*>(arow + 32 * SAS_LDK + (KB) * 8);         \
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) { bc[k][0] = pre2[k][0]; bc[k][1] = pre2[k][1]; }
+            SAS_A2(a0, 0)
+            // (row offset, rel) of row pair i is read one iteration ahead: the feature load that depends on it must not
+            // put an LDS round trip in front of the iteration's MFMAs
+            f32x4 mc = *reinterpret_cast<const f32x4*>(meta + (w * 16 + sub) * 4), mn = mc;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {                                // K-blocks 2i, 2i+1 and row pair i of the next tile
+                if (i < 7) {
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        bn[k][0] = weight_load(wr2, wvoff, (2 * i + 2 + k) * WK2);
+                        bn[k][1] = weight_load(wr2, wvoff, (2 * i + 2 + k) * WK2 + 4 * 1024);
+                    }
+                } else {                                                 // the next tile's first layer-1 weights
+                    pre1[0] = weight_load(wr1, wvoff, 0);
+                    pre1[1] = weight_load(wr1, wvoff, WK1);
+                }
+                SAS_A2(a1, 2 * i + 1)
+                f32x4 v = wx0;
+                if (!(PTT_SAS_EXP & 2)) v = weight_load(rf, __builtin_bit_cast(int, mc[0]) + q * 16, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (i == 0) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int rt = 0; rt < 2; ++rt)
+                            acc[rt][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[rt][0], bc[0][u][0], zero16, 0, 0, 0);
+#pragma unroll
+                    for (int j = 1; j < 4; ++j)
+#pragma unroll
+                        for (int u = 0; u < 2; ++u)
+#pragma unroll
+                            for (int rt = 0; rt < 2; ++rt)
+                                acc[rt][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[rt][j], bc[0][u][j], acc[rt][u], 0, 0, 0);
+                } else {
+                    gemm_mfma_block<2, 2, 2>(a0, bc[0], acc);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (i < 7) {
+                    SAS_A2(a0, 2 * i + 2)
+                    mn = *reinterpret_cast<const f32x4*>(meta + (w * 16 + 2 * (i + 1) + sub) * 4);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                gemm_mfma_block<2, 2, 2>(a1, bc[1], acc);
+                if (!(PTT_SAS_EXP & 2)) sas_pair_store(P, w, i, sub, q, v, mc, wx0, wx1, wx2, floor0);
+#if PTT_SAS_INTERLEAVE
+                // one gather instruction behind each MFMA instead of a block of 17 behind the last one
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);   // VALU
+                }
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);       // the ds_write of the row pair
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+                mc = mn;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) { bc[k][0] = bn[k][0]; bc[k][1] = bn[k][1]; }
+            }
+#undef SAS_A2
+        }
+        prev = first;
+        if (more) { first.advance(2, M); own = own_next; }
     }
+    // ---- the last tile's max over the 32 neighbours (ReLU after the pool), one centre per row tile ----
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pv[i >> 1][i & 1] = sas_pool(acc[i >> 1][i & 1], (i & 1) ? sh2b : sh2a, L2.relu);
+    store_pooled(prev);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1162,140 +1304,172 @@ __device__ __forceinline__ void sa_wave_layer(const SaParams& p, const SaLayerDe
 }
 
 // ------------------------------------------------------------------------------------------
-// SA0 (no point features: rows are [rel.x rel.y rel.z], 3 -> 64 -> 64 -> 128, 32 neighbours): the whole packed weight
-// set is 50 KB, so it lives in LDS for the life of a PERSISTENT workgroup of 8 waves (one per CU, two waves per SIMD):
-//   * B fragments come from LDS (one conflict-free 1 KiB ds_read_b128 per fragment) instead of the L2 -> CU path
-//     that sa_wave_kernel's twelve waves per CU saturate (50 KB of weights per 32-row tile per wave);
-//   * every wave owns 32-row tiles (one centre) in a private LDS tile: no workgroup barrier after the weight load;
-//   * the neighbour indices and coordinates of the NEXT tile are requested while the current tile is in its GEMMs;
-//   * 2 waves per SIMD leave 256 VGPRs: nothing spills (sa_wave_kernel<32,1>: 22 VGPRs, 92 B per lane of scratch).
+// SA0 (no point features: rows are [rel.x rel.y rel.z], 3 -> 64 -> 64 -> 128, 32 neighbours): the activations never
+// leave the registers. A PERSISTENT workgroup of 8 waves per CU holds the packed weights of layers 1 and 2 (48 KB) in
+// LDS; every wave owns whole centres (32 grouped rows x all channels) and chains the layers TRANSPOSED:
+//     layers 0, 1:  H^T[cout][row] = W[cout][k] . H_in^T[k][row]    weights as the MFMA A operand, rows on the lanes
+//     layer  2   :  Y[row][cout]   = H[row][k]  . W^T[k][cout]      activations as the A operand, channels on the lanes
+// The 32x32 accumulator layout (lane = row, half-wave h, register r <-> channel (r&3) + 8(r>>2) + 4h) IS the operand
+// layout of the next MFMA step for K index pair (channel(r,0), channel(r,1)), and the packed weight fragment of K-block
+// 4t + (r>>2), element r&3, holds exactly those two input channels — so a layer's output registers feed the next layer's
+// MFMAs directly (after an in-register ReLU): no LDS round trip, no ds_write, no barrier after the weight load. The last
+// layer is taken un-transposed so that the max over the 32 neighbours is a max over REGISTERS again, not over lanes.
+// Layer 0 is two MFMA steps on (dx, dy) / (dz, 1) with its shift in the fourth K slot; layer 1's shift is one extra
+// step against the constant (1, 0); layer 2's shift is added after the pool.
+// (The earlier form kept a private [32][68] LDS tile per wave: ~250 epilogue instructions per 200 MFMAs, each paid in
+//  matrix time beside the co-resident wave's MFMA stream — 0.71 of peak.)
 // ------------------------------------------------------------------------------------------
-constexpr int SAL_LDK = 68;                      // 64 channels + 4
-
-template <int CT, int NKB>
-__device__ __forceinline__ void gemm_lds_weights(const float* Xw, const float* Wl, int NT, int lane, f32x16 (&acc)[CT]) {
-    const float* arow = Xw + (lane & 31) * SAL_LDK + 4 * (lane >> 5);
-    const float* brow = Wl + lane * 4;
-#pragma unroll
-    for (int kb = 0; kb < NKB; ++kb) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(arow + kb * 8);
-        f32x4 b[CT];
-#pragma unroll
-        for (int u = 0; u < CT; ++u) b[u] = *reinterpret_cast<const f32x4*>(brow + (kb * NT + u) * 256);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int u = 0; u < CT; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[u][j], acc[u], 0, 0, 0);
-    }
-}
-
-__global__ __launch_bounds__(512, 1) void sa_lds_kernel(SaParams p) {
+#ifndef PTT_SAL_WGS
+#define PTT_SAL_WGS 1        // workgroups per CU
+#endif
+#ifndef PTT_SAL_WAVES
+#define PTT_SAL_WAVES 12     // waves per workgroup (three per SIMD: 148 VGPRs)
+#endif
+__global__ __launch_bounds__(64 * PTT_SAL_WAVES) __attribute__((amdgpu_waves_per_eu(PTT_SAL_WAVES * PTT_SAL_WGS / 4)))
+void sa_lds_kernel(SaParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* W0 = smem;                                        // [1][2][256]   3 (-> 8) x 64
-    float* W1 = smem + 512;                                  // [8][2][256]   64 x 64
-    float* W2 = smem + 512 + 4096;                           // [8][4][256]   64 x 128
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6, half = lane >> 5, col = lane & 31;
-    float* Xw = smem + 512 + 4096 + 8192 + w * 32 * SAL_LDK; // this wave's private [32][68] tile
+    float* W1 = smem;                                        // [8][2][256]   64 x 64
+    float* W2 = smem + 4096;                                 // [8][4][256]   64 x 128
+    const int t = threadIdx.x, lane = t & 63, half = lane >> 5, col = lane & 31;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     {
-        const f32x4* g0 = reinterpret_cast<const f32x4*>(p.L[0].Wp);
         const f32x4* g1 = reinterpret_cast<const f32x4*>(p.L[1].Wp);
         const f32x4* g2 = reinterpret_cast<const f32x4*>(p.L[2].Wp);
-        f32x4* s0 = reinterpret_cast<f32x4*>(W0);
         f32x4* s1 = reinterpret_cast<f32x4*>(W1);
         f32x4* s2 = reinterpret_cast<f32x4*>(W2);
-        for (int i = t; i < 128; i += 512) s0[i] = g0[i];
-        for (int i = t; i < 1024; i += 512) s1[i] = g1[i];
-        for (int i = t; i < 2048; i += 512) s2[i] = g2[i];
+        for (int i = t; i < 1024; i += 64 * PTT_SAL_WAVES) s1[i] = g1[i];
+        for (int i = t; i < 2048; i += 64 * PTT_SAL_WAVES) s2[i] = g2[i];
     }
-    __syncthreads();
-    const int total = p.B * p.M;                             // one tile per centre
-    const int gw = logical_block() * 8 + w;
-    const int c0 = gw * p.chunk, c1 = min(total, c0 + p.chunk);
-    if (c0 >= c1) return;
-    float sh0[2], sh1[2], sh2[4];
+    // per-lane constants, parked in LDS (10 registers less: four waves per SIMD fit without a spill). Layer 0's weights
+    // and shift as A operands: lane (channel c, half h) supplies W0[c][h] for step 0 and (h ? shift0[c] : W0[c][2]) for
+    // step 1; layer 1's shift for its extra step; layer 2's for after the pool
+    float* cst = smem + 4096 + 8192 + w * 640 + lane;        // [wave][10][64]
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-        sh0[u] = p.L[0].shift ? p.L[0].shift[u * 32 + col] : 0.f;
-        sh1[u] = p.L[1].shift ? p.L[1].shift[u * 32 + col] : 0.f;
+        const f32x4 f = reinterpret_cast<const f32x4*>(p.L[0].Wp)[u * 64 + col];     // (w_x, w_y, w_z, 0) of channel 32u + col
+        const float s0 = p.L[0].shift ? p.L[0].shift[u * 32 + col] : 0.f;
+        cst[(0 + u) * 64] = half ? f[1] : f[0];
+        cst[(2 + u) * 64] = half ? s0 : f[2];
+        cst[(4 + u) * 64] = p.L[1].shift ? p.L[1].shift[u * 32 + col] : 0.f;
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) sh2[u] = p.L[2].shift ? p.L[2].shift[u * 32 + col] : 0.f;
+    for (int u = 0; u < 4; ++u) cst[(6 + u) * 64] = p.L[2].shift ? p.L[2].shift[u * 32 + col] : 0.f;
+    const float one_zero = half ? 0.f : 1.f, one_hi = 1.f;
+    __syncthreads();
+    const int total = p.B * p.M, M = p.M, N = p.N;           // one tile per centre
+    const int gw = logical_block() * PTT_SAL_WAVES + w;
+    const int c0 = gw * p.chunk, c1 = min(total, c0 + p.chunk);
+    if (c0 >= c1) return;
+    const float rdiv = p.normalize ? p.radius : 1.0f;        // x / 1 is exact: one code path
+    const int osb = (int)p.osb, osm = (int)p.osm, osc = (int)p.osc;
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const float* a1p = W1 + lane * 4;
+    const float* b2p = W2 + lane * 4;
+    const __amdgpu_buffer_rsrc_t rx = weight_rsrc(p.xyz);
 
-    // lanes 0..31: one grouped row each. Request the first tile's neighbour and centre coordinates.
+    SasCentre ce;
+    ce.c = c0; ce.b = c0 / M; ce.m = c0 - ce.b * M;
+    // every lane: grouped row `col` of the tile (both half-waves hold the same rows and supply different K indices)
     int n_cur = p.idx[(size_t)c0 * 32 + col];
     float px, py, pz, cx, cy, cz;
     {
-        const size_t flat = (size_t)(c0 / p.M) * p.N + n_cur;
+        const size_t flat = (size_t)ce.b * N + n_cur;
         px = p.xyz[flat * 3]; py = p.xyz[flat * 3 + 1]; pz = p.xyz[flat * 3 + 2];
         cx = p.new_xyz[(size_t)c0 * 3]; cy = p.new_xyz[(size_t)c0 * 3 + 1]; cz = p.new_xyz[(size_t)c0 * 3 + 2];
     }
+    // Loads are pinned where their latency is covered (sched_barrier: left alone, the scheduler sinks the next tile's
+    // index load to its first use and waits vmcnt(0) in the middle of layer 2, and issues each weight fragment's
+    // ds_read right in front of the MFMAs that consume it)
     for (int c = c0; c < c1; ++c) {
-        const int cn = (c + 1 < c1) ? c + 1 : c;              // the last tile re-requests itself (branch-free loop body)
-        // ---- rows [rel | 0] of this tile ----
-        if (half == 0) {
-            float dx = px - cx, dy = py - cy, dz = pz - cz;
-            if (p.normalize) { dx /= p.radius; dy /= p.radius; dz /= p.radius; }
-            *reinterpret_cast<f32x4*>(Xw + col * SAL_LDK) = f32x4{dx, dy, dz, 0.f};
-            *reinterpret_cast<f32x4*>(Xw + col * SAL_LDK + 4) = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        const int n_next = p.idx[(size_t)cn * 32 + col];      // in flight under layers 0 and 1
-        __builtin_amdgcn_wave_barrier();
-        // ---- layer 0: 3 (padded to 8) -> 64 ----
+        SasCentre nx = ce;                                   // the last tile re-requests itself (branch-free loop body)
+        if (c + 1 < c1) nx.advance(1, M);
+        const int n_next = p.idx[(size_t)nx.c * 32 + col];   // in flight under layers 0 and 1
+        f32x4 wa[2], wn[2];                                  // layer 1's weight fragments: current / next K-block
+#pragma unroll
+        for (int u = 0; u < 2; ++u) wa[u] = *reinterpret_cast<const f32x4*>(a1p + u * 256);
+        const float dx = (px - cx) / rdiv, dy = (py - cy) / rdiv, dz = (pz - cz) / rdiv;
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- layer 0: 3 -> 64 (transposed), K = (dx, dy | dz, 1) ----
+        f32x16 h0[2];
         {
-            f32x16 acc[2];
+            const float k0 = half ? dy : dx, k1 = half ? one_hi : dz;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) h0[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(cst[(0 + u) * 64], k0, zero16, 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) h0[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(cst[(2 + u) * 64], k1, h0[u], 0, 0, 0);
 #pragma unroll
             for (int u = 0; u < 2; ++u)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[u][r] = sh0[u];
-            gemm_lds_weights<2, 1>(Xw, W0, 2, lane, acc);
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) Xw[tile_row(r, half) * SAL_LDK + u * 32 + col] = fmaxf(acc[u][r], 0.f);
+                for (int r = 0; r < 16; ++r) h0[u][r] = fmaxf(h0[u][r], 0.f);
         }
-        __builtin_amdgcn_wave_barrier();
-        // ---- layer 1: 64 -> 64 ----
+        // ---- layer 1: 64 -> 64 (transposed) ----
+        f32x16 h1[2];
+        f32x4 wb[4], wm[4];                                  // layer 2's weight fragments
         {
-            f32x16 acc[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) h1[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(cst[(4 + u) * 64], one_zero, zero16, 0, 0, 0);
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) {
+                if (kb < 7) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) wn[u] = *reinterpret_cast<const f32x4*>(a1p + ((kb + 1) * 2 + u) * 256);
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) wb[u] = *reinterpret_cast<const f32x4*>(b2p + u * 256);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+                        h1[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[u][j], h0[kb >> 2][(kb & 3) * 4 + j], h1[u], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) wa[u] = wn[u];
+            }
 #pragma unroll
             for (int u = 0; u < 2; ++u)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[u][r] = sh1[u];
-            gemm_lds_weights<2, 8>(Xw, W1, 2, lane, acc);
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) Xw[tile_row(r, half) * SAL_LDK + u * 32 + col] = fmaxf(acc[u][r], 0.f);
+                for (int r = 0; r < 16; ++r) h1[u][r] = fmaxf(h1[u][r], 0.f);
         }
         // the next tile's coordinates: in flight under layer 2
-        {
-            const size_t flat = (size_t)(cn / p.M) * p.N + n_next;
-            px = p.xyz[flat * 3]; py = p.xyz[flat * 3 + 1]; pz = p.xyz[flat * 3 + 2];
-            cx = p.new_xyz[(size_t)cn * 3]; cy = p.new_xyz[(size_t)cn * 3 + 1]; cz = p.new_xyz[(size_t)cn * 3 + 2];
+        {   // 32-bit offsets on a buffer descriptor: with 64-bit index arithmetic the sign extension of n_next is hoisted
+            // to the load and the wave waits vmcnt(0) at the top of the tile
+            const int off = (nx.b * N + n_next) * 12;
+            px = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, off, 0, 0));
+            py = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, off + 4, 0, 0));
+            pz = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, off + 8, 0, 0));
+            cx = p.new_xyz[(size_t)nx.c * 3]; cy = p.new_xyz[(size_t)nx.c * 3 + 1]; cz = p.new_xyz[(size_t)nx.c * 3 + 2];
         }
-        __builtin_amdgcn_wave_barrier();
-        // ---- layer 2: 64 -> 128, max over the 32 neighbours, ReLU after the pool ----
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- layer 2: 64 -> 128 (rows back on the M axis), max over the 32 neighbours, shift, ReLU after the pool ----
         {
             f32x16 acc[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int kb = 0; kb < 8; ++kb) {
+                if (kb < 7) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[u][r] = sh2[u];
-            gemm_lds_weights<4, 8>(Xw, W2, 4, lane, acc);
-            const int b = c / p.M, mm = c - b * p.M;
+                    for (int u = 0; u < 4; ++u) wm[u] = *reinterpret_cast<const f32x4*>(b2p + ((kb + 1) * 4 + u) * 256);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(h1[kb >> 2][(kb & 3) * 4 + j], wb[u][j],
+                                                                       (kb == 0 && j == 0) ? zero16 : acc[u], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) wb[u] = wm[u];
+            }
+            float* o = p.out + (ce.b * osb + ce.m * osm);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                float mx = acc[u][0];
-#pragma unroll
-                for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[u][r]);
-                mx = max_halves(mx);
-                if (p.L[2].relu) mx = fmaxf(mx, 0.f);
-                if (half == 0) p.out[b * p.osb + (u * 32 + col) * p.osc + mm * p.osm] = mx;
+                const float mx = sas_pool(acc[u], cst[(6 + u) * 64], p.L[2].relu);
+                if (half == 0) o[(u * 32 + col) * osc] = mx;
             }
         }
-        __builtin_amdgcn_wave_barrier();
+        ce = nx;
     }
 }
 
@@ -1713,12 +1887,12 @@ extern "C" int ptt_sa_fused_fwd_f32(const ptt_sa_desc* d, ptt_stream_t stream) {
     if (d->C == 0 && d->use_xyz && !hoist && d->nsample == 32 && d->n_layers == 3 && p.L[0].Cout == 64 && p.L[1].Cout == 64 &&
         p.L[2].Cout == 128 && !p.L[0].scale && !p.L[1].scale && !p.L[2].scale && p.L[0].relu && p.L[1].relu &&
         dev_switches().sa_lds) {
-        const int waves = 256 * 8;                           // one 8-wave workgroup per CU
+        const int waves = 256 * PTT_SAL_WAVES * PTT_SAL_WGS;   // resident waves of the device
         p.chunk = (total_centres + waves - 1) / waves;
-        int wgs = (total_centres + p.chunk * 8 - 1) / (p.chunk * 8);
-        const int lds = (512 + 4096 + 8192 + 8 * 32 * SAL_LDK) * (int)sizeof(float);
+        int wgs = (total_centres + p.chunk * PTT_SAL_WAVES - 1) / (p.chunk * PTT_SAL_WAVES);
+        const int lds = (4096 + 8192 + PTT_SAL_WAVES * 640) * (int)sizeof(float);
         if ((rc = set_lds_limit(reinterpret_cast<const void*>(sa_lds_kernel), lds))) return rc;
-        hipLaunchKernelGGL(sa_lds_kernel, dim3(wgs), dim3(512), lds, s, p);
+        hipLaunchKernelGGL(sa_lds_kernel, dim3(wgs), dim3(64 * PTT_SAL_WAVES), lds, s, p);
         return check_launch("sa_lds_kernel");
     }
     // small weight set (fits L1/L2 comfortably) and <= 4 column tiles everywhere: barrier-free wave-private kernel
