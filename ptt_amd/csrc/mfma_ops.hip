@@ -327,8 +327,9 @@ __device__ __forceinline__ void prefetch_first_block(const float* Wp, const floa
     if (w < NT) pre.w[0] = bp[0];
     if (w + 4 < NT) pre.w[1] = bp[4 * 64];
     if (shift && !scale) {
-        if (w < NT) pre.sh[0] = shift[w * 32 + (lane & 31)];
-        if (w + 4 < NT) pre.sh[1] = shift[(w + 4) * 32 + (lane & 31)];
+        // unsigned index: SGPR base + 32-bit VGPR offset addressing, no loop-invariant 64-bit address held in VGPRs
+        if (w < NT) pre.sh[0] = shift[(unsigned)(w * 32 + (lane & 31))];
+        if (w + 4 < NT) pre.sh[1] = shift[(unsigned)((w + 4) * 32 + (lane & 31))];
     }
 }
 
@@ -1128,18 +1129,21 @@ __global__ __launch_bounds__(256, 2) void xcorr_fused_kernel(XcorrParams q) {
             // the cosine map of the whole batch was computed once by cos_map_kernel: 64 values to fetch instead of ~340
             // vector-ALU / load instructions per wave in a phase that runs beside another workgroup's MFMA stream
             if (t < 64) {
-                const float cs = q.cos_t[((long long)b * p.M + jj) * q.Nt + i0 + t];
+                const float cs = q.cos_t[(unsigned)((b * p.M + jj) * q.Nt + i0 + t)];
                 simv[t] = cs;
-                if (q.sim_out) q.sim_out[((long long)b * q.Nt + i0 + t) * p.M + jj] = cs;
+                if (q.sim_out) q.sim_out[(unsigned)((b * q.Nt + i0 + t) * p.M + jj)] = cs;
             }
         } else {
             // ---- 64 cosines: thread (i = t>>2, quarter = t&3) covers channels quarter, quarter+4, ... ----
             const int i = t >> 2, qd = t & 3;
-            const float* a = q.tfeat + (long long)b * q.t_sb + (long long)(i0 + i) * q.t_sn;
-            const float* sp = q.sfeat + (long long)b * q.s_sb + (long long)jj * q.s_sn;
+            // 32-bit element offsets (a feature tensor has far fewer than 2^31 elements): the 64-bit form kept eight
+            // loop-invariant address registers alive across the GEMMs and spilled them
+            const float* a = q.tfeat + (b * (int)q.t_sb + (i0 + i) * (int)q.t_sn);
+            const float* sp = q.sfeat + (b * (int)q.s_sb + jj * (int)q.s_sn);
+            const int t_sc = (int)q.t_sc, s_sc = (int)q.s_sc;
             float dot = 0.f, na = 0.f, ns = 0.f;
             for (int c = qd; c < q.C; c += 4) {
-                const float av = a[(long long)c * q.t_sc], sv = sp[(long long)c * q.s_sc];
+                const float av = a[c * t_sc], sv = sp[c * s_sc];
                 dot += av * sv; na += av * av; ns += sv * sv;
             }
             dot += __shfl_xor(dot, 1, 64); dot += __shfl_xor(dot, 2, 64);
@@ -1149,7 +1153,7 @@ __global__ __launch_bounds__(256, 2) void xcorr_fused_kernel(XcorrParams q) {
             const float cs = dot / (fmaxf(sqrtf(na), q.eps) * fmaxf(sqrtf(ns), q.eps));
             if (qd == 0) {
                 simv[i] = cs;
-                if (q.sim_out) q.sim_out[((long long)b * q.Nt + i0 + i) * p.M + jj] = cs;
+                if (q.sim_out) q.sim_out[(unsigned)((b * q.Nt + i0 + i) * p.M + jj)] = cs;
             }
         }
         __syncthreads();
@@ -1475,7 +1479,7 @@ void sa_lds_kernel(SaParams p) {
 
 // RT row tiles (32 * RT grouped rows) per wave; only RT = 1 is launched (see the host entry point).
 template <int NS, int RT>
-__global__ __launch_bounds__(256, RT == 1 ? 3 : 2) void sa_wave_kernel(SaParams p) {
+__global__ __launch_bounds__(256, 2) void sa_wave_kernel(SaParams p) {   // 2 waves per SIMD: at 3 the 168-VGPR cap spilled 92 B per lane
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int CPW = 32 * RT / NS;                        // centres per wave
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;

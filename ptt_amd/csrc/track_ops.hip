@@ -105,7 +105,7 @@ __global__ __launch_bounds__(T) void crop_compact_kernel(const ptt_crop_job* __r
     if (threadIdx.x == 0) *j.count = written;       // may exceed capacity: the caller sized `out` for n_points
 }
 
-__device__ __forceinline__ void seg_point(const ptt_regularize_job& j, const int (&cnt)[PTT_MAX_SEGMENTS], int idx, float* dst) {
+__device__ __forceinline__ void seg_point(const ptt_regularize_job& j, const int* cnt, int idx, float* dst) {
     int s = 0;
     while (s + 1 < j.n_seg && idx >= cnt[s]) { idx -= cnt[s]; ++s; }
     const float* p = j.seg[s] + (size_t)idx * 3;
@@ -117,14 +117,22 @@ template <int T>
 __global__ __launch_bounds__(T) void regularize_kernel(const ptt_regularize_job* __restrict__ jobs,
                                                        const uint32_t* __restrict__ draws, int n_draws) {
     __shared__ int wsum[T / 64];
-    const ptt_regularize_job j = jobs[blockIdx.x];
-    int cnt[PTT_MAX_SEGMENTS];
+    // the job and the segment sizes live in LDS: seg_point() indexes them with a run-time segment number, which as
+    // private arrays meant 112 B of scratch per lane
+    __shared__ ptt_regularize_job j;
+    __shared__ int cnt[PTT_MAX_SEGMENTS];
+    static_assert(sizeof(ptt_regularize_job) % 4 == 0 && sizeof(ptt_regularize_job) / 4 <= T, "job copied one word per thread");
+    if (threadIdx.x < sizeof(ptt_regularize_job) / 4)
+        reinterpret_cast<uint32_t*>(&j)[threadIdx.x] = reinterpret_cast<const uint32_t*>(jobs + blockIdx.x)[threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x < PTT_MAX_SEGMENTS) {
+        const int s = threadIdx.x;
+        cnt[s] = (s < j.n_seg) ? min(*j.seg_count[s], j.seg_capacity[s]) : 0;
+    }
+    __syncthreads();
     int n = 0;
 #pragma unroll
-    for (int s = 0; s < PTT_MAX_SEGMENTS; ++s) {
-        cnt[s] = (s < j.n_seg) ? min(*j.seg_count[s], j.seg_capacity[s]) : 0;
-        n += cnt[s];
-    }
+    for (int s = 0; s < PTT_MAX_SEGMENTS; ++s) n += cnt[s];
     const int size = j.input_size;
     int used = 0;
     if (n <= 2) {                                   // regularize_pc:359-362: an (almost) empty crop is an all-zero cloud
