@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PTT_ABI_VERSION 11
+#define PTT_ABI_VERSION 12
 
 enum {
     PTT_OK = 0,
@@ -381,6 +381,25 @@ int ptt_bn_bwd_f32(const float* G, int ldg, const float* Act, int lda, const flo
                    const float* invstd, const float* gamma, int R, int C, int relu, float* dZ, int ldd,
                    float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, const float* act_scale,
                    const float* act_shift, ptt_stream_t stream);
+/* SyncBatchNorm (tools/train_tracking.py:133-134, --sync_bn -> nn.SyncBatchNorm.convert_sync_batchnorm): the same
+ * statistics split where the ranks exchange them. Forward: ptt_bn_sums_f64 -> all-reduce(sums, row count) ->
+ * ptt_bn_finish_f64. Backward: ptt_bn_bwd_sums_f64 (sum dy, sum dy * xhat; a rank's dbeta / dgamma are its LOCAL sums,
+ * as torch's SyncBatchNorm keeps them) -> all-reduce -> ptt_bn_bwd_apply_f32 with the global sums and the global count.
+ * Forward sums = 2 * C + 1 doubles: sum, sum of squares, and in the last slot the row count R — so one all-reduce carries
+ * everything and the global count never visits the host; ptt_bn_finish_f64 and ptt_bn_bwd_apply_f32 (count = a device
+ * pointer to that slot) read it from device memory. Backward sums = 2 * C doubles. Fixed combination order; C % 4 == 0,
+ * 16-byte aligned rows. */
+int ptt_bn_sums_f64(const float* X, int R, int C, int ldx, double* sums, void* workspace, size_t workspace_bytes,
+                    ptt_stream_t stream);
+int ptt_bn_finish_f64(const double* sums, int C, float eps, float* mean, float* var, float* invstd,
+                      ptt_stream_t stream);
+int ptt_bn_bwd_sums_f64(const float* G, int ldg, const float* Act, int lda, const float* Z, int ldz, const float* mean,
+                        const float* invstd, int R, int C, double* sums, void* workspace, size_t workspace_bytes,
+                        const float* act_scale, const float* act_shift, ptt_stream_t stream);
+int ptt_bn_bwd_apply_f32(const float* G, int ldg, const float* Act, int lda, const float* Z, int ldz, const float* mean,
+                         const float* invstd, const float* gamma, const float* sum_dy, const float* sum_dy_xhat,
+                         const double* count, int R, int C, float* dZ, int ldd, const float* act_scale, const float* act_shift,
+                         ptt_stream_t stream);
 int ptt_pool_rows_f32(const float* X, int ldx, int G, int ns, int C, float* out, int ldo, int32_t* arg,
                       const float* act_scale, const float* act_shift, ptt_stream_t stream);
 int ptt_pool_rows_bwd_f32(const float* dOut, int ldo, const int32_t* arg, int G, int ns, int C, float* dX, int ldx,

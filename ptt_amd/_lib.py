@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libptt_hip.so")
 
 PTT_SA_MAX_LAYERS = 4
-ABI_VERSION = 11            # PTT_ABI_VERSION of include/ptt_hip.h these structures mirror
+ABI_VERSION = 12            # PTT_ABI_VERSION of include/ptt_hip.h these structures mirror
 
 # every symbol include/ptt_hip.h declares (tests check the library exports all of them)
 EXPORTS = [
@@ -28,6 +28,7 @@ EXPORTS = [
     "ptt_gather_rows_f32", "ptt_scatter_csr_i32", "ptt_scatter_rows_csr_f32",
     "ptt_pt_pair_input_f32", "ptt_pt_attn_train_fwd_f32", "ptt_pt_attn_train_bwd_f32", "ptt_linear_act_in_f32",
     "ptt_centres_ball_query_f32",
+    "ptt_bn_sums_f64", "ptt_bn_finish_f64", "ptt_bn_bwd_sums_f64", "ptt_bn_bwd_apply_f32",
 ]
 PTT_MAX_SEGMENTS = 4
 
@@ -118,6 +119,10 @@ def _declare(lib):
         "ptt_bn_stats_f32": [vp, i, i, i, f, vp, vp, vp, vp, c_size_t, vp],
         "ptt_bn_apply_f32": [vp, i, vp, vp, vp, vp, i, i, i, vp, i, vp],
         "ptt_bn_bwd_f32": [vp, i, vp, i, vp, i, vp, vp, vp, i, i, i, vp, i, vp, vp, vp, c_size_t, vp, vp, vp],
+        "ptt_bn_sums_f64": [vp, i, i, i, vp, vp, c_size_t, vp],
+        "ptt_bn_finish_f64": [vp, i, f, vp, vp, vp, vp],
+        "ptt_bn_bwd_sums_f64": [vp, i, vp, i, vp, i, vp, vp, i, i, vp, vp, c_size_t, vp, vp, vp],
+        "ptt_bn_bwd_apply_f32": [vp, i, vp, i, vp, i, vp, vp, vp, vp, vp, vp, i, i, vp, i, vp, vp, vp],
         "ptt_pool_rows_f32": [vp, i, i, i, i, vp, i, vp, vp, vp, vp],
         "ptt_linear_act_in_f32": [vp, i, i, i, vp, vp, vp, i, vp, i, vp],
         "ptt_pool_rows_bwd_f32": [vp, i, vp, i, i, i, vp, i, vp],

@@ -186,6 +186,41 @@ __global__ __launch_bounds__(256) void col_stats_finish2_kernel(const double* __
     }
 }
 
+// SyncBatchNorm pieces: the two column sums themselves in float64 (sums[c], sums[C + c]), combined in the same fixed order
+// as col_stats_finish2_kernel, so that ranks can add their sums before the statistics are formed ...
+__global__ __launch_bounds__(256) void col_sums_finish_kernel(const double* __restrict__ partial, int nchunks, int C,
+                                                              double* __restrict__ sums, double rows) {   // rows < 0: no count slot
+    __shared__ double t0[256], t1[256];
+    const int c = blockIdx.x, t = threadIdx.x;
+    double s0 = 0.0, s1 = 0.0;
+    for (int k = t; k < nchunks; k += 256) {
+        s0 += partial[((size_t)k * 2 + 0) * C + c];
+        s1 += partial[((size_t)k * 2 + 1) * C + c];
+    }
+    t0[t] = s0; t1[t] = s1;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (t < w) { t0[t] += t0[t + w]; t1[t] += t1[t + w]; }
+        __syncthreads();
+    }
+    if (t == 0) {
+        sums[c] = t0[0]; sums[C + c] = t1[0];
+        if (c == 0 && rows >= 0.0) sums[2 * C] = rows;
+    }
+}
+// ... and mean / biased variance / invstd from (possibly all-reduced) sums over `count` rows
+__global__ __launch_bounds__(256) void bn_finish_sums_kernel(const double* __restrict__ sums, int C, float eps,
+                                                             float* __restrict__ mean, float* __restrict__ var,
+                                                             float* __restrict__ invstd) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const double count = sums[2 * C];
+    const double mu = sums[c] / count;
+    double v = sums[C + c] / count - mu * mu;
+    if (v < 0.0) v = 0.0;
+    mean[c] = (float)mu; var[c] = (float)v; invstd[c] = (float)(1.0 / sqrt(v + (double)eps));
+}
+
 // element-wise kernels, vector form: a workgroup walks whole rows, thread = one channel quad (no index division)
 __global__ __launch_bounds__(256) void bn_apply4_kernel(const float* __restrict__ Z, int ldz, const float* __restrict__ mean,
                                                         const float* __restrict__ invstd, const float* __restrict__ gamma,
@@ -215,11 +250,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const float* __restr
                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
                                                             const float* __restrict__ gamma, const float* __restrict__ s0,
                                                             const float* __restrict__ s1, int R, int C, float* __restrict__ dZ,
-                                                            int ldd, const float* __restrict__ act_a, const float* __restrict__ act_b) {
+                                                            int ldd, const float* __restrict__ act_a, const float* __restrict__ act_b,
+                                                            float rinv_value, const double* __restrict__ count) {
+    // 1 / rows the statistics were taken over: by value, or (SyncBatchNorm) from the all-reduced row count in device memory
     const int Cq = C >> 2, span = Cq < 256 ? Cq : 256, RG = 256 / span;
     const int q0 = threadIdx.x % span, rg = threadIdx.x / span;
     if (rg >= RG) return;
-    const float rinv = 1.0f / (float)R;
+    const float rinv = count ? (float)(1.0 / *count) : rinv_value;
     for (int q = q0; q < Cq; q += span) {
         const f32x4t mu = *reinterpret_cast<const f32x4t*>(mean + 4 * q), is = *reinterpret_cast<const f32x4t*>(invstd + 4 * q);
         const f32x4t ga = *reinterpret_cast<const f32x4t*>(gamma + 4 * q);
@@ -690,7 +727,7 @@ extern "C" int ptt_bn_bwd_f32(const float* G, int ldg, const float* Act, int lda
         int grid = (R + RG * 8 - 1) / (RG * 8);
         if (grid > 16384) grid = 16384;
         hipLaunchKernelGGL(bn_bwd_apply4_kernel, dim3(grid), dim3(256), 0, s, G, ldg, Act, lda, Z, ldz, mean, invstd, gamma, dbeta, dgamma,
-                           R, C, dZ, ldd, act_scale, act_shift);
+                           R, C, dZ, ldd, act_scale, act_shift, 1.0f / (float)R, nullptr);
         return check_launch("bn_bwd4_kernels");
     }
     if (!Act) return fail(PTT_EUNSUPPORTED, "ptt_bn_bwd_f32: the mask-from-z form needs C %% 4 == 0 and 16-byte aligned rows");
@@ -708,6 +745,67 @@ extern "C" int ptt_bn_bwd_f32(const float* G, int ldg, const float* Act, int lda
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid((size_t)R * C)), dim3(256), 0, s, G, ldg, Act, lda, Z, ldz, mean, invstd,
                        gamma, dbeta, dgamma, R, C, relu, dZ, ldd);
     return check_launch("bn_bwd_kernels");
+}
+
+// ---- SyncBatchNorm pieces (vector form only: C % 4 == 0, 16-byte aligned rows — every conv output of the shipped nets)
+extern "C" int ptt_bn_sums_f64(const float* X, int R, int C, int ldx, double* sums, void* ws, size_t ws_bytes,
+                               ptt_stream_t stream) {
+    if (R <= 0 || C <= 0 || ldx < C) return fail(PTT_EINVAL, "ptt_bn_sums_f64: R=%d C=%d ldx=%d", R, C, ldx);
+    if (!X || !sums) return fail(PTT_EINVAL, "ptt_bn_sums_f64: null pointer");
+    if (!ws || ws_bytes < ptt_bn_stats_workspace(R, C)) return fail(PTT_EWORKSPACE, "ptt_bn_sums_f64: workspace too small");
+    if (!vec4_ok(X, ldx, C)) return fail(PTT_EUNSUPPORTED, "ptt_bn_sums_f64: needs C %% 4 == 0 and 16-byte aligned rows");
+    hipStream_t s = as_stream(stream);
+    const int nchunks = (R + ST4_ROWS - 1) / ST4_ROWS;
+    hipLaunchKernelGGL((col_stats4_kernel<0>), dim3(nchunks), dim3(256), 256 * 8 * sizeof(double), s, X, nullptr, nullptr, nullptr,
+                       nullptr, R, C, ldx, 0, 0, static_cast<double*>(ws), nullptr, nullptr);
+    hipLaunchKernelGGL(col_sums_finish_kernel, dim3(C), dim3(256), 0, s, static_cast<const double*>(ws), nchunks, C, sums, (double)R);
+    return check_launch("ptt_bn_sums_f64");
+}
+
+extern "C" int ptt_bn_finish_f64(const double* sums, int C, float eps, float* mean, float* var, float* invstd,
+                                 ptt_stream_t stream) {
+    if (C <= 0) return fail(PTT_EINVAL, "ptt_bn_finish_f64: C=%d", C);
+    if (!sums || !mean || !var || !invstd) return fail(PTT_EINVAL, "ptt_bn_finish_f64: null pointer");
+    hipLaunchKernelGGL(bn_finish_sums_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), sums, C, eps, mean, var,
+                       invstd);
+    return check_launch("bn_finish_sums_kernel");
+}
+
+extern "C" int ptt_bn_bwd_sums_f64(const float* G, int ldg, const float* Act, int lda, const float* Z, int ldz, const float* mean,
+                                   const float* invstd, int R, int C, double* sums, void* ws, size_t ws_bytes,
+                                   const float* act_scale, const float* act_shift, ptt_stream_t stream) {
+    if (R <= 0 || C <= 0) return fail(PTT_EINVAL, "ptt_bn_bwd_sums_f64: R=%d C=%d", R, C);
+    if (!G || !Z || !mean || !invstd || !sums || (!Act && !(act_scale && act_shift)))
+        return fail(PTT_EINVAL, "ptt_bn_bwd_sums_f64: null pointer");
+    if (!ws || ws_bytes < ptt_bn_stats_workspace(R, C)) return fail(PTT_EWORKSPACE, "ptt_bn_bwd_sums_f64: workspace too small");
+    if (!(vec4_ok(G, ldg, C) && (Act ? vec4_ok(Act, lda, C) : (vec4_ok(act_scale, 4, 4) && vec4_ok(act_shift, 4, 4))) &&
+          vec4_ok(Z, ldz, C) && vec4_ok(mean, 4, 4) && vec4_ok(invstd, 4, 4)))
+        return fail(PTT_EUNSUPPORTED, "ptt_bn_bwd_sums_f64: needs C %% 4 == 0 and 16-byte aligned rows");
+    hipStream_t s = as_stream(stream);
+    const int nch = (R + ST4_ROWS - 1) / ST4_ROWS;
+    hipLaunchKernelGGL((col_stats4_kernel<1>), dim3(nch), dim3(256), 256 * 8 * sizeof(double), s, G, Act, Z, mean, invstd, R, C, ldg,
+                       lda, ldz, static_cast<double*>(ws), act_scale, act_shift);
+    hipLaunchKernelGGL(col_sums_finish_kernel, dim3(C), dim3(256), 0, s, static_cast<const double*>(ws), nch, C, sums, -1.0);
+    return check_launch("ptt_bn_bwd_sums_f64");
+}
+
+extern "C" int ptt_bn_bwd_apply_f32(const float* G, int ldg, const float* Act, int lda, const float* Z, int ldz, const float* mean,
+                                    const float* invstd, const float* gamma, const float* sum_dy, const float* sum_dy_xhat,
+                                    const double* count, int R, int C, float* dZ, int ldd, const float* act_scale,
+                                    const float* act_shift, ptt_stream_t stream) {
+    if (R <= 0 || C <= 0) return fail(PTT_EINVAL, "ptt_bn_bwd_apply_f32: R=%d C=%d", R, C);
+    if (!G || !Z || !mean || !invstd || !gamma || !sum_dy || !sum_dy_xhat || !count || !dZ || (!Act && !(act_scale && act_shift)))
+        return fail(PTT_EINVAL, "ptt_bn_bwd_apply_f32: null pointer");
+    if (!(vec4_ok(G, ldg, C) && (Act ? vec4_ok(Act, lda, C) : (vec4_ok(act_scale, 4, 4) && vec4_ok(act_shift, 4, 4))) &&
+          vec4_ok(Z, ldz, C) && vec4_ok(dZ, ldd, C) && vec4_ok(mean, 4, 4) && vec4_ok(invstd, 4, 4) && vec4_ok(gamma, 4, 4) &&
+          vec4_ok(sum_dy, 4, 4) && vec4_ok(sum_dy_xhat, 4, 4)))
+        return fail(PTT_EUNSUPPORTED, "ptt_bn_bwd_apply_f32: needs C %% 4 == 0 and 16-byte aligned rows");
+    const int Cq = C >> 2, RG = 256 / (Cq < 256 ? Cq : 256);
+    int grid = (R + RG * 8 - 1) / (RG * 8);
+    if (grid > 16384) grid = 16384;
+    hipLaunchKernelGGL(bn_bwd_apply4_kernel, dim3(grid), dim3(256), 0, as_stream(stream), G, ldg, Act, lda, Z, ldz, mean, invstd, gamma,
+                       sum_dy, sum_dy_xhat, R, C, dZ, ldd, act_scale, act_shift, 0.f, count);
+    return check_launch("bn_bwd_apply4_kernel");
 }
 
 extern "C" int ptt_pool_rows_f32(const float* X, int ldx, int G, int ns, int C, float* out, int ldo, int32_t* arg,

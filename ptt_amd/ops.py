@@ -626,6 +626,59 @@ def bn_bwd(g, act, z, mean, invstd, gamma, out=None, act_scale=None, act_shift=N
     return out, dgamma, dbeta
 
 
+def bn_sums(x):
+    """SyncBatchNorm forward, local part: 2C + 1 float64 = per-channel sum, sum of squares of x (R,C), then the row count
+    (one all-reduce carries all three) — ptt_bn_sums_f64."""
+    _rows(x, "x")
+    R, C = x.shape
+    sums = torch.empty((2 * C + 1,), dtype=torch.float64, device=x.device)
+    ws = _ws(_lib.lib().ptt_bn_stats_workspace(R, C), x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().ptt_bn_sums_f64(_ptr(x), R, C, x.stride(0), _ptr(sums), _ptr(ws), ws.numel() * 8, _stream()),
+                   "ptt_bn_sums_f64")
+    return sums
+
+
+def bn_finish(sums, eps):
+    """(mean, biased var, invstd) from the (all-reduced) output of bn_sums; the row count is its last element and stays on
+    the device — ptt_bn_finish_f64."""
+    C = (sums.numel() - 1) // 2
+    mean, var, invstd = (torch.empty((C,), dtype=torch.float32, device=sums.device) for _ in range(3))
+    with torch.cuda.device(sums.device):
+        _lib.check(_lib.lib().ptt_bn_finish_f64(_ptr(sums), C, float(eps), _ptr(mean), _ptr(var), _ptr(invstd), _stream()),
+                   "ptt_bn_finish_f64")
+    return mean, var, invstd
+
+
+def bn_bwd_sums(g, act, z, mean, invstd, act_scale=None, act_shift=None):
+    """SyncBatchNorm backward, local part: (2, C) float64 = (sum dy, sum dy * xhat) with dy = g under the ReLU mask."""
+    _rows(g, "g"); _rows(z, "z")
+    R, C = z.shape
+    sums = torch.empty((2, C), dtype=torch.float64, device=z.device)
+    ws = _ws(_lib.lib().ptt_bn_stats_workspace(R, C), z.device)
+    with torch.cuda.device(z.device):
+        _lib.check(_lib.lib().ptt_bn_bwd_sums_f64(_ptr(g), g.stride(0), _ptr(act), act.stride(0) if act is not None else 0, _ptr(z),
+                                                  z.stride(0), _ptr(mean), _ptr(invstd), R, C, _ptr(sums), _ptr(ws),
+                                                  ws.numel() * 8, _ptr(act_scale), _ptr(act_shift), _stream()),
+                   "ptt_bn_bwd_sums_f64")
+    return sums
+
+
+def bn_bwd_apply(g, act, z, mean, invstd, gamma, sum_dy, sum_dy_xhat, count, out=None, act_scale=None, act_shift=None):
+    """dz of BatchNorm(train) + ReLU from the (global) float32 sums; count = a one-element float64 device tensor (the global
+    row count, e.g. bn_sums()[-1:] after the all-reduce); `out` may alias g."""
+    _rows(g, "g"); _rows(z, "z")
+    R, C = z.shape
+    if out is None:
+        out = torch.empty((R, C), dtype=torch.float32, device=z.device)
+    with torch.cuda.device(z.device):
+        _lib.check(_lib.lib().ptt_bn_bwd_apply_f32(_ptr(g), g.stride(0), _ptr(act), act.stride(0) if act is not None else 0, _ptr(z),
+                                                   z.stride(0), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(sum_dy),
+                                                   _ptr(sum_dy_xhat), _ptr(count), R, C, _ptr(out), out.stride(0),
+                                                   _ptr(act_scale), _ptr(act_shift), _stream()), "ptt_bn_bwd_apply_f32")
+    return out
+
+
 def pool_rows(x, ns, act_scale=None, act_shift=None):
     """max over every ns consecutive rows: (G*ns, C) -> (G, C) and the int32 arg-max (first among equals); with
     act_scale / act_shift the rows are relu(x * scale + shift), applied on the fly."""

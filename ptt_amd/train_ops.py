@@ -12,6 +12,7 @@ then per layer ptt_bn_bwd_f32 -> ptt_linear_wgrad_f32 (weight gradient) -> ptt_l
 (input gradient). Running statistics are updated as nn.BatchNorm2d does (momentum, unbiased variance, batch counter).
 """
 import torch
+import torch.distributed as dist
 import torch.nn as nn
 
 from . import ops
@@ -26,7 +27,7 @@ def usable(mlp, x):
         bn = getattr(getattr(unit, 'normlayer', None), 'bn', None)
         if not isinstance(conv, nn.Conv2d) or conv.kernel_size != (1, 1) or conv.bias is not None or conv.weight.shape[0] % 4:
             return False
-        if not isinstance(bn, nn.BatchNorm2d) or not bn.affine or not bn.track_running_stats or bn.momentum is None:
+        if not isinstance(bn, (nn.BatchNorm2d, nn.SyncBatchNorm)) or not bn.affine or not bn.track_running_stats or bn.momentum is None:
             return False
         if not isinstance(getattr(unit, 'activation', None), nn.ReLU):
             return False
@@ -79,11 +80,13 @@ class _SharedMlpPool(torch.autograd.Function):
     xcorr_hoisted), so layer 0 is BatchNorm + ReLU only and its W entry is a placeholder that gets no gradient."""
 
     @staticmethod
-    def forward(ctx, x, ns, eps, preact, *params):
+    def forward(ctx, x, ns, eps, preact, sync, *params):
         """Deferred activation: a layer's output relu(BatchNorm(z)) = relu(z * a + b) is never written — the next
-        convolution, its weight gradient, the max-pool and the BatchNorm backward apply it while they load z."""
+        convolution, its weight gradient, the max-pool and the BatchNorm backward apply it while they load z.
+        sync: per layer a torch.distributed process group (nn.SyncBatchNorm: the statistics are those of the rows of ALL
+        ranks — one all-reduce of 2C + 1 float64 per layer and direction) or None."""
         L = len(params) // 3
-        saved, stats = [], []
+        saved, stats, counts = [], [], []
         cur, cur_a, cur_b = x.contiguous(), None, None
         for l in range(L):
             W, gamma, beta = params[3 * l], params[3 * l + 1], params[3 * l + 2]
@@ -94,16 +97,23 @@ class _SharedMlpPool(torch.autograd.Function):
                 z = ops.linear_act_in(cur, cur_a, cur_b, ops.pack_weight(W), cout)
             else:
                 z = ops.linear(cur, ops.pack_weight(W), cout)
-            mean, var, invstd = ops.bn_stats(z, eps[l])
+            if sync[l] is not None:
+                sums = ops.bn_sums(z)
+                dist.all_reduce(sums, group=sync[l])
+                mean, var, invstd = ops.bn_finish(sums, eps[l])
+                count = sums[-1:].clone()                      # global row count, float64, on the device
+            else:
+                mean, var, invstd = ops.bn_stats(z, eps[l])
+                count = torch.full((1,), float(z.shape[0]), dtype=torch.float64, device=z.device)
             a = (gamma.detach() * invstd).contiguous()
             b = (beta.detach() - mean * a).contiguous()
             saved += [cur, cur_a if cur_a is not None else mean.new_empty(0), cur_b if cur_b is not None else mean.new_empty(0),
-                      z, mean, invstd, a, b]
-            stats += [mean, var]
+                      z, mean, invstd, a, b, count]
+            stats += [mean, var, count]
             cur, cur_a, cur_b = z, a, b
         pooled, arg = ops.pool_rows(cur, ns, cur_a, cur_b)
         ctx.save_for_backward(arg, *saved, *[p.detach() for p in params])
-        ctx.L, ctx.ns, ctx.preact = L, int(ns), bool(preact)
+        ctx.L, ctx.ns, ctx.preact, ctx.sync = L, int(ns), bool(preact), tuple(sync)
         ctx.mark_non_differentiable(*stats)
         return (pooled,) + tuple(stats)
 
@@ -111,13 +121,24 @@ class _SharedMlpPool(torch.autograd.Function):
     def backward(ctx, dpooled, *unused):
         L, ns = ctx.L, ctx.ns
         t = ctx.saved_tensors
-        arg, saved, params = t[0], t[1:1 + 8 * L], t[1 + 8 * L:]
+        arg, saved, params = t[0], t[1:1 + 9 * L], t[1 + 9 * L:]
         g = ops.pool_rows_bwd(dpooled.contiguous(), arg, ns)
         grads = [None] * (3 * L)
         for l in range(L - 1, -1, -1):
-            x_in, in_a, in_b, z, mean, invstd, a, b = saved[8 * l:8 * l + 8]
+            x_in, in_a, in_b, z, mean, invstd, a, b, count = saved[9 * l:9 * l + 9]
             W, gamma = params[3 * l], params[3 * l + 1]
-            dz, dgamma, dbeta = ops.bn_bwd(g, None, z, mean, invstd, gamma, out=g, act_scale=a, act_shift=b)   # in place over g
+            if ctx.sync[l] is not None:
+                # torch's SyncBatchNorm: dgamma / dbeta are the rank's LOCAL sums (DDP averages parameter gradients); dz
+                # uses the sums of all ranks
+                sums = ops.bn_bwd_sums(g, None, z, mean, invstd, act_scale=a, act_shift=b)
+                local = sums.float()
+                dbeta, dgamma = local[0].contiguous(), local[1].contiguous()
+                dist.all_reduce(sums, group=ctx.sync[l])
+                glob = sums.float()
+                dz = ops.bn_bwd_apply(g, None, z, mean, invstd, gamma, glob[0].contiguous(), glob[1].contiguous(), count, out=g,
+                                      act_scale=a, act_shift=b)
+            else:
+                dz, dgamma, dbeta = ops.bn_bwd(g, None, z, mean, invstd, gamma, out=g, act_scale=a, act_shift=b)   # in place over g
             grads[3 * l + 1], grads[3 * l + 2] = dgamma, dbeta
             if ctx.preact and l == 0:
                 g = dz                                                                  # d(loss)/d(layer-0 pre-activation)
@@ -129,7 +150,7 @@ class _SharedMlpPool(torch.autograd.Function):
                 g = ops.linear(dz, ops.pack_weight(w2.t().contiguous()), w2.shape[1])   # w.r.t. the activated input of layer l
             else:
                 g = None
-        return (g, None, None, None) + tuple(grads)
+        return (g, None, None, None, None) + tuple(grads)
 
 
 def shared_mlp_pool(grouped, mlp, pool_dim):
@@ -145,23 +166,34 @@ def shared_mlp_pool(grouped, mlp, pool_dim):
     return rows_mlp_pool(rows, mlp, ns, B, keep, preact=False)
 
 
+def _sync_group(bn):
+    """The process group an nn.SyncBatchNorm synchronises over right now, else None (plain BatchNorm, evaluation, no
+    initialised process group, or a single rank: torch's SyncBatchNorm falls back to local statistics in those cases)."""
+    if not isinstance(bn, nn.SyncBatchNorm) or not (dist.is_available() and dist.is_initialized()):
+        return None
+    group = bn.process_group if bn.process_group is not None else dist.group.WORLD
+    return group if dist.get_world_size(group) > 1 else None
+
+
 def rows_mlp_pool(rows, mlp, ns, B, keep, preact):
     """The row form: rows (B * keep * ns, C) ordered (frame, kept position, pooled position) -> (B, C_L, keep).
     preact: rows are layer 0's convolution output already (hoisted by the caller)."""
-    params, eps = [], []
+    params, eps, sync = [], [], []
     for unit in mlp:
         bn = unit.normlayer.bn
         params += [unit.conv.weight, bn.weight, bn.bias]
         eps.append(float(bn.eps))
-    out = _SharedMlpPool.apply(rows, ns, tuple(eps), bool(preact), *params)
+        sync.append(_sync_group(bn))
+    out = _SharedMlpPool.apply(rows, ns, tuple(eps), bool(preact), tuple(sync), *params)
     pooled, stats = out[0], out[1:]
-    R = rows.shape[0]
     with torch.no_grad():                                   # nn.BatchNorm2d's bookkeeping in training mode
         for l, unit in enumerate(mlp):
             bn = unit.normlayer.bn
             m = bn.momentum
-            bn.running_mean.mul_(1 - m).add_(stats[2 * l], alpha=m)
-            bn.running_var.mul_(1 - m).add_(stats[2 * l + 1], alpha=m * R / max(R - 1, 1))
+            n = stats[3 * l + 2]                            # rows the statistics were taken over (all ranks'), float64 (1,)
+            unbias = (n / (n - 1.0).clamp_min(1.0)).float()
+            bn.running_mean.mul_(1 - m).add_(stats[3 * l], alpha=m)
+            bn.running_var.mul_(1 - m).add_(stats[3 * l + 1] * unbias, alpha=m)
             bn.num_batches_tracked.add_(1)
     return pooled.view(B, keep, -1).transpose(1, 2)         # (B, C_L, keep)
 

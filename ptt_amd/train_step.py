@@ -40,9 +40,13 @@ class DataParallelTrainer(object):
         loss = trainer.step(batch)          # forward, backward (all-reduce inside), clip, Adam
     """
 
-    def __init__(self, model, device, lr=1e-3, betas=(0.5, 0.999), eps=1e-6, clip=10.0, bucket_cap_mb=25):
+    def __init__(self, model, device, lr=1e-3, betas=(0.5, 0.999), eps=1e-6, clip=10.0, bucket_cap_mb=25, sync_bn=False):
         self.device = torch.device(device)
         self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        if sync_bn and self.world > 1:
+            # tools/train_tracking.py:133-134 (--sync_bn). The SharedMLP stages keep running on the hand-written row
+            # kernels: their statistics are exchanged as 2C + 1 float64 sums per layer (ptt_amd/train_ops.py)
+            model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
         self.tracker = model
         if self.world > 1:
             ids = [self.device.index] if self.device.type == 'cuda' else None

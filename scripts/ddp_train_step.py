@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=48, help="frames per rank per step")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL on ROCm) or gloo")
+    ap.add_argument("--sync_bn", action="store_true", help="tools/train_tracking.py --sync_bn: batch statistics over all ranks")
     a = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", 1))
     rank = int(os.environ.get("RANK", 0))
@@ -45,7 +46,7 @@ def main():
         dist.init_process_group(a.backend, rank=rank, world_size=world, **kw)
     torch.manual_seed(1)                                   # tools/train_tracking.py:73-79
     model = build_network(ptt_model_cfg(), 1, StubDataset(training=True)).to(dev).train()
-    trainer = DataParallelTrainer(model, dev)
+    trainer = DataParallelTrainer(model, dev, sync_bn=a.sync_bn)
     batch = synthetic_train_batch(100 + rank, a.batch, dev)
 
     def sync():

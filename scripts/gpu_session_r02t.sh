@@ -3,7 +3,8 @@
 O=gpurun_out/r02t; mkdir -p $O
 timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -5
 timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-latency > $O/bench_car.json 2> $O/bench_car.err
+tail -3 $O/bench_car.err
 python -c "
 import json
 d = json.loads(open('$O/bench_car.json').read().strip().splitlines()[-1])
-print(d['value'], d['ms_per_step'], d['kernel_ms_per_step'], d['roofline']['frac'], d.get('sustained'), d['full_model']['value'], d['whole_step'], d['index_ops'])"
+print(d['value'], d['ms_per_step'], d['kernel_ms_per_step'], d['roofline']['frac'], d.get('sustained'), d['full_model']['value'], d['whole_step']['frac_of_mfma_peak'])"
