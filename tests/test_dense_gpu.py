@@ -118,9 +118,10 @@ def test_sa_fused_hoisted_layer0(dev, N, M, C, spec, radius, ns, B, scale_in_wei
     np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), **TOL)
 
 
+@pytest.mark.parametrize("B", [2, 10])      # 128 / 64 workgroups (fewer than CUs) and 640 / 320 (several per CU, staggered slots)
 @pytest.mark.parametrize("N", [128, 64])
-def test_transformer_pair_kernel(dev, N):
-    B, D, k = 2, 512, 16
+def test_transformer_pair_kernel(dev, N, B):
+    D, k = 512, 16
     rs = np.random.RandomState(N)
     P = transformer_params(N)
     s, _ = synth.frames(N, B, N, 64, K_s=N)
