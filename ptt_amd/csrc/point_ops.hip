@@ -147,42 +147,68 @@ static int launch_fps(const float* xyz, int B, int N, int npoint, int32_t* idx, 
 }
 
 // ------------------------------------------------------------------------------------------
-// Ball query. One wave per centre sweeps the cloud 64 points at a time (coalesced), a
-// ballot + prefix popcount keeps hits in index order, and the wave stops as soon as
-// nsample hits are stored.
+// Ball query. A wave owns CPW consecutive centres of one cloud and sweeps the cloud 64 points at a
+// time (coalesced); per centre a ballot + prefix popcount keeps the hits in index order, and a
+// centre stops taking part as soon as nsample hits are stored (the wave stops when all have).
+// CPW = 4 for launches that fill the device anyway: a point is loaded once and tested against four
+// centres — with one centre per wave every wave re-reads the whole cloud from L1/L2, and the
+// 16384-point stress frames ran at half the vector-L1 bandwidth of the chip (6 G tests x 12 B in
+// 4 ms). CPW = 1 for small launches (one tracklet frame: 512 centres), where waves are the scarce
+// thing. The arithmetic per (centre, point) pair and the order of the hits are the same in both.
 // ------------------------------------------------------------------------------------------
+template <int CPW>
+__device__ __forceinline__ void ball_sweep(const float* __restrict__ pts, int N, float r2, int ns, const float (&cx)[CPW],
+                                           const float (&cy)[CPW], const float (&cz)[CPW], int ncentres,
+                                           int32_t* __restrict__ out0, int lane) {
+    int cnt[CPW], first[CPW];
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) { cnt[c] = (c < ncentres) ? 0 : ns; first[c] = 0; }      // absent centres are "done"
+    for (int base = 0; base < N; base += 64) {
+        const int k = base + lane;
+        const bool in = k < N;
+        float px = 0.f, py = 0.f, pz = 0.f;
+        if (in) { px = pts[3 * k + 0]; py = pts[3 * k + 1]; pz = pts[3 * k + 2]; }
+        bool active = false;
+#pragma unroll
+        for (int c = 0; c < CPW; ++c) {
+            if (cnt[c] >= ns) continue;                       // wave-uniform
+            const float d = sqdist3(cx[c], cy[c], cz[c], px, py, pz);
+            const bool hit = in && d < r2;
+            const unsigned long long mask = __ballot(hit);
+            if (mask != 0ull) {
+                if (cnt[c] == 0) first[c] = base + (__ffsll((long long)mask) - 1);
+                const int pos = cnt[c] + __popcll(mask & ((1ull << lane) - 1ull));
+                if (hit && pos < ns) out0[(size_t)c * ns + pos] = k;
+                cnt[c] += __popcll(mask);
+            }
+            active = active || cnt[c] < ns;
+        }
+        if (!active) break;
+    }
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) {
+        if (c >= ncentres) break;
+        const int fill = (cnt[c] > 0) ? first[c] : 0;
+        for (int s = cnt[c] + lane; s < ns; s += 64) out0[(size_t)c * ns + s] = fill;
+    }
+}
+
+template <int CPW>
 __global__ __launch_bounds__(256) void ball_query_kernel(const float* __restrict__ new_xyz,
                                                          const float* __restrict__ xyz, int BM, int M, int N,
                                                          float r2, int ns, int32_t* __restrict__ idx_out) {
-    const int centre = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int centre = (blockIdx.x * 4 + (threadIdx.x >> 6)) * CPW;      // CPW divides M: one cloud per wave
     if (centre >= BM) return;
     const int lane = threadIdx.x & 63;
     const int b = centre / M;
-    const float* __restrict__ pts = xyz + (size_t)b * N * 3;
-    int32_t* __restrict__ out = idx_out + (size_t)centre * ns;
-    const float cx = new_xyz[(size_t)centre * 3 + 0];
-    const float cy = new_xyz[(size_t)centre * 3 + 1];
-    const float cz = new_xyz[(size_t)centre * 3 + 2];
-
-    int cnt = 0, first = 0;
-    for (int base = 0; base < N; base += 64) {
-        const int k = base + lane;
-        bool hit = false;
-        if (k < N) {
-            const float d = sqdist3(cx, cy, cz, pts[3 * k + 0], pts[3 * k + 1], pts[3 * k + 2]);
-            hit = d < r2;
-        }
-        const unsigned long long mask = __ballot(hit);
-        if (mask != 0ull) {
-            if (cnt == 0) first = base + (__ffsll((long long)mask) - 1);
-            const int pos = cnt + __popcll(mask & ((1ull << lane) - 1ull));
-            if (hit && pos < ns) out[pos] = k;
-            cnt += __popcll(mask);
-            if (cnt >= ns) break;
-        }
+    float cx[CPW], cy[CPW], cz[CPW];
+    const int nc = min(CPW, BM - centre);
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) {
+        const int cc = centre + (c < nc ? c : 0);
+        cx[c] = new_xyz[(size_t)cc * 3 + 0]; cy[c] = new_xyz[(size_t)cc * 3 + 1]; cz[c] = new_xyz[(size_t)cc * 3 + 2];
     }
-    const int fill = (cnt > 0) ? first : 0;
-    for (int s = cnt + lane; s < ns; s += 64) out[s] = fill;
+    ball_sweep<CPW>(xyz + (size_t)b * N * 3, N, r2, ns, cx, cy, cz, nc, idx_out + (size_t)centre * ns, lane);
 }
 
 // Centre selection and ball query of one SA level in ONE launch (pointnet2_modules.py:79-83,90): the wave that owns
@@ -190,41 +216,29 @@ __global__ __launch_bounds__(256) void ball_query_kernel(const float* __restrict
 // writes them to new_xyz and the index as int64, then sweeps the cloud as ball_query_kernel does. Same results as
 // select_centres_kernel + ball_query_kernel; one launch and one dependent round trip less per level, which is what a
 // B = 1 tracklet frame is made of.
+template <int CPW>
 __global__ __launch_bounds__(256) void centres_ball_query_kernel(const float* __restrict__ xyz, const int32_t* __restrict__ sel,
                                                                  int BM, int M, int N, float r2, int ns,
                                                                  float* __restrict__ new_xyz, long long* __restrict__ idx64,
                                                                  int32_t* __restrict__ idx_out) {
-    const int centre = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int centre = (blockIdx.x * 4 + (threadIdx.x >> 6)) * CPW;
     if (centre >= BM) return;
     const int lane = threadIdx.x & 63;
     const int b = centre / M;
     const float* __restrict__ pts = xyz + (size_t)b * N * 3;
-    int32_t* __restrict__ out = idx_out + (size_t)centre * ns;
-    const int n = sel ? sel[centre] : centre - b * M;
-    const float cx = pts[3 * n + 0], cy = pts[3 * n + 1], cz = pts[3 * n + 2];
-    if (lane == 0) {
-        new_xyz[(size_t)centre * 3 + 0] = cx; new_xyz[(size_t)centre * 3 + 1] = cy; new_xyz[(size_t)centre * 3 + 2] = cz;
-        if (idx64) idx64[centre] = n;
-    }
-    int cnt = 0, first = 0;
-    for (int base = 0; base < N; base += 64) {
-        const int k = base + lane;
-        bool hit = false;
-        if (k < N) {
-            const float d = sqdist3(cx, cy, cz, pts[3 * k + 0], pts[3 * k + 1], pts[3 * k + 2]);
-            hit = d < r2;
-        }
-        const unsigned long long mask = __ballot(hit);
-        if (mask != 0ull) {
-            if (cnt == 0) first = base + (__ffsll((long long)mask) - 1);
-            const int pos = cnt + __popcll(mask & ((1ull << lane) - 1ull));
-            if (hit && pos < ns) out[pos] = k;
-            cnt += __popcll(mask);
-            if (cnt >= ns) break;
+    float cx[CPW], cy[CPW], cz[CPW];
+    const int nc = min(CPW, BM - centre);
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) {
+        const int cc = centre + (c < nc ? c : 0);
+        const int n = sel ? sel[cc] : cc - b * M;
+        cx[c] = pts[3 * n + 0]; cy[c] = pts[3 * n + 1]; cz[c] = pts[3 * n + 2];
+        if (lane == 0 && c < nc) {
+            new_xyz[(size_t)cc * 3 + 0] = cx[c]; new_xyz[(size_t)cc * 3 + 1] = cy[c]; new_xyz[(size_t)cc * 3 + 2] = cz[c];
+            if (idx64) idx64[cc] = n;
         }
     }
-    const int fill = (cnt > 0) ? first : 0;
-    for (int s = cnt + lane; s < ns; s += 64) out[s] = fill;
+    ball_sweep<CPW>(pts, N, r2, ns, cx, cy, cz, nc, idx_out + (size_t)centre * ns, lane);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -470,6 +484,16 @@ extern "C" int ptt_fps_f32(const float* xyz, int B, int N, int npoint, int32_t* 
     return fail(PTT_EUNSUPPORTED, "ptt_fps_f32: N=%d exceeds the register-resident limit 32768", N);
 }
 
+// centres per wave of the ball-query kernels: 4 when the launch still has at least two waves per SIMD of the device and
+// a wave's centres stay inside one cloud, else 1 (8: dev switch only)
+static int ball_cpw(int BM, int M) {
+    const int force = dev_switches().ball_cpw;
+    if (force == 1 || (M & 3) != 0) return 1;
+    if (force == 8 && (M & 7) == 0) return 8;
+    if (force == 4) return 4;
+    return BM >= 4 * 256 * 8 ? 4 : 1;        // 8 per wave measured slower than 4 on the 16384-point frames (2.72 vs 2.49 ms)
+}
+
 extern "C" int ptt_ball_query_f32(const float* new_xyz, const float* xyz, int B, int M, int N, float radius,
                                   int nsample, int32_t* idx_out, ptt_stream_t stream) {
     if (B < 0 || M < 0 || N <= 0 || nsample <= 0)
@@ -478,8 +502,16 @@ extern "C" int ptt_ball_query_f32(const float* new_xyz, const float* xyz, int B,
     if (!new_xyz || !xyz || !idx_out) return fail(PTT_EINVAL, "ptt_ball_query_f32: null pointer");
     const float r2 = radius * radius;
     const int BM = B * M;
-    hipLaunchKernelGGL(ball_query_kernel, dim3((BM + 3) / 4), dim3(256), 0, as_stream(stream), new_xyz, xyz, BM, M,
-                       N, r2, nsample, idx_out);
+    const int cpw = ball_cpw(BM, M);
+    if (cpw == 8)
+        hipLaunchKernelGGL((ball_query_kernel<8>), dim3((BM / 8 + 3) / 4), dim3(256), 0, as_stream(stream), new_xyz, xyz, BM, M,
+                           N, r2, nsample, idx_out);
+    else if (cpw == 4)
+        hipLaunchKernelGGL((ball_query_kernel<4>), dim3((BM / 4 + 3) / 4), dim3(256), 0, as_stream(stream), new_xyz, xyz, BM, M,
+                           N, r2, nsample, idx_out);
+    else
+        hipLaunchKernelGGL((ball_query_kernel<1>), dim3((BM + 3) / 4), dim3(256), 0, as_stream(stream), new_xyz, xyz, BM, M,
+                           N, r2, nsample, idx_out);
     return check_launch("ball_query_kernel");
 }
 
@@ -539,8 +571,16 @@ extern "C" int ptt_centres_ball_query_f32(const float* xyz, const int32_t* sel, 
     if (B == 0 || M == 0) return PTT_OK;
     if (!xyz || !new_xyz || !idx_out) return fail(PTT_EINVAL, "ptt_centres_ball_query_f32: null pointer");
     const int BM = B * M;
-    hipLaunchKernelGGL(centres_ball_query_kernel, dim3((BM + 3) / 4), dim3(256), 0, as_stream(stream), xyz, sel, BM, M, N,
-                       radius * radius, nsample, new_xyz, reinterpret_cast<long long*>(idx64_out), idx_out);
+    const int cpw = ball_cpw(BM, M);
+    if (cpw == 8)
+        hipLaunchKernelGGL((centres_ball_query_kernel<8>), dim3((BM / 8 + 3) / 4), dim3(256), 0, as_stream(stream), xyz, sel, BM,
+                           M, N, radius * radius, nsample, new_xyz, reinterpret_cast<long long*>(idx64_out), idx_out);
+    else if (cpw == 4)
+        hipLaunchKernelGGL((centres_ball_query_kernel<4>), dim3((BM / 4 + 3) / 4), dim3(256), 0, as_stream(stream), xyz, sel, BM,
+                           M, N, radius * radius, nsample, new_xyz, reinterpret_cast<long long*>(idx64_out), idx_out);
+    else
+        hipLaunchKernelGGL((centres_ball_query_kernel<1>), dim3((BM + 3) / 4), dim3(256), 0, as_stream(stream), xyz, sel, BM, M,
+                           N, radius * radius, nsample, new_xyz, reinterpret_cast<long long*>(idx64_out), idx_out);
     return check_launch("centres_ball_query_kernel");
 }
 

@@ -184,6 +184,28 @@ def test_argument_errors_are_loud(dev):
         ops.group_points(torch.zeros(1, 4, 8, device=dev), torch.zeros(1, 2, 3, device=dev), )   # idx dtype
 
 
+@pytest.mark.parametrize("B,N,M,r,ns", [(24, 1024, 512, 0.3, 32), (20, 2048, 512, 0.3, 32), (48, 512, 256, 0.5, 32),
+                                        (72, 130, 128, 0.7, 16), (40, 300, 252, 5.0, 64)])
+def test_ball_query_four_centres_per_wave(dev, B, N, M, r, ns):
+    """Launches of at least 8192 centres take the kernel in which a wave owns FOUR centres (a point is loaded once and
+    tested against all four; a centre drops out when it has nsample hits): same indices, both entry points. Sparse clouds
+    (duplicates), an all-zero cloud, a cloud whose first centres are far from everything, under-filled and over-full balls."""
+    assert B * M >= 8192 and M % 4 == 0
+    xyz = _clouds(7 * N + M, B, N, kind="ped" if N < 400 else "car", K=max(8, N // 4))
+    xyz[3] = 0.0
+    centres = xyz[:, :M].copy()
+    centres[0, :6] += 100.0                              # centres 0-5 of cloud 0: no hits; 6, 7 share their wave with them
+    got = ops.ball_query(_dev(centres, dev), _dev(xyz, dev), r, ns).cpu().numpy()
+    np.testing.assert_array_equal(got, O.ball_query(centres, xyz, r, ns))
+    assert (got[0, :6] == 0).all()
+    xd = _dev(xyz, dev)
+    sel = ops.furthest_point_sampling(xd, M)
+    new_b, i64_b, idx_b = ops.centres_ball_query(xd, sel, M, r, ns)
+    new_a, i64_a = ops.select_centres(xd, sel, M)
+    assert torch.equal(new_a, new_b) and torch.equal(i64_a, i64_b)
+    np.testing.assert_array_equal(idx_b.cpu().numpy(), O.ball_query(new_b.cpu().numpy(), xyz, r, ns))
+
+
 @pytest.mark.parametrize("N,M,ns,with_sel", [(1024, 512, 32, True), (512, 256, 32, False), (128, 64, 16, True), (100, 7, 5, False)])
 def test_centres_ball_query_equals_the_two_kernels(dev, N, M, ns, with_sel):
     """ptt_centres_ball_query_f32 (one launch per SA level) == ptt_select_centres_f32 followed by ptt_ball_query_f32, and
