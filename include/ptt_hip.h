@@ -209,24 +209,21 @@ int ptt_sa_fused_fwd_f32(const ptt_sa_desc* d, ptt_stream_t stream);
  *   out[b,:,j] = max_i SharedMLP(fusion)[b,:,i,j]
  * Layer 0 is split: W0.fusion = w_sim*cos_ij + P[b,i,:], with P = W0[:,1:].[xyz_i;feat_i] computed
  * once per template point by ptt_linear_f32. `layers` are the REMAINING SharedMLP layers.
- * Nt = 64 template seeds is the instantiated configuration.
+ * The template seeds are walked in chunks of 64 with a running max (Nt % 64 == 0); the cosine map comes from
+ * ptt_cosine_map_f32 (below).
  * ------------------------------------------------------------------------------- */
 typedef struct ptt_xcorr_desc {
-    const float* search_feat;           /* search_feat[b][n][c], element strides below      */
-    int64_t s_sb, s_sn, s_sc;
-    const float* templ_feat;            /* templ_feat[b][i][c]                               */
-    int64_t t_sb, t_sn, t_sc;
+    const float* cos_t;                 /* (B,Ns,Nt) cosine map cos(search_j, templ_i) from ptt_cosine_map_f32 (one launch
+                                           per batch: computing it inside every workgroup cost ~340 vector-ALU / load
+                                           instructions per wave beside the other workgroup's MFMA stream)             */
     const float* P;                     /* (B,Nt,C0) contiguous, see above                   */
     const float* w_sim;                 /* (C0) W0[:,0]                                      */
     const float* scale0;                /* (C0) folded BN of layer 0 (NULL = 1 / 0)          */
     const float* shift0;
     float* out;                         /* out[b][c][j], element strides below               */
     int64_t out_sb, out_sc, out_sn;
-    float* sim_out;                     /* optional (B,Nt,Ns) cosine map, or NULL            */
-    const float* cos_t;                 /* optional (B,Ns,Nt) cosine map from ptt_cosine_map_f32: the kernel then skips
-                                           its own cosine phase (search_feat / templ_feat may be NULL)               */
-    int B, Ns, Nt, C, C0;
-    float eps;                          /* CosineSimilarity eps (1e-8)                       */
+    float* sim_out;                     /* optional (B,Nt,Ns) copy of the cosine map in the reference's orientation, or NULL */
+    int B, Ns, Nt, C0;
     int n_layers;
     ptt_sa_layer layers[PTT_SA_MAX_LAYERS];
 } ptt_xcorr_desc;

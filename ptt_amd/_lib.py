@@ -65,13 +65,11 @@ class SaDesc(Structure):
 
 
 class XcorrDesc(Structure):
-    _fields_ = [("search_feat", c_void_p), ("s_sb", c_int64), ("s_sn", c_int64), ("s_sc", c_int64),
-                ("templ_feat", c_void_p), ("t_sb", c_int64), ("t_sn", c_int64), ("t_sc", c_int64),
-                ("P", c_void_p), ("w_sim", c_void_p), ("scale0", c_void_p), ("shift0", c_void_p),
+    _fields_ = [("cos_t", c_void_p), ("P", c_void_p), ("w_sim", c_void_p), ("scale0", c_void_p), ("shift0", c_void_p),
                 ("out", c_void_p), ("out_sb", c_int64), ("out_sc", c_int64), ("out_sn", c_int64),
-                ("sim_out", c_void_p), ("cos_t", c_void_p),
-                ("B", c_int), ("Ns", c_int), ("Nt", c_int), ("C", c_int), ("C0", c_int),
-                ("eps", c_float), ("n_layers", c_int), ("layers", SaLayer * PTT_SA_MAX_LAYERS)]
+                ("sim_out", c_void_p),
+                ("B", c_int), ("Ns", c_int), ("Nt", c_int), ("C0", c_int),
+                ("n_layers", c_int), ("layers", SaLayer * PTT_SA_MAX_LAYERS)]
 
 
 class AttnDesc(Structure):

@@ -327,9 +327,12 @@ __device__ __forceinline__ void prefetch_first_block(const float* Wp, const floa
     if (w < NT) pre.w[0] = bp[0];
     if (w + 4 < NT) pre.w[1] = bp[4 * 64];
     if (shift && !scale) {
-        // unsigned index: SGPR base + 32-bit VGPR offset addressing, no loop-invariant 64-bit address held in VGPRs
-        if (w < NT) pre.sh[0] = shift[(unsigned)(w * 32 + (lane & 31))];
-        if (w + 4 < NT) pre.sh[1] = shift[(unsigned)((w + 4) * 32 + (lane & 31))];
+        // buffer loads (descriptor in SGPRs + one 32-bit lane offset): a flat load's loop-invariant 64-bit address was
+        // hoisted into a VGPR pair per tile and spilled in the kernels that sit at the 256-register bound
+        const __amdgpu_buffer_rsrc_t rs = weight_rsrc(shift);
+        const int voff = (w * 32 + (lane & 31)) * (int)sizeof(float);
+        if (w < NT) pre.sh[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, 0, 0));
+        if (w + 4 < NT) pre.sh[1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, 4 * 32 * (int)sizeof(float), 0));
     }
 }
 
@@ -1060,12 +1063,10 @@ __global__ __launch_bounds__(256, 2) void sa_stream_kernel(SaParams p) {
 // max over the 64 template points in registers. The (B,260,64,128) fusion tensor never exists.
 // ------------------------------------------------------------------------------------------
 struct XcorrParams {
-    const float* sfeat; const float* tfeat; const float* P; const float* wsim; const float* scale0; const float* shift0;
+    const float* P; const float* wsim; const float* scale0; const float* shift0;
     float* sim_out;
-    const float* cos_t;   // optional (B,Ns,Nt) cosine map from cos_map_kernel: the kernel then skips its own cosine phase
-    long long s_sb, s_sn, s_sc, t_sb, t_sn, t_sc;
-    int C, C0, Nt;
-    float eps;
+    const float* cos_t;   // (B,Ns,Nt) cosine map from cos_map_kernel
+    int C0, Nt;
     SaParams sa;     // B, M (= Ns), out strides, ldk, layers (the remaining SharedMLP layers), stagger
 };
 
@@ -1125,49 +1126,30 @@ __global__ __launch_bounds__(256, 2) void xcorr_fused_kernel(XcorrParams q) {
     for (int i0 = 0; i0 < q.Nt; i0 += 64) {
         prefetch_first_block(p.L[0].Wp, p.L[0].scale, p.L[0].shift, p.L[0].NT, w, lane, pre);
         if (i0) __syncthreads();             // the previous chunk's last GEMM has read Xs / simv
-        if (q.cos_t) {
-            // the cosine map of the whole batch was computed once by cos_map_kernel: 64 values to fetch instead of ~340
-            // vector-ALU / load instructions per wave in a phase that runs beside another workgroup's MFMA stream
-            if (t < 64) {
-                const float cs = q.cos_t[(unsigned)((b * p.M + jj) * q.Nt + i0 + t)];
-                simv[t] = cs;
-                if (q.sim_out) q.sim_out[(unsigned)((b * q.Nt + i0 + t) * p.M + jj)] = cs;
-            }
-        } else {
-            // ---- 64 cosines: thread (i = t>>2, quarter = t&3) covers channels quarter, quarter+4, ... ----
-            const int i = t >> 2, qd = t & 3;
-            // 32-bit element offsets (a feature tensor has far fewer than 2^31 elements): the 64-bit form kept eight
-            // loop-invariant address registers alive across the GEMMs and spilled them
-            const float* a = q.tfeat + (b * (int)q.t_sb + (i0 + i) * (int)q.t_sn);
-            const float* sp = q.sfeat + (b * (int)q.s_sb + jj * (int)q.s_sn);
-            const int t_sc = (int)q.t_sc, s_sc = (int)q.s_sc;
-            float dot = 0.f, na = 0.f, ns = 0.f;
-            for (int c = qd; c < q.C; c += 4) {
-                const float av = a[c * t_sc], sv = sp[c * s_sc];
-                dot += av * sv; na += av * av; ns += sv * sv;
-            }
-            dot += __shfl_xor(dot, 1, 64); dot += __shfl_xor(dot, 2, 64);
-            na += __shfl_xor(na, 1, 64);   na += __shfl_xor(na, 2, 64);
-            ns += __shfl_xor(ns, 1, 64);   ns += __shfl_xor(ns, 2, 64);
-            // torch.nn.functional.cosine_similarity: x1.x2 / (max(|x1|, eps) * max(|x2|, eps))
-            const float cs = dot / (fmaxf(sqrtf(na), q.eps) * fmaxf(sqrtf(ns), q.eps));
-            if (qd == 0) {
-                simv[i] = cs;
-                if (q.sim_out) q.sim_out[(unsigned)((b * q.Nt + i0 + i) * p.M + jj)] = cs;
-            }
+        // the cosine map of the whole batch is computed once by cos_map_kernel (ptt_cosine_map_f32): 64 values to fetch
+        // here instead of ~340 vector-ALU / load instructions per wave in a phase that runs beside another workgroup's
+        // MFMA stream (and its address registers pushed this kernel over the 256-VGPR bound)
+        if (t < 64) {
+            const float cs = q.cos_t[(unsigned)((b * p.M + jj) * q.Nt + i0 + t)];
+            simv[t] = cs;
+            if (q.sim_out) q.sim_out[(unsigned)((b * q.Nt + i0 + t) * p.M + jj)] = cs;
         }
         __syncthreads();
 
         // ---- layer 0: relu(bn0(w_sim * cos_i + P[b,i,:])) -> X ----
-        if (!q.scale0 && !q.shift0 && (q.C0 & 3) == 0) {
+        const int nq = q.C0 >> 2;
+        if (!q.scale0 && !q.shift0 && (q.C0 & 3) == 0 && (256 % nq) == 0) {
             // BatchNorm already folded into P and w_sim by the caller: relu(P'_i + w' * cos_i), four channels per lane
-            // (one 16-byte load, two packed FMAs, four max, one 16-byte LDS write) — 8 instructions per 4 values
+            // (one 16-byte load, two packed FMAs, four max, one 16-byte LDS write). A thread keeps ONE channel quad and
+            // walks rows i, i + 256/nq, ...: no integer division per element (a run-time divisor is ~25 vector-ALU
+            // instructions, paid in matrix time beside the other workgroup's GEMM) and w_sim's quad is loaded once.
+            // (C0 / 4 not a power of two: the scalar form below.)
             typedef float f32x2 __attribute__((ext_vector_type(2)));
-            const int nq = q.C0 >> 2;
-            for (int e = t; e < 64 * nq; e += 256) {
-                const int i = e / nq, c4 = e - i * nq;
-                const f32x4 pv = *reinterpret_cast<const f32x4*>(q.P + ((long long)b * q.Nt + i0 + i) * q.C0 + c4 * 4);
-                const f32x4 w4 = *reinterpret_cast<const f32x4*>(q.wsim + c4 * 4);
+            const int c4 = t % nq, step = 256 / nq;
+            const f32x4 w4 = *reinterpret_cast<const f32x4*>(q.wsim + c4 * 4);
+            const float* prow = q.P + ((size_t)(b * q.Nt + i0) * q.C0 + c4 * 4);
+            for (int i = t / nq; i < 64; i += step) {
+                const f32x4 pv = *reinterpret_cast<const f32x4*>(prow + (unsigned)(i * q.C0));
                 const float cs = simv[i];
                 const f32x2 c2 = {cs, cs};
                 f32x2 lo = __builtin_elementwise_fma(f32x2{w4[0], w4[1]}, c2, f32x2{pv[0], pv[1]});
@@ -1955,21 +1937,19 @@ extern "C" int ptt_sa_fused_fwd_f32(const ptt_sa_desc* d, ptt_stream_t stream) {
 
 extern "C" int ptt_xcorr_fused_fwd_f32(const ptt_xcorr_desc* d, ptt_stream_t stream) {
     if (!d) return fail(PTT_EINVAL, "ptt_xcorr_fused_fwd_f32: null descriptor");
-    if (d->B < 0 || d->Ns <= 0 || d->C <= 0 || d->C0 <= 0 || d->n_layers < 1 || d->n_layers > PTT_SA_MAX_LAYERS)
-        return fail(PTT_EINVAL, "ptt_xcorr_fused_fwd_f32: B=%d Ns=%d C=%d C0=%d layers=%d", d->B, d->Ns, d->C, d->C0,
-                    d->n_layers);
+    if (d->B < 0 || d->Ns <= 0 || d->C0 <= 0 || d->n_layers < 1 || d->n_layers > PTT_SA_MAX_LAYERS)
+        return fail(PTT_EINVAL, "ptt_xcorr_fused_fwd_f32: B=%d Ns=%d C0=%d layers=%d", d->B, d->Ns, d->C0, d->n_layers);
     if (d->Nt <= 0 || (d->Nt % 64) != 0)
         return fail(PTT_EUNSUPPORTED, "ptt_xcorr_fused_fwd_f32: Nt=%d (the template seeds are walked in chunks of 64)", d->Nt);
     if (d->n_layers < 2) return fail(PTT_EUNSUPPORTED, "ptt_xcorr_fused_fwd_f32: needs at least two MFMA layers after layer 0");
     if ((d->C0 % 8) != 0 || d->C0 > 256) return fail(PTT_EUNSUPPORTED, "ptt_xcorr_fused_fwd_f32: C0=%d", d->C0);
     if (d->B == 0) return PTT_OK;
-    if ((!d->cos_t && (!d->search_feat || !d->templ_feat)) || !d->P || !d->w_sim || !d->out)
-        return fail(PTT_EINVAL, "ptt_xcorr_fused_fwd_f32: null pointer");
+    if (!d->cos_t || !d->P || !d->w_sim || !d->out)
+        return fail(PTT_EINVAL, "ptt_xcorr_fused_fwd_f32: null pointer (cos_t comes from ptt_cosine_map_f32)");
     XcorrParams q;
-    q.sfeat = d->search_feat; q.tfeat = d->templ_feat; q.P = d->P; q.wsim = d->w_sim; q.scale0 = d->scale0;
+    q.P = d->P; q.wsim = d->w_sim; q.scale0 = d->scale0;
     q.shift0 = d->shift0; q.sim_out = d->sim_out; q.cos_t = d->cos_t;
-    q.s_sb = d->s_sb; q.s_sn = d->s_sn; q.s_sc = d->s_sc; q.t_sb = d->t_sb; q.t_sn = d->t_sn; q.t_sc = d->t_sc;
-    q.C = d->C; q.C0 = d->C0; q.Nt = d->Nt; q.eps = d->eps;
+    q.C0 = d->C0; q.Nt = d->Nt;
     SaParams& p = q.sa;
     memset(&p, 0, sizeof(p));
     p.out = d->out; p.osb = d->out_sb; p.osc = d->out_sc; p.osm = d->out_sn;

@@ -409,6 +409,7 @@ def xcorr_fused(search_feats, templ_feats, P, w_sim, scale0, shift0, layers, eps
     """Fused CosineSimAug core (similarity_modules/p2b_xcoor.py:25-42): cosine map, concat, SharedMLP, max over
     the template axis. search_feats (B,C,Ns) / templ_feats (B,C,Nt) in any strides; P (B,Nt,C0) = layer-0
     pre-activation without the similarity term; layers = remaining (wpacked, scale, shift, cin, cout, relu).
+    cos_t: the (B,Ns,Nt) map of cosine_map() if the caller already has it (else computed here, one launch).
     Returns (out (B,Cout,Ns) as a view of point-major storage, sim (B,Nt,Ns) | None)."""
     for t_, n_ in ((search_feats, "search_feats"), (templ_feats, "templ_feats")):
         if not t_.is_cuda or t_.dtype != torch.float32 or t_.dim() != 3:
@@ -422,25 +423,24 @@ def xcorr_fused(search_feats, templ_feats, P, w_sim, scale0, shift0, layers, eps
         raise RuntimeError("xcorr_fused: Nt=%d (ptt_xcorr_fused_fwd_f32 walks the template seeds in chunks of 64)" % Nt)
     if P.shape[0] != B or P.shape[1] != Nt or w_sim.shape[0] != C0 or templ_feats.shape[:2] != search_feats.shape[:2]:
         raise RuntimeError("xcorr_fused: inconsistent shapes")
-    if cos_t is not None:
-        _chk(cos_t, "cos_t", torch.float32, 3)
+    if cos_t is None:
+        cos_t = cosine_map(search_feats, templ_feats, eps=eps)
+    _chk(cos_t, "cos_t", torch.float32, 3)
+    if tuple(cos_t.shape) != (B, Ns, Nt):
+        raise RuntimeError("xcorr_fused: cos_t must be (B,Ns,Nt)")
     cout = layers[-1][4]
     store = torch.empty((B, Ns, cout), dtype=torch.float32, device=P.device)
     out = store.transpose(1, 2)
     sim = torch.empty((B, Nt, Ns), dtype=torch.float32, device=P.device) if want_sim else None
     d = XcorrDesc()
-    d.search_feat = search_feats.data_ptr()
-    d.s_sb, d.s_sc, d.s_sn = search_feats.stride()
-    d.templ_feat = templ_feats.data_ptr()
-    d.t_sb, d.t_sc, d.t_sn = templ_feats.stride()
+    d.cos_t = cos_t.data_ptr()
     d.P, d.w_sim = P.data_ptr(), w_sim.data_ptr()
     d.scale0 = scale0.data_ptr() if scale0 is not None else None
     d.shift0 = shift0.data_ptr() if shift0 is not None else None
     d.out = out.data_ptr()
     d.out_sb, d.out_sc, d.out_sn = out.stride()
     d.sim_out = sim.data_ptr() if sim is not None else None
-    d.cos_t = cos_t.data_ptr() if cos_t is not None else None
-    d.B, d.Ns, d.Nt, d.C, d.C0, d.eps = B, Ns, Nt, C, C0, float(eps)
+    d.B, d.Ns, d.Nt, d.C0 = B, Ns, Nt, C0
     d.n_layers = len(layers)
     for i, (wp, sc, sh, cin, co, relu) in enumerate(layers):
         L = d.layers[i]
