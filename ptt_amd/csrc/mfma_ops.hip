@@ -1860,6 +1860,13 @@ extern "C" int ptt_sa_fused_fwd_f32(const ptt_sa_desc* d, ptt_stream_t stream) {
         if (l + 1 < d->n_layers && s.Cout > maxk) maxk = s.Cout;
         cin = s.Cout;
     }
+    {   // several kernels address these arrays with 32-bit byte offsets (buffer descriptors, scalar index arithmetic)
+        const unsigned long long lim = 0x7fffffffull, B = (unsigned long long)d->B;
+        if (B * d->N * 12ull >= lim || B * d->M * d->nsample * 4ull >= lim || B * d->M * (unsigned long long)cin * 4ull >= lim ||
+            B * d->N * (unsigned long long)(p.C > 0 ? p.C : 1) * 4ull >= lim)
+            return fail(PTT_EUNSUPPORTED, "ptt_sa_fused_fwd_f32: B=%d N=%d M=%d: an array of this launch exceeds 2 GiB "
+                        "(32-bit offsets) — split the batch", d->B, d->N, d->M);
+    }
     p.ldk = maxk + 4;
     p.vec_gather = (p.C > 0 && p.fsc == 1 && (p.C & 3) == 0 && p.C <= 256 && (p.fsn & 3) == 0 &&
                     (p.fsb & 3) == 0 && (reinterpret_cast<uintptr_t>(p.feat) & 15) == 0) ? 1 : 0;
@@ -1946,6 +1953,9 @@ extern "C" int ptt_xcorr_fused_fwd_f32(const ptt_xcorr_desc* d, ptt_stream_t str
     if (d->B == 0) return PTT_OK;
     if (!d->cos_t || !d->P || !d->w_sim || !d->out)
         return fail(PTT_EINVAL, "ptt_xcorr_fused_fwd_f32: null pointer (cos_t comes from ptt_cosine_map_f32)");
+    if ((unsigned long long)d->B * d->Ns * d->Nt >= 0x7fffffffull || (unsigned long long)d->B * d->Nt * d->C0 >= 0x7fffffffull)
+        return fail(PTT_EUNSUPPORTED, "ptt_xcorr_fused_fwd_f32: B=%d Ns=%d Nt=%d: 32-bit element offsets — split the batch",
+                    d->B, d->Ns, d->Nt);
     XcorrParams q;
     q.P = d->P; q.wsim = d->w_sim; q.scale0 = d->scale0;
     q.shift0 = d->shift0; q.sim_out = d->sim_out; q.cos_t = d->cos_t;
