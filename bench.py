@@ -187,6 +187,7 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(spawn_ranks(args.gpus))
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this host driver (RCCL needs it)
     import torch
     from ptt_amd import ops, synth
     from ptt_amd.hot_path import (FrameHotPath, GraphedHotPath, InterleavedHotPath, PipelinedHotPath, TrackerThroughput,
