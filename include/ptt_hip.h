@@ -172,6 +172,16 @@ typedef struct ptt_sa_layer {
     int relu;
 } ptt_sa_layer;
 
+/* A stack of up to PTT_SA_MAX_LAYERS 1x1 convolutions (+ folded BatchNorm + ReLU) over point rows in one launch:
+ * out = L_n(... L_1(X)) (+ residual). Replaces the eval-mode Conv1d stacks of the heads
+ * (voting_heads/centroids_voting_head.py: vote_layer, cla_layer; voting_heads/box_voting_head.py: refine_layer) and the
+ * two trailing convolutions of CosineSimAug (similarity_modules/p2b_xcoor.py:43-45), which the reference runs as one
+ * cuDNN convolution + batch_norm + relu per layer. X (rows, K <= 264) with row stride ldx; inner layers Cout <= 256, the
+ * last layer any Cout <= 384 (e.g. 1, 5, 259); layers[i].Wpacked from ptt_pack_weight_f32, scale NULL when the BatchNorm
+ * scale is folded into the weights (one instruction less per value in the epilogue). */
+int ptt_rows_mlp_f32(const float* X, int rows, int K, int ldx, const ptt_sa_layer* layers, int n_layers,
+                     const float* residual, int ldr, float* out, int ldo, ptt_stream_t stream);
+
 typedef struct ptt_sa_desc {
     const float* xyz;     /* (B,N,3)                                                   */
     const float* new_xyz; /* (B,M,3) centres                                           */

@@ -29,6 +29,7 @@ EXPORTS = [
     "ptt_pt_pair_input_f32", "ptt_pt_attn_train_fwd_f32", "ptt_pt_attn_train_bwd_f32", "ptt_linear_act_in_f32",
     "ptt_centres_ball_query_f32",
     "ptt_bn_sums_f64", "ptt_bn_finish_f64", "ptt_bn_bwd_sums_f64", "ptt_bn_bwd_apply_f32",
+    "ptt_rows_mlp_f32",
 ]
 PTT_MAX_SEGMENTS = 4
 
@@ -105,6 +106,7 @@ def _declare(lib):
         "ptt_pack_weight_rot_f32": [vp, i, i, i, vp, vp],
         "ptt_linear_f32": [vp, i, i, i, vp, i, vp, vp, i, vp, i, vp, i, vp],
         "ptt_sa_fused_fwd_f32": [POINTER(SaDesc), vp],
+        "ptt_rows_mlp_f32": [vp, i, i, i, POINTER(SaLayer), i, vp, i, vp, i, vp],
         "ptt_xcorr_fused_fwd_f32": [POINTER(XcorrDesc), vp],
         "ptt_cosine_map_f32": [vp, c_int64, c_int64, c_int64, vp, c_int64, c_int64, c_int64, i, i, i, i, f, vp, vp],
         "ptt_pt_attn_pair_f32": [POINTER(AttnDesc), vp],

@@ -481,6 +481,97 @@ struct SaParams {
 };
 
 // ------------------------------------------------------------------------------------------
+// A stack of up to four 1x1 convolutions (+ folded BatchNorm, + ReLU) over point rows in ONE launch: the heads'
+// Conv1d stacks (vote_layer 259 -> 256 -> 256 -> 259 with the input as residual, cla_layer 256 -> 256 -> 256 -> 1,
+// refine_layer ... -> 5) and CosineSimAug's two trailing convolutions. A workgroup owns 32 rows and all columns; the
+// activations stay in its LDS tile between layers. One launch instead of one ptt_linear_f32 launch per layer: at
+// 128 - 6144 rows each of those is launch- and tail-bound (14 us at one frame, 27 us at 48).
+// Inner layers: Cout <= 256 (two column tiles per wave); last layer: Cout <= 384, any width (padded tiles are not
+// stored); K <= 264.
+// ------------------------------------------------------------------------------------------
+struct RowsMlpParams {
+    const float* X; const float* residual; float* out;
+    int rows, K0, ldx, ldr, ldo, n_layers, ldk, vec_in;
+    SaLayerDev L[PTT_SA_MAX_LAYERS];
+};
+
+__global__ __launch_bounds__(256, 2) void rows_mlp_kernel(RowsMlpParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Xs = smem;                                       // [32][ldk]
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, half = lane >> 5;
+    const int row0 = blockIdx.x * 32;
+    f32x4 pw[3];
+    float psh[3];
+    auto prefetch = [&](const SaLayerDev& L) {               // first K-block of this wave's column tiles + their shifts
+        const f32x4* bp = reinterpret_cast<const f32x4*>(L.Wp) + (size_t)w * 64 + lane;
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            psh[u] = 0.f;
+            if (w + 4 * u < L.NT) {
+                pw[u] = bp[(size_t)u * 4 * 64];
+                const int col = (w + 4 * u) * 32 + (lane & 31);
+                if (L.shift && !L.scale && col < L.Cout) psh[u] = L.shift[col];
+            }
+        }
+    };
+    prefetch(p.L[0]);
+    // ---- stage the 32 input rows, zero-padded to the K-block boundary (rows past the end: zeros) ----
+    {
+        const int Kpad = p.L[0].nkb * 8;
+        if (p.vec_in) {
+            const int nq = Kpad >> 2;
+            for (int e = t; e < 32 * nq; e += 256) {
+                const int r = e / nq, c4 = (e - r * nq) * 4;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (row0 + r < p.rows && c4 < p.K0) v = *reinterpret_cast<const f32x4*>(p.X + (size_t)(row0 + r) * p.ldx + c4);
+                *reinterpret_cast<f32x4*>(Xs + r * p.ldk + c4) = v;
+            }
+        } else {
+            for (int e = t; e < 32 * Kpad; e += 256) {
+                const int r = e / Kpad, c = e - r * Kpad;
+                Xs[r * p.ldk + c] = (row0 + r < p.rows && c < p.K0) ? p.X[(size_t)(row0 + r) * p.ldx + c] : 0.f;
+            }
+        }
+    }
+    lds_barrier();
+    for (int l = 0; l < p.n_layers; ++l) {
+        const SaLayerDev& L = p.L[l];
+        const bool last = l == p.n_layers - 1, affine = L.scale != nullptr;
+        f32x16 acc[1][3];
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][u][r] = psh[u];
+        int nvalid = 0;
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+            if (w + 4 * u < L.NT) nvalid = u + 1;
+        if (nvalid) gemm_tiles<1, 3, 0>(Xs, p.ldk, L.nkb, reinterpret_cast<const f32x4*>(L.Wp), L.NT, w, nvalid, lane, acc, pw);
+        if (!last) { prefetch(p.L[l + 1]); lds_barrier(); }     // every wave has read this layer's input
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            if (u >= nvalid) break;
+            const int col = (w + 4 * u) * 32 + (lane & 31);
+            float sc = 1.f, sh = 0.f;
+            if (affine && col < L.Cout) { sc = L.scale[col]; sh = L.shift ? L.shift[col] : 0.f; }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float y = affine ? acc[0][u][r] * sc + sh : acc[0][u][r];
+                if (L.relu) y = fmaxf(y, 0.f);
+                const int row = tile_row(r, half);
+                if (!last) {
+                    Xs[row * p.ldk + col] = (col < L.Cout) ? y : 0.f;       // padded columns feed the next layer as zeros
+                } else if (col < L.Cout && row0 + row < p.rows) {
+                    if (p.residual) y += p.residual[(size_t)(row0 + row) * p.ldr + col];
+                    p.out[(size_t)(row0 + row) * p.ldo + col] = y;
+                }
+            }
+        }
+        if (!last) lds_barrier();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Grouping for the SA kernels: the calling wave fills ROWS consecutive rows of an LDS tile with
 // [ neighbour features (C) | (xyz_nbr - centre)(/radius) (3) | zeros up to Kpad0 ]
 // (features FIRST so that point-major rows land 16-byte aligned; layer 0's weight is packed with
@@ -1807,6 +1898,41 @@ static int linear_launch(const float* X, int rows, int K, int ldx, const float* 
     PTT_LIN_CASE(1, false, 1) PTT_LIN_CASE(1, false, 2) PTT_LIN_CASE(2, false, 1) PTT_LIN_CASE(2, false, 2)
 #undef PTT_LIN_CASE
     return check_launch("linear_kernel");
+}
+
+extern "C" int ptt_rows_mlp_f32(const float* X, int rows, int K, int ldx, const ptt_sa_layer* layers, int n_layers,
+                                const float* residual, int ldr, float* out, int ldo, ptt_stream_t stream) {
+    if (rows < 0 || K <= 0 || ldx < K || n_layers < 1 || n_layers > PTT_SA_MAX_LAYERS || !layers)
+        return fail(PTT_EINVAL, "ptt_rows_mlp_f32: rows=%d K=%d ldx=%d layers=%d", rows, K, ldx, n_layers);
+    if (rows == 0) return PTT_OK;
+    if (!X || !out) return fail(PTT_EINVAL, "ptt_rows_mlp_f32: null pointer");
+    if (K > 264) return fail(PTT_EUNSUPPORTED, "ptt_rows_mlp_f32: K=%d (at most 264 input channels)", K);
+    RowsMlpParams p;
+    p.X = X; p.residual = residual; p.out = out; p.rows = rows; p.K0 = K; p.ldx = ldx; p.ldr = ldr; p.ldo = ldo;
+    p.n_layers = n_layers;
+    int maxk = 0, cin = K;
+    for (int l = 0; l < n_layers; ++l) {
+        const ptt_sa_layer& s = layers[l];
+        const bool last = l == n_layers - 1;
+        if (s.Cin != cin) return fail(PTT_EINVAL, "ptt_rows_mlp_f32: layer %d Cin=%d, expected %d", l, s.Cin, cin);
+        if (s.Cout <= 0 || s.Cout > (last ? 384 : 256))
+            return fail(PTT_EUNSUPPORTED, "ptt_rows_mlp_f32: layer %d Cout=%d (inner layers <= 256, the last <= 384)", l, s.Cout);
+        if (!s.Wpacked) return fail(PTT_EINVAL, "ptt_rows_mlp_f32: layer %d has no weights", l);
+        SaLayerDev& L = p.L[l];
+        L.Wp = s.Wpacked; L.scale = s.scale; L.shift = s.shift; L.Cin = s.Cin; L.Cout = s.Cout; L.relu = s.relu;
+        L.nkb = (s.Cin + 7) / 8; L.NT = (s.Cout + 31) / 32;
+        if (L.nkb * 8 > maxk) maxk = L.nkb * 8;
+        if (!last && L.NT * 32 > maxk) maxk = L.NT * 32;      // an inner layer writes whole (zero-padded) column tiles
+        cin = s.Cout;
+    }
+    if (ldo < cin || (residual && ldr < cin)) return fail(PTT_EINVAL, "ptt_rows_mlp_f32: ldo=%d ldr=%d Cout=%d", ldo, ldr, cin);
+    p.ldk = maxk + 4;
+    p.vec_in = ((K & 3) == 0 && (ldx & 3) == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0) ? 1 : 0;
+    const int lds = 32 * p.ldk * (int)sizeof(float);
+    int rc = set_lds_limit(reinterpret_cast<const void*>(rows_mlp_kernel), lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(rows_mlp_kernel, dim3((rows + 31) / 32), dim3(256), lds, as_stream(stream), p);
+    return check_launch("rows_mlp_kernel");
 }
 
 extern "C" int ptt_sa_fused_fwd_f32(const ptt_sa_desc* d, ptt_stream_t stream) {

@@ -212,19 +212,35 @@ def _rows_params(seq):
                     shift = (shift + unit.conv.bias * scale).contiguous()
             elif unit.conv.bias is not None:
                 shift = unit.conv.bias.detach().float().contiguous()
-            layers.append((ops.pack_weight(w.reshape(w.shape[0], w.shape[1])), w.shape[0], scale, shift,
-                           hasattr(unit, 'activation')))
+            w2 = w.reshape(w.shape[0], w.shape[1])
+            layers.append((ops.pack_weight(w2), w.shape[0], scale, shift, hasattr(unit, 'activation'),
+                           # the one-launch form (ptt_rows_mlp_f32): BatchNorm scale folded into the packed weights
+                           ops.pack_weight(w2 if scale is None else w2 * scale[:, None]), w.shape[1]))
     ops.publish_params(layers[0][0].device)
     object.__setattr__(seq, '_rows_cache', (key, layers))
     return layers
 
 
+def _one_launch(layers, rows):
+    """ptt_rows_mlp_f32's envelope (at most 4 layers, K <= 264, inner widths <= 256, last <= 384) — and enough rows: the
+    one-launch form runs a 32-row tile's layers back to back on ONE CU (25 us for 259 -> 256 -> 256 -> 259), while
+    per-layer launches spread each layer's column tiles over idle CUs. At one tracklet frame (128 rows) the per-layer form
+    is faster (1.12 vs 1.14 ms per frame); at 48 frames the one-launch form (4.19 vs 4.21 ms per step)."""
+    n_rows = rows.numel() // rows.shape[-1]
+    return (n_rows >= 1024 and len(layers) <= 4 and rows.shape[-1] <= 264 and all(L[1] <= 256 for L in layers[:-1])
+            and layers[-1][1] <= 384)
+
+
 def rows_forward(seq, rows, residual=None):
     """seq(rows^T)^T for an eval-mode Conv1d(k=1) stack: rows (..., Cin) -> (..., Cout); `residual` (..., Cout) is
-    added to the last layer's output. Call only when rows_fusable(seq, rows)."""
+    added to the last layer's output. Call only when rows_fusable(seq, rows). The whole stack is one launch when it fits
+    ptt_rows_mlp_f32, else one ptt_linear_f32 launch per layer."""
     from .... import ops
     layers = _rows_params(seq)
+    if _one_launch(layers, rows) and rows.stride(-1) == 1:
+        return ops.rows_mlp(rows, [(L[5], None, L[3], L[6], L[1], L[4]) for L in layers], residual)
     x = rows
-    for i, (wp, cout, scale, shift, relu) in enumerate(layers):
+    for i, L in enumerate(layers):
+        wp, cout, scale, shift, relu = L[:5]
         x = ops.linear(x, wp, cout, scale, shift, relu, residual if i == len(layers) - 1 else None)
     return x

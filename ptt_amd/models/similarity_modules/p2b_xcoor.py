@@ -83,16 +83,10 @@ class CosineSimAug(nn.Module):
                 w = u.conv.weight
                 # BatchNorm scale folded into the packed weights: the kernel starts its accumulators at the shift
                 layers.append((ops.pack_weight(w * sc.view(-1, 1, 1, 1)), None, sh, w.shape[1], w.shape[0], True))
-            c0, c1 = self.conv[0], self.conv[1]
-            cs, ct = self._fold(c0)
             # layer 0's BatchNorm is folded into its two halves: the per-template-point term comes out of the linear
             # kernel as s0 * (W0[:,1:] . [xyz;feat]) + t0, the similarity column as s0 * w_sim
             P = dict(w_sim=(w0[:, 0].float() * s0).contiguous(), w_rest=ops.pack_weight(w0[:, 1:]), c0=w0.shape[0],
-                     scale0=s0, shift0=t0, layers=layers,
-                     conv0=ops.pack_weight(c0.conv.weight), conv0_scale=cs, conv0_shift=ct,
-                     conv0_relu=hasattr(c0, 'activation'),
-                     conv1=ops.pack_weight(c1.conv.weight),
-                     conv1_bias=c1.conv.bias.detach().float().contiguous() if c1.conv.bias is not None else None)
+                     scale0=s0, shift0=t0, layers=layers)
         ops.publish_params(self.conv[0].conv.weight.device)
         self._cache = (key, P)
         return P
@@ -111,9 +105,7 @@ class CosineSimAug(nn.Module):
             cos_t = ops.cosine_map(search_feats, template_feats, eps=self.cosine.eps)         # (B,n2,n1), one launch
             fused, _ = ops.xcorr_fused(search_feats, template_feats, pre, P['w_sim'], None, None,
                                        P['layers'], eps=self.cosine.eps, cos_t=cos_t)         # (B,C,n2) view
-            y = ops.linear(fused.transpose(1, 2), P['conv0'], self.conv[0].conv.weight.shape[0],
-                           P['conv0_scale'], P['conv0_shift'], P['conv0_relu'])
-            y = ops.linear(y, P['conv1'], self.conv[1].conv.weight.shape[0], None, P['conv1_bias'])
+            y = layer_utils.rows_forward(self.conv, fused.transpose(1, 2))                   # both convolutions, one launch
             batch_dict['cosine_feats'] = y.transpose(1, 2)                                    # (B,c,n2) view
             return batch_dict
 

@@ -405,6 +405,35 @@ def cosine_map(search_feats, templ_feats, eps=1e-8):
     return out
 
 
+def rows_mlp(x, layers, residual=None):
+    """A stack of 1x1 convolutions over rows in ONE launch — ptt_rows_mlp_f32. x (..., K) float32 with contiguous rows,
+    layers = [(wpacked, scale | None, shift | None, cin, cout, relu)] (at most 4; inner cout <= 256, last <= 384, K <= 264),
+    residual (..., cout_last) added to the result. -> (..., cout_last)."""
+    if not x.is_cuda or x.dtype != torch.float32 or x.stride(-1) != 1:
+        raise RuntimeError("rows_mlp: x must be a float32 device tensor with contiguous rows")
+    K = x.shape[-1]
+    x2 = x.reshape(-1, K)
+    rows = x2.shape[0]
+    cout = int(layers[-1][4])
+    out = torch.empty((rows, cout), dtype=torch.float32, device=x.device)
+    res2 = None
+    if residual is not None:
+        res2 = residual.reshape(-1, cout)
+        _chk(res2 if res2.is_contiguous() else res2.contiguous(), "residual", torch.float32, 2)
+        res2 = res2 if res2.stride(1) == 1 else res2.contiguous()
+    arr = (SaLayer * len(layers))()
+    for i, (wp, sc, sh, cin, co, relu) in enumerate(layers):
+        arr[i].Wpacked = wp.data_ptr()
+        arr[i].scale = sc.data_ptr() if sc is not None else None
+        arr[i].shift = sh.data_ptr() if sh is not None else None
+        arr[i].Cin, arr[i].Cout, arr[i].relu = int(cin), int(co), int(bool(relu))
+    with torch.cuda.device(x.device), _timed('ptt_rows_mlp_f32'):
+        _lib.check(_lib.lib().ptt_rows_mlp_f32(_ptr(x2), rows, K, x2.stride(0), arr, len(layers), _ptr(res2),
+                                               res2.stride(0) if res2 is not None else 0, _ptr(out), cout, _stream()),
+                   "ptt_rows_mlp_f32")
+    return out.view(*x.shape[:-1], cout)
+
+
 def xcorr_fused(search_feats, templ_feats, P, w_sim, scale0, shift0, layers, eps=1e-8, want_sim=False, cos_t=None):
     """Fused CosineSimAug core (similarity_modules/p2b_xcoor.py:25-42): cosine map, concat, SharedMLP, max over
     the template axis. search_feats (B,C,Ns) / templ_feats (B,C,Nt) in any strides; P (B,Nt,C0) = layer-0

@@ -36,6 +36,39 @@ def test_linear(dev, rows, K, Cout, relu, res):
     np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), **TOL)
 
 
+@pytest.mark.parametrize("rows,widths,res,folded", [
+    (77, [259, 256, 256, 259], True, True),        # vote_layer: (xyz | features) -> offsets + feature residual, 9 column tiles
+    (6144, [256, 256, 256, 1], False, True),       # cla_layer at 48 frames
+    (130, [256, 256, 256, 5], False, False),       # refine_layer, BatchNorm scale kept separate
+    (128, [256, 256, 256], False, True),           # CosineSimAug's trailing convolutions at one frame
+    (33, [40, 64], False, False), (500, [12, 96, 33, 200, 384], True, True)])
+def test_rows_mlp_one_launch_equals_the_layer_chain(dev, rows, widths, res, folded):
+    """ptt_rows_mlp_f32 (a Conv1d stack in one launch) against float64 torch on the CPU: every layer linear + per-channel
+    scale / shift (a folded BatchNorm) + ReLU except the last, odd widths, rows that do not fill the last tile."""
+    rs = np.random.RandomState(rows + len(widths))
+    x = torch.from_numpy(rs.standard_normal((rows, widths[0])).astype(np.float32))
+    r = torch.from_numpy(rs.standard_normal((rows, widths[-1])).astype(np.float32)) if res else None
+    ref = x.double()
+    layers = []
+    for i, (cin, cout) in enumerate(zip(widths[:-1], widths[1:])):
+        w = torch.from_numpy((rs.standard_normal((cout, cin)) / np.sqrt(cin)).astype(np.float32))
+        sc = torch.from_numpy(rs.uniform(0.5, 1.5, cout).astype(np.float32))
+        sh = torch.from_numpy(rs.standard_normal(cout).astype(np.float32))
+        relu = i < len(widths) - 2
+        ref = ref @ w.double().t() * sc.double() + sh.double()
+        if relu:
+            ref = ref.clamp_min(0)
+        if folded:
+            layers.append((ops.pack_weight((w * sc[:, None]).to(dev)), None, sh.to(dev), cin, cout, relu))
+        else:
+            layers.append((ops.pack_weight(w.to(dev)), sc.to(dev), sh.to(dev), cin, cout, relu))
+    if res:
+        ref = ref + r.double()
+    got = ops.rows_mlp(x.to(dev), layers, r.to(dev) if res else None)
+    assert tuple(got.shape) == (rows, widths[-1])
+    np.testing.assert_allclose(got.cpu().numpy(), ref.float().numpy(), **TOL)
+
+
 def test_pack_weight_is_transpose_detecting(dev):
     """A = I against an asymmetric W: the GEMM must return W^T rows exactly."""
     K, Cout = 40, 64
