@@ -89,8 +89,8 @@ __device__ __forceinline__ void stagger_second_slot(int first_wave_blocks, int q
 // launch 443 -> 88 MB (55 MB compulsory), L2 hit rate 95.6 -> 99.1 %, kernel time -2 %.
 // -DPTT_XCD_REMAP=0 restores the plain numbering.
 #ifndef PTT_LINEAR_PF
-#define PTT_LINEAR_PF 1
-#endif
+#define PTT_LINEAR_PF 0      // the hand-pinned two-register-set K loop: 5 % faster than the rotating prefetch on the linear
+#endif                      // kernel's short launches (0.272 -> 0.259 ms per step; the pair kernel prefers form 1)
 #ifndef PTT_XCD_REMAP
 #define PTT_XCD_REMAP 1
 #endif
