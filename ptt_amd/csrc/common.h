@@ -35,6 +35,7 @@ struct DevSwitches {
     int pair_stagger = 8;                // PTT_PAIR_STAGGER
     int pair_lds_pad = 0;                // PTT_PAIR_LDS_PAD: extra LDS bytes (forces one workgroup per CU)
     int sa_lds_chunk = 2;                // PTT_SA_LDS_CHUNK=n: at most n centres per wave of sa_lds_kernel (0: one pass)
+    int fps_plain = 0;                   // PTT_FPS_PLAIN=1: coordinates carried through the selects for every cloud size
     int ball_cpw = 0;                    // PTT_BALL_CPW=1|4: centres per wave of the ball-query kernels (0: by launch size)
     int fps_t = 0;                       // PTT_FPS_T: FPS threads per cloud at N <= 2048
     int group_grad_global = 0;           // PTT_GROUP_GRAD_GLOBAL: global atomics in ptt_group_grad_f32

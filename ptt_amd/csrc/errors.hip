@@ -39,6 +39,7 @@ static DevSwitches read_switches() {
     if (const char* e = getenv("PTT_PAIR_STAGGER")) d.pair_stagger = atoi(e);
     if (const char* e = getenv("PTT_PAIR_LDS_PAD")) d.pair_lds_pad = atoi(e);
     if (const char* e = getenv("PTT_BALL_CPW")) d.ball_cpw = atoi(e);
+    if (const char* e = getenv("PTT_FPS_PLAIN")) d.fps_plain = atoi(e);
     if (const char* e = getenv("PTT_SA_LDS_CHUNK")) d.sa_lds_chunk = atoi(e);
     if (const char* e = getenv("PTT_FPS_T")) d.fps_t = atoi(e);
     if (getenv("PTT_GROUP_GRAD_GLOBAL")) d.group_grad_global = 1;
