@@ -534,17 +534,17 @@ extern "C" int ptt_fps_f32(const float* xyz, int B, int N, int npoint, int32_t* 
         if (const int T = dev_switches().fps_t) {
             if (T == 64) return launch_fps<64, 16>(xyz, B, N, npoint, idx_out, s);
             if (T == 128) return launch_fps<128, 8>(xyz, B, N, npoint, idx_out, s);
-            if (T == 256) return launch_fps<256, 4>(xyz, B, N, npoint, idx_out, s);
+            if (T == 512) return launch_fps<512, 2>(xyz, B, N, npoint, idx_out, s);
         }
-        return launch_fps<512, 2>(xyz, B, N, npoint, idx_out, s);    // 0.43 us / iteration (256 threads: 0.47; scripts/fps_sweep.py)
+        return launch_fps<256, 4>(xyz, B, N, npoint, idx_out, s);    // 0.37 us / iteration (512 threads: 0.39; scripts/fps_sweep.py)
     }
     if (N <= 2048) {
         if (const int T = dev_switches().fps_t) {       // dev: workgroup-size sweep
-            if (T == 256) return launch_fps<256, 8>(xyz, B, N, npoint, idx_out, s);
+            if (T == 512) return launch_fps<512, 4>(xyz, B, N, npoint, idx_out, s);
             if (T == 1024) return launch_fps<1024, 2>(xyz, B, N, npoint, idx_out, s);
             if (T == 128) return launch_fps<128, 16>(xyz, B, N, npoint, idx_out, s);
         }
-        return launch_fps<512, 4>(xyz, B, N, npoint, idx_out, s);   // measured fastest of 128/256/512/1024 at N = 2048
+        return launch_fps<256, 8>(xyz, B, N, npoint, idx_out, s);   // 0.45 us / iteration; 512 threads 0.46, 128 / 1024: 0.52
     }
     if (N <= 4096) return launch_fps<512, 8>(xyz, B, N, npoint, idx_out, s);
     if (N <= 8192) return launch_fps<1024, 8>(xyz, B, N, npoint, idx_out, s);
