@@ -41,8 +41,8 @@ __device__ __forceinline__ float lane_bcast(float v, int src_lane) {
 // the squared distances are formed two points at a time with packed fp32 instructions (v_pk_add / v_pk_mul: the same
 // IEEE operations, no FMA) — 8 instead of 15 vector-ALU instructions per point. It is every instruction of this
 // kernel, not its 0.4 ms, that the pipelined step pays for: the FPS of the next batch runs beside the MFMA kernels
-// and costs them 0.14 ms per step (scripts/fps_interference_probe.py, fps_vs_pair_probe.py). LX needs 12 N bytes of
-// LDS: clouds up to 4096 points; larger ones keep the coordinates in the selects.
+// and costs them 0.14 ms per step (scripts/fps_interference_probe.py, fps_vs_pair_probe.py; 0.07 with LX). LX needs
+// 12 N bytes of LDS beside the index buffer: clouds up to ~4096 points; larger ones keep the coordinates in the selects.
 typedef float fps_f2 __attribute__((ext_vector_type(2)));
 
 template <int T, int P, bool LX>
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
 template <int T, int P>
 static int launch_fps(const float* xyz, int B, int N, int npoint, int32_t* idx, hipStream_t s) {
     const size_t sel_bytes = (size_t)((npoint + 3) & ~3) * sizeof(int);
-    if (N <= 4096 && !dev_switches().fps_plain) {          // 12 N + 4 npoint <= 64 KB: no LDS attribute needed
+    if (sel_bytes + (size_t)N * 12 + 1024 <= 65536 && !dev_switches().fps_plain) {   // fits the default 64 KB with the slots
         hipLaunchKernelGGL((fps_kernel<T, P, true>), dim3(B), dim3(T), sel_bytes + (size_t)N * 12, s, xyz, N, npoint, idx);
         return check_launch("fps_kernel");
     }

@@ -26,7 +26,8 @@ def _clouds(seed, B, N, kind="car", K=None, zero=0):
 
 
 @pytest.mark.parametrize("N,npoint", [(64, 32), (128, 64), (200, 77), (256, 256), (512, 256), (1024, 512),
-                                      (2048, 512), (4096, 1024), (8192, 512), (16384, 64)])
+                                      (2048, 512), (4096, 1024), (8192, 512), (16384, 64),
+                                      (4096, 4096), (3000, 2500), (4096, 3800)])   # index buffer + cloud copy around the 64 KB LDS line
 def test_fps_matches_oracle(dev, N, npoint):
     xyz = _clouds(N, 3, N)
     got = ops.furthest_point_sampling(_dev(xyz, dev), npoint).cpu().numpy()
