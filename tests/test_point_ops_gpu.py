@@ -221,3 +221,19 @@ def test_centres_ball_query_equals_the_two_kernels(dev, N, M, ns, with_sel):
     assert torch.equal(new_a, new_b) and torch.equal(idx_a, idx_b)
     assert (i64_a is None and i64_b is None) or torch.equal(i64_a, i64_b)
     np.testing.assert_array_equal(idx_b.cpu().numpy(), O.ball_query(new_b.cpu().numpy(), xyz, 0.4, ns))
+
+
+def test_empty_batches_and_empty_sample_sets_are_no_ops(dev):
+    """B = 0 (a rank whose shard is empty) and npoint / M = 0: every op returns a tensor of the right (empty) shape and
+    launches nothing — the reference's ops behave the same way on empty inputs."""
+    e = torch.zeros((0, 64, 3), device=dev)
+    assert tuple(ops.furthest_point_sampling(e, 16).shape) == (0, 16)
+    assert tuple(ops.ball_query(torch.zeros((0, 8, 3), device=dev), e, 0.3, 4).shape) == (0, 8, 4)
+    assert tuple(ops.knn(e, 16).shape) == (0, 64, 16)
+    new_xyz, i64, idx = ops.centres_ball_query(e, None, 8, 0.3, 4)
+    assert tuple(new_xyz.shape) == (0, 8, 3) and tuple(idx.shape) == (0, 8, 4)
+    x = torch.from_numpy(_clouds(3, 2, 64)).to(dev)
+    assert tuple(ops.furthest_point_sampling(x, 0).shape) == (2, 0)
+    assert tuple(ops.ball_query(x[:, :0].contiguous(), x, 0.3, 4).shape) == (2, 0, 4)
+    assert tuple(ops.linear(torch.zeros((0, 32), device=dev), ops.pack_weight(torch.randn(64, 32, device=dev)), 64).shape) == (0, 64)
+    torch.cuda.synchronize()
