@@ -18,6 +18,9 @@
 //   * C/D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
 //     a tile's 32 rows are the neighbours of one centre (or of two, 16 each), so max-pool
 //     and the softmax over neighbours are register-local plus one lane^32 exchange.
+// Two kernels leave that common structure (round 2): sa_stream_kernel keeps everything that is not a GEMM inside the
+// waves' own MFMA streams (persistent workgroups, two LDS tiles), and sa_lds_kernel chains its layers through the
+// accumulator layout itself (transposed products, activations never leave the registers). DESIGN.md lessons 8, 12-14.
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -33,8 +36,8 @@
 #define PTT_SA_WAVES 2
 #endif
 // GEMM loop flavours (gemm_core's PF): 0 = two register sets pinned with sched_barrier (best for the SA
-// chain, measured), 1 = one-block prefetch scheduled by hipcc (best for the pair kernel and the linear
-// layers), 2 = two blocks in flight (slower everywhere: the L2->CU path saturates).
+// chains and the linear kernel, measured), 1 = one-block prefetch scheduled by hipcc (best for the pair
+// kernel), 2 = two blocks in flight (slower everywhere: the L2->CU path saturates).
 
 namespace ptt {
 
