@@ -95,6 +95,20 @@ def main():
                 print("%-14s %8.4f ms  %7.2f TFLOP/s" % (name + "_sg%d" % sg, ms, fl / ms / 1e9))
             os.environ.pop("PTT_SA_STAGGER")
 
+    # ---- CosineSimAug core (N1): cosine map + fused layer chain, 128 search x 64 template seeds ----
+    if want("xcorr"):
+        raw = mlp_layers(5, [260, 256, 256, 256])
+        layers = fold_layers(raw[1:], dev, ops, scale_in_weights=True)
+        sf = torch.randn(B, 128, 256, device=dev).transpose(1, 2)
+        tf = torch.randn(B, 64, 256, device=dev).transpose(1, 2)
+        Pm = torch.randn(B, 64, 256, device=dev)
+        wsim = torch.randn(256, device=dev)
+        cos_t = ops.cosine_map(sf, tf)
+        fn = lambda: ops.xcorr_fused(sf, tf, Pm, wsim, None, None, layers, cos_t=cos_t)
+        ms = timeit(fn, a.iters)
+        fl = 2.0 * B * 128 * 64 * 2 * 256 * 256
+        print("%-14s %8.4f ms  %7.2f TFLOP/s   (cosine map %.4f ms)" % ("xcorr", ms, fl / ms / 1e9, timeit(lambda: ops.cosine_map(sf, tf), a.iters)))
+
     # ---- linear ----
     for name, rows, K, Cout in (("lin_qkvf", B * 128, 256, 1536), ("lin_qkvf64", B * 64, 256, 1536), ("lin_fc1", B * 128, 256, 512), ("lin_qkv", B * 128, 512, 1536), ("lin_fc2", B * 128, 512, 256),
                                 ("lin_cov", B * 128, 256, 256), ("lin_qkv64", B * 64, 512, 1536), ("lin_fc2_64", B * 64, 512, 256)):

@@ -183,6 +183,27 @@ def test_transformer_pair_kernel(dev, N, B):
     np.testing.assert_array_equal(res2.cpu().numpy(), res.cpu().numpy())
 
 
+@pytest.mark.parametrize("B,C,Ns,Nt,point_major", [(3, 256, 128, 64, True), (2, 256, 37, 70, False), (2, 300, 5, 130, True),
+                                                   (1, 20, 9, 3, False)])
+def test_cosine_map_equals_torch_cosine_similarity(dev, B, C, Ns, Nt, point_major):
+    """ptt_cosine_map_f32 = F.cosine_similarity of every (search, template) feature pair (p2b_xcoor.py:35-36), for both
+    memory layouts the features arrive in, odd search / template counts and channel counts; an all-zero feature row (norm
+    clamped at eps) gives 0."""
+    rs = np.random.RandomState(C + Ns)
+    sf = torch.from_numpy(rs.standard_normal((B, C, Ns)).astype(np.float32))
+    tf = torch.from_numpy(rs.standard_normal((B, C, Nt)).astype(np.float32))
+    tf[0, :, 0] = 0.0
+    ref = F.cosine_similarity(sf[:, :, :, None], tf[:, :, None, :], dim=1, eps=1e-8)          # (B,Ns,Nt)
+    if point_major:
+        sd, td = sf.transpose(1, 2).contiguous().to(dev).transpose(1, 2), tf.transpose(1, 2).contiguous().to(dev).transpose(1, 2)
+    else:
+        sd, td = sf.to(dev), tf.to(dev)
+    got = ops.cosine_map(sd, td, eps=1e-8)
+    assert tuple(got.shape) == (B, Ns, Nt)
+    np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), atol=2e-6, rtol=1e-5)
+    assert float(got[0, :, 0].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("n1,n2", [(128, 96), (192, 64), (512, 40)])
 def test_cosine_sim_aug_fused_for_other_template_sizes(dev, n1, n2):
     """The fused CosineSimAug kernel walks the template seeds in chunks of 64 (BASELINE configs[4] leaves 512 of them):
