@@ -23,7 +23,7 @@ static inline hipStream_t as_stream(ptt_stream_t s) { return reinterpret_cast<hi
 struct DevSwitches {
     int linear_rt = 1, linear_ct = 1;    // PTT_LINEAR_TILE="11|12|21|22"
     int sa_gather1 = 0;                  // PTT_SA_GATHER1: one row per gather instruction
-    int sa_stagger = 2;                  // PTT_SA_STAGGER
+    int sa_stagger = 0;                  // PTT_SA_STAGGER (quanta of ~8k cycles the second co-resident workgroup starts late)
     int sa_wave = 1;                     // PTT_SA_WAVE=0: column-split kernel for small-weight levels
     int sa_rt = 2;                       // PTT_SA_RT=1: 32-row workgroups
     int sa_lds = 1;                      // PTT_SA_LDS=0: SA0 on sa_wave_kernel instead of sa_lds_kernel
@@ -32,7 +32,7 @@ struct DevSwitches {
                                          // Measured (profiles/r02d): 2, 3, 4, 6 and 12 tiles per workgroup run the
                                          // kernel equally fast; short chunks leave CU slots for the concurrent FPS /
                                          // template-branch kernels of the graphed step (3.26 vs 3.29 ms per step)
-    int pair_stagger = 8;                // PTT_PAIR_STAGGER
+    int pair_stagger = 0;                // PTT_PAIR_STAGGER (round 1: 8 was +3 %; with the round-2 kernels 0 is 0.9 % faster, alone and in the step)
     int pair_lds_pad = 0;                // PTT_PAIR_LDS_PAD: extra LDS bytes (forces one workgroup per CU)
     int sa_lds_chunk = 2;                // PTT_SA_LDS_CHUNK=n: at most n centres per wave of sa_lds_kernel (0: one pass)
     int fps_plain = 0;                   // PTT_FPS_PLAIN=1: coordinates carried through the selects for every cloud size
