@@ -84,7 +84,7 @@ def parse_args():
                     help="do not overlap the FPS of batch n+1 with the dense kernels of batch n")
     ap.add_argument("--ways", type=int, default=0,
                     help="independent batches in flight (InterleavedHotPath: that many pipelined graphs on their own "
-                         "streams, replayed round-robin); 1 = a single pipelined graph; 0 = 2 for clouds up to 4096 points, "
+                         "streams, replayed round-robin); 1 = a single pipelined graph; 0 = 3 for clouds up to 4096 points, "
                          "1 above (the long FPS chains of two 16384-point batches compete: measured 1147 vs 1177 frames/s)")
     ap.add_argument("--cpu-frames", type=int, default=8)
     return ap.parse_args()
@@ -223,7 +223,7 @@ def main():
     B = args.batch or W["batch"]
     NS, NT = args.ns or W["ns"], args.nt or W["nt"]
     if args.ways <= 0:
-        args.ways = 2 if NS <= 4096 else 1
+        args.ways = 3 if NS <= 4096 else 1
     s_np, t_np = synth.frames(1000 + rank, B, NS, NT, K_s=min(W["K_s"], NS), K_t=min(W["K_t"], NT), kind=W["kind"],
                               zero_clouds=W["zero"])
 
