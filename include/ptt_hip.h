@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PTT_ABI_VERSION 12
+#define PTT_ABI_VERSION 13
 
 enum {
     PTT_OK = 0,
@@ -462,6 +462,36 @@ int ptt_linear_batched_f32(const float* X, int rows, int K, int ldx, int64_t x_b
                            const float* residual, int ldr, int64_t r_batch_stride, float* out, int ldo,
                            int64_t o_batch_stride, int batch, ptt_stream_t stream);
 int ptt_softmax_rows_f32(float* X, int64_t rows, int n, int ld, float scale, ptt_stream_t stream);
+
+/* ---------------------------------------------------------------------------------
+ * N3  the row GEMMs of the training step at 10^4 - 10^6 rows (round 3): a persistent, software-pipelined form of
+ * ptt_linear_f32 / ptt_linear_wgrad_f32 for the forward, input-gradient and weight-gradient GEMMs of every 1x1
+ * convolution and nn.Linear the training step runs over (centre, neighbour) / (point, neighbour) rows:
+ *   SharedMLP convolutions and their backward      pytorch_utils.py:12-36 (loss.backward(): tools/train_utils/train_utils.py:47-48)
+ *   TransformerBlock fc1, w_qs/w_ks/w_vs, fc_delta[2], fc_gamma[0], fc_gamma[2], fc2       transformer_block/variants.py:154-165
+ *   the Conv1d stacks of the heads                 voting_heads/centroids_voting_head.py:15-21, box_voting_head.py:25
+ * ptt_rows_gemm_f32:  out[r, :] = relu?( act_in(X[r, :]) . W^T + bias ) (+ residual[r, :]),  act_in(x) = relu(x * in_scale + in_shift)
+ *   when in_scale / in_shift are given (the producing layer's BatchNorm + ReLU, never materialised), else x.
+ *   Wpacked from ptt_pack_weight_f32 (Cout = N, K). Needs K % 64 == 0, N % 64 == 0, ldx % 4 == 0, 16-byte aligned X
+ *   (ptt_rows_gemm_supported says so; otherwise use ptt_linear_f32).
+ *   stats != NULL (then bias must be NULL): also the per-channel sums and sums of squares of `out` over the rows — the
+ *   BatchNorm batch statistics of a convolution output without a second pass over it — as float64 partials
+ *   stats[chunk][2][N], chunk < ptt_rows_gemm_stat_chunks(rows, K, N) (a pure function of the shape: the summation order
+ *   is fixed); ptt_bn_finish_partials_f32 / ptt_bn_sums_partials_f64 combine them in chunk order.
+ * ptt_linear_wgrad2_f32: ptt_linear_wgrad_f32 with up to 256 x 256 outputs per workgroup (every operand row read once);
+ *   needs R >= 2048, Cout % 128 == 0, Cin % 128 == 0; same partial-sum scheme (fixed order), own workspace size. */
+int ptt_rows_gemm_supported(int rows, int K, int N, int ldx, int ldo);
+int ptt_rows_gemm_stat_chunks(int rows, int K, int N);
+int ptt_rows_gemm_f32(const float* X, int rows, int K, int ldx, const float* in_scale, const float* in_shift,
+                      const float* Wpacked, int N, const float* bias, int relu, const float* residual, int ldr,
+                      float* out, int ldo, double* stats, size_t stats_elems, ptt_stream_t stream);
+int ptt_bn_finish_partials_f32(const double* partial, int chunks, int C, int R, float eps, float* mean, float* var, float* invstd,
+                               ptt_stream_t stream);
+int ptt_bn_sums_partials_f64(const double* partial, int chunks, int C, int R, double* sums, ptt_stream_t stream);
+size_t ptt_linear_wgrad2_workspace(int R, int Cout, int Cin);
+int ptt_linear_wgrad2_f32(const float* dZ, int ldz, const float* X, int ldx, int R, int Cout, int Cin, float* dW,
+                          int accumulate, void* workspace, size_t workspace_bytes, const float* x_scale, const float* x_shift,
+                          ptt_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libptt_hip.so")
 
 PTT_SA_MAX_LAYERS = 4
-ABI_VERSION = 12            # PTT_ABI_VERSION of include/ptt_hip.h these structures mirror
+ABI_VERSION = 13            # PTT_ABI_VERSION of include/ptt_hip.h these structures mirror
 
 # every symbol include/ptt_hip.h declares (tests check the library exports all of them)
 EXPORTS = [
@@ -30,6 +30,8 @@ EXPORTS = [
     "ptt_centres_ball_query_f32",
     "ptt_bn_sums_f64", "ptt_bn_finish_f64", "ptt_bn_bwd_sums_f64", "ptt_bn_bwd_apply_f32",
     "ptt_rows_mlp_f32",
+    "ptt_rows_gemm_supported", "ptt_rows_gemm_stat_chunks", "ptt_rows_gemm_f32", "ptt_bn_finish_partials_f32",
+    "ptt_bn_sums_partials_f64", "ptt_linear_wgrad2_workspace", "ptt_linear_wgrad2_f32",
 ]
 PTT_MAX_SEGMENTS = 4
 
@@ -136,6 +138,12 @@ def _declare(lib):
         "ptt_pt_pair_input_f32": [vp, vp, vp, vp, i, i, i, i, vp, vp],
         "ptt_pt_attn_train_fwd_f32": [vp, vp, vp, vp, i, i, i, i, f, vp, vp, vp],
         "ptt_pt_attn_train_bwd_f32": [vp, vp, vp, vp, vp, i, i, i, i, f, vp, vp, vp],
+        "ptt_rows_gemm_supported": [i, i, i, i, i],
+        "ptt_rows_gemm_stat_chunks": [i, i, i],
+        "ptt_rows_gemm_f32": [vp, i, i, i, vp, vp, vp, i, vp, i, vp, i, vp, i, vp, c_size_t, vp],
+        "ptt_bn_finish_partials_f32": [vp, i, i, i, f, vp, vp, vp, vp],
+        "ptt_bn_sums_partials_f64": [vp, i, i, i, vp, vp],
+        "ptt_linear_wgrad2_f32": [vp, i, vp, i, i, i, i, vp, i, vp, c_size_t, vp, vp, vp],
     }
     for name, args in sigs.items():
         fn = getattr(lib, name)
@@ -149,6 +157,8 @@ def _declare(lib):
     lib.ptt_bn_stats_workspace.argtypes = [i, i]
     lib.ptt_linear_wgrad_workspace.restype = c_size_t
     lib.ptt_linear_wgrad_workspace.argtypes = [i, i, i]
+    lib.ptt_linear_wgrad2_workspace.restype = c_size_t
+    lib.ptt_linear_wgrad2_workspace.argtypes = [i, i, i]
 
 
 def lib():

@@ -1,0 +1,555 @@
+// Row GEMMs of the TRAINING step (N3) on exact-fp32 MFMA, gfx950:
+//   rows_gemm_kernel   Y[R, N] = act_in(X)[R, K] . W^T (+ bias, ReLU, residual; optional column statistics of Y)
+//                      forward and input gradient of every 1x1 convolution / nn.Linear over 10^4 - 10^6 rows
+//                      (pytorch_utils.py:12-36 SharedMLP, transformer_block/variants.py:154-165, voting heads)
+//   wgrad2_kernel      dW[N, K] = dZ^T[N, R] . X[R, K]      the weight gradients of the same layers
+// The inference linear kernel (mfma_ops.hip: linear_kernel) launches one short-lived workgroup per 32-row tile: fetch,
+// barrier, GEMM, epilogue in sequence, overlap only between the two workgroups of a CU. At 10^5 rows that leaves the
+// matrix pipe 35-45 % idle (35-112 TFLOP/s against hipBLASLt's 55-138 on the same shapes, scripts/rows_gemm_bench.py).
+// Here a PERSISTENT workgroup walks (row tile, K chunk) units: the global loads of unit u+1 are issued before unit u's
+// first MFMAs and written to the other LDS buffer inside the second half of unit u's MFMA stream (with the deferred
+// BatchNorm+ReLU of the producing layer applied in registers on the way), weight fragments stream from L2 two K-blocks
+// ahead and across unit boundaries, ONE workgroup barrier per unit (LDS traffic only: global loads stay in flight across
+// it). Same operand layouts as mfma_ops.hip: packed weights [K/8][N/32][64 lanes][4], LDS row stride == 4 (mod 8) floats.
+#include <math.h>
+#include <stdlib.h>
+#include <type_traits>
+#include "common.h"
+
+namespace ptt {
+
+typedef float g32x16 __attribute__((ext_vector_type(16)));
+typedef float g32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t g_rsrc(const void* p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);   // raw, 32-bit offsets
+}
+__device__ __forceinline__ g32x4 g_load4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(g32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ float g_load1(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ void g_store1(float v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, voff, soff, 0);
+}
+// workgroup barrier that orders LDS traffic only (global loads / stores stay in flight across it)
+__device__ __forceinline__ void g_lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ int g_tile_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
+// lane <-> lane^32 sum on v_permlane32_swap (inline asm: hipcc folds the builtin when both operands are equal)
+__device__ __forceinline__ float g_add_halves(float v) {
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+// the dispatcher places block b on XCD b % 8: consecutive LOGICAL blocks share an XCD (and its L2)
+__device__ __forceinline__ int g_logical_block() {
+    const int bid = blockIdx.x, per = (int)gridDim.x >> 3;
+    if (bid >= (per << 3)) return bid;
+    return (bid & 7) * per + (bid >> 3);
+}
+
+}  // namespace
+
+struct RowsGemmParams {
+    const float* X; const float* Wp; const float* bias; const float* residual; float* out;
+    const float* in_a; const float* in_b;       // optional x <- relu(x * in_a[k] + in_b[k]) while the A operand is staged
+    double* stats;                              // optional [chunks][2][N] partial column sums / sums of squares of Y
+    int rows, K, ldx, N, NT, relu, ldr, ldo, ntiles, G, ncg, nchunks;
+};
+
+// WR x WC waves (WR * WC = 4): wave (wr, wc) owns row tiles wr*RT .. wr*RT+RT-1 of the workgroup's 32*RT*WR rows and the
+// column tiles cg*WC*CT + wc + WC*u, u < CT, of its column group; KC input channels per staged chunk.
+// EXP (timing experiments of a -DPTT_GEMM_DEV build only, wrong results): 1 no output stores, 2 no row fetch / staging,
+// 4 every weight fragment from K-block 0 (L1-resident), 8 no barriers
+#ifndef PTT_RG_PD
+#define PTT_RG_PD 3          // weight fragments requested this many K-blocks ahead
+#endif
+template <int WR, int RT, int CT, int KC, bool STATS, bool ACT, int EXP = 0>
+__global__ __launch_bounds__(256, 2) void rows_gemm_kernel(RowsGemmParams p) {
+    constexpr int WC = 4 / WR, TR = 32 * RT * WR, NKB = KC / 8, LDK = KC + 4, BUF = TR * LDK, QPR = KC / 4;
+    constexpr int SLOTS = TR * QPR / 256, PD = PTT_RG_PD;
+    constexpr int WI = SLOTS < NKB / 2 ? SLOTS : NKB / 2;       // K-blocks (the last ones of a unit) that carry a staging piece
+    constexpr int PIECES = SLOTS / WI;
+    static_assert(SLOTS % WI == 0 && PIECES >= 1 && PD >= 1 && PD <= NKB, "unit shape");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int t = threadIdx.x, lane = t & 63, half = lane >> 5, col = lane & 31;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wr = w / WC, wc = w % WC;
+    const int lb = g_logical_block();
+    const int cg = lb % p.ncg, g = lb / p.ncg;
+    if (g >= p.ntiles) return;
+    const int ntw = (p.ntiles - g + p.G - 1) / p.G;             // this workgroup's tiles: g, g + G, ...
+    const int nunits = ntw * p.nchunks;
+
+    // X through a descriptor whose size ends with the last row: rows past the end read as zeros (the row part of an
+    // address is in the VGPR offset, which the range check covers; the chunk part in the scalar offset never leaves a row)
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0,
+                                                                         ((p.rows - 1) * p.ldx + p.K) * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = g_rsrc(p.Wp), ro = g_rsrc(p.out);
+    const int ct0 = cg * (WC * CT) + wc;
+    const int wvoff = (ct0 * 64 + lane) * 16;                   // this lane's byte offset inside a K-block row of fragments
+    const int wkstep = p.NT * 1024;                             // bytes per K-block of the packed weights
+    // staging slots of this thread: slot i = float4 (row r0 + i * RSTEP, channel quad q) of the unit's [TR][KC] block
+    constexpr int RSTEP = 256 / QPR;
+    const int q = t % QPR, r0 = t / QPR;
+    const int lds_slot = (r0 * LDK + 4 * q);                    // + i * RSTEP * LDK floats
+    const int ldx4 = p.ldx * 4;
+    const int slot_off = r0 * ldx4 + q * 16;                    // + i * RSTEP * ldx4 + tile * TR * ldx4 bytes
+    const int tile_bytes = TR * ldx4;
+
+    g32x16 acc[RT][CT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int u = 0; u < CT; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[rt][u][r] = 0.f;
+    double dsum[CT], dsq[CT];
+#pragma unroll
+    for (int u = 0; u < CT; ++u) { dsum[u] = 0.0; dsq[u] = 0.0; }
+
+    g32x4 st[SLOTS];
+    g32x4 ta = {1.f, 1.f, 1.f, 1.f}, tb = {0.f, 0.f, 0.f, 0.f};
+    auto fetch = [&](int tile, int c) {
+        // tiles past the last one (the prefetch of the final unit): any offset beyond the descriptor reads zeros
+        const int tb_off = (tile < p.ntiles ? tile : p.ntiles) * tile_bytes + slot_off;
+#pragma unroll
+        for (int i = 0; i < SLOTS; ++i) st[i] = g_load4(rx, tb_off + i * (RSTEP * ldx4), c * (KC * 4));
+        if (ACT) {
+            ta = *reinterpret_cast<const g32x4*>(p.in_a + c * KC + 4 * q);
+            tb = *reinterpret_cast<const g32x4*>(p.in_b + c * KC + 4 * q);
+        }
+    };
+    auto stage = [&](float* buf, int i) {                       // deferred BatchNorm + ReLU of the producing layer, LDS write
+        g32x4 v = st[i];
+        if (ACT) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = fmaxf(__builtin_fmaf(v[k], ta[k], tb[k]), 0.f);
+        }
+        *reinterpret_cast<g32x4*>(buf + lds_slot + i * (RSTEP * LDK)) = v;
+    };
+
+    // bias / ReLU branch-free: a missing bias reads any valid address and is replaced by 0, no ReLU = floor -inf
+    const bool has_bias = p.bias != nullptr;
+    const __amdgpu_buffer_rsrc_t rb = g_rsrc(has_bias ? p.bias : p.Wp), rr = g_rsrc(p.residual ? p.residual : p.X);
+    const float rfloor = p.relu ? 0.f : -__builtin_inff();
+    auto epilogue = [&](int row_w, auto full_c, auto res_c) {
+        constexpr bool FULL = decltype(full_c)::value, RES = decltype(res_c)::value;
+#pragma unroll
+        for (int u = 0; u < CT; ++u) {
+            const int cn = (ct0 + u * WC) * 32 + col;
+            const float bl = g_load1(rb, cn * 4, 0);
+            const float bv = has_bias ? bl : 0.f;
+            const int obase = ((row_w + 4 * half) * p.ldo + cn) * 4, rbase = ((row_w + 4 * half) * p.ldr + cn) * 4;
+            float s = 0.f, sq = 0.f;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                float rv[16];
+                if (RES) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int dr = rt * 32 + (r & 3) + 8 * (r >> 2);
+                        const int grc = FULL ? 0 : ((row_w + 4 * half + dr < p.rows) ? 0 : (p.rows - 1 - (row_w + 4 * half + dr)));
+                        rv[r] = g_load1(rr, rbase + (dr + grc) * (p.ldr * 4), 0);      // rows past the end: clamped, never stored
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int dr = rt * 32 + (r & 3) + 8 * (r >> 2);
+                    const bool in = FULL || row_w + 4 * half + dr < p.rows;
+                    float y = acc[rt][u][r] + bv;
+                    if (STATS) {                                // rows past the end: relu(shift) . W with a deferred activation
+                        const float ys = (FULL || !ACT || in) ? y : 0.f;
+                        s += ys; sq = __builtin_fmaf(ys, ys, sq);
+                    }
+                    y = fmaxf(y, rfloor);
+                    if (RES) y += rv[r];
+                    if (!(EXP & 1) || r == 15)
+                        if (in) g_store1(y, ro, obase + dr * (p.ldo * 4), 0);
+                    acc[rt][u][r] = 0.f;
+                }
+            }
+            if (STATS) {
+                dsum[u] += (double)g_add_halves(s);
+                dsq[u] += (double)g_add_halves(sq);
+            }
+        }
+    };
+
+    // ---- prologue: the first unit is staged in the open ----
+    int tile = g, c = 0;
+    fetch(tile, c);
+    g32x4 wq[PD][CT];                                           // the weights of the current unit's first PD K-blocks
+#pragma unroll
+    for (int k = 0; k < PD; ++k)
+#pragma unroll
+        for (int u = 0; u < CT; ++u) wq[k][u] = g_load4(rw, wvoff, k * wkstep + u * (WC * 1024));
+#pragma unroll
+    for (int i = 0; i < SLOTS; ++i) stage(smem, i);
+    g_lds_barrier();
+
+    for (int un = 0; un < nunits; ++un) {
+        int c_n = c + 1, tile_n = tile;
+        if (c_n == p.nchunks) { c_n = 0; tile_n = tile + p.G; }
+        float* cur = smem + (un & 1) * BUF;
+        float* nxt = smem + ((un + 1) & 1) * BUF;
+        const int wk_cur = c * (NKB * wkstep), wk_nxt = c_n * (NKB * wkstep);
+        const float* arow = cur + (wr * RT * 32 + (lane & 31)) * LDK + 4 * half;
+        g32x4 av[2][RT];
+        g32x4 wv[NKB + PD][CT];
+#pragma unroll
+        for (int k = 0; k < PD; ++k)
+#pragma unroll
+            for (int u = 0; u < CT; ++u) wv[k][u] = wq[k][u];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) av[0][rt] = *reinterpret_cast<const g32x4*>(arow + rt * 32 * LDK);
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            {   // weight fragments PD K-blocks ahead; past the end of this unit they are the next unit's first ones
+                const int kq = kb + PD;
+                const int base = (EXP & 4) ? 0 : (kq < NKB ? wk_cur + kq * wkstep : wk_nxt + (kq - NKB) * wkstep);
+#pragma unroll
+                for (int u = 0; u < CT; ++u) wv[kq][u] = g_load4(rw, wvoff, base + u * (WC * 1024));
+            }
+            if (kb + 1 < NKB) {
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+                    av[(kb + 1) & 1][rt] = *reinterpret_cast<const g32x4*>(arow + rt * 32 * LDK + (kb + 1) * 8);
+            }
+            if (kb == 0 && !(EXP & 2)) fetch(tile_n, c_n);      // the next unit's rows: in flight under this unit's MFMAs
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int u = 0; u < CT; ++u)
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt)
+                        acc[rt][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kb & 1][rt][j], wv[kb][u][j], acc[rt][u], 0, 0, 0);
+            if (kb >= NKB - WI && !(EXP & 2)) {                 // the tail of the stream: the row loads have landed
+#pragma unroll
+                for (int k = 0; k < PIECES; ++k) stage(nxt, (kb - (NKB - WI)) * PIECES + k);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int k = 0; k < PD; ++k)
+#pragma unroll
+            for (int u = 0; u < CT; ++u) wq[k][u] = wv[NKB + k][u];
+        if (c == p.nchunks - 1) {
+            // ---- epilogue of a row tile (in the open: the co-resident workgroup owns the matrix pipe meanwhile) ----
+            const int row_w = tile * TR + wr * RT * 32;
+            if (row_w + RT * 32 <= p.rows) {
+                if (p.residual) epilogue(row_w, std::true_type(), std::true_type());
+                else epilogue(row_w, std::true_type(), std::false_type());
+            } else {
+                if (p.residual) epilogue(row_w, std::false_type(), std::true_type());
+                else epilogue(row_w, std::false_type(), std::false_type());
+            }
+        }
+        if (!(EXP & 8)) g_lds_barrier();
+        tile = tile_n; c = c_n;
+    }
+    if (STATS && half == 0) {
+        double* sp = p.stats + (size_t)(g * WR + wr) * 2 * p.N;
+#pragma unroll
+        for (int u = 0; u < CT; ++u) {
+            const int cn = (ct0 + u * WC) * 32 + col;
+            sp[cn] = dsum[u];
+            sp[p.N + cn] = dsq[u];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Weight gradient dW[o, i] = sum_r dZ[r, o] * X[r, i]: the reduction axis is the ROW axis. linear_wgrad_kernel
+// (train_ops.hip) gives a workgroup a 128 x 128 output block, so a 256 x 256 gradient reads both operands twice
+// (32 flop per byte: HBM-bound at ~half the matrix peak). Here 8 waves own up to 256 x 256 outputs (wave tile
+// 128 x 64 = 8 accumulator tiles), each operand row is read once, 32-row sub-chunks double-buffered in LDS (one
+// barrier each). Partials per row chunk go to the workspace and are summed in chunk order by wgrad_finish_kernel.
+// ------------------------------------------------------------------------------------------
+template <int TN, int TK>   // wave tile (32 TN) x (32 TK); waves 2 (N) x 4 (K); block BN = 64 TN, BK = 128 TK
+__global__ __launch_bounds__(512, 1) void wgrad2_kernel(const float* __restrict__ dZ, int ldz, const float* __restrict__ X, int ldx,
+                                                       int R, int Cout, int Cin, int nbk, int chunk_rows,
+                                                       float* __restrict__ partial, const float* __restrict__ xa,
+                                                       const float* __restrict__ xb) {
+    constexpr int BN = 64 * TN, BK = 128 * TK, LDA = BN + 4, LDB = BK + 4, RS = 32;
+    constexpr int QA = BN / 4, QB = BK / 4, SA = RS * QA / 512, SB = RS * QB / 512;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const As = smem;                         // [2][RS][LDA]
+    float* const Bs = smem + 2 * RS * LDA;          // [2][RS][LDB]
+    const int t = threadIdx.x, lane = t & 63, half = lane >> 5, col = lane & 31;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6), wn = w >> 2, wk = w & 3;
+    const int bo = blockIdx.x / nbk, bi = blockIdx.x - bo * nbk;
+    const int o0 = bo * BN, i0 = bi * BK;
+    const int r_begin = blockIdx.y * chunk_rows, r_end = min(R, r_begin + chunk_rows);
+    const __amdgpu_buffer_rsrc_t rz = g_rsrc(dZ), rxx = g_rsrc(X);
+    const int qa = t % QA, ra = t / QA, qb = t % QB, rb = t / QB;
+    constexpr int RSA = 512 / QA, RSB = 512 / QB;
+    g32x4 ta = {1.f, 1.f, 1.f, 1.f}, tb = {0.f, 0.f, 0.f, 0.f};
+    if (xa) { ta = *reinterpret_cast<const g32x4*>(xa + i0 + 4 * qb); tb = *reinterpret_cast<const g32x4*>(xb + i0 + 4 * qb); }
+
+    g32x16 acc[TN][TK];
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TK; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    g32x4 sa[SA], sb[SB];
+    int va = 0, vb = 0;
+    auto fetch = [&](int rs0) {
+        va = 0; vb = 0;
+#pragma unroll
+        for (int i = 0; i < SA; ++i) {
+            const int row = rs0 + ra + i * RSA;
+            const int rc = row < r_end ? row : r_end - 1;
+            if (row < r_end) va |= 1 << i;
+            sa[i] = g_load4(rz, (rc * ldz + o0 + 4 * qa) * 4, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < SB; ++i) {
+            const int row = rs0 + rb + i * RSB;
+            const int rc = row < r_end ? row : r_end - 1;
+            if (row < r_end) vb |= 1 << i;
+            sb[i] = g_load4(rxx, (rc * ldx + i0 + 4 * qb) * 4, 0);
+        }
+    };
+    auto stage = [&](int buf) {
+        float* A = As + buf * (RS * LDA);
+        float* B = Bs + buf * (RS * LDB);
+#pragma unroll
+        for (int i = 0; i < SA; ++i) {
+            g32x4 v = sa[i];
+            if (!((va >> i) & 1)) v = g32x4{0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<g32x4*>(A + (ra + i * RSA) * LDA + 4 * qa) = v;
+        }
+#pragma unroll
+        for (int i = 0; i < SB; ++i) {
+            g32x4 v = sb[i];
+            if (xa) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = fmaxf(__builtin_fmaf(v[k], ta[k], tb[k]), 0.f);
+            }
+            if (!((vb >> i) & 1)) v = g32x4{0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<g32x4*>(B + (rb + i * RSB) * LDB + 4 * qb) = v;
+        }
+    };
+    fetch(r_begin);
+    stage(0);
+    __syncthreads();
+    int buf = 0;
+    for (int rs0 = r_begin; rs0 < r_end; rs0 += RS) {
+        fetch(rs0 + RS);                                        // past the end: clamped rows, zeroed by stage()
+        const float* A = As + buf * (RS * LDA) + half * LDA + wn * (32 * TN) + col;
+        const float* B = Bs + buf * (RS * LDB) + half * LDB + wk * (32 * TK) + col;
+#pragma unroll
+        for (int j = 0; j < RS / 2; ++j) {
+            float av[TN], bv[TK];
+#pragma unroll
+            for (int a = 0; a < TN; ++a) av[a] = A[2 * j * LDA + a * 32];
+#pragma unroll
+            for (int b = 0; b < TK; ++b) bv[b] = B[2 * j * LDB + b * 32];
+#pragma unroll
+            for (int a = 0; a < TN; ++a)
+#pragma unroll
+                for (int b = 0; b < TK; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+        }
+        stage(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    // C/D layout: column (input channel) = lane & 31, row (output channel) = (reg & 3) + 8 (reg >> 2) + 4 half
+    float* P = partial + (size_t)blockIdx.y * Cout * Cin;
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TK; ++b) {
+            const int ci = i0 + wk * (32 * TK) + b * 32 + col;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = o0 + wn * (32 * TN) + a * 32 + g_tile_row(r, half);
+                P[(size_t)co * Cin + ci] = acc[a][b][r];
+            }
+        }
+}
+
+// the fixed-order sum over row chunks (train_ops.hip)
+void launch_wgrad_finish(const float* partial, int nchunks, size_t n, int accumulate, float* dW, hipStream_t s);
+
+static int cu_count() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+            n = v;
+        else
+            n = 256;
+    }
+    return n;
+}
+
+// launch geometry of ptt_rows_gemm_f32 (shared by the workspace query)
+struct RowsGemmGeom { int WR, RT, CT, KC, TR, ncg, ntiles, G, chunks; bool ok; };
+static RowsGemmGeom rows_gemm_geom(int rows, int K, int N) {
+    RowsGemmGeom g{};
+    g.ok = false;
+    if (rows <= 0 || K <= 0 || N <= 0) return g;
+    if (N % 128 == 0 && K % 128 == 0) { g.WR = 1; g.RT = 2; g.CT = (N % 256 == 0) ? 2 : 1; g.KC = 128; }
+    else if (N % 128 == 0 && K % 64 == 0) { g.WR = 1; g.RT = 4; g.CT = 1; g.KC = 64; }
+    else if (N % 64 == 0 && K % 64 == 0) { g.WR = 2; g.RT = 2; g.CT = 1; g.KC = 64; }
+    else return g;
+    const int WC = 4 / g.WR;
+    g.TR = 32 * g.RT * g.WR;
+    g.ncg = N / (32 * WC * g.CT);
+    g.ntiles = (rows + g.TR - 1) / g.TR;
+    int cap = 2 * cu_count() / g.ncg;                   // two workgroups per CU resident
+    if (cap >= 8) cap &= ~7;
+    if (cap < 1) cap = 1;
+    g.G = g.ntiles < cap ? g.ntiles : cap;
+    g.chunks = g.G * g.WR;
+    g.ok = true;
+    return g;
+}
+
+}  // namespace ptt
+
+using namespace ptt;
+
+extern "C" int ptt_rows_gemm_supported(int rows, int K, int N, int ldx, int ldo) {
+    const RowsGemmGeom g = rows_gemm_geom(rows, K, N);
+    if (!g.ok) return 0;
+    if ((long long)rows * ldx >= (1LL << 29) || (long long)rows * ldo >= (1LL << 29) || (ldx & 3)) return 0;
+    return 1;
+}
+
+extern "C" int ptt_rows_gemm_stat_chunks(int rows, int K, int N) {
+    const RowsGemmGeom g = rows_gemm_geom(rows, K, N);
+    return g.ok ? g.chunks : 0;
+}
+
+extern "C" int ptt_rows_gemm_f32(const float* X, int rows, int K, int ldx, const float* in_scale, const float* in_shift,
+                                 const float* Wpacked, int N, const float* bias, int relu, const float* residual, int ldr,
+                                 float* out, int ldo, double* stats, size_t stats_elems, ptt_stream_t stream) {
+    if (rows < 0 || K <= 0 || N <= 0 || ldx < K || ldo < N || (residual && ldr < N))
+        return fail(PTT_EINVAL, "ptt_rows_gemm_f32: rows=%d K=%d N=%d ldx=%d ldo=%d ldr=%d", rows, K, N, ldx, ldo, ldr);
+    if (rows == 0) return PTT_OK;
+    if (!X || !Wpacked || !out) return fail(PTT_EINVAL, "ptt_rows_gemm_f32: null pointer");
+    if (!ptt_rows_gemm_supported(rows, K, N, ldx, ldo))
+        return fail(PTT_EUNSUPPORTED, "ptt_rows_gemm_f32: rows=%d K=%d N=%d ldx=%d (needs K %% 64 == 0, N %% 64 == 0, ldx %% 4 == 0, "
+                                      "rows * ld < 2^29)", rows, K, N, ldx);
+    if ((reinterpret_cast<uintptr_t>(X) & 15) || (in_scale && ((reinterpret_cast<uintptr_t>(in_scale) | reinterpret_cast<uintptr_t>(in_shift)) & 15)))
+        return fail(PTT_EINVAL, "ptt_rows_gemm_f32: X / in_scale / in_shift must be 16-byte aligned");
+    if ((in_scale == nullptr) != (in_shift == nullptr)) return fail(PTT_EINVAL, "ptt_rows_gemm_f32: in_scale and in_shift go together");
+    const RowsGemmGeom g = rows_gemm_geom(rows, K, N);
+    if (stats && (bias || stats_elems < (size_t)g.chunks * 2 * N))
+        return fail(PTT_EINVAL, "ptt_rows_gemm_f32: statistics need bias == NULL and %zu doubles of workspace", (size_t)g.chunks * 2 * N);
+    RowsGemmParams p;
+    p.X = X; p.Wp = Wpacked; p.bias = bias; p.residual = residual; p.out = out; p.in_a = in_scale; p.in_b = in_shift;
+    p.stats = stats; p.rows = rows; p.K = K; p.ldx = ldx; p.N = N; p.NT = N / 32; p.relu = relu; p.ldr = ldr; p.ldo = ldo;
+    p.ntiles = g.ntiles; p.G = g.G; p.ncg = g.ncg; p.nchunks = K / g.KC;
+    const int lds = 2 * g.TR * (g.KC + 4) * (int)sizeof(float);
+    const dim3 grid(g.G * g.ncg);
+    hipStream_t s = as_stream(stream);
+    int rc = PTT_OK;
+#ifdef PTT_GEMM_DEV
+    if (const char* e = getenv("PTT_RG_EXP")) {
+        const int x = atoi(e);
+        if (g.WR == 1 && g.RT == 2 && g.CT == 2 && g.KC == 128 && x && !in_scale) {
+#define PTT_RG_EXP_CASE(X)                                                                                              \
+            if (x == X) {                                                                                               \
+                if ((rc = set_lds_limit(reinterpret_cast<const void*>(rows_gemm_kernel<1, 2, 2, 128, false, false, X>), lds))) return rc; \
+                hipLaunchKernelGGL((rows_gemm_kernel<1, 2, 2, 128, false, false, X>), grid, dim3(256), lds, s, p);      \
+                return check_launch("rows_gemm_kernel(exp)");                                                           \
+            }
+            PTT_RG_EXP_CASE(1) PTT_RG_EXP_CASE(2) PTT_RG_EXP_CASE(3) PTT_RG_EXP_CASE(4) PTT_RG_EXP_CASE(7) PTT_RG_EXP_CASE(8) PTT_RG_EXP_CASE(15)
+#undef PTT_RG_EXP_CASE
+        }
+    }
+#endif
+#define PTT_RG_LAUNCH(WR_, RT_, CT_, KC_, ST_, AC_)                                                                     \
+    {                                                                                                                   \
+        if ((rc = set_lds_limit(reinterpret_cast<const void*>(rows_gemm_kernel<WR_, RT_, CT_, KC_, ST_, AC_>), lds))) return rc; \
+        hipLaunchKernelGGL((rows_gemm_kernel<WR_, RT_, CT_, KC_, ST_, AC_>), grid, dim3(256), lds, s, p);               \
+    }
+#define PTT_RG_CASE(WR_, RT_, CT_, KC_)                                                                                 \
+    if (g.WR == WR_ && g.RT == RT_ && g.CT == CT_ && g.KC == KC_) {                                                     \
+        if (stats && in_scale) PTT_RG_LAUNCH(WR_, RT_, CT_, KC_, true, true)                                            \
+        else if (stats) PTT_RG_LAUNCH(WR_, RT_, CT_, KC_, true, false)                                                  \
+        else if (in_scale) PTT_RG_LAUNCH(WR_, RT_, CT_, KC_, false, true)                                               \
+        else PTT_RG_LAUNCH(WR_, RT_, CT_, KC_, false, false)                                                            \
+    }
+    PTT_RG_CASE(1, 2, 2, 128) PTT_RG_CASE(1, 2, 1, 128) PTT_RG_CASE(1, 4, 1, 64) PTT_RG_CASE(2, 2, 1, 64)
+#undef PTT_RG_CASE
+#undef PTT_RG_LAUNCH
+    return check_launch("rows_gemm_kernel");
+}
+
+// ---- weight gradient, large blocks ----
+namespace ptt {
+struct Wgrad2Geom { int TN, TK, BN, BK, nbo, nbk, chunk_rows, nchunks; bool ok; };
+static Wgrad2Geom wgrad2_geom(int R, int Cout, int Cin) {
+    Wgrad2Geom g{};
+    g.ok = false;
+    if (R < 2048 || Cout % 128 || Cin % 128) return g;
+    // the largest block that still fills the chip with row chunks of >= 768 rows (one workgroup per CU, one round)
+    const int ncu = cu_count();
+    const int cand[4][2] = {{4, 2}, {4, 1}, {2, 2}, {2, 1}};
+    for (int k = 0; k < 4; ++k) {
+        const int TN = cand[k][0], TK = cand[k][1];
+        if (Cout % (64 * TN) || Cin % (128 * TK)) continue;
+        const int blocks = (Cout / (64 * TN)) * (Cin / (128 * TK));
+        if (blocks > ncu) continue;
+        int nch = ncu / blocks;                                 // floor: never a second round of workgroups
+        int rows = (R + nch - 1) / nch;
+        if (rows < 768) rows = 768;
+        rows = (rows + 31) & ~31;
+        const int nchunks = (R + rows - 1) / rows;
+        if (nchunks * blocks * 4 < ncu * 3 && k < 3) continue;  // under 3/4 of the CUs busy: try a smaller block
+        if (nchunks * blocks * 2 < ncu) break;                  // still under half: the 128 x 128-block kernel of round 2
+        g.TN = TN; g.TK = TK; g.BN = 64 * TN; g.BK = 128 * TK; g.nbo = Cout / g.BN; g.nbk = Cin / g.BK;
+        g.chunk_rows = rows; g.nchunks = nchunks; g.ok = true;
+        return g;
+    }
+    return g;
+}
+}  // namespace ptt
+
+extern "C" size_t ptt_linear_wgrad2_workspace(int R, int Cout, int Cin) {
+    const Wgrad2Geom g = wgrad2_geom(R, Cout, Cin);
+    return g.ok ? (size_t)g.nchunks * Cout * Cin * sizeof(float) : 0;
+}
+
+extern "C" int ptt_linear_wgrad2_f32(const float* dZ, int ldz, const float* X, int ldx, int R, int Cout, int Cin, float* dW,
+                                     int accumulate, void* ws, size_t ws_bytes, const float* x_scale, const float* x_shift,
+                                     ptt_stream_t stream) {
+    const Wgrad2Geom g = wgrad2_geom(R, Cout, Cin);
+    if (!g.ok || (ldz & 3) || (ldx & 3) || ((reinterpret_cast<uintptr_t>(dZ) | reinterpret_cast<uintptr_t>(X)) & 15) ||
+        (long long)R * ldz >= (1LL << 29) || (long long)R * ldx >= (1LL << 29))
+        return fail(PTT_EUNSUPPORTED, "ptt_linear_wgrad2_f32: R=%d Cout=%d Cin=%d ldz=%d ldx=%d (needs R >= 2048, Cout %% 128 == 0, "
+                                      "Cin %% 128 == 0, 16-byte aligned rows)", R, Cout, Cin, ldz, ldx);
+    if (ldz < Cout || ldx < Cin || !dZ || !X || !dW) return fail(PTT_EINVAL, "ptt_linear_wgrad2_f32: bad argument");
+    if (x_scale && (!x_shift || ((reinterpret_cast<uintptr_t>(x_scale) | reinterpret_cast<uintptr_t>(x_shift)) & 15)))
+        return fail(PTT_EINVAL, "ptt_linear_wgrad2_f32: the input transform needs 16-byte aligned scale / shift");
+    if (!ws || ws_bytes < ptt_linear_wgrad2_workspace(R, Cout, Cin)) return fail(PTT_EWORKSPACE, "ptt_linear_wgrad2_f32: workspace too small");
+    hipStream_t s = as_stream(stream);
+    const int lds = 2 * 32 * (g.BN + 4 + g.BK + 4) * (int)sizeof(float);
+    const dim3 grid(g.nbo * g.nbk, g.nchunks);
+    int rc = PTT_OK;
+#define PTT_WG2_CASE(TN_, TK_)                                                                                          \
+    if (g.TN == TN_ && g.TK == TK_) {                                                                                   \
+        if ((rc = set_lds_limit(reinterpret_cast<const void*>(wgrad2_kernel<TN_, TK_>), lds))) return rc;               \
+        hipLaunchKernelGGL((wgrad2_kernel<TN_, TK_>), grid, dim3(512), lds, s, dZ, ldz, X, ldx, R, Cout, Cin, g.nbk, g.chunk_rows, \
+                           static_cast<float*>(ws), x_scale, x_shift);                                                  \
+    }
+    PTT_WG2_CASE(4, 2) PTT_WG2_CASE(4, 1) PTT_WG2_CASE(2, 2) PTT_WG2_CASE(2, 1)
+#undef PTT_WG2_CASE
+    launch_wgrad_finish(static_cast<const float*>(ws), g.nchunks, (size_t)Cout * Cin, accumulate, dW, s);
+    return check_launch("wgrad2_kernel");
+}

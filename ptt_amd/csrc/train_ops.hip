@@ -652,6 +652,12 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
     }
 }
 
+void launch_wgrad_finish(const float* partial, int nchunks, size_t n, int accumulate, float* dW, hipStream_t s) {
+    int fgrid = (int)((n + 31) / 32);
+    if (fgrid > 4096) fgrid = 4096;
+    hipLaunchKernelGGL(wgrad_finish_kernel, dim3(fgrid), dim3(256), 0, s, partial, nchunks, n, accumulate, dW);
+}
+
 static inline int ew_grid(size_t total) {
     size_t g = (total + 255) / 256;
     return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
@@ -939,4 +945,19 @@ extern "C" int ptt_linear_wgrad_f32(const float* dZ, int ldz, const float* X, in
     if (fgrid > 4096) fgrid = 4096;
     hipLaunchKernelGGL(wgrad_finish_kernel, dim3(fgrid), dim3(256), 0, s, static_cast<const float*>(ws), nchunks, n, accumulate, dW);
     return check_launch("linear_wgrad_kernel");
+}
+
+extern "C" int ptt_bn_finish_partials_f32(const double* partial, int chunks, int C, int R, float eps, float* mean, float* var,
+                                          float* invstd, ptt_stream_t stream) {
+    if (chunks <= 0 || C <= 0 || R <= 0 || !partial || !mean || !var || !invstd)
+        return fail(PTT_EINVAL, "ptt_bn_finish_partials_f32: chunks=%d C=%d R=%d", chunks, C, R);
+    hipLaunchKernelGGL((col_stats_finish2_kernel<0>), dim3(C), dim3(256), 0, as_stream(stream), partial, chunks, C, R, eps, mean, var,
+                       invstd);
+    return check_launch("col_stats_finish2_kernel");
+}
+
+extern "C" int ptt_bn_sums_partials_f64(const double* partial, int chunks, int C, int R, double* sums, ptt_stream_t stream) {
+    if (chunks <= 0 || C <= 0 || R <= 0 || !partial || !sums) return fail(PTT_EINVAL, "ptt_bn_sums_partials_f64: chunks=%d C=%d R=%d", chunks, C, R);
+    hipLaunchKernelGGL(col_sums_finish_kernel, dim3(C), dim3(256), 0, as_stream(stream), partial, chunks, C, sums, (double)R);
+    return check_launch("col_sums_finish_kernel");
 }

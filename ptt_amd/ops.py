@@ -600,6 +600,9 @@ def select_box(pred_box_data, out=None, idx_out=None):
 
 
 # --------------------------------------------------------------------------- N3: training-step kernels (rows x channels)
+WGRAD2 = os.environ.get("PTT_WGRAD2", "1") != "0"        # dev A/B: the round-2 128 x 128-block weight-gradient kernel
+
+
 def _rows(t, name):
     if not t.is_cuda or t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1:
         raise RuntimeError("%s must be a (rows, channels) float32 device tensor with contiguous channels" % name)
@@ -743,14 +746,74 @@ def linear_act_in(x, in_scale, in_shift, wpacked, cout):
     return out
 
 
+def rows_gemm_supported(rows, K, N, ldx=None, ldo=None):
+    """True when ptt_rows_gemm_f32 takes the shape (K and N multiples of 64, ...): the persistent row GEMM of the training step."""
+    return bool(_lib.lib().ptt_rows_gemm_supported(int(rows), int(K), int(N), int(ldx if ldx is not None else K),
+                                                   int(ldo if ldo is not None else N)))
+
+
+def rows_gemm(x, wpacked, cout, in_scale=None, in_shift=None, bias=None, relu=False, residual=None, want_stats=False, out=None):
+    """out = relu?(act_in(x) @ W^T + bias) (+ residual) over (rows, K) activations — ptt_rows_gemm_f32, the persistent
+    software-pipelined row GEMM of the training step. act_in(x) = relu(x * in_scale + in_shift) when given.
+    want_stats: also return the float64 partial column sums / sums of squares of `out`, (chunks, 2, cout), for
+    bn_finish_partials / bn_sums_partials (the BatchNorm statistics without a second pass over the output)."""
+    _rows(x, "x")
+    rows, K = x.shape
+    cout = int(cout)
+    if out is None:
+        out = torch.empty((rows, cout), dtype=torch.float32, device=x.device)
+    stats = None
+    if want_stats:
+        chunks = _lib.lib().ptt_rows_gemm_stat_chunks(rows, K, cout)
+        stats = torch.empty((max(1, chunks), 2, cout), dtype=torch.float64, device=x.device)
+    r2 = None
+    if residual is not None:
+        r2 = _rows(residual, "residual")
+    with torch.cuda.device(x.device), _timed('ptt_rows_gemm_f32'):
+        _lib.check(_lib.lib().ptt_rows_gemm_f32(_ptr(x), rows, K, x.stride(0), _ptr(in_scale), _ptr(in_shift), _ptr(wpacked), cout,
+                                                _ptr(bias), 1 if relu else 0, _ptr(r2), r2.stride(0) if r2 is not None else cout,
+                                                _ptr(out), out.stride(0), _ptr(stats), stats.numel() if stats is not None else 0,
+                                                _stream()), "ptt_rows_gemm_f32")
+    return (out, stats) if want_stats else out
+
+
+def bn_finish_partials(partials, rows, eps):
+    """(mean, biased var, invstd) from rows_gemm's partial sums (chunks, 2, C), combined in chunk order."""
+    chunks, _, C = partials.shape
+    mean, var, invstd = (torch.empty((C,), dtype=torch.float32, device=partials.device) for _ in range(3))
+    with torch.cuda.device(partials.device):
+        _lib.check(_lib.lib().ptt_bn_finish_partials_f32(_ptr(partials), chunks, C, int(rows), float(eps), _ptr(mean), _ptr(var),
+                                                         _ptr(invstd), _stream()), "ptt_bn_finish_partials_f32")
+    return mean, var, invstd
+
+
+def bn_sums_partials(partials, rows):
+    """rows_gemm's partial sums -> the 2C + 1 float64 vector of bn_sums (sum, sum of squares, row count) for SyncBatchNorm."""
+    chunks, _, C = partials.shape
+    sums = torch.empty((2 * C + 1,), dtype=torch.float64, device=partials.device)
+    with torch.cuda.device(partials.device):
+        _lib.check(_lib.lib().ptt_bn_sums_partials_f64(_ptr(partials), chunks, C, int(rows), _ptr(sums), _stream()),
+                   "ptt_bn_sums_partials_f64")
+    return sums
+
+
 def linear_wgrad(dz, x, out=None, accumulate=False, x_scale=None, x_shift=None):
-    """dW (Cout,Cin) = dz^T x over the rows, on fp32 MFMA — ptt_linear_wgrad_f32; with x_scale / x_shift the rows of x
-    are relu(x * scale + shift), applied while they are staged."""
+    """dW (Cout,Cin) = dz^T x over the rows, on fp32 MFMA — ptt_linear_wgrad2_f32 (up to 256 x 256 outputs per workgroup)
+    where it applies, else ptt_linear_wgrad_f32; with x_scale / x_shift the rows of x are relu(x * scale + shift), applied
+    while they are staged."""
     _rows(dz, "dz"); _rows(x, "x")
     R, Cout = dz.shape
     Cin = x.shape[1]
     if out is None:
         out = torch.empty((Cout, Cin), dtype=torch.float32, device=dz.device)
+    nb2 = _lib.lib().ptt_linear_wgrad2_workspace(R, Cout, Cin) if (dz.stride(0) % 4 == 0 and x.stride(0) % 4 == 0) else 0
+    if nb2 and WGRAD2:
+        ws = _ws(nb2, dz.device)
+        with torch.cuda.device(dz.device), _timed('ptt_linear_wgrad_f32'):
+            _lib.check(_lib.lib().ptt_linear_wgrad2_f32(_ptr(dz), dz.stride(0), _ptr(x), x.stride(0), R, Cout, Cin, _ptr(out),
+                                                        int(bool(accumulate)), _ptr(ws), ws.numel() * 8, _ptr(x_scale), _ptr(x_shift),
+                                                        _stream()), "ptt_linear_wgrad2_f32")
+        return out
     ws = _ws(_lib.lib().ptt_linear_wgrad_workspace(R, Cout, Cin), dz.device)
     with torch.cuda.device(dz.device), _timed('ptt_linear_wgrad_f32'):
         _lib.check(_lib.lib().ptt_linear_wgrad_f32(_ptr(dz), dz.stride(0), _ptr(x), x.stride(0), R, Cout, Cin, _ptr(out),

@@ -27,13 +27,34 @@ def usable(mlp, x):
         bn = getattr(getattr(unit, 'normlayer', None), 'bn', None)
         if not isinstance(conv, nn.Conv2d) or conv.kernel_size != (1, 1) or conv.bias is not None or conv.weight.shape[0] % 4:
             return False
+        if conv.stride != (1, 1) or conv.padding != (0, 0) or conv.dilation != (1, 1) or conv.groups != 1:
+            return False
         if not isinstance(bn, (nn.BatchNorm2d, nn.SyncBatchNorm)) or not bn.affine or not bn.track_running_stats or bn.momentum is None:
+            return False
+        # a BatchNorm frozen inside a training model (bn.eval(): fine-tuning) normalises with its RUNNING statistics and
+        # must not have them updated — the row kernels use batch statistics, so such a stack takes the stock path
+        if not bn.training:
             return False
         if not isinstance(getattr(unit, 'activation', None), nn.ReLU):
             return False
         if list(unit._modules.keys()) != ['conv', 'normlayer', 'activation']:
             return False
     return True
+
+
+def conv_rows(x, W2d, in_a=None, in_b=None, want_stats=False):
+    """z = act_in(x) @ W2d^T over (rows, K) activations, act_in = relu(x * in_a + in_b) when given (the deferred BatchNorm +
+    ReLU of the producing layer). On the persistent row GEMM (ptt_rows_gemm_f32) where the shape allows, else on the linear
+    kernel. want_stats: also the float64 partial column sums of z from the GEMM's epilogue (None on the linear kernel: the
+    caller then takes the statistics in a pass of their own)."""
+    cout, K = W2d.shape
+    wp = ops.pack_weight(W2d)
+    if ops.rows_gemm_supported(x.shape[0], K, cout, x.stride(0), cout):
+        if want_stats:
+            return ops.rows_gemm(x, wp, cout, in_scale=in_a, in_shift=in_b, want_stats=True)
+        return ops.rows_gemm(x, wp, cout, in_scale=in_a, in_shift=in_b), None
+    z = ops.linear_act_in(x, in_a, in_b, wp, cout) if in_a is not None else ops.linear(x, wp, cout)
+    return z, None
 
 
 class _GatherRows(torch.autograd.Function):
@@ -91,19 +112,18 @@ class _SharedMlpPool(torch.autograd.Function):
         for l in range(L):
             W, gamma, beta = params[3 * l], params[3 * l + 1], params[3 * l + 2]
             cout = gamma.shape[0]
+            part = None
             if preact and l == 0:
                 z = cur
-            elif cur_a is not None:
-                z = ops.linear_act_in(cur, cur_a, cur_b, ops.pack_weight(W), cout)
-            else:
-                z = ops.linear(cur, ops.pack_weight(W), cout)
+            else:       # the statistics of z come out of the GEMM's epilogue where the persistent row GEMM runs
+                z, part = conv_rows(cur, W.reshape(cout, -1), cur_a, cur_b, want_stats=True)
             if sync[l] is not None:
-                sums = ops.bn_sums(z)
+                sums = ops.bn_sums_partials(part, z.shape[0]) if part is not None else ops.bn_sums(z)
                 dist.all_reduce(sums, group=sync[l])
                 mean, var, invstd = ops.bn_finish(sums, eps[l])
                 count = sums[-1:].clone()                      # global row count, float64, on the device
             else:
-                mean, var, invstd = ops.bn_stats(z, eps[l])
+                mean, var, invstd = ops.bn_finish_partials(part, z.shape[0], eps[l]) if part is not None else ops.bn_stats(z, eps[l])
                 count = torch.full((1,), float(z.shape[0]), dtype=torch.float64, device=z.device)
             a = (gamma.detach() * invstd).contiguous()
             b = (beta.detach() - mean * a).contiguous()
@@ -147,7 +167,7 @@ class _SharedMlpPool(torch.autograd.Function):
             has_t = in_a.numel() > 0
             grads[3 * l] = ops.linear_wgrad(dz, x_in, x_scale=in_a if has_t else None, x_shift=in_b if has_t else None).view_as(W)
             if l > 0 or ctx.needs_input_grad[0]:
-                g = ops.linear(dz, ops.pack_weight(w2.t().contiguous()), w2.shape[1])   # w.r.t. the activated input of layer l
+                g, _ = conv_rows(dz, w2.t().contiguous())                               # w.r.t. the activated input of layer l
             else:
                 g = None
         return (g, None, None, None, None) + tuple(grads)
