@@ -488,6 +488,21 @@ int ptt_rows_gemm_f32(const float* X, int rows, int K, int ldx, const float* in_
 int ptt_bn_finish_partials_f32(const double* partial, int chunks, int C, int R, float eps, float* mean, float* var, float* invstd,
                                ptt_stream_t stream);
 int ptt_bn_sums_partials_f64(const double* partial, int chunks, int C, int R, double* sums, ptt_stream_t stream);
+/* BatchNorm(train) + ReLU backward of the LAST layer of a SharedMLP + max-pool stage, with the gradient still POOLED:
+ * dy[g*ns + k, c] = dPooled[g, c] if k == arg[g, c] else 0 (F.max_pool2d's backward, pointnet2_modules.py:84-88) is formed
+ * on the fly — ptt_pool_rows_bwd_f32's (R, C) tensor is never written, the two sums run over G x C entries instead of R x C.
+ * The ReLU mask is z * act_scale + act_shift > 0 (deferred activation). _sums / _apply: the SyncBatchNorm split, as
+ * ptt_bn_bwd_sums_f64 / ptt_bn_bwd_apply_f32. Workspace: ptt_bn_stats_workspace(R, C). */
+int ptt_bn_bwd_pooled_f32(const float* dPooled, int ldp, const int32_t* arg, int ns, const float* Z, int ldz, const float* mean,
+                          const float* invstd, const float* gamma, int R, int C, float* dZ, int ldd, float* dgamma, float* dbeta,
+                          void* workspace, size_t workspace_bytes, const float* act_scale, const float* act_shift, ptt_stream_t stream);
+int ptt_bn_bwd_pooled_sums_f64(const float* dPooled, int ldp, const int32_t* arg, int ns, const float* Z, int ldz, const float* mean,
+                               const float* invstd, int R, int C, double* sums, void* workspace, size_t workspace_bytes,
+                               const float* act_scale, const float* act_shift, ptt_stream_t stream);
+int ptt_bn_bwd_pooled_apply_f32(const float* dPooled, int ldp, const int32_t* arg, int ns, const float* Z, int ldz, const float* mean,
+                                const float* invstd, const float* gamma, const float* sum_dy, const float* sum_dy_xhat,
+                                const double* count, int R, int C, float* dZ, int ldd, const float* act_scale,
+                                const float* act_shift, ptt_stream_t stream);
 size_t ptt_linear_wgrad2_workspace(int R, int Cout, int Cin);
 int ptt_linear_wgrad2_f32(const float* dZ, int ldz, const float* X, int ldx, int R, int Cout, int Cin, float* dW,
                           int accumulate, void* workspace, size_t workspace_bytes, const float* x_scale, const float* x_shift,

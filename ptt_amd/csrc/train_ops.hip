@@ -245,13 +245,17 @@ __global__ __launch_bounds__(256) void bn_apply4_kernel(const float* __restrict_
     }
 }
 
+// POOLED: the incoming gradient is the POOLED one — dy[g * ns + k, c] = G[g, c] (row stride ldg) if k == arg[g, c] else 0,
+// the backward of the max over the ns rows of group g; the (R, C) gradient tensor itself is never written or read.
+template <bool POOLED>
 __global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const float* __restrict__ G, int ldg, const float* __restrict__ Act,
                                                             int lda, const float* __restrict__ Z, int ldz,
                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
                                                             const float* __restrict__ gamma, const float* __restrict__ s0,
                                                             const float* __restrict__ s1, int R, int C, float* __restrict__ dZ,
                                                             int ldd, const float* __restrict__ act_a, const float* __restrict__ act_b,
-                                                            float rinv_value, const double* __restrict__ count) {
+                                                            float rinv_value, const double* __restrict__ count,
+                                                            const int32_t* __restrict__ arg, int ns) {
     // 1 / rows the statistics were taken over: by value, or (SyncBatchNorm) from the all-reduced row count in device memory
     const int Cq = C >> 2, span = Cq < 256 ? Cq : 256, RG = 256 / span;
     const int q0 = threadIdx.x % span, rg = threadIdx.x / span;
@@ -264,7 +268,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const float* __restr
         f32x4t ca = {0, 0, 0, 0}, cb = {0, 0, 0, 0};
         if (!Act) { ca = *reinterpret_cast<const f32x4t*>(act_a + 4 * q); cb = *reinterpret_cast<const f32x4t*>(act_b + 4 * q); }
         for (int r = blockIdx.x * RG + rg; r < R; r += gridDim.x * RG) {
-            const f32x4t g = *reinterpret_cast<const f32x4t*>(G + (size_t)r * ldg + 4 * q);
+            f32x4t g;
+            if (POOLED) {
+                const int grp = r / ns, k = r - grp * ns;
+                const f32x4t gp = *reinterpret_cast<const f32x4t*>(G + (size_t)grp * ldg + 4 * q);
+                const int4 ar = *reinterpret_cast<const int4*>(arg + (size_t)grp * C + 4 * q);
+                g[0] = ar.x == k ? gp[0] : 0.f; g[1] = ar.y == k ? gp[1] : 0.f;
+                g[2] = ar.z == k ? gp[2] : 0.f; g[3] = ar.w == k ? gp[3] : 0.f;
+            } else {
+                g = *reinterpret_cast<const f32x4t*>(G + (size_t)r * ldg + 4 * q);
+            }
             const f32x4t z = *reinterpret_cast<const f32x4t*>(Z + (size_t)r * ldz + 4 * q);
             f32x4t a;
             if (Act) a = *reinterpret_cast<const f32x4t*>(Act + (size_t)r * lda + 4 * q);
@@ -281,6 +294,34 @@ __global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const float* __restr
             }
             *reinterpret_cast<f32x4t*>(dZ + (size_t)r * ldd + 4 * q) = d;
         }
+    }
+}
+
+// BatchNorm + ReLU backward sums when the gradient arrives POOLED: dy is non-zero only at the arg-max row of every
+// (group, channel), so s0 = sum_g dy and s1 = sum_g dy * xhat run over G x C entries instead of R x C. One workgroup per
+// chunk of PB_GROUPS groups, thread = channel (coalesced dP / arg rows; z is gathered at the arg-max row), float64 partials
+// [chunk][2][C] in group order, combined by col_stats_finish2_kernel<1> / col_sums_finish_kernel as the dense form's.
+constexpr int PB_GROUPS = 64;
+__global__ __launch_bounds__(256) void pool_bwd_stats_kernel(const float* __restrict__ dP, int ldp, const int32_t* __restrict__ arg,
+                                                             int G, int ns, const float* __restrict__ Z, int ldz,
+                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                             const float* __restrict__ act_a, const float* __restrict__ act_b, int C,
+                                                             double* __restrict__ partial) {
+    const int g0 = blockIdx.x * PB_GROUPS, g1 = min(G, g0 + PB_GROUPS);
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float mu = mean[c], is = invstd[c], a = act_a[c], b = act_b[c];
+        double s0 = 0.0, s1 = 0.0;
+        for (int g = g0; g < g1; ++g) {
+            const int k = arg[(size_t)g * C + c];
+            const float z = Z[((size_t)g * ns + k) * ldz + c];
+            const float d = dP[(size_t)g * ldp + c];
+            const float dy = __builtin_fmaf(z, a, b) > 0.f ? d : 0.f;
+            const float xh = (z - mu) * is;
+            s0 += (double)dy;
+            s1 += (double)dy * (double)xh;
+        }
+        partial[((size_t)blockIdx.x * 2 + 0) * C + c] = s0;
+        partial[((size_t)blockIdx.x * 2 + 1) * C + c] = s1;
     }
 }
 
@@ -732,8 +773,8 @@ extern "C" int ptt_bn_bwd_f32(const float* G, int ldg, const float* Act, int lda
         const int Cq = C >> 2, RG = 256 / (Cq < 256 ? Cq : 256);
         int grid = (R + RG * 8 - 1) / (RG * 8);
         if (grid > 16384) grid = 16384;
-        hipLaunchKernelGGL(bn_bwd_apply4_kernel, dim3(grid), dim3(256), 0, s, G, ldg, Act, lda, Z, ldz, mean, invstd, gamma, dbeta, dgamma,
-                           R, C, dZ, ldd, act_scale, act_shift, 1.0f / (float)R, nullptr);
+        hipLaunchKernelGGL((bn_bwd_apply4_kernel<false>), dim3(grid), dim3(256), 0, s, G, ldg, Act, lda, Z, ldz, mean, invstd, gamma, dbeta,
+                           dgamma, R, C, dZ, ldd, act_scale, act_shift, 1.0f / (float)R, nullptr, nullptr, 1);
         return check_launch("bn_bwd4_kernels");
     }
     if (!Act) return fail(PTT_EUNSUPPORTED, "ptt_bn_bwd_f32: the mask-from-z form needs C %% 4 == 0 and 16-byte aligned rows");
@@ -809,9 +850,72 @@ extern "C" int ptt_bn_bwd_apply_f32(const float* G, int ldg, const float* Act, i
     const int Cq = C >> 2, RG = 256 / (Cq < 256 ? Cq : 256);
     int grid = (R + RG * 8 - 1) / (RG * 8);
     if (grid > 16384) grid = 16384;
-    hipLaunchKernelGGL(bn_bwd_apply4_kernel, dim3(grid), dim3(256), 0, as_stream(stream), G, ldg, Act, lda, Z, ldz, mean, invstd, gamma,
-                       sum_dy, sum_dy_xhat, R, C, dZ, ldd, act_scale, act_shift, 0.f, count);
+    hipLaunchKernelGGL((bn_bwd_apply4_kernel<false>), dim3(grid), dim3(256), 0, as_stream(stream), G, ldg, Act, lda, Z, ldz, mean, invstd,
+                       gamma, sum_dy, sum_dy_xhat, R, C, dZ, ldd, act_scale, act_shift, 0.f, count, nullptr, 1);
     return check_launch("bn_bwd_apply4_kernel");
+}
+
+// ---- the same backward when the gradient arrives pooled (the last layer of a SharedMLP + max-pool stage)
+static int pooled_args_ok(const char* what, const float* dP, int ldp, const int32_t* arg, int ns, const float* Z, int ldz, const float* mean,
+                          const float* invstd, int R, int C, const float* act_scale, const float* act_shift) {
+    if (R <= 0 || C <= 0 || ns <= 0 || R % ns || ldp < C || ldz < C) return fail(PTT_EINVAL, "%s: R=%d C=%d ns=%d ldp=%d ldz=%d", what, R, C, ns, ldp, ldz);
+    if (!dP || !arg || !Z || !mean || !invstd || !act_scale || !act_shift) return fail(PTT_EINVAL, "%s: null pointer", what);
+    if (!(vec4_ok(dP, ldp, C) && vec4_ok(arg, C, C) && vec4_ok(Z, ldz, C) && vec4_ok(mean, 4, 4) && vec4_ok(invstd, 4, 4) &&
+          vec4_ok(act_scale, 4, 4) && vec4_ok(act_shift, 4, 4)))
+        return fail(PTT_EUNSUPPORTED, "%s: needs C %% 4 == 0 and 16-byte aligned rows", what);
+    return PTT_OK;
+}
+
+extern "C" int ptt_bn_bwd_pooled_f32(const float* dPooled, int ldp, const int32_t* arg, int ns, const float* Z, int ldz,
+                                     const float* mean, const float* invstd, const float* gamma, int R, int C, float* dZ, int ldd,
+                                     float* dgamma, float* dbeta, void* ws, size_t ws_bytes, const float* act_scale,
+                                     const float* act_shift, ptt_stream_t stream) {
+    if (int rc = pooled_args_ok("ptt_bn_bwd_pooled_f32", dPooled, ldp, arg, ns, Z, ldz, mean, invstd, R, C, act_scale, act_shift)) return rc;
+    if (!gamma || !dZ || !dgamma || !dbeta || !vec4_ok(dZ, ldd, C) || !vec4_ok(gamma, 4, 4) || !vec4_ok(dgamma, 4, 4) || !vec4_ok(dbeta, 4, 4))
+        return fail(PTT_EINVAL, "ptt_bn_bwd_pooled_f32: bad output / gamma pointer");
+    if (!ws || ws_bytes < ptt_bn_stats_workspace(R, C)) return fail(PTT_EWORKSPACE, "ptt_bn_bwd_pooled_f32: workspace too small");
+    hipStream_t s = as_stream(stream);
+    const int G = R / ns, nch = (G + PB_GROUPS - 1) / PB_GROUPS;
+    hipLaunchKernelGGL(pool_bwd_stats_kernel, dim3(nch), dim3(256), 0, s, dPooled, ldp, arg, G, ns, Z, ldz, mean, invstd, act_scale,
+                       act_shift, C, static_cast<double*>(ws));
+    hipLaunchKernelGGL((col_stats_finish2_kernel<1>), dim3(C), dim3(256), 0, s, static_cast<const double*>(ws), nch, C, R, 0.f, dbeta,
+                       dgamma, nullptr);
+    const int Cq = C >> 2, RG = 256 / (Cq < 256 ? Cq : 256);
+    int grid = (R + RG * 8 - 1) / (RG * 8);
+    if (grid > 16384) grid = 16384;
+    hipLaunchKernelGGL((bn_bwd_apply4_kernel<true>), dim3(grid), dim3(256), 0, s, dPooled, ldp, nullptr, 0, Z, ldz, mean, invstd, gamma,
+                       dbeta, dgamma, R, C, dZ, ldd, act_scale, act_shift, 1.0f / (float)R, nullptr, arg, ns);
+    return check_launch("ptt_bn_bwd_pooled_f32");
+}
+
+extern "C" int ptt_bn_bwd_pooled_sums_f64(const float* dPooled, int ldp, const int32_t* arg, int ns, const float* Z, int ldz,
+                                          const float* mean, const float* invstd, int R, int C, double* sums, void* ws,
+                                          size_t ws_bytes, const float* act_scale, const float* act_shift, ptt_stream_t stream) {
+    if (int rc = pooled_args_ok("ptt_bn_bwd_pooled_sums_f64", dPooled, ldp, arg, ns, Z, ldz, mean, invstd, R, C, act_scale, act_shift)) return rc;
+    if (!sums) return fail(PTT_EINVAL, "ptt_bn_bwd_pooled_sums_f64: null pointer");
+    if (!ws || ws_bytes < ptt_bn_stats_workspace(R, C)) return fail(PTT_EWORKSPACE, "ptt_bn_bwd_pooled_sums_f64: workspace too small");
+    hipStream_t s = as_stream(stream);
+    const int G = R / ns, nch = (G + PB_GROUPS - 1) / PB_GROUPS;
+    hipLaunchKernelGGL(pool_bwd_stats_kernel, dim3(nch), dim3(256), 0, s, dPooled, ldp, arg, G, ns, Z, ldz, mean, invstd, act_scale,
+                       act_shift, C, static_cast<double*>(ws));
+    hipLaunchKernelGGL(col_sums_finish_kernel, dim3(C), dim3(256), 0, s, static_cast<const double*>(ws), nch, C, sums, -1.0);
+    return check_launch("ptt_bn_bwd_pooled_sums_f64");
+}
+
+extern "C" int ptt_bn_bwd_pooled_apply_f32(const float* dPooled, int ldp, const int32_t* arg, int ns, const float* Z, int ldz,
+                                           const float* mean, const float* invstd, const float* gamma, const float* sum_dy,
+                                           const float* sum_dy_xhat, const double* count, int R, int C, float* dZ, int ldd,
+                                           const float* act_scale, const float* act_shift, ptt_stream_t stream) {
+    if (int rc = pooled_args_ok("ptt_bn_bwd_pooled_apply_f32", dPooled, ldp, arg, ns, Z, ldz, mean, invstd, R, C, act_scale, act_shift)) return rc;
+    if (!gamma || !sum_dy || !sum_dy_xhat || !count || !dZ || !vec4_ok(dZ, ldd, C) || !vec4_ok(gamma, 4, 4) || !vec4_ok(sum_dy, 4, 4) ||
+        !vec4_ok(sum_dy_xhat, 4, 4))
+        return fail(PTT_EINVAL, "ptt_bn_bwd_pooled_apply_f32: bad pointer");
+    const int Cq = C >> 2, RG = 256 / (Cq < 256 ? Cq : 256);
+    int grid = (R + RG * 8 - 1) / (RG * 8);
+    if (grid > 16384) grid = 16384;
+    hipLaunchKernelGGL((bn_bwd_apply4_kernel<true>), dim3(grid), dim3(256), 0, as_stream(stream), dPooled, ldp, nullptr, 0, Z, ldz, mean,
+                       invstd, gamma, sum_dy, sum_dy_xhat, R, C, dZ, ldd, act_scale, act_shift, 0.f, count, arg, ns);
+    return check_launch("bn_bwd_apply4_kernel<pooled>");
 }
 
 extern "C" int ptt_pool_rows_f32(const float* X, int ldx, int G, int ns, int C, float* out, int ldo, int32_t* arg,

@@ -711,6 +711,51 @@ def bn_bwd_apply(g, act, z, mean, invstd, gamma, sum_dy, sum_dy_xhat, count, out
     return out
 
 
+def bn_bwd_pooled(dpooled, arg, ns, z, mean, invstd, gamma, act_scale, act_shift, out=None):
+    """bn_bwd for the last layer of a SharedMLP + max-pool stage with the gradient still pooled (dpooled (G,C), arg (G,C)
+    int32 from pool_rows): -> (dz (G*ns,C), dgamma, dbeta) — ptt_bn_bwd_pooled_f32."""
+    _rows(dpooled, "dpooled"); _rows(z, "z")
+    R, C = z.shape
+    if out is None:
+        out = torch.empty((R, C), dtype=torch.float32, device=z.device)
+    dgamma = torch.empty((C,), dtype=torch.float32, device=z.device)
+    dbeta = torch.empty((C,), dtype=torch.float32, device=z.device)
+    ws = _ws(_lib.lib().ptt_bn_stats_workspace(R, C), z.device)
+    with torch.cuda.device(z.device):
+        _lib.check(_lib.lib().ptt_bn_bwd_pooled_f32(_ptr(dpooled), dpooled.stride(0), _ptr(arg), int(ns), _ptr(z), z.stride(0), _ptr(mean),
+                                                    _ptr(invstd), _ptr(gamma), R, C, _ptr(out), out.stride(0), _ptr(dgamma), _ptr(dbeta),
+                                                    _ptr(ws), ws.numel() * 8, _ptr(act_scale), _ptr(act_shift), _stream()),
+                   "ptt_bn_bwd_pooled_f32")
+    return out, dgamma, dbeta
+
+
+def bn_bwd_pooled_sums(dpooled, arg, ns, z, mean, invstd, act_scale, act_shift):
+    """SyncBatchNorm backward, local part, pooled gradient: (2, C) float64 = (sum dy, sum dy * xhat)."""
+    _rows(dpooled, "dpooled"); _rows(z, "z")
+    R, C = z.shape
+    sums = torch.empty((2, C), dtype=torch.float64, device=z.device)
+    ws = _ws(_lib.lib().ptt_bn_stats_workspace(R, C), z.device)
+    with torch.cuda.device(z.device):
+        _lib.check(_lib.lib().ptt_bn_bwd_pooled_sums_f64(_ptr(dpooled), dpooled.stride(0), _ptr(arg), int(ns), _ptr(z), z.stride(0),
+                                                         _ptr(mean), _ptr(invstd), R, C, _ptr(sums), _ptr(ws), ws.numel() * 8,
+                                                         _ptr(act_scale), _ptr(act_shift), _stream()), "ptt_bn_bwd_pooled_sums_f64")
+    return sums
+
+
+def bn_bwd_pooled_apply(dpooled, arg, ns, z, mean, invstd, gamma, sum_dy, sum_dy_xhat, count, act_scale, act_shift, out=None):
+    """dz from the (global) sums, pooled gradient — ptt_bn_bwd_pooled_apply_f32."""
+    _rows(dpooled, "dpooled"); _rows(z, "z")
+    R, C = z.shape
+    if out is None:
+        out = torch.empty((R, C), dtype=torch.float32, device=z.device)
+    with torch.cuda.device(z.device):
+        _lib.check(_lib.lib().ptt_bn_bwd_pooled_apply_f32(_ptr(dpooled), dpooled.stride(0), _ptr(arg), int(ns), _ptr(z), z.stride(0),
+                                                          _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(sum_dy), _ptr(sum_dy_xhat),
+                                                          _ptr(count), R, C, _ptr(out), out.stride(0), _ptr(act_scale),
+                                                          _ptr(act_shift), _stream()), "ptt_bn_bwd_pooled_apply_f32")
+    return out
+
+
 def pool_rows(x, ns, act_scale=None, act_shift=None):
     """max over every ns consecutive rows: (G*ns, C) -> (G, C) and the int32 arg-max (first among equals); with
     act_scale / act_shift the rows are relu(x * scale + shift), applied on the fly."""

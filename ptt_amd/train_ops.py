@@ -142,21 +142,34 @@ class _SharedMlpPool(torch.autograd.Function):
         L, ns = ctx.L, ctx.ns
         t = ctx.saved_tensors
         arg, saved, params = t[0], t[1:1 + 9 * L], t[1 + 9 * L:]
-        g = ops.pool_rows_bwd(dpooled.contiguous(), arg, ns)
+        dpooled = dpooled.contiguous()
+        g = None
         grads = [None] * (3 * L)
         for l in range(L - 1, -1, -1):
             x_in, in_a, in_b, z, mean, invstd, a, b, count = saved[9 * l:9 * l + 9]
             W, gamma = params[3 * l], params[3 * l + 1]
+            last = l == L - 1
+            # the last layer's gradient arrives POOLED: max-pool backward, BatchNorm sums and dz are formed from (dpooled,
+            # arg) — the (R, C) gradient of the pooled layer is never written (ptt_bn_bwd_pooled_f32)
             if ctx.sync[l] is not None:
                 # torch's SyncBatchNorm: dgamma / dbeta are the rank's LOCAL sums (DDP averages parameter gradients); dz
                 # uses the sums of all ranks
-                sums = ops.bn_bwd_sums(g, None, z, mean, invstd, act_scale=a, act_shift=b)
+                if last:
+                    sums = ops.bn_bwd_pooled_sums(dpooled, arg, ns, z, mean, invstd, a, b)
+                else:
+                    sums = ops.bn_bwd_sums(g, None, z, mean, invstd, act_scale=a, act_shift=b)
                 local = sums.float()
                 dbeta, dgamma = local[0].contiguous(), local[1].contiguous()
                 dist.all_reduce(sums, group=ctx.sync[l])
                 glob = sums.float()
-                dz = ops.bn_bwd_apply(g, None, z, mean, invstd, gamma, glob[0].contiguous(), glob[1].contiguous(), count, out=g,
-                                      act_scale=a, act_shift=b)
+                if last:
+                    dz = ops.bn_bwd_pooled_apply(dpooled, arg, ns, z, mean, invstd, gamma, glob[0].contiguous(), glob[1].contiguous(),
+                                                 count, a, b)
+                else:
+                    dz = ops.bn_bwd_apply(g, None, z, mean, invstd, gamma, glob[0].contiguous(), glob[1].contiguous(), count, out=g,
+                                          act_scale=a, act_shift=b)
+            elif last:
+                dz, dgamma, dbeta = ops.bn_bwd_pooled(dpooled, arg, ns, z, mean, invstd, gamma, a, b)
             else:
                 dz, dgamma, dbeta = ops.bn_bwd(g, None, z, mean, invstd, gamma, out=g, act_scale=a, act_shift=b)   # in place over g
             grads[3 * l + 1], grads[3 * l + 2] = dgamma, dbeta

@@ -288,3 +288,34 @@ def test_transformer_block_training_path_equals_the_reference_op_sequence(dev, N
     for (n1, p1), (_, p2) in zip(a.named_parameters(), b.named_parameters()):
         err = float((p1.grad - p2.grad).abs().max()) / max(float(p2.grad.abs().max()), 1e-3 * gmax)   # fc_gamma.2.bias: exactly 0
         assert err < 1e-3, (n1, err)
+
+
+@pytest.mark.parametrize("G,ns,C", [(300, 32, 128), (77, 16, 256), (5000, 32, 64)])
+def test_pooled_bn_backward_equals_pool_backward_then_dense_bn_backward(dev, G, ns, C):
+    """ptt_bn_bwd_pooled_f32 (max-pool backward + BatchNorm/ReLU backward from the POOLED gradient; the (R, C) gradient is
+    never materialised) against the two-step form ptt_pool_rows_bwd_f32 -> ptt_bn_bwd_f32 it replaces: dz to rounding (the
+    sums run over the same non-zero terms in a different grouping), bit-reproducible run to run."""
+    g = torch.Generator(device="cpu").manual_seed(G + C)
+    R = G * ns
+    z = (torch.randn(R, C, generator=g) * 2 + torch.randn(C, generator=g)).to(dev)
+    gamma = (torch.rand(C, generator=g) + 0.5).to(dev)
+    beta = (torch.randn(C, generator=g) * 0.2).to(dev)
+    mean, var, invstd = ops.bn_stats(z, 1e-5)
+    a = (gamma * invstd).contiguous()
+    b = (beta - mean * a).contiguous()
+    pooled, arg = ops.pool_rows(z, ns, a, b)
+    up = torch.randn(G, C, generator=g).to(dev)
+    dense = ops.pool_rows_bwd(up, arg, ns)
+    dz_ref, dgamma_ref, dbeta_ref = ops.bn_bwd(dense, None, z, mean, invstd, gamma, act_scale=a, act_shift=b)
+    dz, dgamma, dbeta = ops.bn_bwd_pooled(up, arg, ns, z, mean, invstd, gamma, a, b)
+    scale = float(dz_ref.abs().max())
+    assert float((dz - dz_ref).abs().max()) <= 2e-6 * scale
+    torch.testing.assert_close(dgamma, dgamma_ref, rtol=1e-5, atol=1e-5 * float(dgamma_ref.abs().max()))
+    torch.testing.assert_close(dbeta, dbeta_ref, rtol=1e-5, atol=1e-5 * float(dbeta_ref.abs().max()))
+    dz2, dgamma2, _ = ops.bn_bwd_pooled(up, arg, ns, z, mean, invstd, gamma, a, b)
+    assert torch.equal(dz, dz2) and torch.equal(dgamma, dgamma2)
+    # the SyncBatchNorm split gives the same numbers from the same sums
+    sums = ops.bn_bwd_pooled_sums(up, arg, ns, z, mean, invstd, a, b).float()
+    count = torch.full((1,), float(R), dtype=torch.float64, device=dev)
+    dz3 = ops.bn_bwd_pooled_apply(up, arg, ns, z, mean, invstd, gamma, sums[0].contiguous(), sums[1].contiguous(), count, a, b)
+    assert float((dz3 - dz).abs().max()) <= 1e-6 * scale
