@@ -485,6 +485,11 @@ int ptt_rows_gemm_stat_chunks(int rows, int K, int N);
 int ptt_rows_gemm_f32(const float* X, int rows, int K, int ldx, const float* in_scale, const float* in_shift,
                       const float* Wpacked, int N, const float* bias, int relu, const float* residual, int ldr,
                       float* out, int ldo, double* stats, size_t stats_elems, ptt_stream_t stream);
+/* the input gradient of a Linear + ReLU layer's successor, masked by that ReLU: out = (mask > 0) ? X . W^T : 0, mask = the
+ * ReLU's output (rows, N), row stride ldm; statistics (optional) are those of the MASKED output, whose column sums are
+ * the bias gradient of the masked layer (nn.Sequential(Linear, ReLU, Linear): fc_delta / fc_gamma, variants.py:139-148). */
+int ptt_rows_gemm_masked_f32(const float* X, int rows, int K, int ldx, const float* Wpacked, int N, const float* mask, int ldm,
+                             float* out, int ldo, double* stats, size_t stats_elems, ptt_stream_t stream);
 int ptt_bn_finish_partials_f32(const double* partial, int chunks, int C, int R, float eps, float* mean, float* var, float* invstd,
                                ptt_stream_t stream);
 int ptt_bn_sums_partials_f64(const double* partial, int chunks, int C, int R, double* sums, ptt_stream_t stream);
@@ -503,6 +508,18 @@ int ptt_bn_bwd_pooled_apply_f32(const float* dPooled, int ldp, const int32_t* ar
                                 const float* invstd, const float* gamma, const float* sum_dy, const float* sum_dy_xhat,
                                 const double* count, int R, int C, float* dZ, int ldd, const float* act_scale,
                                 const float* act_shift, ptt_stream_t stream);
+/* nn.BatchNorm's training-mode bookkeeping in ONE launch (running statistics with momentum, unbiased variance, batch counter);
+ * count = the rows the statistics were taken over, a float64 in device memory (SyncBatchNorm: the all-reduced count). */
+int ptt_bn_update_running_f32(const float* mean, const float* var, const double* count, float momentum, int C, float* running_mean,
+                              float* running_var, int64_t* num_batches_tracked, ptt_stream_t stream);
+/* CosineSimAug's first convolution in training mode with its similarity channel split off (p2b_xcoor.py:35-40):
+ * z0[b,j,i,:] = P[b,i,:] + cos_t[b,j,i] * w_sim[:]  (rows ordered (b, j, i): search point j, template point i), and its
+ * backward in one pass over dz0: dP[b,i,:] = sum_j dz0, dcos[b,j,i] = <dz0[b,j,i,:], w_sim>, dw[:] = sum dz0 * cos_t
+ * (fixed summation order). C % 4 == 0; the backward needs C <= 256. */
+int ptt_xcorr_z0_f32(const float* P, const float* cos_t, const float* w_sim, int B, int n2, int n1, int C, float* z0, ptt_stream_t stream);
+size_t ptt_xcorr_z0_bwd_workspace(int B, int n1, int C);
+int ptt_xcorr_z0_bwd_f32(const float* dz0, const float* cos_t, const float* w_sim, int B, int n2, int n1, int C, float* dP, float* dcos,
+                         float* dw, void* workspace, size_t workspace_bytes, ptt_stream_t stream);
 size_t ptt_linear_wgrad2_workspace(int R, int Cout, int Cin);
 int ptt_linear_wgrad2_f32(const float* dZ, int ldz, const float* X, int ldx, int R, int Cout, int Cin, float* dW,
                           int accumulate, void* workspace, size_t workspace_bytes, const float* x_scale, const float* x_shift,

@@ -30,9 +30,10 @@ EXPORTS = [
     "ptt_centres_ball_query_f32",
     "ptt_bn_sums_f64", "ptt_bn_finish_f64", "ptt_bn_bwd_sums_f64", "ptt_bn_bwd_apply_f32",
     "ptt_rows_mlp_f32",
-    "ptt_rows_gemm_supported", "ptt_rows_gemm_stat_chunks", "ptt_rows_gemm_f32", "ptt_bn_finish_partials_f32",
+    "ptt_rows_gemm_supported", "ptt_rows_gemm_stat_chunks", "ptt_rows_gemm_f32", "ptt_rows_gemm_masked_f32", "ptt_bn_finish_partials_f32",
     "ptt_bn_sums_partials_f64", "ptt_linear_wgrad2_workspace", "ptt_linear_wgrad2_f32",
     "ptt_bn_bwd_pooled_f32", "ptt_bn_bwd_pooled_sums_f64", "ptt_bn_bwd_pooled_apply_f32",
+    "ptt_bn_update_running_f32", "ptt_xcorr_z0_f32", "ptt_xcorr_z0_bwd_workspace", "ptt_xcorr_z0_bwd_f32",
 ]
 PTT_MAX_SEGMENTS = 4
 
@@ -142,9 +143,13 @@ def _declare(lib):
         "ptt_rows_gemm_supported": [i, i, i, i, i],
         "ptt_rows_gemm_stat_chunks": [i, i, i],
         "ptt_rows_gemm_f32": [vp, i, i, i, vp, vp, vp, i, vp, i, vp, i, vp, i, vp, c_size_t, vp],
+        "ptt_rows_gemm_masked_f32": [vp, i, i, i, vp, i, vp, i, vp, i, vp, c_size_t, vp],
         "ptt_bn_finish_partials_f32": [vp, i, i, i, f, vp, vp, vp, vp],
         "ptt_bn_sums_partials_f64": [vp, i, i, i, vp, vp],
         "ptt_linear_wgrad2_f32": [vp, i, vp, i, i, i, i, vp, i, vp, c_size_t, vp, vp, vp],
+        "ptt_bn_update_running_f32": [vp, vp, vp, f, i, vp, vp, vp, vp],
+        "ptt_xcorr_z0_f32": [vp, vp, vp, i, i, i, i, vp, vp],
+        "ptt_xcorr_z0_bwd_f32": [vp, vp, vp, i, i, i, i, vp, vp, vp, vp, c_size_t, vp],
         "ptt_bn_bwd_pooled_f32": [vp, i, vp, i, vp, i, vp, vp, vp, i, i, vp, i, vp, vp, vp, c_size_t, vp, vp, vp],
         "ptt_bn_bwd_pooled_sums_f64": [vp, i, vp, i, vp, i, vp, vp, i, i, vp, vp, c_size_t, vp, vp, vp],
         "ptt_bn_bwd_pooled_apply_f32": [vp, i, vp, i, vp, i, vp, vp, vp, vp, vp, vp, i, i, vp, i, vp, vp, vp],
@@ -161,6 +166,8 @@ def _declare(lib):
     lib.ptt_bn_stats_workspace.argtypes = [i, i]
     lib.ptt_linear_wgrad_workspace.restype = c_size_t
     lib.ptt_linear_wgrad_workspace.argtypes = [i, i, i]
+    lib.ptt_xcorr_z0_bwd_workspace.restype = c_size_t
+    lib.ptt_xcorr_z0_bwd_workspace.argtypes = [i, i, i]
     lib.ptt_linear_wgrad2_workspace.restype = c_size_t
     lib.ptt_linear_wgrad2_workspace.argtypes = [i, i, i]
 

@@ -60,6 +60,8 @@ __device__ __forceinline__ int g_logical_block() {
 struct RowsGemmParams {
     const float* X; const float* Wp; const float* bias; const float* residual; float* out;
     const float* in_a; const float* in_b;       // optional x <- relu(x * in_a[k] + in_b[k]) while the A operand is staged
+    const float* mask; int ldm;                 // optional out <- mask > 0 ? out : 0 (the ReLU backward of the layer this
+                                                // GEMM is the input gradient of; mask = that layer's output), before the statistics
     double* stats;                              // optional [chunks][2][N] partial column sums / sums of squares of Y
     int rows, K, ldx, N, NT, relu, ldr, ldo, ntiles, G, ncg, nchunks;
 };
@@ -138,16 +140,20 @@ __global__ __launch_bounds__(256, 2) void rows_gemm_kernel(RowsGemmParams p) {
 
     // bias / ReLU branch-free: a missing bias reads any valid address and is replaced by 0, no ReLU = floor -inf
     const bool has_bias = p.bias != nullptr;
-    const __amdgpu_buffer_rsrc_t rb = g_rsrc(has_bias ? p.bias : p.Wp), rr = g_rsrc(p.residual ? p.residual : p.X);
+    const __amdgpu_buffer_rsrc_t rb = g_rsrc(has_bias ? p.bias : p.Wp);
+    const __amdgpu_buffer_rsrc_t rr = g_rsrc(p.residual ? p.residual : (p.mask ? p.mask : p.X));
+    const int ldr = p.residual ? p.ldr : p.ldm;
     const float rfloor = p.relu ? 0.f : -__builtin_inff();
-    auto epilogue = [&](int row_w, auto full_c, auto res_c) {
-        constexpr bool FULL = decltype(full_c)::value, RES = decltype(res_c)::value;
+    auto epilogue = [&](int row_w, auto full_c, auto mode_c) {      // mode 0: plain, 1: + residual, 2: masked by `mask` > 0
+        constexpr bool FULL = decltype(full_c)::value;
+        constexpr int MODE = decltype(mode_c)::value;
+        constexpr bool RES = MODE != 0;
 #pragma unroll
         for (int u = 0; u < CT; ++u) {
             const int cn = (ct0 + u * WC) * 32 + col;
             const float bl = g_load1(rb, cn * 4, 0);
             const float bv = has_bias ? bl : 0.f;
-            const int obase = ((row_w + 4 * half) * p.ldo + cn) * 4, rbase = ((row_w + 4 * half) * p.ldr + cn) * 4;
+            const int obase = ((row_w + 4 * half) * p.ldo + cn) * 4, rbase = ((row_w + 4 * half) * ldr + cn) * 4;
             float s = 0.f, sq = 0.f;
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
@@ -157,7 +163,7 @@ __global__ __launch_bounds__(256, 2) void rows_gemm_kernel(RowsGemmParams p) {
                     for (int r = 0; r < 16; ++r) {
                         const int dr = rt * 32 + (r & 3) + 8 * (r >> 2);
                         const int grc = FULL ? 0 : ((row_w + 4 * half + dr < p.rows) ? 0 : (p.rows - 1 - (row_w + 4 * half + dr)));
-                        rv[r] = g_load1(rr, rbase + (dr + grc) * (p.ldr * 4), 0);      // rows past the end: clamped, never stored
+                        rv[r] = g_load1(rr, rbase + (dr + grc) * (ldr * 4), 0);        // rows past the end: clamped, never stored
                     }
                 }
 #pragma unroll
@@ -165,12 +171,13 @@ __global__ __launch_bounds__(256, 2) void rows_gemm_kernel(RowsGemmParams p) {
                     const int dr = rt * 32 + (r & 3) + 8 * (r >> 2);
                     const bool in = FULL || row_w + 4 * half + dr < p.rows;
                     float y = acc[rt][u][r] + bv;
+                    if (MODE == 2) y = rv[r] > 0.f ? y : 0.f;
                     if (STATS) {                                // rows past the end: relu(shift) . W with a deferred activation
                         const float ys = (FULL || !ACT || in) ? y : 0.f;
                         s += ys; sq = __builtin_fmaf(ys, ys, sq);
                     }
                     y = fmaxf(y, rfloor);
-                    if (RES) y += rv[r];
+                    if (MODE == 1) y += rv[r];
                     if (!(EXP & 1) || r == 15)
                         if (in) g_store1(y, ro, obase + dr * (p.ldo * 4), 0);
                     acc[rt][u][r] = 0.f;
@@ -245,12 +252,17 @@ __global__ __launch_bounds__(256, 2) void rows_gemm_kernel(RowsGemmParams p) {
         if (c == p.nchunks - 1) {
             // ---- epilogue of a row tile (in the open: the co-resident workgroup owns the matrix pipe meanwhile) ----
             const int row_w = tile * TR + wr * RT * 32;
+            typedef std::integral_constant<int, 0> M0;
+            typedef std::integral_constant<int, 1> M1;
+            typedef std::integral_constant<int, 2> M2;
             if (row_w + RT * 32 <= p.rows) {
-                if (p.residual) epilogue(row_w, std::true_type(), std::true_type());
-                else epilogue(row_w, std::true_type(), std::false_type());
+                if (p.residual) epilogue(row_w, std::true_type(), M1());
+                else if (p.mask) epilogue(row_w, std::true_type(), M2());
+                else epilogue(row_w, std::true_type(), M0());
             } else {
-                if (p.residual) epilogue(row_w, std::false_type(), std::true_type());
-                else epilogue(row_w, std::false_type(), std::false_type());
+                if (p.residual) epilogue(row_w, std::false_type(), M1());
+                else if (p.mask) epilogue(row_w, std::false_type(), M2());
+                else epilogue(row_w, std::false_type(), M0());
             }
         }
         if (!(EXP & 8)) g_lds_barrier();
@@ -434,9 +446,27 @@ extern "C" int ptt_rows_gemm_stat_chunks(int rows, int K, int N) {
     return g.ok ? g.chunks : 0;
 }
 
+static int rows_gemm_launch(const float* X, int rows, int K, int ldx, const float* in_scale, const float* in_shift,
+                            const float* Wpacked, int N, const float* bias, int relu, const float* residual, int ldr,
+                            const float* mask, int ldm, float* out, int ldo, double* stats, size_t stats_elems, ptt_stream_t stream);
+
 extern "C" int ptt_rows_gemm_f32(const float* X, int rows, int K, int ldx, const float* in_scale, const float* in_shift,
                                  const float* Wpacked, int N, const float* bias, int relu, const float* residual, int ldr,
                                  float* out, int ldo, double* stats, size_t stats_elems, ptt_stream_t stream) {
+    return rows_gemm_launch(X, rows, K, ldx, in_scale, in_shift, Wpacked, N, bias, relu, residual, ldr, nullptr, 0, out, ldo, stats,
+                            stats_elems, stream);
+}
+
+extern "C" int ptt_rows_gemm_masked_f32(const float* X, int rows, int K, int ldx, const float* Wpacked, int N, const float* mask,
+                                        int ldm, float* out, int ldo, double* stats, size_t stats_elems, ptt_stream_t stream) {
+    if (!mask || ldm < N) return fail(PTT_EINVAL, "ptt_rows_gemm_masked_f32: mask=%p ldm=%d", (const void*)mask, ldm);
+    return rows_gemm_launch(X, rows, K, ldx, nullptr, nullptr, Wpacked, N, nullptr, 0, nullptr, 0, mask, ldm, out, ldo, stats,
+                            stats_elems, stream);
+}
+
+static int rows_gemm_launch(const float* X, int rows, int K, int ldx, const float* in_scale, const float* in_shift,
+                            const float* Wpacked, int N, const float* bias, int relu, const float* residual, int ldr,
+                            const float* mask, int ldm, float* out, int ldo, double* stats, size_t stats_elems, ptt_stream_t stream) {
     if (rows < 0 || K <= 0 || N <= 0 || ldx < K || ldo < N || (residual && ldr < N))
         return fail(PTT_EINVAL, "ptt_rows_gemm_f32: rows=%d K=%d N=%d ldx=%d ldo=%d ldr=%d", rows, K, N, ldx, ldo, ldr);
     if (rows == 0) return PTT_OK;
@@ -450,7 +480,10 @@ extern "C" int ptt_rows_gemm_f32(const float* X, int rows, int K, int ldx, const
     const RowsGemmGeom g = rows_gemm_geom(rows, K, N);
     if (stats && (bias || stats_elems < (size_t)g.chunks * 2 * N))
         return fail(PTT_EINVAL, "ptt_rows_gemm_f32: statistics need bias == NULL and %zu doubles of workspace", (size_t)g.chunks * 2 * N);
+    if (mask && (long long)rows * ldm >= (1LL << 29)) return fail(PTT_EUNSUPPORTED, "ptt_rows_gemm_masked_f32: rows * ldm >= 2^29");
+    if (residual && (long long)rows * ldr >= (1LL << 29)) return fail(PTT_EUNSUPPORTED, "ptt_rows_gemm_f32: rows * ldr >= 2^29");
     RowsGemmParams p;
+    p.mask = mask; p.ldm = ldm;
     p.X = X; p.Wp = Wpacked; p.bias = bias; p.residual = residual; p.out = out; p.in_a = in_scale; p.in_b = in_shift;
     p.stats = stats; p.rows = rows; p.K = K; p.ldx = ldx; p.N = N; p.NT = N / 32; p.relu = relu; p.ldr = ldr; p.ldo = ldo;
     p.ntiles = g.ntiles; p.G = g.G; p.ncg = g.ncg; p.nchunks = K / g.KC;

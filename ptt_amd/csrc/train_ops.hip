@@ -302,27 +302,125 @@ __global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const float* __restr
 // chunk of PB_GROUPS groups, thread = channel (coalesced dP / arg rows; z is gathered at the arg-max row), float64 partials
 // [chunk][2][C] in group order, combined by col_stats_finish2_kernel<1> / col_sums_finish_kernel as the dense form's.
 constexpr int PB_GROUPS = 64;
+// groups per workgroup: PB_GROUPS, but never more chunks than ptt_bn_stats_workspace(R, C) holds (one per ST4_ROWS rows)
+static inline int pool_bwd_groups_per_chunk(int ns) { const int m = (ST4_ROWS + ns - 1) / ns; return m > PB_GROUPS ? m : PB_GROUPS; }
 __global__ __launch_bounds__(256) void pool_bwd_stats_kernel(const float* __restrict__ dP, int ldp, const int32_t* __restrict__ arg,
                                                              int G, int ns, const float* __restrict__ Z, int ldz,
                                                              const float* __restrict__ mean, const float* __restrict__ invstd,
                                                              const float* __restrict__ act_a, const float* __restrict__ act_b, int C,
-                                                             double* __restrict__ partial) {
-    const int g0 = blockIdx.x * PB_GROUPS, g1 = min(G, g0 + PB_GROUPS);
-    for (int c = threadIdx.x; c < C; c += 256) {
-        const float mu = mean[c], is = invstd[c], a = act_a[c], b = act_b[c];
+                                                             double* __restrict__ partial, int per) {
+    // thread = (group slot rg, channel): span channels side by side (coalesced dP / arg rows), the 256 / span group slots
+    // walk the chunk's groups rg, rg + RG, ... with independent gathers in flight; slots combined through LDS in slot order
+    __shared__ double red[2][256];
+    const int span = C < 256 ? C : 256, RG = 256 / span;
+    const int c0 = threadIdx.x % span, rg = threadIdx.x / span;
+    const int g0 = blockIdx.x * per, g1 = min(G, g0 + per);
+    for (int cb = 0; cb < C; cb += span) {
+        const int c = cb + c0;
         double s0 = 0.0, s1 = 0.0;
-        for (int g = g0; g < g1; ++g) {
-            const int k = arg[(size_t)g * C + c];
-            const float z = Z[((size_t)g * ns + k) * ldz + c];
-            const float d = dP[(size_t)g * ldp + c];
-            const float dy = __builtin_fmaf(z, a, b) > 0.f ? d : 0.f;
-            const float xh = (z - mu) * is;
-            s0 += (double)dy;
-            s1 += (double)dy * (double)xh;
+        if (rg < RG && c < C) {
+            const float mu = mean[c], is = invstd[c], a = act_a[c], b = act_b[c];
+#pragma unroll 4
+            for (int g = g0 + rg; g < g1; g += RG) {
+                const int k = arg[(size_t)g * C + c];
+                const float z = Z[((size_t)g * ns + k) * ldz + c];
+                const float d = dP[(size_t)g * ldp + c];
+                const float dy = __builtin_fmaf(z, a, b) > 0.f ? d : 0.f;
+                const float xh = (z - mu) * is;
+                s0 += (double)dy;
+                s1 += (double)dy * (double)xh;
+            }
         }
-        partial[((size_t)blockIdx.x * 2 + 0) * C + c] = s0;
-        partial[((size_t)blockIdx.x * 2 + 1) * C + c] = s1;
+        red[0][threadIdx.x] = s0;
+        red[1][threadIdx.x] = s1;
+        __syncthreads();
+        if (rg == 0 && c < C) {
+            double t0 = 0.0, t1 = 0.0;
+            for (int r = 0; r < RG; ++r) { t0 += red[0][r * span + c0]; t1 += red[1][r * span + c0]; }
+            partial[((size_t)blockIdx.x * 2 + 0) * C + c] = t0;
+            partial[((size_t)blockIdx.x * 2 + 1) * C + c] = t1;
+        }
+        __syncthreads();
     }
+}
+
+// nn.BatchNorm's training-mode bookkeeping in one launch: running_mean / running_var <- (1 - m) * running + m * batch
+// (the variance unbiased by n / (n - 1), n = rows the statistics were taken over, in device memory: with SyncBatchNorm it
+// is the all-reduced count), num_batches_tracked += 1 (torch/nn/modules/batchnorm.py; pytorch_utils.py:94-114 builds the units)
+__global__ __launch_bounds__(256) void bn_running_update_kernel(const float* __restrict__ mean, const float* __restrict__ var,
+                                                                const double* __restrict__ count, float momentum, int C,
+                                                                float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                                long long* __restrict__ tracked) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c == 0 && tracked) *tracked += 1;
+    if (c >= C) return;
+    const double n = *count;
+    const float unbias = (float)(n / (n > 1.0 ? n - 1.0 : 1.0));
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean[c];
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (var[c] * unbias);
+}
+
+// CosineSimAug's hoisted layer 0 in TRAINING mode (train_ops.xcorr_hoisted; p2b_xcoor.py:35-40): the only channel of the
+// (B,260,n1,n2) fusion tensor that depends on the search point is the cosine, so the first convolution's output is
+//   z0[b, j, i, :] = P[b, i, :] + cos[b, j, i] * w[:]          (j search point, i template point)
+// forward: one pass that writes z0 (rows ordered (b, j, i)); backward: ONE pass over dz0 gives dP[b,i,:] = sum_j dz0,
+// dcos[b,j,i] = <dz0[b,j,i,:], w> and the per-workgroup partials of dw[:] = sum dz0 * cos (summed in workgroup order).
+__global__ __launch_bounds__(256) void xcorr_z0_kernel(const float* __restrict__ P, const float* __restrict__ cosm,
+                                                       const float* __restrict__ w, int n2, int n1, int C, long long total_rows,
+                                                       float* __restrict__ z0) {
+    const int Cq = C >> 2, span = Cq < 256 ? Cq : 256, RG = 256 / span;
+    const int q0 = threadIdx.x % span, rg = threadIdx.x / span;
+    if (rg >= RG) return;
+    for (int q = q0; q < Cq; q += span) {
+        const f32x4t w4 = *reinterpret_cast<const f32x4t*>(w + 4 * q);
+        for (long long r = (long long)blockIdx.x * RG + rg; r < total_rows; r += (long long)gridDim.x * RG) {
+            const long long bj = r / n1;                       // (b, j)
+            const int i = (int)(r - bj * n1);
+            const long long b = bj / n2;
+            const float cv = cosm[r];
+            const f32x4t pv = *reinterpret_cast<const f32x4t*>(P + (b * n1 + i) * C + 4 * q);
+            f32x4t o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = __builtin_fmaf(cv, w4[k], pv[k]);
+            *reinterpret_cast<f32x4t*>(z0 + r * C + 4 * q) = o;
+        }
+    }
+}
+
+// one wave per (b, i): walks the n2 search points; lane = channel quad (C <= 256)
+__global__ __launch_bounds__(256) void xcorr_z0_bwd_kernel(const float* __restrict__ dz0, const float* __restrict__ cosm,
+                                                           const float* __restrict__ w, int B, int n2, int n1, int C,
+                                                           float* __restrict__ dP, float* __restrict__ dcos,
+                                                           float* __restrict__ dw_partial) {
+    __shared__ float red[4][256];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int bi = blockIdx.x * 4 + wv;                        // flat (b, i)
+    const int Cq = C >> 2;
+    const bool on = lane < Cq && bi < B * n1;
+    f32x4t accP = {0.f, 0.f, 0.f, 0.f}, accW = {0.f, 0.f, 0.f, 0.f};
+    if (bi < B * n1) {
+        const int b = bi / n1, i = bi - b * n1;
+        f32x4t w4 = {0.f, 0.f, 0.f, 0.f};
+        if (on) w4 = *reinterpret_cast<const f32x4t*>(w + 4 * lane);
+        for (int j = 0; j < n2; ++j) {
+            const long long r = ((long long)b * n2 + j) * n1 + i;
+            f32x4t v = {0.f, 0.f, 0.f, 0.f};
+            if (on) v = *reinterpret_cast<const f32x4t*>(dz0 + r * C + 4 * lane);
+            const float cv = cosm[r];
+            float dot = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { accP[k] += v[k]; accW[k] = __builtin_fmaf(v[k], cv, accW[k]); dot = __builtin_fmaf(v[k], w4[k], dot); }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) dot += __shfl_xor(dot, off, 64);
+            if (lane == 0) dcos[r] = dot;
+        }
+        if (on) *reinterpret_cast<f32x4t*>(dP + (size_t)bi * C + 4 * lane) = accP;
+    }
+    // dw: the four waves' sums in wave order -> one partial row per workgroup
+#pragma unroll
+    for (int k = 0; k < 4; ++k) red[wv][4 * lane + k] = on ? accW[k] : 0.f;
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) dw_partial[(size_t)blockIdx.x * C + c] = ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
 }
 
 static inline bool vec4_ok(const void* p, int ld, int C) {
@@ -406,7 +504,7 @@ __global__ __launch_bounds__(256) void pool_rows_bwd_kernel(const float* __restr
 constexpr int WG_KC = 32;            // rows per staged sub-chunk
 constexpr int WG_LD = 132;           // LDS row stride (floats)
 constexpr int WG_ROWS = 4096;        // rows per workgroup at most (fewer when that leaves CUs idle)
-constexpr int WG_MIN_ROWS = 512;
+constexpr int WG_MIN_ROWS = 256;
 
 template <bool VEC>   // VEC: ld % 4 == 0 and P 16-byte aligned -> whole float4s (channels past cmax are zeroed afterwards)
 __device__ __forceinline__ void wg_fetch(const float* __restrict__ P, int ld, int r0, int rmax, int c0, int cmax, int t,
@@ -875,9 +973,9 @@ extern "C" int ptt_bn_bwd_pooled_f32(const float* dPooled, int ldp, const int32_
         return fail(PTT_EINVAL, "ptt_bn_bwd_pooled_f32: bad output / gamma pointer");
     if (!ws || ws_bytes < ptt_bn_stats_workspace(R, C)) return fail(PTT_EWORKSPACE, "ptt_bn_bwd_pooled_f32: workspace too small");
     hipStream_t s = as_stream(stream);
-    const int G = R / ns, nch = (G + PB_GROUPS - 1) / PB_GROUPS;
+    const int G = R / ns, per = pool_bwd_groups_per_chunk(ns), nch = (G + per - 1) / per;
     hipLaunchKernelGGL(pool_bwd_stats_kernel, dim3(nch), dim3(256), 0, s, dPooled, ldp, arg, G, ns, Z, ldz, mean, invstd, act_scale,
-                       act_shift, C, static_cast<double*>(ws));
+                       act_shift, C, static_cast<double*>(ws), per);
     hipLaunchKernelGGL((col_stats_finish2_kernel<1>), dim3(C), dim3(256), 0, s, static_cast<const double*>(ws), nch, C, R, 0.f, dbeta,
                        dgamma, nullptr);
     const int Cq = C >> 2, RG = 256 / (Cq < 256 ? Cq : 256);
@@ -895,9 +993,9 @@ extern "C" int ptt_bn_bwd_pooled_sums_f64(const float* dPooled, int ldp, const i
     if (!sums) return fail(PTT_EINVAL, "ptt_bn_bwd_pooled_sums_f64: null pointer");
     if (!ws || ws_bytes < ptt_bn_stats_workspace(R, C)) return fail(PTT_EWORKSPACE, "ptt_bn_bwd_pooled_sums_f64: workspace too small");
     hipStream_t s = as_stream(stream);
-    const int G = R / ns, nch = (G + PB_GROUPS - 1) / PB_GROUPS;
+    const int G = R / ns, per = pool_bwd_groups_per_chunk(ns), nch = (G + per - 1) / per;
     hipLaunchKernelGGL(pool_bwd_stats_kernel, dim3(nch), dim3(256), 0, s, dPooled, ldp, arg, G, ns, Z, ldz, mean, invstd, act_scale,
-                       act_shift, C, static_cast<double*>(ws));
+                       act_shift, C, static_cast<double*>(ws), per);
     hipLaunchKernelGGL(col_sums_finish_kernel, dim3(C), dim3(256), 0, s, static_cast<const double*>(ws), nch, C, sums, -1.0);
     return check_launch("ptt_bn_bwd_pooled_sums_f64");
 }
@@ -1064,4 +1162,44 @@ extern "C" int ptt_bn_sums_partials_f64(const double* partial, int chunks, int C
     if (chunks <= 0 || C <= 0 || R <= 0 || !partial || !sums) return fail(PTT_EINVAL, "ptt_bn_sums_partials_f64: chunks=%d C=%d R=%d", chunks, C, R);
     hipLaunchKernelGGL(col_sums_finish_kernel, dim3(C), dim3(256), 0, as_stream(stream), partial, chunks, C, sums, (double)R);
     return check_launch("col_sums_finish_kernel");
+}
+
+extern "C" int ptt_bn_update_running_f32(const float* mean, const float* var, const double* count, float momentum, int C,
+                                         float* running_mean, float* running_var, int64_t* num_batches_tracked, ptt_stream_t stream) {
+    if (C <= 0 || !mean || !var || !count || !running_mean || !running_var) return fail(PTT_EINVAL, "ptt_bn_update_running_f32: C=%d or null pointer", C);
+    hipLaunchKernelGGL(bn_running_update_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), mean, var, count, momentum, C,
+                       running_mean, running_var, reinterpret_cast<long long*>(num_batches_tracked));
+    return check_launch("bn_running_update_kernel");
+}
+
+extern "C" int ptt_xcorr_z0_f32(const float* P, const float* cos_t, const float* w_sim, int B, int n2, int n1, int C, float* z0,
+                                ptt_stream_t stream) {
+    if (B <= 0 || n2 <= 0 || n1 <= 0 || C <= 0 || (C & 3)) return fail(PTT_EINVAL, "ptt_xcorr_z0_f32: B=%d n2=%d n1=%d C=%d", B, n2, n1, C);
+    if (!P || !cos_t || !w_sim || !z0 || !vec4_ok(P, C, C) || !vec4_ok(z0, C, C) || !vec4_ok(w_sim, 4, 4))
+        return fail(PTT_EINVAL, "ptt_xcorr_z0_f32: null or misaligned pointer");
+    const long long rows = (long long)B * n2 * n1;
+    const int Cq = C >> 2, RG = 256 / (Cq < 256 ? Cq : 256);
+    long long grid = (rows + RG * 8 - 1) / (RG * 8);
+    if (grid > 16384) grid = 16384;
+    hipLaunchKernelGGL(xcorr_z0_kernel, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), P, cos_t, w_sim, n2, n1, C, rows, z0);
+    return check_launch("xcorr_z0_kernel");
+}
+
+extern "C" size_t ptt_xcorr_z0_bwd_workspace(int B, int n1, int C) {
+    if (B <= 0 || n1 <= 0 || C <= 0) return 0;
+    return (size_t)((B * n1 + 3) / 4) * C * sizeof(float);
+}
+
+extern "C" int ptt_xcorr_z0_bwd_f32(const float* dz0, const float* cos_t, const float* w_sim, int B, int n2, int n1, int C, float* dP,
+                                    float* dcos, float* dw, void* ws, size_t ws_bytes, ptt_stream_t stream) {
+    if (B <= 0 || n2 <= 0 || n1 <= 0 || C <= 0 || (C & 3) || C > 256)
+        return fail(PTT_EINVAL, "ptt_xcorr_z0_bwd_f32: B=%d n2=%d n1=%d C=%d (C %% 4 == 0, C <= 256)", B, n2, n1, C);
+    if (!dz0 || !cos_t || !w_sim || !dP || !dcos || !dw || !vec4_ok(dz0, C, C) || !vec4_ok(dP, C, C) || !vec4_ok(w_sim, 4, 4))
+        return fail(PTT_EINVAL, "ptt_xcorr_z0_bwd_f32: null or misaligned pointer");
+    if (!ws || ws_bytes < ptt_xcorr_z0_bwd_workspace(B, n1, C)) return fail(PTT_EWORKSPACE, "ptt_xcorr_z0_bwd_f32: workspace too small");
+    hipStream_t s = as_stream(stream);
+    const int nwg = (B * n1 + 3) / 4;
+    hipLaunchKernelGGL(xcorr_z0_bwd_kernel, dim3(nwg), dim3(256), 0, s, dz0, cos_t, w_sim, B, n2, n1, C, dP, dcos, static_cast<float*>(ws));
+    launch_wgrad_finish(static_cast<const float*>(ws), nwg, (size_t)C, 0, dw, s);
+    return check_launch("xcorr_z0_bwd_kernel");
 }

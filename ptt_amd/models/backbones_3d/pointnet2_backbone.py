@@ -12,7 +12,7 @@ from typing import List
 import torch
 import torch.nn as nn
 
-from ... import ops
+from ... import ops, train_ops
 from .pointnet2 import pointnet2_modules
 
 
@@ -46,8 +46,14 @@ class PointNet2BackboneLight(nn.Module):
 
     def _cov_final(self, features):
         """features (B,256,M). Eval + HIP + point-major storage: MFMA linear; else stock Conv1d."""
-        if self.training or not features.is_cuda:
+        if not features.is_cuda:
             return self.cov_final(features)
+        if self.training:
+            if features.dtype != torch.float32:
+                return self.cov_final(features)
+            # training on a HIP device: the 1x1 convolution over point-major rows on the row kernels (forward, input and
+            # weight gradient: train_ops._RowsLinear); the SA level's output already is (B,M,C) storage
+            return train_ops.rows_linear(self.cov_final, features.transpose(1, 2)).transpose(1, 2)
         if ops.autograd_recording(self.cov_final, features) or features.dtype != torch.float32:
             ops.note_unfused('PointNet2BackboneLight.cov_final', 'autograd is recording or input is not float32')
             return self.cov_final(features)

@@ -113,8 +113,11 @@ class CosineSimAug(nn.Module):
                 and self.mlp[0].conv.weight.shape[0] % 4 == 0):
             # training on a HIP device: layer 0 split per template point + similarity term (train_ops.xcorr_hoisted),
             # the remaining SharedMLP layers and the max over the template axis on the row kernels
-            batch_dict['cosine_feats'] = self.conv(train_ops.xcorr_hoisted(search_feats, template_feats, template_xyz,
-                                                                           self.mlp, self.cosine.eps))
+            fused = train_ops.xcorr_hoisted(search_feats, template_feats, template_xyz, self.mlp, self.cosine.eps)   # (B,C,n2) view
+            if train_ops.conv1d_stack_usable(self.conv, fused):
+                batch_dict['cosine_feats'] = train_ops.conv1d_stack_rows(self.conv, fused.transpose(1, 2)).transpose(1, 2)
+            else:
+                batch_dict['cosine_feats'] = self.conv(fused)
             return batch_dict
         sim_feat = self.cosine(template_feats.unsqueeze(-1).expand(b, f, n1, n2),
                                search_feats.unsqueeze(2).expand(b, f, n1, n2))

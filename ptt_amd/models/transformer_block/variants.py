@@ -103,26 +103,25 @@ class TransformerBlock(nn.Module):
             return res, attn
 
         if train_ops.pt_block_usable(self, xyz, features):
-            # training mode on a HIP device: the GEMMs stay nn.Linear (autograd), the element-wise chains over the
-            # (B,N,k,D) tensors run as one hand-written pass each (ptt_amd/train_ops.py: _PairInput, _AttnAggregate); the
-            # neighbour gathers of k and v happen inside those passes and their gradients come back through the
-            # deterministic row scatter-add. kNN: the HIP kernel (ascending (distance, index), a stable refinement of the
-            # reference's argsort).
+            # training mode on a HIP device: the GEMMs on the persistent row GEMM / weight-gradient kernels, the element-wise
+            # chains over the (B,N,k,D) tensors as one hand-written pass each (ptt_amd/train_ops.py: _PairInput,
+            # _AttnAggregate); the neighbour gathers of k and v happen inside those passes and their gradients come back
+            # through the deterministic row scatter-add. kNN: the HIP kernel (ascending (distance, index), a stable
+            # refinement of the reference's argsort).
             knn_idx, rel = ops.knn(xyz.contiguous(), self.k, want_rel=True)          # rel = xyz_i - xyz_j (:158)
             if xyz.requires_grad:                                                     # the box head's proposals carry grad
                 knn_xyz = index_points(xyz, knn_idx.long())
                 rel = xyz[:, :, None] - knn_xyz
-            pre = features
-            x = self.fc1(features)
-            q, kf, vf = self.w_qs(x), self.w_ks(x), self.w_vs(x)
-            # fc_delta: Linear(3 -> d) -> ReLU -> Linear(d -> d); the K = 3 layer runs on the hand-written linear / weight-
-            # gradient kernels (stock BLAS spends 0.45 ms per call on its skinny GEMMs), the d x d layer stays on hipBLASLt
-            h = torch.relu(train_ops.rows_linear(self.fc_delta[0], rel.reshape(-1, 3)))
-            pos_enc = self.fc_delta[2](h).view(*rel.shape[:-1], self.d_model)
+            # every Linear on the row kernels (train_ops._RowsLinear / _RowsMlp2): bias, ReLU, the residual and the ReLU
+            # backward live in GEMM epilogues; the K = 3 layer fc_delta[0] and its 512 x 3 weight gradient on the linear /
+            # weight-gradient kernels
+            x = train_ops.rows_linear(self.fc1, features)
+            q, kf, vf = (train_ops.rows_linear(m, x) for m in (self.w_qs, self.w_ks, self.w_vs))
+            pos_enc = train_ops.rows_mlp2(self.fc_delta, rel)                          # (B,N,k,D)
             t = train_ops._PairInput.apply(q, kf, knn_idx, pos_enc)
-            a = _rows2d(self.fc_gamma, t)
+            a = train_ops.rows_mlp2(self.fc_gamma, t)
             res, attn = train_ops._AttnAggregate.apply(a, vf, knn_idx, pos_enc, 1.0 / np.sqrt(self.d_model))
-            res = self.fc2(res) + pre
+            res = train_ops.rows_linear(self.fc2, res, residual=features)
             return res, attn
 
         # CPU: the reference's op sequence in stock torch (variants.py:149-165)

@@ -4,6 +4,7 @@ the second Point-Track-Transformer block and a small Conv1d stack that regresses
 proposal. `vote_aggregation`, `refine_layer`, `transformer_block` are the checkpoint names."""
 import torch
 
+from ... import train_ops
 from ..backbones_3d.pointnet2 import pointnet2_modules
 from ..backbones_3d.pointnet2 import pytorch_utils as layer_utils
 from ..transformer_block import build_transformer
@@ -55,21 +56,42 @@ class BoxVotingHead(VotingHeadTemplate):
 
     # ------------------------------------------------------------------ forward (reference :68-112)
     def _fusable(self, feats):
-        return not self.training and layer_utils.rows_fusable(self.refine_layer, feats)
+        if self.training:
+            return train_ops.conv1d_stack_usable(self.refine_layer, feats)
+        return layer_utils.rows_fusable(self.refine_layer, feats)
+
+    def _train_labels(self, batch_dict, centres):
+        dist = torch.sqrt(torch.sum((centres - batch_dict['reg_label'][:, None, 0:3]) ** 2, dim=-1) + 1e-6)
+        label = torch.zeros_like(dist, dtype=torch.float)
+        mask = torch.zeros_like(label, dtype=torch.float)
+        label[dist < 0.3] = 1
+        mask[dist < 0.3] = 1
+        mask[dist > 0.6] = 1
+        self.forward_ret_dict = {
+            'pred_boxes_cls': batch_dict['pred_box_data'][:, :, -1],
+            'pred_boxes_reg': batch_dict['pred_box_data'][:, :, :-1],
+            'mask': mask, 'cls_label': label, 'reg_label': batch_dict['reg_label'],
+        }
 
     def forward(self, batch_dict):
         centres, feats, _ = self.vote_aggregation(xyz=batch_dict['pred_centroids_votes'],
                                                   features=batch_dict['votes_feats'],
                                                   npoint=self.model_cfg.SA_CONFIG.NPOINTS)
         if self._fusable(feats):
-            # eval mode on a HIP device: stay on point-major rows (the SA output already is), one folded-BN linear
-            # launch per refine layer, and the (B,M,5) result is produced directly in the layout the caller wants
+            # on a HIP device: stay on point-major rows (the SA output already is); eval: one folded-BN linear launch per
+            # refine layer; training: the row kernels of ptt_amd/train_ops.py. The (B,M,5) result is produced directly in
+            # the layout the caller wants
             rows = feats.transpose(1, 2)                                                         # (B,M,C)
             if hasattr(self, 'transformer_block'):
                 rows = self.transformer_block(xyz=centres, features=rows.contiguous())[0]
-            offsets = layer_utils.rows_forward(self.refine_layer, rows)                          # (B,M,5)
+            if self.training:
+                offsets = train_ops.conv1d_stack_rows(self.refine_layer, rows)                   # (B,M,5)
+            else:
+                offsets = layer_utils.rows_forward(self.refine_layer, rows)                      # (B,M,5)
             batch_dict['pred_box_center'] = centres
             batch_dict['pred_box_data'] = torch.cat((offsets[..., 0:3] + centres, offsets[..., 3:]), dim=2)
+            if self.training:
+                self._train_labels(batch_dict, centres)
             return batch_dict
         if hasattr(self, 'transformer_block'):
             fused = self.transformer_block(xyz=centres, features=feats.transpose(1, 2).contiguous())[0]
@@ -81,15 +103,5 @@ class BoxVotingHead(VotingHeadTemplate):
         batch_dict['pred_box_data'] = boxes.transpose(1, 2).contiguous()                         # (B,M,5)
 
         if self.training:
-            dist = torch.sqrt(torch.sum((centres - batch_dict['reg_label'][:, None, 0:3]) ** 2, dim=-1) + 1e-6)
-            label = torch.zeros_like(dist, dtype=torch.float)
-            mask = torch.zeros_like(label, dtype=torch.float)
-            label[dist < 0.3] = 1
-            mask[dist < 0.3] = 1
-            mask[dist > 0.6] = 1
-            self.forward_ret_dict = {
-                'pred_boxes_cls': batch_dict['pred_box_data'][:, :, -1],
-                'pred_boxes_reg': batch_dict['pred_box_data'][:, :, :-1],
-                'mask': mask, 'cls_label': label, 'reg_label': batch_dict['reg_label'],
-            }
+            self._train_labels(batch_dict, centres)
         return batch_dict

@@ -5,6 +5,7 @@ tiny (0.05 GFLOP/frame): stock torch layers in training, folded-BN linear launch
 on a HIP device; names `cla_layer`, `vote_layer`, `transformer_block` are the checkpoint contract."""
 import torch
 
+from ... import train_ops
 from ..backbones_3d.pointnet2 import pytorch_utils as layer_utils
 from ..transformer_block import build_transformer
 from .voting_head_template import VotingHeadTemplate
@@ -52,28 +53,41 @@ class CentroidVotingHead(VotingHeadTemplate):
         return (loss_cls + loss_reg).float(), tb_dict
 
     # ------------------------------------------------------------------ forward (reference :64-109)
+    def _stack(self, seq, rows, residual=None):
+        if self.training:
+            return train_ops.conv1d_stack_rows(seq, rows, residual)
+        return layer_utils.rows_forward(seq, rows, residual)
+
     def _forward_rows(self, batch_dict):
-        """Eval mode on a HIP device: the same computation on point-major rows — the transformer already works on
-        (B,N,C) rows, the two Conv1d stacks run as folded-BN linear layers (one launch each), and `votes_feats` is
-        handed to the box head as the (B,1+C,N) view of (B,N,1+C) storage, which its grouping kernel gathers
-        coalesced. No layout copies."""
+        """On a HIP device: the same computation on point-major rows — the transformer already works on (B,N,C) rows,
+        the two Conv1d stacks run as linear layers over rows (eval: BatchNorm folded, one launch each; training: the row
+        kernels of ptt_amd/train_ops.py, batch statistics out of the GEMM epilogues), and `votes_feats` is handed to the box
+        head as the (B,1+C,N) view of (B,N,1+C) storage, which its grouping kernels gather coalesced. No layout copies."""
         seeds = batch_dict['search_seeds']                                        # (B,N,3)
         rows = batch_dict['cosine_feats'].transpose(1, 2)                         # (B,N,C)
         if hasattr(self, 'transformer_block'):
             rows = self.transformer_block(xyz=seeds, features=rows.contiguous())[0]
         with_xyz = torch.cat((seeds, rows), dim=2)                                # (B,N,3+C)
         cls_in = with_xyz if getattr(self.model_cfg, 'CLS_USE_SEARCH_XYZ', False) else rows
-        cls_out = layer_utils.rows_forward(self.cla_layer, cls_in).squeeze(-1)    # (B,N)
-        voted = layer_utils.rows_forward(self.vote_layer, with_xyz, residual=with_xyz)
+        cls_out = self._stack(self.cla_layer, cls_in).squeeze(-1)                 # (B,N)
+        voted = self._stack(self.vote_layer, with_xyz, residual=with_xyz)
         batch_dict['pred_centroids_cls'] = cls_out.squeeze(0)
         batch_dict['pred_centroids_votes'] = voted[..., 0:3].contiguous()         # (B,N,3)
         batch_dict['votes_feats'] = torch.cat((cls_out.sigmoid().unsqueeze(-1), voted[..., 3:]),
                                               dim=2).transpose(1, 2)              # (B,1+C,N) view
+        if self.training:
+            self.forward_ret_dict = {
+                'pred_centroids_cls': batch_dict['pred_centroids_cls'],
+                'pred_centroids_votes': batch_dict['pred_centroids_votes'],
+                'cls_label': batch_dict['cls_label'].gather(1, batch_dict['search_inds']),
+                'reg_label': batch_dict['reg_label'],
+            }
         return batch_dict
 
     def _fusable(self, feats):
-        return (not self.training and layer_utils.rows_fusable(self.cla_layer, feats)
-                and layer_utils.rows_fusable(self.vote_layer, feats))
+        if self.training:
+            return (train_ops.conv1d_stack_usable(self.cla_layer, feats) and train_ops.conv1d_stack_usable(self.vote_layer, feats))
+        return layer_utils.rows_fusable(self.cla_layer, feats) and layer_utils.rows_fusable(self.vote_layer, feats)
 
     def forward(self, batch_dict):
         if self._fusable(batch_dict['cosine_feats']):

@@ -711,6 +711,43 @@ def bn_bwd_apply(g, act, z, mean, invstd, gamma, sum_dy, sum_dy_xhat, count, out
     return out
 
 
+def bn_update_running(bn, mean, var, count):
+    """nn.BatchNorm's training-mode bookkeeping for module `bn` from the batch statistics, one launch
+    (ptt_bn_update_running_f32); count: float64 (1,) device tensor = rows the statistics were taken over."""
+    tracked = bn.num_batches_tracked
+    with torch.cuda.device(mean.device):
+        _lib.check(_lib.lib().ptt_bn_update_running_f32(_ptr(mean), _ptr(var), _ptr(count), float(bn.momentum), mean.numel(),
+                                                        _ptr(bn.running_mean), _ptr(bn.running_var),
+                                                        _ptr(tracked) if tracked is not None else None, _stream()),
+                   "ptt_bn_update_running_f32")
+    for t in (bn.running_mean, bn.running_var, tracked):          # the eval-mode parameter caches key on tensor versions
+        if t is not None:
+            torch.autograd.graph.increment_version(t)
+
+
+def xcorr_z0(P, cos_t, w_sim):
+    """z0[b,j,i,:] = P[b,i,:] + cos_t[b,j,i] * w_sim — (B*n2*n1, C0) rows ordered (b, j, i) — ptt_xcorr_z0_f32."""
+    B, n1, C = P.shape
+    n2 = cos_t.shape[1]
+    z0 = torch.empty((B * n2 * n1, C), dtype=torch.float32, device=P.device)
+    with torch.cuda.device(P.device):
+        _lib.check(_lib.lib().ptt_xcorr_z0_f32(_ptr(P), _ptr(cos_t), _ptr(w_sim), B, n2, n1, C, _ptr(z0), _stream()), "ptt_xcorr_z0_f32")
+    return z0
+
+
+def xcorr_z0_bwd(dz0, cos_t, w_sim, B, n2, n1):
+    """-> (dP (B,n1,C), dcos (B,n2,n1), dw (C,)) in one pass over dz0 (B*n2*n1, C) — ptt_xcorr_z0_bwd_f32."""
+    C = dz0.shape[1]
+    dP = torch.empty((B, n1, C), dtype=torch.float32, device=dz0.device)
+    dcos = torch.empty((B, n2, n1), dtype=torch.float32, device=dz0.device)
+    dw = torch.empty((C,), dtype=torch.float32, device=dz0.device)
+    ws = _ws(_lib.lib().ptt_xcorr_z0_bwd_workspace(B, n1, C), dz0.device)
+    with torch.cuda.device(dz0.device):
+        _lib.check(_lib.lib().ptt_xcorr_z0_bwd_f32(_ptr(dz0), _ptr(cos_t), _ptr(w_sim), B, n2, n1, C, _ptr(dP), _ptr(dcos), _ptr(dw),
+                                                   _ptr(ws), ws.numel() * 8, _stream()), "ptt_xcorr_z0_bwd_f32")
+    return dP, dcos, dw
+
+
 def bn_bwd_pooled(dpooled, arg, ns, z, mean, invstd, gamma, act_scale, act_shift, out=None):
     """bn_bwd for the last layer of a SharedMLP + max-pool stage with the gradient still pooled (dpooled (G,C), arg (G,C)
     int32 from pool_rows): -> (dz (G*ns,C), dgamma, dbeta) — ptt_bn_bwd_pooled_f32."""
@@ -820,6 +857,27 @@ def rows_gemm(x, wpacked, cout, in_scale=None, in_shift=None, bias=None, relu=Fa
                                                 _ptr(out), out.stride(0), _ptr(stats), stats.numel() if stats is not None else 0,
                                                 _stream()), "ptt_rows_gemm_f32")
     return (out, stats) if want_stats else out
+
+
+def rows_gemm_masked(x, wpacked, cout, mask, want_colsum=False):
+    """out = (mask > 0) ? x @ W^T : 0 — the input gradient of the layer behind a ReLU whose output is `mask`
+    (ptt_rows_gemm_masked_f32). want_colsum: also the column sums of the masked result (float32 (cout,)), i.e. the bias
+    gradient of the Linear in front of that ReLU, from the GEMM's own epilogue."""
+    _rows(x, "x"); _rows(mask, "mask")
+    rows, K = x.shape
+    cout = int(cout)
+    out = torch.empty((rows, cout), dtype=torch.float32, device=x.device)
+    stats = None
+    if want_colsum:
+        chunks = _lib.lib().ptt_rows_gemm_stat_chunks(rows, K, cout)
+        stats = torch.empty((max(1, chunks), 2, cout), dtype=torch.float64, device=x.device)
+    with torch.cuda.device(x.device), _timed('ptt_rows_gemm_f32'):
+        _lib.check(_lib.lib().ptt_rows_gemm_masked_f32(_ptr(x), rows, K, x.stride(0), _ptr(wpacked), cout, _ptr(mask), mask.stride(0),
+                                                       _ptr(out), cout, _ptr(stats), stats.numel() if stats is not None else 0,
+                                                       _stream()), "ptt_rows_gemm_masked_f32")
+    if want_colsum:
+        return out, bn_sums_partials(stats, rows)[:cout].float()
+    return out
 
 
 def bn_finish_partials(partials, rows, eps):

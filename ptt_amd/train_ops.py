@@ -219,15 +219,9 @@ def rows_mlp_pool(rows, mlp, ns, B, keep, preact):
         sync.append(_sync_group(bn))
     out = _SharedMlpPool.apply(rows, ns, tuple(eps), bool(preact), tuple(sync), *params)
     pooled, stats = out[0], out[1:]
-    with torch.no_grad():                                   # nn.BatchNorm2d's bookkeeping in training mode
+    with torch.no_grad():                                   # nn.BatchNorm's bookkeeping in training mode, one launch per layer
         for l, unit in enumerate(mlp):
-            bn = unit.normlayer.bn
-            m = bn.momentum
-            n = stats[3 * l + 2]                            # rows the statistics were taken over (all ranks'), float64 (1,)
-            unbias = (n / (n - 1.0).clamp_min(1.0)).float()
-            bn.running_mean.mul_(1 - m).add_(stats[3 * l], alpha=m)
-            bn.running_var.mul_(1 - m).add_(stats[3 * l + 1] * unbias, alpha=m)
-            bn.num_batches_tracked.add_(1)
+            ops.bn_update_running(unit.normlayer.bn, stats[3 * l], stats[3 * l + 1], stats[3 * l + 2])
     return pooled.view(B, keep, -1).transpose(1, 2)         # (B, C_L, keep)
 
 
@@ -266,8 +260,25 @@ def xcorr_hoisted(search_feats, template_feats, template_xyz, mlp, eps):
     cos = torch.bmm(sn.transpose(1, 2), tn)                                             # (B,n2,n1)
     rows_i = torch.cat((template_xyz, template_feats.transpose(1, 2)), dim=2)           # (B,n1,3+C)
     P = torch.nn.functional.linear(rows_i, w0[:, 1:])                                   # (B,n1,C0)
-    z0 = P.unsqueeze(1) + cos.unsqueeze(-1) * w0[:, 0]                                  # (B,n2,n1,C0)
-    return rows_mlp_pool(z0.reshape(B * n2 * n1, -1), mlp, n1, B, n2, preact=True)
+    z0 = _XcorrZ0.apply(P.contiguous(), cos.contiguous(), w0[:, 0].contiguous())      # (B*n2*n1, C0) rows ordered (b, j, i)
+    return rows_mlp_pool(z0, mlp, n1, B, n2, preact=True)
+
+
+class _XcorrZ0(torch.autograd.Function):
+    """z0[b,j,i,:] = P[b,i,:] + cos[b,j,i] * w[:] in one pass; backward in one pass over dz0 (ptt_xcorr_z0(_bwd)_f32)."""
+
+    @staticmethod
+    def forward(ctx, P, cos, w):
+        ctx.save_for_backward(cos, w)
+        ctx.dims = (P.shape[0], cos.shape[1], P.shape[1])
+        return ops.xcorr_z0(P, cos, w)
+
+    @staticmethod
+    def backward(ctx, dz0):
+        cos, w = ctx.saved_tensors
+        B, n2, n1 = ctx.dims
+        dP, dcos, dw = ops.xcorr_z0_bwd(dz0.contiguous(), cos, w, B, n2, n1)
+        return dP, dcos, dw
 
 
 class _PairInput(torch.autograd.Function):
@@ -316,31 +327,121 @@ def pt_block_usable(block, xyz, features):
             and xyz.shape[1] * block.k <= 16384)
 
 
+def lin_rows(x2, W, b=None, relu=False, residual=None):
+    """relu?(x2 @ W^T + b) (+ residual) over (rows, K) activations: the persistent row GEMM where the shape allows, else the
+    linear kernel (K = 3, N = 1 / 5 / 259, ...)."""
+    cout, K = W.shape
+    wp = ops.pack_weight(W)
+    if ops.rows_gemm_supported(x2.shape[0], K, cout, x2.stride(0), cout):
+        return ops.rows_gemm(x2, wp, cout, bias=b, relu=relu, residual=residual)
+    return ops.linear(x2, wp, cout, None, b, relu, residual)
+
+
 class _RowsLinear(torch.autograd.Function):
-    """y = x W^T + b over (rows, K) on the hand-written kernels: forward and input gradient on ptt_linear_f32, weight
-    gradient on ptt_linear_wgrad_f32, bias gradient = column sums. Used where stock BLAS picks badly shaped kernels —
-    the K = 3 layer fc_delta[0] over ~10^5 (point, neighbour) rows and its 512 x 3 weight gradient."""
+    """y = x W^T + b (+ residual) over (rows, K) on the hand-written kernels: forward and input gradient on the row GEMM /
+    linear kernel, weight gradient on ptt_linear_wgrad(2)_f32, bias gradient = column sums. Every nn.Linear of the
+    Point-Transformer block in training mode (fc1, w_qs, w_ks, w_vs, fc2: variants.py:154-156,164), cov_final
+    (pointnet2_backbone.py:46) and the last Conv1d of the heads' stacks."""
 
     @staticmethod
-    def forward(ctx, x, W, b):
+    def forward(ctx, x, W, b, residual):
         x2 = x.reshape(-1, x.shape[-1]).contiguous()
-        ctx.save_for_backward(x2, W)
+        W2 = W.detach().reshape(W.shape[0], -1)
+        ctx.save_for_backward(x2, W2)
         ctx.shape = x.shape
-        y = ops.linear(x2, ops.pack_weight(W.detach().contiguous()), W.shape[0], None, b.detach() if b is not None else None)
-        return y.view(*x.shape[:-1], W.shape[0])
+        r2 = residual.reshape(-1, W2.shape[0]).contiguous() if residual is not None else None
+        y = lin_rows(x2, W2.contiguous(), b.detach() if b is not None else None, residual=r2)
+        return y.view(*x.shape[:-1], W2.shape[0])
 
     @staticmethod
     def backward(ctx, g):
-        x2, W = ctx.saved_tensors
+        x2, W2 = ctx.saved_tensors
         g2 = g.reshape(-1, g.shape[-1]).contiguous()
-        dx = None
-        if ctx.needs_input_grad[0]:
-            dx = ops.linear(g2, ops.pack_weight(W.detach().t().contiguous()), W.shape[1]).view(ctx.shape)
+        dx = lin_rows(g2, W2.t().contiguous()).view(ctx.shape) if ctx.needs_input_grad[0] else None
         dW = ops.linear_wgrad(g2, x2) if ctx.needs_input_grad[1] else None
         db = g2.sum(0) if ctx.needs_input_grad[2] else None
-        return dx, dW, db
+        return dx, dW, db, (g if ctx.needs_input_grad[3] else None)
 
 
-def rows_linear(layer, x):
-    """nn.Linear `layer` applied to x (..., K) through _RowsLinear."""
-    return _RowsLinear.apply(x, layer.weight, layer.bias)
+def rows_linear(layer, x, residual=None):
+    """nn.Linear / 1x1 Conv1d `layer` applied to x (..., K) (+ residual (..., Cout)) through _RowsLinear."""
+    W = layer.weight
+    return _RowsLinear.apply(x, W.reshape(W.shape[0], -1) if W.dim() > 2 else W, layer.bias, residual)
+
+
+class _RowsMlp2(torch.autograd.Function):
+    """y = relu(x W1^T + b1) W2^T + b2 over (rows, K): nn.Sequential(Linear, ReLU, Linear) — fc_delta and fc_gamma of the
+    Point-Transformer block (variants.py:139-148) over the (point, neighbour) rows, 92 % of the block's FLOPs. Forward: bias
+    and ReLU in the first GEMM's epilogue. Backward: the input gradient of the second layer comes out of its GEMM already
+    masked by the ReLU, together with its column sums (= db1) — ptt_rows_gemm_masked_f32."""
+
+    @staticmethod
+    def forward(ctx, x, W1, b1, W2, b2):
+        x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        h = lin_rows(x2, W1.detach().contiguous(), b1.detach(), relu=True)
+        y = lin_rows(h, W2.detach().contiguous(), b2.detach())
+        ctx.save_for_backward(x2, h, W1.detach(), W2.detach())
+        ctx.shape = x.shape
+        return y.view(*x.shape[:-1], W2.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, h, W1, W2 = ctx.saved_tensors
+        dy2 = dy.reshape(-1, dy.shape[-1]).contiguous()
+        rows, D1 = h.shape
+        dW2 = ops.linear_wgrad(dy2, h)
+        db2 = dy2.sum(0)
+        w2t = W2.t().contiguous()
+        if ops.rows_gemm_supported(rows, W2.shape[0], D1, dy2.stride(0), D1):
+            dz1, db1 = ops.rows_gemm_masked(dy2, ops.pack_weight(w2t), D1, h, want_colsum=True)
+        else:
+            dz1 = lin_rows(dy2, w2t) * (h > 0)
+            db1 = dz1.sum(0)
+        dW1 = ops.linear_wgrad(dz1, x2)
+        dx = lin_rows(dz1, W1.t().contiguous()).view(ctx.shape) if ctx.needs_input_grad[0] else None
+        return dx, dW1, db1, dW2, db2
+
+
+def rows_mlp2(seq, x):
+    """nn.Sequential(Linear, ReLU, Linear) `seq` applied to x (..., K) through _RowsMlp2."""
+    return _RowsMlp2.apply(x, seq[0].weight, seq[0].bias, seq[2].weight, seq[2].bias)
+
+
+def conv1d_stack_usable(seq, x):
+    """A heads-style Conv1d stack in training mode on a HIP device: [Conv1d(k=1, no bias) -> BatchNorm1d -> ReLU] units
+    followed by at most one plain Conv1d(k=1) (centroids_voting_head.py:15-21, box_voting_head.py:25, p2b_xcoor.py:20-24)."""
+    if not (seq.training and x.is_cuda and x.dtype == torch.float32 and len(seq) > 0):
+        return False
+    units = list(seq)
+    for k, unit in enumerate(units):
+        conv = getattr(unit, 'conv', None)
+        if not isinstance(conv, nn.Conv1d) or conv.kernel_size != (1,) or conv.stride != (1,) or conv.padding != (0,) or conv.groups != 1:
+            return False
+        if hasattr(unit, 'normlayer'):
+            bn = getattr(unit.normlayer, 'bn', None)
+            if (not isinstance(bn, (nn.BatchNorm1d, nn.SyncBatchNorm)) or not bn.affine or not bn.track_running_stats
+                    or bn.momentum is None or not bn.training or conv.bias is not None or conv.weight.shape[0] % 4):
+                return False
+            if not isinstance(getattr(unit, 'activation', None), nn.ReLU) or list(unit._modules.keys()) != ['conv', 'normlayer', 'activation']:
+                return False
+        elif k != len(units) - 1 or list(unit._modules.keys()) != ['conv']:
+            return False
+    return True
+
+
+def conv1d_stack_rows(seq, rows, residual=None):
+    """seq(rows^T)^T in TRAINING mode for such a stack: rows (B, N, Cin) -> (B, N, Cout) (+ residual). The BatchNorm'd units run
+    as one _SharedMlpPool over B * N rows (pool width 1: convolution + batch statistics out of the GEMM epilogue, deferred
+    activation, fused BatchNorm / ReLU backward), the trailing plain convolution through _RowsLinear."""
+    B, N, _ = rows.shape
+    units = list(seq)
+    bn_units = [u for u in units if hasattr(u, 'normlayer')]
+    x = rows.reshape(B * N, -1)
+    if bn_units:
+        x = rows_mlp_pool(x, bn_units, 1, 1, B * N, preact=False)[0].t()          # (B*N, C): a view of row-major storage
+    if len(bn_units) < len(units):
+        last = units[-1].conv
+        res2 = residual.reshape(B * N, -1) if residual is not None else None
+        return rows_linear(last, x, res2).view(B, N, -1)
+    assert residual is None
+    return x.reshape(B, N, -1)
