@@ -110,8 +110,7 @@ class TransformerBlock(nn.Module):
             # refinement of the reference's argsort).
             knn_idx, rel = ops.knn(xyz.contiguous(), self.k, want_rel=True)          # rel = xyz_i - xyz_j (:158)
             if xyz.requires_grad:                                                     # the box head's proposals carry grad
-                knn_xyz = index_points(xyz, knn_idx.long())
-                rel = xyz[:, :, None] - knn_xyz
+                rel = train_ops._KnnRel.apply(xyz, knn_idx, rel)
             # every Linear on the row kernels (train_ops._RowsLinear / _RowsMlp2): bias, ReLU, the residual and the ReLU
             # backward live in GEMM epilogues; the K = 3 layer fc_delta[0] and its 512 x 3 weight gradient on the linear /
             # weight-gradient kernels

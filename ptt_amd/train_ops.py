@@ -240,7 +240,7 @@ def sa_level_hoisted(xyz, new_xyz, features, idx, mlp, radius, normalize_xyz):
     if normalize_xyz:
         rel = rel / radius
     rel_rows = rel.permute(0, 2, 3, 1).reshape(B * M * ns, 3)
-    term = torch.nn.functional.linear(features.transpose(1, 2), w0[:, 3:])              # (B,N,C0), once per point
+    term = _RowsLinear.apply(features.transpose(1, 2), w0[:, 3:], None, None)           # (B,N,C0), once per point
     z0 = _AddRelTerm.apply(gather_rows(term, idx.view(B, M * ns)).view(B * M * ns, -1), rel_rows, w0[:, 0:3])
     return rows_mlp_pool(z0, mlp, ns, B, M, preact=True)
 
@@ -259,7 +259,7 @@ def xcorr_hoisted(search_feats, template_feats, template_xyz, mlp, eps):
     sn = search_feats / search_feats.norm(dim=1, keepdim=True).clamp_min(eps)           # (B,C,n2)
     cos = torch.bmm(sn.transpose(1, 2), tn)                                             # (B,n2,n1)
     rows_i = torch.cat((template_xyz, template_feats.transpose(1, 2)), dim=2)           # (B,n1,3+C)
-    P = torch.nn.functional.linear(rows_i, w0[:, 1:])                                   # (B,n1,C0)
+    P = _RowsLinear.apply(rows_i, w0[:, 1:], None, None)                                # (B,n1,C0)
     z0 = _XcorrZ0.apply(P.contiguous(), cos.contiguous(), w0[:, 0].contiguous())      # (B*n2*n1, C0) rows ordered (b, j, i)
     return rows_mlp_pool(z0, mlp, n1, B, n2, preact=True)
 
@@ -279,6 +279,25 @@ class _XcorrZ0(torch.autograd.Function):
         B, n2, n1 = ctx.dims
         dP, dcos, dw = ops.xcorr_z0_bwd(dz0.contiguous(), cos, w, B, n2, n1)
         return dP, dcos, dw
+
+
+class _KnnRel(torch.autograd.Function):
+    """rel[b,i,j,:] = xyz[b,i] - xyz[b, knn[b,i,j]] (variants.py:158) with the kNN kernel's own output as the value and a
+    DETERMINISTIC backward: d xyz[b,i] = sum_j g[b,i,j] - (sum of g over the pairs whose neighbour is i, in a fixed order).
+    The stock form (index_points + subtraction) scatters with atomics: run-to-run different low bits in every gradient
+    upstream of the box head's proposal centres."""
+
+    @staticmethod
+    def forward(ctx, xyz, knn, rel):
+        ctx.save_for_backward(knn)
+        return rel.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        (knn,) = ctx.saved_tensors
+        B, N, k, _ = g.shape
+        back = ops.scatter_add_det(g.permute(0, 3, 1, 2).reshape(B, 3, N * k).contiguous(), knn.view(B, N * k), N)   # (B,3,N)
+        return g.sum(dim=2) - back.transpose(1, 2), None, None
 
 
 class _PairInput(torch.autograd.Function):

@@ -38,5 +38,8 @@ f)  # the training path on the persistent row GEMM: parity tests, then the step
     timeout 600 python bench.py --workload train --steps 10 --warmup 3 > $O/bench_train.json 2> $O/bench_train.err; python -c "import json;d=json.load(open('$O/bench_train.json'));print(d['ms_per_step'],d['value'],d['sustained'])"
     ktrace train_kernel_stats python $REPO/bench.py --workload train --steps 5 --warmup 2 --sustain 0
     ;;
+g)  timeout 2400 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; echo "rc=$?" >> $O/pytest_gpu.log
+    tail -30 $O/pytest_gpu.log
+    ;;
 *)  echo "unknown session $S"; exit 2;;
 esac
