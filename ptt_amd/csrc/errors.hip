@@ -2,7 +2,9 @@
 #include <stdarg.h>
 #include <stdlib.h>
 #include <string.h>
+#include <map>
 #include <mutex>
+#include <utility>
 #include "common.h"
 
 namespace ptt {
@@ -60,21 +62,20 @@ const DevSwitches& dev_switches() {
 
 int set_lds_limit(const void* fn, int bytes) {
     if (bytes <= 48 * 1024) return PTT_OK;
-    struct Entry { const void* fn; int dev; int bytes; };
-    static Entry table[64];
-    static int used = 0;
+    // (kernel, device) -> the largest limit set so far. A map, not a fixed table: a process that drives eight devices, or one
+    // that runs every workload of bench.py, registers a few hundred pairs — and a pair that does not fit would fall back to
+    // hipFuncSetAttribute on EVERY launch, which inside a stream capture is an error, not a slowdown.
+    static std::map<std::pair<const void*, int>, int> table;
     static std::mutex mu;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return check_launch("hipGetDevice");
     std::lock_guard<std::mutex> g(mu);
-    Entry* slot = nullptr;
-    for (int i = 0; i < used; ++i)
-        if (table[i].fn == fn && table[i].dev == dev) { slot = &table[i]; break; }
-    if (slot && slot->bytes >= bytes) return PTT_OK;
+    const auto key = std::make_pair(fn, dev);
+    const auto it = table.find(key);
+    if (it != table.end() && it->second >= bytes) return PTT_OK;
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess)
         return check_launch("hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
-    if (!slot && used < 64) slot = &table[used++];
-    if (slot) { slot->fn = fn; slot->dev = dev; slot->bytes = bytes; }
+    table[key] = bytes;
     return PTT_OK;
 }
 

@@ -41,5 +41,27 @@ f)  # the training path on the persistent row GEMM: parity tests, then the step
 g)  timeout 2400 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; echo "rc=$?" >> $O/pytest_gpu.log
     tail -30 $O/pytest_gpu.log
     ;;
+h)  # the default driver command
+    SECONDS=0; PTT_BENCH_VERBOSE=1 timeout 1500 python -X faulthandler bench.py > $O/bench_default.json 2> $O/bench_default.err; tail -c 1500 $O/bench_default.json; grep -i "elapsed\|error\|Traceback" $O/bench_default.err | head
+    ;;
+i)  # isolate the stress-after-car crash
+    for w in stress ped,stress; do
+        PTT_BENCH_VERBOSE=1 timeout 600 python -X faulthandler bench.py --no-cpu-baseline --no-full-model --no-latency --steps 5 --warmup 2 --sustain 0 --workloads $w > $O/b_$w.json 2> $O/b_$w.err
+        echo "== $w rc=$?"; grep -v amdgpu.ids $O/b_$w.err | head -12 | cut -c1-160
+    done
+    PTT_BENCH_VERBOSE=1 timeout 600 python -X faulthandler bench.py --workload stress --no-cpu-baseline --steps 5 --warmup 2 --sustain 0 > $O/b_stress_alone.json 2> $O/b_stress_alone.err
+    echo "== stress alone rc=$?"; grep -v amdgpu.ids $O/b_stress_alone.err | head -12 | cut -c1-160
+    ;;
+j)  # which stage poisons the later stress graph: full model + latency, or the CPU baseline
+    PTT_BENCH_VERBOSE=1 timeout 900 python -X faulthandler bench.py --no-cpu-baseline --workloads stress > $O/b_nocpu.json 2> $O/b_nocpu.err
+    echo "== no cpu baseline rc=$?"; grep -v amdgpu.ids $O/b_nocpu.err | head -14 | cut -c1-160
+    PTT_BENCH_VERBOSE=1 timeout 900 python -X faulthandler bench.py --no-full-model --no-latency --workloads stress > $O/b_cpu.json 2> $O/b_cpu.err
+    echo "== cpu baseline only rc=$?"; grep -v amdgpu.ids $O/b_cpu.err | head -14 | cut -c1-160
+    nproc; python -c "import os;print(len(os.sched_getaffinity(0)), os.cpu_count())"; cat /sys/fs/cgroup/cpu.max 2>/dev/null
+    ;;
+k)  true
+    true
+    SECONDS=0; PTT_BENCH_VERBOSE=1 timeout 1500 python -X faulthandler bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "== default rc=$? wall ${SECONDS}s"; grep -v amdgpu.ids $O/bench_default.err | head -30 | cut -c1-160
+    ;;
 *)  echo "unknown session $S"; exit 2;;
 esac
