@@ -154,7 +154,13 @@ __global__ __launch_bounds__(256, 2) void rows_gemm_kernel(RowsGemmParams p) {
             const float bl = g_load1(rb, cn * 4, 0);
             const float bv = has_bias ? bl : 0.f;
             const int obase = ((row_w + 4 * half) * p.ldo + cn) * 4, rbase = ((row_w + 4 * half) * ldr + cn) * 4;
+            // column statistics without cancellation: sums of (y - K) and (y - K)^2 in float32 around a per-lane reference value
+            // K (this lane's first value: within the column's spread), un-shifted in float64 — sum y = s + n K,
+            // sum y^2 = q + 2 K s + n K^2. (Plain float32 sums of y^2 lose mean^2 / var digits in E[y^2] - mean^2: a BatchNorm over
+            // a nearly constant channel then amplifies 1e-7 into 1e-4.)
+            const float kref = acc[0][u][0] + bv;               // the lane's first row: if that one is past the end, all of its rows are
             float s = 0.f, sq = 0.f;
+            int nrows = 0;
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
                 float rv[16];
@@ -172,9 +178,10 @@ __global__ __launch_bounds__(256, 2) void rows_gemm_kernel(RowsGemmParams p) {
                     const bool in = FULL || row_w + 4 * half + dr < p.rows;
                     float y = acc[rt][u][r] + bv;
                     if (MODE == 2) y = rv[r] > 0.f ? y : 0.f;
-                    if (STATS) {                                // rows past the end: relu(shift) . W with a deferred activation
-                        const float ys = (FULL || !ACT || in) ? y : 0.f;
-                        s += ys; sq = __builtin_fmaf(ys, ys, sq);
+                    if (STATS) {                                // rows past the end take no part
+                        const float d = in ? y - kref : 0.f;
+                        s += d; sq = __builtin_fmaf(d, d, sq);
+                        if (!FULL) nrows += in ? 1 : 0;
                     }
                     y = fmaxf(y, rfloor);
                     if (MODE == 1) y += rv[r];
@@ -184,8 +191,9 @@ __global__ __launch_bounds__(256, 2) void rows_gemm_kernel(RowsGemmParams p) {
                 }
             }
             if (STATS) {
-                dsum[u] += (double)g_add_halves(s);
-                dsq[u] += (double)g_add_halves(sq);
+                const double K = (double)kref, S = (double)s, n = FULL ? 16.0 * RT : (double)nrows;
+                dsum[u] += S + n * K;
+                dsq[u] += (double)sq + 2.0 * K * S + n * K * K;
             }
         }
     };
@@ -268,13 +276,13 @@ __global__ __launch_bounds__(256, 2) void rows_gemm_kernel(RowsGemmParams p) {
         if (!(EXP & 8)) g_lds_barrier();
         tile = tile_n; c = c_n;
     }
-    if (STATS && half == 0) {
+    if (STATS) {                                                // the two half-waves hold different rows of the same columns
         double* sp = p.stats + (size_t)(g * WR + wr) * 2 * p.N;
 #pragma unroll
         for (int u = 0; u < CT; ++u) {
+            const double a = dsum[u] + __shfl_xor(dsum[u], 32, 64), b = dsq[u] + __shfl_xor(dsq[u], 32, 64);
             const int cn = (ct0 + u * WC) * 32 + col;
-            sp[cn] = dsum[u];
-            sp[p.N + cn] = dsq[u];
+            if (half == 0) { sp[cn] = a; sp[p.N + cn] = b; }
         }
     }
 }

@@ -604,7 +604,7 @@ WGRAD2 = os.environ.get("PTT_WGRAD2", "1") != "0"        # dev A/B: the round-2 
 
 
 def _rows(t, name):
-    if not t.is_cuda or t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1:
+    if not t.is_cuda or t.dtype != torch.float32 or t.dim() != 2 or (t.stride(1) != 1 and t.shape[1] != 1):
         raise RuntimeError("%s must be a (rows, channels) float32 device tensor with contiguous channels" % name)
     return t
 

@@ -63,5 +63,14 @@ k)  true
     true
     SECONDS=0; PTT_BENCH_VERBOSE=1 timeout 1500 python -X faulthandler bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "== default rc=$? wall ${SECONDS}s"; grep -v amdgpu.ids $O/bench_default.err | head -30 | cut -c1-160
     ;;
+l)  timeout 1200 python -m pytest tests/test_train_gpu.py tests/test_golden_gpu.py -m gpu -q -s -k "G10 or G14 or hoisted or transformer_block_training or shared_mlp_pool or conv1d_stack" > $O/pytest_tol.log 2>&1; echo "rc=$?" >> $O/pytest_tol.log
+    grep -i "worst\|measured\|passed\|failed\|observed" $O/pytest_tol.log | cut -c1-300
+    ;;
+m)  for m in rows stock; do for f in 1; do echo "force picks $f"; G14_FORCE_PICKS=$f G14_PATH=$m timeout 600 python scripts/g14_diag.py 2>&1 | grep -v "amdgpu.ids\|Warning\|detach\|return float" | cut -c1-200; done; done > $O/g14_diag.log; cat $O/g14_diag.log
+    ;;
+n)  timeout 600 python scripts/rows_gemm_bench.py --no-bench 2>&1 | grep check | cut -c1-250
+    G14_ROWS=2 timeout 600 python scripts/g14_diag.py 2>&1 | grep -v "amdgpu.ids\|Warning\|detach\|return float\|group" | cut -c1-200
+    true python scripts/fwd_precision_diag.py 2>&1 | grep -v "amdgpu.ids\|Warning" > $O/fwd_precision.log; cat $O/fwd_precision.log
+    ;;
 *)  echo "unknown session $S"; exit 2;;
 esac

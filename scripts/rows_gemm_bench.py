@@ -34,6 +34,13 @@ def check():
         mean, var, invstd = ops.bn_finish_partials(st, R, 1e-5)
         v64, m64 = torch.var_mean(ref, 0, unbiased=False)
         e2 = float((mean.double() - m64).abs().max()), float(((var.double() - v64) / v64).abs().max())
+        # a nearly constant output channel (|mean| = 300 std): E[y^2] - mean^2 in float32 would keep no digit of the variance
+        xb = torch.cat([x[:, :K - 1] * 1e-2, torch.ones(R, 1, device=dev)], 1).contiguous()
+        wb = w.clone(); wb[:, K - 1] = 3.0
+        yb, stb = ops.rows_gemm(xb, ops.pack_weight(wb), C, want_stats=True)
+        mb, vb, _ = ops.bn_finish_partials(stb, R, 1e-5)
+        v64b, m64b = torch.var_mean(yb.double(), 0, unbiased=False)
+        e2 = e2 + (float(((vb.double() - v64b) / v64b).abs().max()),)
         y2, st2 = ops.rows_gemm(x, wp, C, want_stats=True)
         same = torch.equal(y, y2) and torch.equal(st, st2)
         # deferred activation on the input + bias + relu + residual
@@ -49,10 +56,10 @@ def check():
         g2 = ops.linear_wgrad(dz, x, x_scale=a, x_shift=b)
         gref2 = dz.double().t() @ torch.relu(x.double() * a.double() + b.double())
         e5 = float((g2.double() - gref2).abs().max() / gref2.abs().max())
-        ok = e < 2e-6 and e3 < 2e-6 and e4 < 1e-5 and e5 < 1e-5 and e2[0] < 1e-5 and e2[1] < 1e-4 and same
+        ok = e < 2e-6 and e3 < 2e-6 and e4 < 1e-5 and e5 < 1e-5 and e2[0] < 1e-5 and e2[1] < 1e-4 and e2[2] < 1e-4 and same
         worst = max(worst, e, e3)
-        print("check R=%d K=%d N=%d: y %.1e  act/bias/relu/res %.1e  mean %.1e var %.1e  wgrad %.1e / %.1e  reproducible %s  %s"
-              % (R, K, C, e, e3, e2[0], e2[1], e4, e5, same, "ok" if ok else "FAIL"))
+        print("check R=%d K=%d N=%d: y %.1e  act/bias/relu/res %.1e  mean %.1e var %.1e (offset channel %.1e)  wgrad %.1e / %.1e  reproducible %s  %s"
+              % (R, K, C, e, e3, e2[0], e2[1], e2[2], e4, e5, same, "ok" if ok else "FAIL"))
     return worst
 
 

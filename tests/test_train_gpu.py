@@ -11,6 +11,11 @@ import torch
 
 from ptt_amd import ops, train_ops
 from ptt_amd.models.backbones_3d.pointnet2 import pytorch_utils as pt_utils
+from tests.util import outside
+
+# forward values are held against the north_star bar (1e-4) and the COUNT of elements outside it is asserted (measured on
+# MI355X, printed by the tests): a handful of max-pool outputs whose arg-max row flips between two fp32 evaluations
+Y_OUTSIDE_SA, Y_OUTSIDE_XCORR = 0, 14               # measured: 0 and 7 (of 98304)
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -100,24 +105,25 @@ def test_shared_mlp_pool_equals_stock_torch_training_step(dev, B, Cin, M, ns, sp
     up = torch.randn_like(y2)
     y1.backward(up)
     y2.backward(up)
+    seen = {}
 
-    def close(p, q, name, tol=2e-3):
+    def close(p, q, name, tol=3e-6):                      # measured: 1.2e-6 at worst
         err = float((p - q).abs().max()) / (float(q.abs().max()) + 1e-12)
+        seen[name] = err
         assert err < tol, (name, err)
 
     close(x1.grad, x2.grad, "input grad")
     for (n1, p1), (_, p2) in zip(a.named_parameters(), b.named_parameters()):
         close(p1.grad, p2.grad, n1)
+    print("measured shared_mlp_pool %s: worst relative gradient error %.2e (%s)" % (spec, max(seen.values()), max(seen, key=seen.get)))
     for (n1, b1), (_, b2) in zip(a.named_buffers(), b.named_buffers()):
         torch.testing.assert_close(b1.float(), b2.float(), rtol=1e-4, atol=1e-5, msg=n1)
 
 
 def test_G10_training_step_on_the_row_kernels_matches_the_reference_gradients(dev):
-    """Fixture G10 = loss and parameter gradients of the REFERENCE model for one seeded training step. The mirror in
-    train mode on the GPU runs the SA levels and CosineSimAug on the hand-written row kernels; loss within 1e-4; every
-    non-vanishing gradient's norm within 8 % and direction cos > 0.99 — the same bars as the stock-torch training path
-    (tests/test_golden_gpu.py::test_G10_...): max-pool / ReLU routing flips under 1e-6 perturbations between any two
-    fp32 implementations. The measured figures are printed."""
+    """Fixture G10 = loss and parameter gradients of the REFERENCE model (float32, CPU) for one seeded training step. The
+    mirror in train mode on the GPU runs every stage on the hand-written row kernels; loss within 1e-5; every non-vanishing
+    gradient's norm within 0.4 % and direction cos > 0.99997 (measured 0.21 % / 0.999989, printed)."""
     from ptt_amd.config import StubDataset, ptt_model_cfg
     from ptt_amd.models import build_network
     from tests.util import fill_state_dict_
@@ -128,23 +134,78 @@ def test_G10_training_step_on_the_row_kernels_matches_the_reference_gradients(de
                        'cls_label': t(g["cls_label"]), 'reg_label': t(g["reg_label"])})
     loss = ret['loss'].mean()
     loss.backward()
-    assert abs(float(loss) - float(g["loss"])) <= 1e-4 * abs(float(g["loss"]))
+    assert abs(float(loss.detach()) - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))             # measured 1.8e-6
     named = dict(model.named_parameters())
     keys = [str(k) for k in g["grad_keys"]]
     worst_norm, worst_cos = 0.0, 1.0
+    per = {}
     for k, ref_norm in zip(keys, g["grad_norms"]):
         if ref_norm <= 1e-3:                                # mathematically zero (a bias in front of a softmax / BatchNorm)
             continue
         n = float(named[k].grad.double().norm())
+        per[k] = abs(n - ref_norm) / ref_norm
         worst_norm = max(worst_norm, abs(n - ref_norm) / ref_norm)
+    for k in sorted(per, key=per.get, reverse=True)[:8]:
+        print("   G10 norm error %.4f  %s" % (per[k], k))
     for i, k in enumerate(str(k) for k in g["full_keys"]):
         ref = torch.from_numpy(g["grad_%d" % i]).double().flatten()
         if float(ref.norm()) <= 1e-3:
             continue
         got = named[k].grad.double().cpu().flatten()
         worst_cos = min(worst_cos, float(torch.dot(ref, got) / (ref.norm() * got.norm() + 1e-30)))
-    print("G10 on the row kernels: worst gradient-norm error %.4f, worst cosine %.6f" % (worst_norm, worst_cos))
-    assert worst_norm < 0.08 and worst_cos > 0.99, (worst_norm, worst_cos)
+    above = sum(1 for v in per.values() if v > 1e-3)
+    print("G10 on the row kernels: worst gradient-norm error %.4f, worst cosine %.6f, %d of %d gradients more than 0.1 %% off the "
+          "reference's norm" % (worst_norm, worst_cos, above, len(per)))
+    # measured on MI355X: 0.0021 / 0.999989 / 5 of 96 (round 2, before the BatchNorm variance of the fused statistics was made
+    # cancellation-free: 0.022 / 0.9990; the reference's own float32 run is 0.0028 off its float64 gradient, fixture G14)
+    assert worst_norm < 0.004 and worst_cos > 0.99997 and above <= 12, (worst_norm, worst_cos, above)
+
+
+def test_G14_float32_step_is_as_close_to_the_float64_gradient_as_the_references_float32_run(dev):
+    """Fixture G14 = the reference's training step of G10 in FLOAT64 (tests/golden/make_golden_f64.py). The tracker's max-pools
+    and ReLUs make per-cent differences between two float32 evaluations possible, so the yardstick is the float64 gradient: this
+    build's float32 step on the row kernels must be no further from it than twice what the reference's own float32 run (G10)
+    is — measured: 0.0019 (ours) against 0.0028 (reference float32) in the worst gradient norm — and must pick the reference's
+    64 proposals out of the 128 votes (the one data-dependent sampling of the step)."""
+    from ptt_amd.config import StubDataset, ptt_model_cfg
+    from ptt_amd.models import build_network
+    from ptt_amd.models.backbones_3d.pointnet2 import pointnet2_utils as PU
+    from tests.util import fill_state_dict_
+    g = np.load(os.path.join(GOLD, "G10_train_step.npz"))
+    g14 = np.load(os.path.join(GOLD, "G14_train_step_f64.npz"))
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    model = fill_state_dict_(build_network(ptt_model_cfg(), 1, StubDataset(training=True)), int(g["seed"])).to(dev).train()
+    picks, fps = [], PU.furthest_point_sample
+
+    def spy(xyz, npoint):
+        out = fps(xyz, npoint)
+        if xyz.shape[1] == 128 and npoint == 64:
+            picks.append(out.cpu().numpy())
+        return out
+    PU.furthest_point_sample = spy
+    try:
+        ret, _, _ = model({'search_points': t(g["search"]), 'template_points': t(g["template"]), 'batch_size': 3,
+                           'cls_label': t(g["cls_label"]), 'reg_label': t(g["reg_label"])})
+    finally:
+        PU.furthest_point_sample = fps
+    loss = ret['loss'].mean()
+    loss.backward()
+    assert len(picks) == 1 and [set(r) for r in picks[0].tolist()] == [set(r) for r in g14["vote_picks"].tolist()]
+    assert abs(float(loss.detach()) - float(g14["loss"])) <= 5e-6 * abs(float(g14["loss"]))          # measured 1.4e-6
+    named = dict(model.named_parameters())
+    keys = [str(k) for k in g14["grad_keys"]]
+    n64 = dict(zip(keys, g14["grad_norms"]))
+    n32 = dict(zip([str(k) for k in g["grad_keys"]], g["grad_norms"]))
+    ours = max(abs(float(named[k].grad.double().norm()) - n64[k]) / n64[k] for k in keys if n64[k] > 1e-3)
+    ref = max(abs(n32[k] - n64[k]) / n64[k] for k in keys if n64[k] > 1e-3)
+    l2 = 0.0
+    for i, k in enumerate(str(k) for k in g14["full_keys"]):
+        r64 = torch.from_numpy(g14["grad_%d" % i]).double().flatten()
+        if float(r64.norm()) > 1e-3:
+            l2 = max(l2, float((named[k].grad.double().cpu().flatten() - r64).norm() / r64.norm()))
+    print("G14: worst gradient-norm error against float64 — this build (float32) %.4f, the reference's float32 run %.4f; worst "
+          "relative L2 error of a full gradient %.4f" % (ours, ref, l2))
+    assert ours <= 2.0 * ref and l2 <= 0.011, (ours, ref, l2)                                           # measured 0.0019 / 0.0028 / 0.0054
 
 
 def _clone_module(m):
@@ -176,19 +237,24 @@ def test_hoisted_sa_level_training_equals_the_reference_op_sequence(dev, B, N, M
     finally:
         train_ops.usable = orig
     assert torch.equal(i1, i2) and torch.equal(nx1, nx2)
-    torch.testing.assert_close(y1, y2, rtol=2e-4, atol=2e-4)
+    n_out, worst_y = outside(y1, y2)
+    print("measured hoisted SA level %s: %d of %d outputs outside 1e-4, worst %.2f x the tolerance" % (spec, n_out, y2.numel(), worst_y))
+    assert n_out <= Y_OUTSIDE_SA and worst_y <= 0.1, (n_out, worst_y)      # measured: 0.03 x the tolerance
     up = torch.randn_like(y2)
     (y1 * up).sum().backward()
     (y2 * up).sum().backward()
+    seen = {}
 
-    def close(p, q, name, tol=3e-3):
+    def close(p, q, name, tol=1.5e-5):                    # measured: 7.3e-6 at worst
         err = float((p - q).abs().max()) / (float(q.abs().max()) + 1e-12)
+        seen[name] = err
         assert err < tol, (name, err)
 
     close(f1.grad, f2.grad, "feature grad")
     close(xyz1.grad, xyz2.grad, "xyz grad")
     for (n1, p1), (_, p2) in zip(a.named_parameters(), b.named_parameters()):
         close(p1.grad, p2.grad, n1)
+    print("measured hoisted SA level %s: worst relative gradient error %.2e (%s)" % (spec, max(seen.values()), max(seen, key=seen.get)))
     for (n1, b1), (_, b2) in zip(a.named_buffers(), b.named_buffers()):
         torch.testing.assert_close(b1.float(), b2.float(), rtol=1e-3, atol=1e-5, msg=n1)
 
@@ -212,7 +278,10 @@ def test_hoisted_cosine_sim_aug_training_equals_the_reference_op_sequence(dev):
         y2 = b({'search_feats': sf2, 'template_feats': tf2, 'template_seeds': tx2})['cosine_feats']
     finally:
         train_ops.usable = orig
-    torch.testing.assert_close(y1, y2, rtol=3e-4, atol=3e-4)
+    n_out, worst_y = outside(y1, y2)
+    print("measured hoisted CosineSimAug: %d of %d outputs outside 1e-4, worst %.2f x the tolerance" % (n_out, y2.numel(), worst_y))
+    assert n_out <= Y_OUTSIDE_XCORR and worst_y <= 2.0, (n_out, worst_y)   # measured: 7 outside, worst 1.09 x (the stock side's
+                                                                         # float32 BatchNorm variance is the less accurate one)
     up = torch.randn_like(y2)
     (y1 * up).sum().backward()
     (y2 * up).sum().backward()
@@ -220,17 +289,22 @@ def test_hoisted_cosine_sim_aug_training_equals_the_reference_op_sequence(dev):
     # small sum of max-pool routes and a handful of routes that flip between two fp32 evaluations of z0 (1e-6 apart)
     # shows: L2-relative 2e-2 there, 1e-2 of the maximum everywhere else (observed 4e-3)
     err = float((sf1.grad - sf2.grad).norm() / sf2.grad.norm())
-    assert err < 2e-2, ("search grad", err)
+    print("measured hoisted CosineSimAug: search-feature gradient L2-relative error %.2e" % err)
+    assert err < 4e-4, ("search grad", err)               # measured 1.6e-4
     for p, q, name in ((tf1.grad, tf2.grad, "template grad"), (tx1.grad, tx2.grad, "xyz grad")):
         err = float((p - q).abs().max()) / (float(q.abs().max()) + 1e-12)
-        assert err < 1e-2, (name, err)
+        print("measured hoisted CosineSimAug: %s error %.2e of the maximum" % (name, err))
+        assert err < 1e-3, (name, err)                     # measured 4.5e-4
     # scale: a gradient that is mathematically zero (mlp.layer2's BatchNorm bias: a per-channel shift in front of the
     # train-mode BatchNorm of conv[0]) is rounding noise in both implementations — errors are measured against
     # max(|reference gradient|, 1e-3 of the largest parameter gradient)
     gmax = max(float(p.grad.abs().max()) for p in b.parameters())
+    worst_p = 0.0
     for (n1, p1), (_, p2) in zip(a.named_parameters(), b.named_parameters()):
         err = float((p1.grad - p2.grad).abs().max()) / max(float(p2.grad.abs().max()), 1e-3 * gmax)
-        assert err < 2e-2, (n1, err)              # observed: up to 1.04e-2 (max-pool routes that flip between the two evaluations)
+        worst_p = max(worst_p, err)
+        assert err < 2.5e-3, (n1, err)            # measured: up to 1.1e-3 (max-pool routes that flip between the two evaluations)
+    print("measured hoisted CosineSimAug: worst parameter-gradient error %.2e" % worst_p)
 
 
 @pytest.mark.parametrize("B,N,E,C", [(3, 256, 128 * 32, 128), (2, 100, 37, 8), (1, 16, 16384, 64)])
@@ -277,8 +351,11 @@ def test_transformer_block_training_path_equals_the_reference_op_sequence(dev, N
     (r1 * up).sum().backward()
     (r2 * up).sum().backward()
 
-    def close(p, q, name, tol=1e-3):
+    seen = {}
+
+    def close(p, q, name, tol=8e-6):                      # measured: 3.3e-6 at worst
         err = float((p - q).abs().max()) / max(float(q.abs().max()), 1e-6)
+        seen[name] = err
         assert err < tol, (name, err)
 
     close(f1.grad, f2.grad, "feature grad")
@@ -287,7 +364,9 @@ def test_transformer_block_training_path_equals_the_reference_op_sequence(dev, N
     gmax = max(float(p.grad.abs().max()) for p in b.parameters())
     for (n1, p1), (_, p2) in zip(a.named_parameters(), b.named_parameters()):
         err = float((p1.grad - p2.grad).abs().max()) / max(float(p2.grad.abs().max()), 1e-3 * gmax)   # fc_gamma.2.bias: exactly 0
-        assert err < 1e-3, (n1, err)
+        seen[n1] = err
+        assert err < 8e-6, (n1, err)
+    print("measured transformer block (training, N = %d): worst relative gradient error %.2e (%s)" % (N, max(seen.values()), max(seen, key=seen.get)))
 
 
 @pytest.mark.parametrize("G,ns,C", [(300, 32, 128), (77, 16, 256), (5000, 32, 64)])
@@ -319,3 +398,39 @@ def test_pooled_bn_backward_equals_pool_backward_then_dense_bn_backward(dev, G, 
     count = torch.full((1,), float(R), dtype=torch.float64, device=dev)
     dz3 = ops.bn_bwd_pooled_apply(up, arg, ns, z, mean, invstd, gamma, sums[0].contiguous(), sums[1].contiguous(), count, a, b)
     assert float((dz3 - dz).abs().max()) <= 1e-6 * scale
+
+
+@pytest.mark.parametrize("channels,residual", [([256, 256, 256, 1], False), ([259, 256, 256, 259], True), ([256, 256, 256, 5], False)])
+def test_conv1d_stack_training_rows_path_equals_stock_torch(dev, channels, residual):
+    """The heads' Conv1d stacks ([Conv1d + BatchNorm1d + ReLU] x 2 + Conv1d with bias; centroids_voting_head.py:15-21,
+    box_voting_head.py:25) in TRAINING mode on the row kernels against the same modules in stock torch on (B,C,N) tensors:
+    output, input gradient, every parameter gradient, the running statistics."""
+    import copy
+    torch.manual_seed(7)
+    a = (pt_utils.Seq(channels[0]).conv1d(channels[1], bn=True).conv1d(channels[2], bn=True).conv1d(channels[3], activation=None)).to(dev).train()
+    with torch.no_grad():
+        for u in a:
+            if hasattr(u, 'normlayer'):
+                u.normlayer.bn.weight.uniform_(0.5, 1.5)
+                u.normlayer.bn.bias.normal_(0, 0.2)
+    b = copy.deepcopy(a)
+    B, N = 4, 128
+    x1 = torch.randn(B, N, channels[0], device=dev, requires_grad=True)
+    x2 = x1.detach().clone().requires_grad_(True)
+    assert train_ops.conv1d_stack_usable(a, x1)
+    y1 = train_ops.conv1d_stack_rows(a, x1, residual=x1 if residual else None)
+    y2 = b(x2.transpose(1, 2)).transpose(1, 2)
+    if residual:
+        y2 = y2 + x2
+    n_out, worst = outside(y1, y2)
+    assert n_out == 0, (n_out, worst)
+    up = torch.randn_like(y2)
+    (y1 * up).sum().backward()
+    (y2 * up).sum().backward()
+    seen = {"input": float((x1.grad - x2.grad).abs().max() / x2.grad.abs().max())}
+    for (n1, p1), (_, p2) in zip(a.named_parameters(), b.named_parameters()):
+        seen[n1] = float((p1.grad - p2.grad).abs().max()) / max(float(p2.grad.abs().max()), 1e-6)
+    print("measured conv1d stack %s: worst relative gradient error %.2e (%s)" % (channels, max(seen.values()), max(seen, key=seen.get)))
+    assert max(seen.values()) < 2e-6, seen                 # measured: 5.7e-7
+    for (n1, b1), (_, b2) in zip(a.named_buffers(), b.named_buffers()):
+        torch.testing.assert_close(b1.float(), b2.float(), rtol=1e-4, atol=1e-5, msg=n1)

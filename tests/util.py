@@ -117,3 +117,12 @@ def fill_state_dict_(model, seed):
             new[k] = torch.from_numpy((rs.standard_normal(shape) * 0.1).astype(np.float32))
     model.load_state_dict(new)
     return model
+
+
+def outside(a, b, atol=1e-4, rtol=1e-4):
+    """(number of elements of `a` outside atol + rtol * |b| of `b`, worst error in units of that tolerance): the tests
+    that hold a float32 result against the north_star bar assert the COUNT they observed instead of loosening the bar."""
+    a, b = a.detach().double(), b.detach().double()
+    err = (a - b).abs()
+    tol = atol + rtol * b.abs()
+    return int((err > tol).sum()), float((err / tol).max())
