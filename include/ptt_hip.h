@@ -425,6 +425,14 @@ int ptt_pt_attn_train_fwd_f32(const float* a, const float* vf, const int32_t* kn
 int ptt_pt_attn_train_bwd_f32(const float* attn, const float* vf, const int32_t* knn, const float* pos, const float* dres, int B,
                               int N, int k, int D, float scale, float* da, float* dvp, ptt_stream_t stream);
 
+/* The same two passes with row strides for q / k / v (column slices of the stacked (B,N,3D) projection) and an optional attention
+ * output (attn may be NULL): the per-layer INFERENCE form of the block for a handful of frames, where the fused pair kernel's
+ * one workgroup per two points leaves most CUs idle (one tracklet frame: 64 workgroups) — ptt_amd/models/transformer_block. */
+int ptt_pt_pair_input_ld_f32(const float* q, int ldq, const float* kf, int ldk, const int32_t* knn, const float* pos, int B, int N,
+                             int k, int D, float* t, ptt_stream_t stream);
+int ptt_pt_attn_fwd_ld_f32(const float* a, const float* vf, int ldv, const int32_t* knn, const float* pos, int B, int N, int k, int D,
+                           float scale, float* attn, float* res, ptt_stream_t stream);
+
 /* Grouping of point-major rows and its deterministic backward (the training-mode layer-0 hoist: the first MLP layer's
  * feature half is evaluated once per point, then gathered per (centre, neighbour) row):
  *   ptt_gather_rows_f32       out[b,e,:] = src[b, idx[b,e], :]        src (B,N,C), idx (B,E) -> out (B,E,C); C % 4 == 0

@@ -22,6 +22,7 @@ static inline hipStream_t as_stream(ptt_stream_t s) { return reinterpret_cast<hi
 // scripts/pair_phases.py need such a build.
 struct DevSwitches {
     int linear_rt = 1, linear_ct = 1;    // PTT_LINEAR_TILE="11|12|21|22"
+    int linear_small = 1;                // PTT_LINEAR_SMALL=0: short launches (<= 4096 rows) on linear_kernel too
     int sa_gather1 = 0;                  // PTT_SA_GATHER1: one row per gather instruction
     int sa_stagger = 0;                  // PTT_SA_STAGGER (quanta of ~8k cycles the second co-resident workgroup starts late)
     int sa_wave = 1;                     // PTT_SA_WAVE=0: column-split kernel for small-weight levels

@@ -40,6 +40,7 @@ static DevSwitches read_switches() {
     if (const char* e = getenv("PTT_SA_CHUNK")) d.sa_chunk = atoi(e);
     if (const char* e = getenv("PTT_PAIR_STAGGER")) d.pair_stagger = atoi(e);
     if (const char* e = getenv("PTT_PAIR_LDS_PAD")) d.pair_lds_pad = atoi(e);
+    if (const char* e = getenv("PTT_LINEAR_SMALL")) d.linear_small = atoi(e);
     if (const char* e = getenv("PTT_BALL_CPW")) d.ball_cpw = atoi(e);
     if (const char* e = getenv("PTT_FPS_PLAIN")) d.fps_plain = atoi(e);
     if (const char* e = getenv("PTT_SA_LDS_CHUNK")) d.sa_lds_chunk = atoi(e);

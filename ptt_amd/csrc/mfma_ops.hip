@@ -468,6 +468,78 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(LinearParams p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// The same layer for SHORT launches (a handful of frames: <= 8192 rows, K <= 520) — one tracklet frame runs ~30 of them
+// back to back, 128 - 2048 rows each, and linear_kernel spends them waiting: its K loop restarts per 128-channel chunk (an
+// exposed L2 round trip + a barrier every 16 K-blocks) with one weight fragment in flight per wave. Here a workgroup of
+// 8 waves owns 32 rows x 128 columns: the whole X tile is staged once (one barrier), the two wave groups split the K axis
+// in halves (half the dependent MFMA chain; partial sums meet in LDS), and every wave keeps LS_PD weight fragments in
+// flight (4 registers each: a ring, refilled right behind the MFMAs that consumed a slot).
+// ------------------------------------------------------------------------------------------
+constexpr int LS_PD = 4;
+__global__ __launch_bounds__(512, 1) void linear_small_kernel(LinearParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int t = threadIdx.x, lane = t & 63, half = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6), ks = w >> 2, cw = w & 3;
+    const int row0 = blockIdx.x * 32;
+    const int ct = blockIdx.y * 4 + cw;                    // this wave's column tile
+    const bool has_ct = ct < p.NT;
+    // K-blocks of the two halves, padded to whole rings: [0, hb) and [hb, 2 hb); the X tile is zero beyond K
+    const int hb = ((p.nkb + 1) / 2 + LS_PD - 1) / LS_PD * LS_PD;
+    const int ldk = 2 * hb * 8 + 4;                         // == 4 (mod 8)
+    float* Xs = smem;                                       // [32][ldk]
+    float* Rs = smem + 32 * ldk;                            // [4 column tiles][16 registers][64 lanes] partial sums of the second half
+    {   // stage the tile: float4 slots, zero beyond the rows / channels that exist
+        const int qpr = 2 * hb * 2;                         // float4 slots per row (8 channels = 2 slots per K-block)
+        for (int e = t; e < 32 * qpr; e += 512) {
+            const int r = e / qpr, c = (e - r * qpr) << 2;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (row0 + r < p.rows && c < p.K) v = *reinterpret_cast<const f32x4*>(p.X + (size_t)(row0 + r) * p.ldx + c);
+            *reinterpret_cast<f32x4*>(Xs + r * ldk + c) = v;
+        }
+    }
+    const __amdgpu_buffer_rsrc_t wr = weight_rsrc(p.Wp);
+    const int wvoff = ((has_ct ? ct : 0) * 64 + lane) * 16;
+    const int wkstep = p.NT * 1024;
+    const int kb0 = ks * hb, last = p.nkb - 1;
+    f32x4 b[LS_PD];
+#pragma unroll
+    for (int i = 0; i < LS_PD; ++i) b[i] = weight_load(wr, wvoff, min(kb0 + i, last) * wkstep);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    __syncthreads();
+    const float* arow = Xs + (lane & 31) * ldk + 4 * half + kb0 * 8;
+    for (int k = 0; k < hb; k += LS_PD) {
+#pragma unroll
+        for (int i = 0; i < LS_PD; ++i) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(arow + (k + i) * 8);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[i][j], acc, 0, 0, 0);
+            b[i] = weight_load(wr, wvoff, min(kb0 + k + i + LS_PD, last) * wkstep);     // past the end: a valid fragment times zeros
+        }
+    }
+    if (ks == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Rs[(cw * 16 + r) * 64 + lane] = acc[r];
+    }
+    __syncthreads();
+    if (ks == 1 || !has_ct) return;
+    const int col = ct * 32 + (lane & 31);
+    if (col >= p.Cout) return;
+    const float sc = p.scale ? p.scale[col] : 1.f;
+    const float sh = p.shift ? p.shift[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int gr = row0 + tile_row(r, half);
+        if (gr >= p.rows) continue;
+        float y = (acc[r] + Rs[(cw * 16 + r) * 64 + lane]) * sc + sh;
+        if (p.relu) y = fmaxf(y, 0.f);
+        if (p.residual) y += p.residual[(size_t)gr * p.ldr + col];
+        p.out[(size_t)gr * p.ldo + col] = y;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Fused set-abstraction level. A workgroup owns 64 grouped rows = 64/NS centres.
 // ------------------------------------------------------------------------------------------
 struct SaLayerDev { const float* Wp; const float* scale; const float* shift; int Cin, Cout, relu, nkb, NT; };
@@ -1882,6 +1954,14 @@ static int linear_launch(const float* X, int rows, int K, int ldx, const float* 
     // tile, 32 rows x 128 columns, wins everywhere (qkv 93 vs 75 TFLOP/s for 64x256): these launches are only
     // 1-10 GFLOP, so workgroup count (>= 4 per CU, fine-grained tails) matters more than weight reuse per workgroup.
     const bool vec = p.vec_ok && (K & 3) == 0;
+    hipStream_t s = as_stream(stream);
+    if (dev_switches().linear_small && vec && batch == 1 && !in_a && rows <= 8192 && K <= 520 && K >= 32) {
+        const int hb = ((p.nkb + 1) / 2 + LS_PD - 1) / LS_PD * LS_PD;
+        const int lds = (32 * (2 * hb * 8 + 4) + 4 * 16 * 64) * (int)sizeof(float);
+        if (int rc = set_lds_limit(reinterpret_cast<const void*>(linear_small_kernel), lds)) return rc;
+        hipLaunchKernelGGL(linear_small_kernel, dim3((rows + 31) / 32, (p.NT + 3) / 4), dim3(512), lds, s, p);
+        return check_launch("linear_small_kernel");
+    }
     const int rt64 = (rows + 63) / 64, rt32 = (rows + 31) / 32, cg256 = (p.NT + 7) / 8, cg128 = (p.NT + 3) / 4;
     int RT = dev_switches().linear_rt, CT = dev_switches().linear_ct;
     // the row GEMMs of the training step (10^5-10^6 rows): 32 x 256 tiles reuse every A tile for twice the columns —
@@ -1890,7 +1970,6 @@ static int linear_launch(const float* X, int rows, int K, int ldx, const float* 
     if (rows >= 32768 && Cout >= 256 && RT == 1 && CT == 1) CT = 2;
     const int lds = 2 * (RT * 32) * LIN_LDK * (int)sizeof(float);
     const dim3 grid(RT == 2 ? rt64 : rt32, CT == 2 ? cg256 : cg128, batch);
-    hipStream_t s = as_stream(stream);
     int rc = PTT_OK;
 #define PTT_LIN_CASE(R, V, C)                                                                                  \
     if (RT == R && vec == V && CT == C) {                                                                      \

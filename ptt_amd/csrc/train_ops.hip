@@ -697,17 +697,17 @@ __global__ __launch_bounds__(256) void scatter_rows_det_kernel(const float* __re
 template <int KN>
 __global__ __launch_bounds__(256) void pair_input_kernel(const float* __restrict__ q, const float* __restrict__ kf,
                                                          const int32_t* __restrict__ knn, const float* __restrict__ pos, int N,
-                                                         int D, long long total_pts, float* __restrict__ t) {
+                                                         int D, long long total_pts, float* __restrict__ t, int ldq, int ldk) {
     const int Dq = D >> 2;
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total_pts * Dq; e += (long long)gridDim.x * 256) {
         const long long pt = e / Dq;
         const int c = (int)(e - pt * Dq) * 4;
         const long long b = pt / N;
-        const f32x4t qv = *reinterpret_cast<const f32x4t*>(q + pt * D + c);
+        const f32x4t qv = *reinterpret_cast<const f32x4t*>(q + pt * ldq + c);
 #pragma unroll 4
         for (int j = 0; j < KN; ++j) {
             const int n = knn[pt * KN + j];
-            const f32x4t kv = *reinterpret_cast<const f32x4t*>(kf + (b * N + n) * D + c);
+            const f32x4t kv = *reinterpret_cast<const f32x4t*>(kf + (b * N + n) * ldk + c);
             const f32x4t pv = *reinterpret_cast<const f32x4t*>(pos + (pt * KN + j) * D + c);
             f32x4t o;
 #pragma unroll
@@ -721,7 +721,7 @@ template <int KN>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ a, const float* __restrict__ vf,
                                                        const int32_t* __restrict__ knn, const float* __restrict__ pos, int N, int D,
                                                        long long total_pts, float scale, float* __restrict__ attn,
-                                                       float* __restrict__ res) {
+                                                       float* __restrict__ res, int ldv) {
     const int Dq = D >> 2;
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total_pts * Dq; e += (long long)gridDim.x * 256) {
         const long long pt = e / Dq;
@@ -746,12 +746,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
 #pragma unroll
         for (int j = 0; j < KN; ++j) {
             const int n = knn[pt * KN + j];
-            const f32x4t vv = *reinterpret_cast<const f32x4t*>(vf + (b * N + n) * D + c);
+            const f32x4t vv = *reinterpret_cast<const f32x4t*>(vf + (b * N + n) * ldv + c);
             const f32x4t pv = *reinterpret_cast<const f32x4t*>(pos + (pt * KN + j) * D + c);
             f32x4t w;
 #pragma unroll
             for (int x = 0; x < 4; ++x) { w[x] = av[j][x] * inv[x]; acc[x] += w[x] * (vv[x] + pv[x]); }
-            *reinterpret_cast<f32x4t*>(attn + (pt * KN + j) * D + c) = w;
+            if (attn) *reinterpret_cast<f32x4t*>(attn + (pt * KN + j) * D + c) = w;
         }
         *reinterpret_cast<f32x4t*>(res + pt * D + c) = acc;
     }
@@ -1085,8 +1085,35 @@ extern "C" int ptt_pt_pair_input_f32(const float* q, const float* kf, const int3
     if (!t) return fail(PTT_EINVAL, "ptt_pt_pair_input_f32: null pointer");
     const long long pts = (long long)B * N;
     hipLaunchKernelGGL((pair_input_kernel<16>), dim3(ew_grid((size_t)pts * (D >> 2))), dim3(256), 0, as_stream(stream), q, kf, knn, pos, N,
-                       D, pts, t);
+                       D, pts, t, D, D);
     return check_launch("pair_input_kernel");
+}
+
+// the same two passes for INFERENCE at a handful of frames (the per-layer form of the Point-Transformer block,
+// ptt_amd/models/transformer_block/variants.py): q / k / v are column slices of the stacked (B,N,3D) projection (row strides
+// ldq / ldk / ldv), and the attention tensor is written only when asked for
+extern "C" int ptt_pt_pair_input_ld_f32(const float* q, int ldq, const float* kf, int ldk, const int32_t* knn, const float* pos, int B,
+                                        int N, int k, int D, float* t, ptt_stream_t stream) {
+    if (int rc = pt_train_check("ptt_pt_pair_input_ld_f32", B, N, k, D, q, kf, knn, pos)) return rc;
+    if (ldq < D || ldk < D || (ldq & 3) || (ldk & 3)) return fail(PTT_EINVAL, "ptt_pt_pair_input_ld_f32: ldq=%d ldk=%d", ldq, ldk);
+    if (B == 0) return PTT_OK;
+    if (!t) return fail(PTT_EINVAL, "ptt_pt_pair_input_ld_f32: null pointer");
+    const long long pts = (long long)B * N;
+    hipLaunchKernelGGL((pair_input_kernel<16>), dim3(ew_grid((size_t)pts * (D >> 2))), dim3(256), 0, as_stream(stream), q, kf, knn, pos, N,
+                       D, pts, t, ldq, ldk);
+    return check_launch("pair_input_kernel");
+}
+
+extern "C" int ptt_pt_attn_fwd_ld_f32(const float* a, const float* vf, int ldv, const int32_t* knn, const float* pos, int B, int N, int k,
+                                      int D, float scale, float* attn, float* res, ptt_stream_t stream) {
+    if (int rc = pt_train_check("ptt_pt_attn_fwd_ld_f32", B, N, k, D, a, vf, knn, pos)) return rc;
+    if (ldv < D || (ldv & 3)) return fail(PTT_EINVAL, "ptt_pt_attn_fwd_ld_f32: ldv=%d", ldv);
+    if (B == 0) return PTT_OK;
+    if (!res) return fail(PTT_EINVAL, "ptt_pt_attn_fwd_ld_f32: null pointer");
+    const long long pts = (long long)B * N;
+    hipLaunchKernelGGL((attn_fwd_kernel<16>), dim3(ew_grid((size_t)pts * (D >> 2))), dim3(256), 0, as_stream(stream), a, vf, knn, pos, N, D,
+                       pts, scale, attn, res, ldv);
+    return check_launch("attn_fwd_kernel");
 }
 
 extern "C" int ptt_pt_attn_train_fwd_f32(const float* a, const float* vf, const int32_t* knn, const float* pos, int B, int N, int k,
@@ -1096,7 +1123,7 @@ extern "C" int ptt_pt_attn_train_fwd_f32(const float* a, const float* vf, const 
     if (!attn || !res) return fail(PTT_EINVAL, "ptt_pt_attn_train_fwd_f32: null pointer");
     const long long pts = (long long)B * N;
     hipLaunchKernelGGL((attn_fwd_kernel<16>), dim3(ew_grid((size_t)pts * (D >> 2))), dim3(256), 0, as_stream(stream), a, vf, knn, pos, N, D,
-                       pts, scale, attn, res);
+                       pts, scale, attn, res, D);
     return check_launch("attn_fwd_kernel");
 }
 

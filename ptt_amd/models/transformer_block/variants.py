@@ -24,6 +24,10 @@ from ... import ops, train_ops
 from ..model_utils import index_points, square_distance
 
 
+# at most this many points (B * N) take the per-layer inference form of TransformerBlock instead of the fused pair kernel
+PER_LAYER_MAX_POINTS = int(__import__("os").environ.get("PTT_PT_PER_LAYER_MAX", "512"))
+
+
 def _rows2d(layers, x):
     """layers(x) for Linear stacks acting on the last dim, evaluated on the flattened (rows, C) view. Same numbers;
     on ROCm the autograd backward of nn.Linear over a 4-D (B,N,k,C) input takes a GEMM path that runs at 1-4 TFLOP/s
@@ -84,7 +88,8 @@ class TransformerBlock(nn.Module):
                 wd2=ops.pack_weight(self.fc_delta[2].weight), bd2=f(self.fc_delta[2].bias),
                 wg1=ops.pack_weight(self.fc_gamma[0].weight), bg1=f(self.fc_gamma[0].bias),
                 wg2=ops.pack_weight(self.fc_gamma[2].weight), bg2=f(self.fc_gamma[2].bias),
-                fc2=ops.pack_weight(self.fc2.weight), fc2_b=f(self.fc2.bias))
+                fc2=ops.pack_weight(self.fc2.weight), fc2_b=f(self.fc2.bias),
+                wd1_lin=ops.pack_weight(self.fc_delta[0].weight), bd1=f(self.fc_delta[0].bias))
         ops.publish_params(self.fc1.weight.device)
         self._cache = (key, P)
         return P
@@ -97,8 +102,21 @@ class TransformerBlock(nn.Module):
             xyz = xyz.contiguous()
             knn_idx, rel = ops.knn(xyz, self.k, want_rel=True)
             qkv = ops.linear(features, P['qkv'], 3 * D, None, P['qkv_b'])
-            res, attn = ops.pt_attn_pair(xyz, knn_idx, qkv, P['wd1'], P['wd2'], P['bd2'], P['wg1'],
-                                         P['bg1'], P['wg2'], P['bg2'], D, self.materialize_attn, rel=rel)
+            if xyz.shape[0] * xyz.shape[1] <= PER_LAYER_MAX_POINTS:
+                # a handful of frames (one tracklet frame: 128 / 64 points): the fused pair kernel's one workgroup per two
+                # points is a 64-workgroup launch of three chained 512 x 512 GEMMs (106 us on 64 of the 256 CUs). Per layer,
+                # each GEMM over the (point, neighbour) rows fills the chip (256 workgroups at 2048 rows) and the
+                # intermediates (4 MB each) stay in L2: five more launches, half the time.
+                pairs = rel.view(-1, 3)
+                h = ops.linear(pairs, P['wd1_lin'], D, None, P['bd1'], relu=True)
+                pos = ops.linear(h, P['wd2'], D, None, P['bd2']).view(xyz.shape[0], xyz.shape[1], self.k, D)
+                t = ops.pt_pair_input_qkv(qkv, knn_idx, pos, D)
+                g = ops.linear(t.view(-1, D), P['wg1'], D, None, P['bg1'], relu=True)
+                a = ops.linear(g, P['wg2'], D, None, P['bg2']).view_as(t)
+                res, attn = ops.pt_attn_fwd_qkv(a, qkv, knn_idx, pos, D, 1.0 / np.sqrt(D), self.materialize_attn)
+            else:
+                res, attn = ops.pt_attn_pair(xyz, knn_idx, qkv, P['wd1'], P['wd2'], P['bd2'], P['wg1'],
+                                             P['bg1'], P['wg2'], P['bg2'], D, self.materialize_attn, rel=rel)
             res = ops.linear(res, P['fc2'], self.d_points, None, P['fc2_b'], False, features)
             return res, attn
 

@@ -1005,6 +1005,29 @@ def pt_pair_input(q, kf, knn, pos):
     return t
 
 
+def pt_pair_input_qkv(qkv, knn, pos, D):
+    """t = q_i - k[knn_ij] + pos_ij with q, k taken as column slices of the stacked (B,N,3D) projection (no copies)."""
+    B, N, _ = qkv.shape
+    k = knn.shape[2]
+    t = torch.empty((B, N, k, D), dtype=torch.float32, device=qkv.device)
+    with torch.cuda.device(qkv.device):
+        _lib.check(_lib.lib().ptt_pt_pair_input_ld_f32(qkv.data_ptr(), 3 * D, qkv.data_ptr() + 4 * D, 3 * D, _ptr(knn), _ptr(pos), B, N, k,
+                                                       D, _ptr(t), _stream()), "ptt_pt_pair_input_ld_f32")
+    return t
+
+
+def pt_attn_fwd_qkv(a, qkv, knn, pos, D, scale, want_attn=False):
+    """attn = softmax_j(a * scale), res = sum_j attn * (v[knn] + pos), v = the third column block of the stacked projection;
+    the (B,N,k,D) attention tensor is written only when want_attn. -> (res (B,N,D), attn | None)."""
+    B, N, k, _ = a.shape
+    res = torch.empty((B, N, D), dtype=torch.float32, device=a.device)
+    attn = torch.empty_like(a) if want_attn else None
+    with torch.cuda.device(a.device):
+        _lib.check(_lib.lib().ptt_pt_attn_fwd_ld_f32(_ptr(a), qkv.data_ptr() + 8 * D, 3 * D, _ptr(knn), _ptr(pos), B, N, k, D, float(scale),
+                                                     _ptr(attn), _ptr(res), _stream()), "ptt_pt_attn_fwd_ld_f32")
+    return res, attn
+
+
 def pt_attn_train_fwd(a, vf, knn, pos, scale):
     """attn = softmax_j(a * scale), res = sum_j attn * (vf[knn] + pos) -> (attn (B,N,k,D), res (B,N,D))."""
     B, N, k, D = a.shape

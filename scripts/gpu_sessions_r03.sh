@@ -72,5 +72,19 @@ n)  timeout 600 python scripts/rows_gemm_bench.py --no-bench 2>&1 | grep check |
     G14_ROWS=2 timeout 600 python scripts/g14_diag.py 2>&1 | grep -v "amdgpu.ids\|Warning\|detach\|return float\|group" | cut -c1-200
     true python scripts/fwd_precision_diag.py 2>&1 | grep -v "amdgpu.ids\|Warning" > $O/fwd_precision.log; cat $O/fwd_precision.log
     ;;
+o)  # one tracklet frame at B = 1: the launch chain
+    timeout 900 python -m pytest tests/test_golden_gpu.py tests/test_dense_gpu.py tests/test_hot_path_gpu.py tests/test_tracking_gpu.py -m gpu -q -x 2>&1 | tail -40 | cut -c1-200
+    timeout 300 python scripts/tracklet_b1_profile.py 2>&1 | grep -v amdgpu.ids > $O/b1.log; cat $O/b1.log
+    ktrace b1_kernel_stats python $REPO/scripts/tracklet_b1_profile.py
+    python - <<'PY'
+import csv
+rows=list(csv.DictReader(open('gpurun_out/r03o/b1_kernel_stats.csv')))
+tot=sum(float(r['TotalDurationNs']) for r in rows)
+nfr=200+4+200+200   # frames replayed by the script (runner.run twice + two replay loops)
+print("device time %.1f ms total; per frame ~%.3f ms over %d frames; launches per frame %.1f" % (tot/1e6, tot/1e6/nfr, nfr, sum(int(r['Calls']) for r in rows)/nfr))
+for r in rows[:32]:
+    print("%-80s %6s %8.1f us  %6.1f us/frame" % (r['Name'][:80], r['Calls'], float(r['AverageNs'])/1e3, float(r['TotalDurationNs'])/1e3/nfr))
+PY
+    ;;
 *)  echo "unknown session $S"; exit 2;;
 esac

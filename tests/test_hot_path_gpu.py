@@ -190,8 +190,19 @@ def test_full_size_batch_properties(dev):
         assert torch.equal(seeds, out["search_seeds"])
         for k in ("search_feats", "box_feats", "centroid_feats"):
             assert torch.isfinite(out[k]).all(), k
-            # frames are independent: a half batch gives bit-identical results for its frames
-            assert torch.equal(out[k][:24], out_half[k]), k
+            # frames are independent: a half batch gives the same results for its frames — to float32 rounding, not to the
+            # bit: launches of at most 8192 rows take the short-launch linear kernel, which splits the K axis between two
+            # wave groups (a different summation order than the 6144-row launches of the full batch)
+            if k != "box_feats":
+                torch.testing.assert_close(out[k][:24], out_half[k], rtol=2e-5, atol=2e-5, msg=k)
+        assert torch.equal(out["search_inds"][:24], out_half["search_inds"]) and torch.equal(out["template_inds"][:24], out_half["template_inds"])
+        # the 64 proposals are a data-dependent FPS over the predicted votes: a vote that moves in its last bit can flip a
+        # near-tie pick, so the box features are compared proposal by proposal where both runs picked the same vote
+        same = (out["pred_box_center"][:24] - out_half["pred_box_center"]).abs().amax(-1) <= 1e-5          # (24, 64)
+        assert float(same.float().mean()) > 0.97, float(same.float().mean())
+        assert out_half["box_feats"].shape[:2] == same.shape   # (B, 64, C) rows
+        a, b = out["box_feats"][:24][same], out_half["box_feats"][same]
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-4, msg="box_feats of the proposals both runs picked")
         if kind == "ped":                                   # the all-zero cloud: every index 0, finite features
             assert int(inds[-1].abs().max()) == 0
 
