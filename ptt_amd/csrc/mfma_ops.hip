@@ -473,9 +473,10 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(LinearParams p) {
 // exposed L2 round trip + a barrier every 16 K-blocks) with one weight fragment in flight per wave. Here a workgroup of
 // 8 waves owns 32 rows x 128 columns: the whole X tile is staged once (one barrier), the two wave groups split the K axis
 // in halves (half the dependent MFMA chain; partial sums meet in LDS), and every wave keeps LS_PD weight fragments in
-// flight (4 registers each: a ring, refilled right behind the MFMAs that consumed a slot).
+// flight (4 registers each: a ring, refilled right behind the MFMAs that consumed a slot; at a handful of workgroups per
+// launch the fragments come from HBM / Infinity Cache, ~1 us away: with 4 in flight a K-block cost 0.27 us, 4x its MFMA time).
 // ------------------------------------------------------------------------------------------
-constexpr int LS_PD = 4;
+constexpr int LS_PD = 8;
 __global__ __launch_bounds__(512, 1) void linear_small_kernel(LinearParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int t = threadIdx.x, lane = t & 63, half = lane >> 5;

@@ -86,5 +86,7 @@ for r in rows[:32]:
     print("%-80s %6s %8.1f us  %6.1f us/frame" % (r['Name'][:80], r['Calls'], float(r['AverageNs'])/1e3, float(r['TotalDurationNs'])/1e3/nfr))
 PY
     ;;
+p)  timeout 600 python scripts/linear_infer_bench.py 2>&1 | grep -v amdgpu.ids > $O/linear_infer.log; cat $O/linear_infer.log
+    ;;
 *)  echo "unknown session $S"; exit 2;;
 esac
