@@ -57,7 +57,21 @@ def build_hip(force=False, verbose=False):
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+    _write_build_id()
     return LIB
+
+
+def _write_build_id():
+    """ptt_amd/lib/BUILD_ID = the source revision the library was built from (the GPU boxes get the tree without .git;
+    profile summaries record this string)."""
+    try:
+        rev = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, stderr=subprocess.DEVNULL).decode().strip()
+        dirty = subprocess.check_output(["git", "status", "--porcelain", "--", "ptt_amd/csrc", "include"], cwd=ROOT,
+                                        stderr=subprocess.DEVNULL).decode().strip()
+        with open(os.path.join(LIBDIR, "BUILD_ID"), "w") as fh:
+            fh.write("git %s%s\n" % (rev, " + uncommitted kernel changes" if dirty else ""))
+    except (OSError, subprocess.CalledProcessError):
+        pass
 
 
 def build_oracle(force=False, verbose=False):

@@ -1977,8 +1977,10 @@ static int linear_launch(const float* X, int rows, int K, int ldx, const float* 
         if ((rc = set_lds_limit(reinterpret_cast<const void*>(linear_kernel<R, V, C>), lds))) return rc;       \
         hipLaunchKernelGGL((linear_kernel<R, V, C>), grid, dim3(256), lds, s, p);                              \
     }
-    PTT_LIN_CASE(1, true, 1) PTT_LIN_CASE(1, true, 2) PTT_LIN_CASE(2, true, 1) PTT_LIN_CASE(2, true, 2)
-    PTT_LIN_CASE(1, false, 1) PTT_LIN_CASE(1, false, 2) PTT_LIN_CASE(2, false, 1) PTT_LIN_CASE(2, false, 2)
+    PTT_LIN_CASE(1, true, 1) PTT_LIN_CASE(1, true, 2) PTT_LIN_CASE(1, false, 1) PTT_LIN_CASE(1, false, 2)
+#ifdef PTT_DEV      // 64-row tiles are a sweep option only (PTT_LINEAR_TILE=21|22): the 64 x 256 one spills 80 bytes per lane
+    PTT_LIN_CASE(2, true, 1) PTT_LIN_CASE(2, true, 2) PTT_LIN_CASE(2, false, 1) PTT_LIN_CASE(2, false, 2)
+#endif
 #undef PTT_LIN_CASE
     return check_launch("linear_kernel");
 }

@@ -42,6 +42,10 @@ for (k, grid), c in sorted(vals.items()):
             if w in m:
                 e[w.lower() + "_frac_of_wave_cycles"] = m[w] / m["SQ_WAVE_CYCLES"]
     out["kernels"]["%s grid=%d" % (k, grid)] = e
+try:
+    out["build"] = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ptt_amd", "lib", "BUILD_ID")).read().strip()
+except OSError:
+    out["build"] = "unknown (no ptt_amd/lib/BUILD_ID: see the directory name for the session)"
 json.dump(out, open(os.path.join(d, "pmc_summary.json"), "w"), indent=1)
 for k, e in out["kernels"].items():
     print(k, {x: (round(y, 4) if isinstance(y, float) else y) for x, y in e.items() if x != "counters"})
