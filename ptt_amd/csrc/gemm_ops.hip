@@ -341,32 +341,32 @@ __global__ __launch_bounds__(512, 1) void wgrad2_kernel(const float* __restrict_
             sb[i] = g_load4(rxx, (rc * ldx + i0 + 4 * qb) * 4, 0);
         }
     };
-    auto stage = [&](int buf) {
-        float* A = As + buf * (RS * LDA);
-        float* B = Bs + buf * (RS * LDB);
-#pragma unroll
-        for (int i = 0; i < SA; ++i) {
+    // staging piece i < SA + SB of the fetched sub-chunk: one float4 of dZ (i < SA) or of X (deferred activation applied)
+    auto stage_piece = [&](int buf, int i) {
+        if (i < SA) {
             g32x4 v = sa[i];
             if (!((va >> i) & 1)) v = g32x4{0.f, 0.f, 0.f, 0.f};
-            *reinterpret_cast<g32x4*>(A + (ra + i * RSA) * LDA + 4 * qa) = v;
-        }
-#pragma unroll
-        for (int i = 0; i < SB; ++i) {
-            g32x4 v = sb[i];
+            *reinterpret_cast<g32x4*>(As + buf * (RS * LDA) + (ra + i * RSA) * LDA + 4 * qa) = v;
+        } else {
+            const int k2 = i - SA;
+            g32x4 v = sb[k2];
             if (xa) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) v[k] = fmaxf(__builtin_fmaf(v[k], ta[k], tb[k]), 0.f);
             }
-            if (!((vb >> i) & 1)) v = g32x4{0.f, 0.f, 0.f, 0.f};
-            *reinterpret_cast<g32x4*>(B + (rb + i * RSB) * LDB + 4 * qb) = v;
+            if (!((vb >> k2) & 1)) v = g32x4{0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<g32x4*>(Bs + buf * (RS * LDB) + (rb + k2 * RSB) * LDB + 4 * qb) = v;
         }
     };
+    constexpr int NP = SA + SB;                                 // pieces per sub-chunk (4 .. 8), one behind each of the last j-steps
+    static_assert(NP <= RS / 2, "one staging piece per MFMA step");
     fetch(r_begin);
-    stage(0);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) stage_piece(0, i);
     __syncthreads();
     int buf = 0;
     for (int rs0 = r_begin; rs0 < r_end; rs0 += RS) {
-        fetch(rs0 + RS);                                        // past the end: clamped rows, zeroed by stage()
+        fetch(rs0 + RS);                                        // past the end: clamped rows, zeroed when staged
         const float* A = As + buf * (RS * LDA) + half * LDA + wn * (32 * TN) + col;
         const float* B = Bs + buf * (RS * LDB) + half * LDB + wk * (32 * TK) + col;
 #pragma unroll
@@ -380,9 +380,11 @@ __global__ __launch_bounds__(512, 1) void wgrad2_kernel(const float* __restrict_
             for (int a = 0; a < TN; ++a)
 #pragma unroll
                 for (int b = 0; b < TK; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+            // the next sub-chunk goes to the OTHER buffer (free since the barrier that ended the previous iteration), one
+            // piece behind each of the last MFMA steps: its global loads were issued RS/2 - NP steps ago
+            if (j >= RS / 2 - NP) stage_piece(buf ^ 1, j - (RS / 2 - NP));
         }
-        stage(buf ^ 1);
-        __syncthreads();
+        g_lds_barrier();
         buf ^= 1;
     }
     // C/D layout: column (input channel) = lane & 31, row (output channel) = (reg & 3) + 8 (reg >> 2) + 4 half

@@ -57,6 +57,17 @@ def conv_rows(x, W2d, in_a=None, in_b=None, want_stats=False):
     return z, None
 
 
+_row_counts = {}
+
+
+def _row_count(rows, device):
+    """The constant float64 (1,) device tensor `rows` (the row count a BatchNorm's statistics were taken over), cached."""
+    key = (int(rows), str(device))
+    if key not in _row_counts:
+        _row_counts[key] = torch.full((1,), float(rows), dtype=torch.float64, device=device)
+    return _row_counts[key]
+
+
 class _GatherRows(torch.autograd.Function):
     """rows (B,N,C), idx (B,E) -> (B,E,C); backward = the deterministic row scatter-add."""
 
@@ -106,6 +117,7 @@ class _SharedMlpPool(torch.autograd.Function):
         convolution, its weight gradient, the max-pool and the BatchNorm backward apply it while they load z.
         sync: per layer a torch.distributed process group (nn.SyncBatchNorm: the statistics are those of the rows of ALL
         ranks — one all-reduce of 2C + 1 float64 per layer and direction) or None."""
+        ctx.set_materialize_grads(False)          # the statistics outputs carry no gradient: no zero tensors made for them
         L = len(params) // 3
         saved, stats, counts = [], [], []
         cur, cur_a, cur_b = x.contiguous(), None, None
@@ -124,7 +136,7 @@ class _SharedMlpPool(torch.autograd.Function):
                 count = sums[-1:].clone()                      # global row count, float64, on the device
             else:
                 mean, var, invstd = ops.bn_finish_partials(part, z.shape[0], eps[l]) if part is not None else ops.bn_stats(z, eps[l])
-                count = torch.full((1,), float(z.shape[0]), dtype=torch.float64, device=z.device)
+                count = _row_count(z.shape[0], z.device)
             a = (gamma.detach() * invstd).contiguous()
             b = (beta.detach() - mean * a).contiguous()
             saved += [cur, cur_a if cur_a is not None else mean.new_empty(0), cur_b if cur_b is not None else mean.new_empty(0),
@@ -325,6 +337,7 @@ class _AttnAggregate(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, a, vf, knn, pos, scale):
+        ctx.set_materialize_grads(False)
         a, vf, pos = a.contiguous(), vf.contiguous(), pos.contiguous()
         attn, res = ops.pt_attn_train_fwd(a, vf, knn, pos, scale)
         ctx.save_for_backward(attn, vf, knn, pos)

@@ -88,5 +88,7 @@ PY
     ;;
 p)  timeout 600 python scripts/linear_infer_bench.py 2>&1 | grep -v amdgpu.ids > $O/linear_infer.log; cat $O/linear_infer.log
     ;;
+q)  timeout 600 python scripts/train_aten_ops.py 2>&1 | grep -v "amdgpu.ids\|Warning" > $O/train_aten_ops.log; cat $O/train_aten_ops.log | cut -c1-230
+    ;;
 *)  echo "unknown session $S"; exit 2;;
 esac
