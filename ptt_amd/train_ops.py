@@ -11,6 +11,8 @@ per layer ptt_linear_f32 -> ptt_bn_stats_f32 -> ptt_bn_apply_f32, then ptt_pool_
 then per layer ptt_bn_bwd_f32 -> ptt_linear_wgrad_f32 (weight gradient) -> ptt_linear_f32 on the transposed weight
 (input gradient). Running statistics are updated as nn.BatchNorm2d does (momentum, unbiased variance, batch counter).
 """
+import weakref
+
 import torch
 import torch.distributed as dist
 import torch.nn as nn
@@ -42,13 +44,47 @@ def usable(mlp, x):
     return True
 
 
-def conv_rows(x, W2d, in_a=None, in_b=None, want_stats=False):
+_pack_cache = {}       # id(parameter tensor) -> (weak reference to it, {(offset, shape, stride, version, transposed): packed})
+
+
+def _pack_slot(base):
+    e = _pack_cache.get(id(base))
+    if e is not None and e[0]() is base:
+        return e[1]
+    slot = {}
+    try:
+        ref = weakref.ref(base, lambda _r, k=id(base): _pack_cache.pop(k, None))     # the entry dies with the parameter
+    except TypeError:
+        return slot
+    _pack_cache[id(base)] = (ref, slot)
+    return slot
+
+
+def packed(W, transpose=False):
+    """ops.pack_weight(W) (or of W^T) cached per weight VERSION on the PARAMETER the view belongs to: within one training step
+    a weight is packed for its forward GEMM and, transposed, for its input gradient, and the search / template branches share
+    the backbone's weights; the optimiser's in-place update bumps the version. The cache lives and dies with the parameter
+    object (weak references): a new model whose parameter lands on a freed one's address never sees its entries. W: a 2-D (out, in)
+    parameter, or a view / column slice of one, passed as the caller holds it (not detached: the view's base is the key)."""
+    base = W._base if W._base is not None else W
+    slot = _pack_slot(base)
+    key = (W.data_ptr() - base.data_ptr(), tuple(W.shape), tuple(W.stride()), W._version, bool(transpose))
+    hit = slot.get(key)
+    if hit is None:
+        for k in [k for k in slot if k[3] != W._version]:   # retire the previous step's packs
+            del slot[k]
+        w = W.detach()
+        hit = slot[key] = ops.pack_weight((w.t() if transpose else w).contiguous())
+    return hit
+
+
+def conv_rows(x, W2d, in_a=None, in_b=None, want_stats=False, transpose=False):
     """z = act_in(x) @ W2d^T over (rows, K) activations, act_in = relu(x * in_a + in_b) when given (the deferred BatchNorm +
     ReLU of the producing layer). On the persistent row GEMM (ptt_rows_gemm_f32) where the shape allows, else on the linear
     kernel. want_stats: also the float64 partial column sums of z from the GEMM's epilogue (None on the linear kernel: the
-    caller then takes the statistics in a pass of their own)."""
-    cout, K = W2d.shape
-    wp = ops.pack_weight(W2d)
+    caller then takes the statistics in a pass of their own). transpose: multiply by W2d instead of W2d^T (input gradients)."""
+    cout, K = (W2d.shape[1], W2d.shape[0]) if transpose else W2d.shape
+    wp = packed(W2d, transpose)
     if ops.rows_gemm_supported(x.shape[0], K, cout, x.stride(0), cout):
         if want_stats:
             return ops.rows_gemm(x, wp, cout, in_scale=in_a, in_shift=in_b, want_stats=True)
@@ -95,13 +131,14 @@ class _AddRelTerm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, gathered, rel, wx):
         ctx.save_for_backward(rel, wx)
-        return ops.linear(rel.contiguous(), ops.pack_weight(wx.detach().contiguous()), wx.shape[0], residual=gathered.contiguous())
+        ctx.wx = wx
+        return ops.linear(rel.contiguous(), packed(wx), wx.shape[0], residual=gathered.contiguous())
 
     @staticmethod
     def backward(ctx, g):
         rel, wx = ctx.saved_tensors
         g = g.contiguous()
-        d_rel = ops.linear(g, ops.pack_weight(wx.detach().t().contiguous()), 3) if ctx.needs_input_grad[1] else None
+        d_rel = ops.linear(g, packed(ctx.wx, True), 3) if ctx.needs_input_grad[1] else None
         d_wx = ops.linear_wgrad(g, rel.contiguous()) if ctx.needs_input_grad[2] else None
         return g, d_rel, d_wx
 
@@ -145,6 +182,7 @@ class _SharedMlpPool(torch.autograd.Function):
             cur, cur_a, cur_b = z, a, b
         pooled, arg = ops.pool_rows(cur, ns, cur_a, cur_b)
         ctx.save_for_backward(arg, *saved, *[p.detach() for p in params])
+        ctx.weights = tuple(params[3 * l] for l in range(L))     # the parameter objects themselves: keys of the pack cache
         ctx.L, ctx.ns, ctx.preact, ctx.sync = L, int(ns), bool(preact), tuple(sync)
         ctx.mark_non_differentiable(*stats)
         return (pooled,) + tuple(stats)
@@ -188,11 +226,12 @@ class _SharedMlpPool(torch.autograd.Function):
             if ctx.preact and l == 0:
                 g = dz                                                                  # d(loss)/d(layer-0 pre-activation)
                 break
-            w2 = W.reshape(W.shape[0], -1)
+            Wp = ctx.weights[l]
+            w2 = Wp.reshape(Wp.shape[0], -1)
             has_t = in_a.numel() > 0
             grads[3 * l] = ops.linear_wgrad(dz, x_in, x_scale=in_a if has_t else None, x_shift=in_b if has_t else None).view_as(W)
             if l > 0 or ctx.needs_input_grad[0]:
-                g, _ = conv_rows(dz, w2.t().contiguous())                               # w.r.t. the activated input of layer l
+                g, _ = conv_rows(dz, w2, transpose=True)                                # w.r.t. the activated input of layer l
             else:
                 g = None
         return (g, None, None, None, None) + tuple(grads)
@@ -359,11 +398,11 @@ def pt_block_usable(block, xyz, features):
             and xyz.shape[1] * block.k <= 16384)
 
 
-def lin_rows(x2, W, b=None, relu=False, residual=None):
-    """relu?(x2 @ W^T + b) (+ residual) over (rows, K) activations: the persistent row GEMM where the shape allows, else the
-    linear kernel (K = 3, N = 1 / 5 / 259, ...)."""
-    cout, K = W.shape
-    wp = ops.pack_weight(W)
+def lin_rows(x2, W, b=None, relu=False, residual=None, transpose=False):
+    """relu?(x2 @ W^T + b) (+ residual) over (rows, K) activations (transpose: x2 @ W): the persistent row GEMM where the
+    shape allows, else the linear kernel (K = 3, N = 1 / 5 / 259, ...)."""
+    cout, K = (W.shape[1], W.shape[0]) if transpose else W.shape
+    wp = packed(W, transpose)
     if ops.rows_gemm_supported(x2.shape[0], K, cout, x2.stride(0), cout):
         return ops.rows_gemm(x2, wp, cout, bias=b, relu=relu, residual=residual)
     return ops.linear(x2, wp, cout, None, b, relu, residual)
@@ -378,18 +417,19 @@ class _RowsLinear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, W, b, residual):
         x2 = x.reshape(-1, x.shape[-1]).contiguous()
-        W2 = W.detach().reshape(W.shape[0], -1)
-        ctx.save_for_backward(x2, W2)
+        assert W.dim() == 2
+        ctx.save_for_backward(x2)
+        ctx.W = W                                            # as passed (a parameter or a view of one): key of the pack cache
         ctx.shape = x.shape
-        r2 = residual.reshape(-1, W2.shape[0]).contiguous() if residual is not None else None
-        y = lin_rows(x2, W2.contiguous(), b.detach() if b is not None else None, residual=r2)
-        return y.view(*x.shape[:-1], W2.shape[0])
+        r2 = residual.reshape(-1, W.shape[0]).contiguous() if residual is not None else None
+        y = lin_rows(x2, W, b.detach() if b is not None else None, residual=r2)
+        return y.view(*x.shape[:-1], W.shape[0])
 
     @staticmethod
     def backward(ctx, g):
-        x2, W2 = ctx.saved_tensors
+        (x2,) = ctx.saved_tensors
         g2 = g.reshape(-1, g.shape[-1]).contiguous()
-        dx = lin_rows(g2, W2.t().contiguous()).view(ctx.shape) if ctx.needs_input_grad[0] else None
+        dx = lin_rows(g2, ctx.W, transpose=True).view(ctx.shape) if ctx.needs_input_grad[0] else None
         dW = ops.linear_wgrad(g2, x2) if ctx.needs_input_grad[1] else None
         db = g2.sum(0) if ctx.needs_input_grad[2] else None
         return dx, dW, db, (g if ctx.needs_input_grad[3] else None)
@@ -410,27 +450,28 @@ class _RowsMlp2(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, W1, b1, W2, b2):
         x2 = x.reshape(-1, x.shape[-1]).contiguous()
-        h = lin_rows(x2, W1.detach().contiguous(), b1.detach(), relu=True)
-        y = lin_rows(h, W2.detach().contiguous(), b2.detach())
-        ctx.save_for_backward(x2, h, W1.detach(), W2.detach())
+        h = lin_rows(x2, W1, b1.detach(), relu=True)
+        y = lin_rows(h, W2, b2.detach())
+        ctx.save_for_backward(x2, h)
+        ctx.Ws = (W1, W2)
         ctx.shape = x.shape
         return y.view(*x.shape[:-1], W2.shape[0])
 
     @staticmethod
     def backward(ctx, dy):
-        x2, h, W1, W2 = ctx.saved_tensors
+        x2, h = ctx.saved_tensors
+        W1, W2 = ctx.Ws
         dy2 = dy.reshape(-1, dy.shape[-1]).contiguous()
         rows, D1 = h.shape
         dW2 = ops.linear_wgrad(dy2, h)
         db2 = dy2.sum(0)
-        w2t = W2.t().contiguous()
         if ops.rows_gemm_supported(rows, W2.shape[0], D1, dy2.stride(0), D1):
-            dz1, db1 = ops.rows_gemm_masked(dy2, ops.pack_weight(w2t), D1, h, want_colsum=True)
+            dz1, db1 = ops.rows_gemm_masked(dy2, packed(W2, True), D1, h, want_colsum=True)
         else:
-            dz1 = lin_rows(dy2, w2t) * (h > 0)
+            dz1 = lin_rows(dy2, W2, transpose=True) * (h > 0)
             db1 = dz1.sum(0)
         dW1 = ops.linear_wgrad(dz1, x2)
-        dx = lin_rows(dz1, W1.t().contiguous()).view(ctx.shape) if ctx.needs_input_grad[0] else None
+        dx = lin_rows(dz1, W1, transpose=True).view(ctx.shape) if ctx.needs_input_grad[0] else None
         return dx, dW1, db1, dW2, db2
 
 
