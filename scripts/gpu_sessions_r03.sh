@@ -90,5 +90,17 @@ p)  timeout 600 python scripts/linear_infer_bench.py 2>&1 | grep -v amdgpu.ids >
     ;;
 q)  timeout 600 python scripts/train_aten_ops.py 2>&1 | grep -v "amdgpu.ids\|Warning" > $O/train_aten_ops.log; cat $O/train_aten_ops.log | cut -c1-230
     ;;
+z)  # closing evidence of the round: parity tests, the default bench line (all configs), serial + training kernel traces, PMC passes
+    timeout 2400 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log; tail -3 $O/pytest_gpu.log
+    SECONDS=0; timeout 1500 python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "default bench rc=$? wall ${SECONDS}s"
+    timeout 600 python bench.py --workload train --steps 20 --warmup 5 > $O/bench_train.json 2> $O/bench_train.err
+    ktrace serial_kernel_stats python $REPO/bench.py --serial --steps 10 --warmup 3 --no-cpu-baseline --sustain 0 --no-workloads
+    cp $O/serial_kernel_stats.stdout $O/serial_bench_line.json 2>/dev/null
+    ktrace train_kernel_stats python $REPO/bench.py --workload train --steps 5 --warmup 2 --sustain 0
+    cp $O/train_kernel_stats.stdout $O/train_profiled_bench_line.json 2>/dev/null
+    ktrace b1_kernel_stats python $REPO/scripts/tracklet_b1_profile.py
+    bash scripts/pmc_passes.sh $O/pmc "pair,sa0_s,sa1_s,sa2_s,sa_box" > $O/pmc.log 2>&1; tail -8 $O/pmc.log | cut -c1-300
+    bash scripts/pmc_passes.sh $O/pmc_train_gemm - "python scripts/rows_gemm_bench.py --no-check --pmc" > $O/pmc_train_gemm.log 2>&1; tail -8 $O/pmc_train_gemm.log | cut -c1-300
+    ;;
 *)  echo "unknown session $S"; exit 2;;
 esac
