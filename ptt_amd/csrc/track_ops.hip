@@ -164,6 +164,7 @@ __global__ __launch_bounds__(T) void regularize_kernel(const ptt_regularize_job*
             for (int i = filled + threadIdx.x; i < size; i += T) {
                 j.out[(size_t)i * 3] = j.out[(size_t)i * 3 + 1] = j.out[(size_t)i * 3 + 2] = __builtin_nanf("");
             }
+            if (threadIdx.x == 0 && j.info) j.info[1] = -1;        // says so: the host raises (never a stale draw count)
         }
     }
     if (j.info) {

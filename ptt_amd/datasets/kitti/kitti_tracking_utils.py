@@ -143,8 +143,9 @@ class PointCloud(object):
 def get_box_by_offset(box, offset, use_z=False):
     """:186-216 for one box; `offset` (x, y, z, theta in degrees) is updated in place when the reference would redraw
     it (:205-208, from numpy's global generator — the same generator is used here)."""
-    c, q, used = bm.get_box_by_offset(box.center[None], box.wlh[None], box.orientation.q[None],
-                                      np.asarray(offset, np.float64)[None], use_z)
+    off = np.asarray(offset)
+    off = off.astype(np.float32 if off.dtype == np.float32 else np.float64)      # the caller's precision (the loop hands over float32)
+    c, q, used = bm.get_box_by_offset(box.center[None], box.wlh[None], box.orientation.q[None], off[None], use_z)
     try:
         offset[0], offset[1] = used[0, 0], used[0, 1]
     except TypeError:
@@ -246,5 +247,16 @@ def regularize_pc(pc, input_size, ratio=1, label=None, reg=None, istrain=True):
     jobs['out'][0] = out.data_ptr()
     jobs['n_seg'][0] = 1
     jobs['input_size'][0] = size
+    info = torch.zeros(2, dtype=torch.int32, device=dev)
+    jobs['info'][0] = info.data_ptr()
     ops.regularize(ops.upload_jobs(jobs), 1, ops.mt19937_draws(dev, max(8192, 4 * size + 1024)))
+    # the reference reseeds numpy's GLOBAL generator here (set_manual_seed(1), :349-350) and draws from it (:351-353);
+    # get_box_by_offset later redraws implausible offsets from that same generator (:205-208). Leave it in the state the
+    # reference would: seeded with 1 and advanced by exactly the draws the resampling consumed (reported by the kernel).
+    if n > 2 and n != size:
+        used = int(info.cpu()[1])
+        if used < 0:
+            raise RuntimeError("ptt_regularize_f32 ran out of pre-drawn MT19937 outputs")
+        np.random.seed(1)
+        np.random.randint(low=0, high=n, size=size, dtype=np.int64)
     return out

@@ -188,6 +188,9 @@ class TrackletRunner(object):
             # post_process (:266-274): box_i = get_box_by_offset(box_{i-1}, best proposal, USE_Z_AXIS). An implausibly
             # large x / y offset is redrawn from numpy's GLOBAL generator (:205-208), whose state then is "seeded with 1
             # and advanced by the template's (else the search's) resampling draws" — the draw counts come back with the boxes
+            if (info[:, :, 1] < 0).any():
+                raise RuntimeError("ptt_regularize_f32 ran out of pre-drawn MT19937 outputs (a cloud was filled with NaN): "
+                                   "give mt19937_draws a longer table")
             used = np.where(info[:, 1, 1] > 0, info[:, 1, 1], info[:, 0, 1])
             rng_pos = np.where(used > 0, used, rng_pos).astype(np.int64)
             ops.track_box_by_offset(boxes, est, self.use_z, active, rng_pos)

@@ -67,6 +67,27 @@ def test_resampling_index_stream_is_numpys(dev, n):
     np.testing.assert_array_equal(got[:, 0].astype(np.int64), want)
 
 
+def test_regularize_pc_leaves_numpys_global_generator_where_the_reference_does(dev):
+    """regularize_pc (istrain=False) reseeds numpy's GLOBAL generator with 1 and draws the resampling indices from it
+    (kitti_tracking_utils.py:349-353); get_box_by_offset later redraws implausible offsets from that same generator
+    (:205-208). The device-side mirror leaves the generator in exactly that state."""
+    import ptt.datasets.kitti.kitti_tracking_utils as ku
+    for n in (5, 700, 1024, 2):
+        pts = np.zeros((3, n), np.float32)
+        pts[0] = np.arange(n)
+        np.random.seed(12345)
+        before = np.random.get_state()[1].copy()
+        ku.regularize_pc(ku.PointCloud(pts), 1024, istrain=False)
+        got = np.random.uniform(-1, 1)
+        if n > 2 and n != 1024:
+            np.random.seed(1)
+            np.random.randint(low=0, high=n, size=1024, dtype=np.int64)
+        else:                                            # no resampling: the reference leaves the generator alone (:354-362)
+            np.random.seed(12345)
+            assert np.array_equal(before, np.random.get_state()[1])
+        assert got == np.random.uniform(-1, 1), n
+
+
 def test_select_box_is_first_argmax(dev):
     rs = np.random.RandomState(3)
     x = rs.standard_normal((7, 64, 5)).astype(np.float32)
