@@ -498,6 +498,18 @@ int ptt_rows_gemm_f32(const float* X, int rows, int K, int ldx, const float* in_
  * the bias gradient of the masked layer (nn.Sequential(Linear, ReLU, Linear): fc_delta / fc_gamma, variants.py:139-148). */
 int ptt_rows_gemm_masked_f32(const float* X, int rows, int K, int ldx, const float* Wpacked, int N, const float* mask, int ldm,
                              float* out, int ldo, double* stats, size_t stats_elems, ptt_stream_t stream);
+/* The input gradient g = dZ_next . W_next of a layer whose INPUT is relu(BatchNorm(Z)) (Z = the producing layer's convolution
+ * output, deferred activation act_scale / act_shift): the GEMM's epilogue also takes that producing layer's BatchNorm backward
+ * sums, sum dy and sum dy * xhat with dy = g where Z * act_scale + act_shift > 0, as float64 partials [chunk][2][N] — the pass
+ * over (g, Z) that ptt_bn_bwd_f32 starts with disappears. ptt_bn_bwd_from_partials_f32 combines the partials (dbeta, dgamma) and
+ * writes dZ; ptt_bn_bwd_sums_partials_f64 is the SyncBatchNorm form of the combine (all-reduce, then ptt_bn_bwd_apply_f32). */
+int ptt_rows_gemm_bnbwd_f32(const float* X, int rows, int K, int ldx, const float* Wpacked, int N, const float* Z, int ldz,
+                            const float* mean, const float* invstd, const float* act_scale, const float* act_shift, float* out,
+                            int ldo, double* sums_partial, size_t partial_elems, ptt_stream_t stream);
+int ptt_bn_bwd_from_partials_f32(const double* partial, int chunks, const float* G, int ldg, const float* Z, int ldz, const float* mean,
+                                 const float* invstd, const float* gamma, int R, int C, float* dZ, int ldd, float* dgamma, float* dbeta,
+                                 const float* act_scale, const float* act_shift, ptt_stream_t stream);
+int ptt_bn_bwd_sums_partials_f64(const double* partial, int chunks, int C, double* sums, ptt_stream_t stream);
 int ptt_bn_finish_partials_f32(const double* partial, int chunks, int C, int R, float eps, float* mean, float* var, float* invstd,
                                ptt_stream_t stream);
 int ptt_bn_sums_partials_f64(const double* partial, int chunks, int C, int R, double* sums, ptt_stream_t stream);

@@ -34,6 +34,7 @@ EXPORTS = [
     "ptt_bn_sums_partials_f64", "ptt_linear_wgrad2_workspace", "ptt_linear_wgrad2_f32",
     "ptt_bn_bwd_pooled_f32", "ptt_bn_bwd_pooled_sums_f64", "ptt_bn_bwd_pooled_apply_f32",
     "ptt_pt_pair_input_ld_f32", "ptt_pt_attn_fwd_ld_f32",
+    "ptt_rows_gemm_bnbwd_f32", "ptt_bn_bwd_from_partials_f32", "ptt_bn_bwd_sums_partials_f64",
     "ptt_bn_update_running_f32", "ptt_xcorr_z0_f32", "ptt_xcorr_z0_bwd_workspace", "ptt_xcorr_z0_bwd_f32",
 ]
 PTT_MAX_SEGMENTS = 4
@@ -148,6 +149,9 @@ def _declare(lib):
         "ptt_bn_finish_partials_f32": [vp, i, i, i, f, vp, vp, vp, vp],
         "ptt_bn_sums_partials_f64": [vp, i, i, i, vp, vp],
         "ptt_linear_wgrad2_f32": [vp, i, vp, i, i, i, i, vp, i, vp, c_size_t, vp, vp, vp],
+        "ptt_rows_gemm_bnbwd_f32": [vp, i, i, i, vp, i, vp, i, vp, vp, vp, vp, vp, i, vp, c_size_t, vp],
+        "ptt_bn_bwd_from_partials_f32": [vp, i, vp, i, vp, i, vp, vp, vp, i, i, vp, i, vp, vp, vp, vp, vp],
+        "ptt_bn_bwd_sums_partials_f64": [vp, i, i, vp, vp],
         "ptt_pt_pair_input_ld_f32": [vp, i, vp, i, vp, vp, i, i, i, i, vp, vp],
         "ptt_pt_attn_fwd_ld_f32": [vp, vp, i, vp, vp, i, i, i, i, f, vp, vp, vp],
         "ptt_bn_update_running_f32": [vp, vp, vp, f, i, vp, vp, vp, vp],

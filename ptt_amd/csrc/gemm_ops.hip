@@ -62,6 +62,11 @@ struct RowsGemmParams {
     const float* in_a; const float* in_b;       // optional x <- relu(x * in_a[k] + in_b[k]) while the A operand is staged
     const float* mask; int ldm;                 // optional out <- mask > 0 ? out : 0 (the ReLU backward of the layer this
                                                 // GEMM is the input gradient of; mask = that layer's output), before the statistics
+    const float* bz; const float* bmean; const float* binv; const float* ba; const float* bb; int ldbz;
+                                                // optional (with stats): the launch is the INPUT GRADIENT g of a layer whose input
+                                                // is relu(BatchNorm(bz)) — its epilogue also takes the BatchNorm backward sums of
+                                                // that producing layer, sum dy and sum dy * xhat (dy = g where bz * ba + bb > 0,
+                                                // xhat = (bz - bmean) * binv), instead of the statistics of the output
     double* stats;                              // optional [chunks][2][N] partial column sums / sums of squares of Y
     int rows, K, ldx, N, NT, relu, ldr, ldo, ntiles, G, ncg, nchunks;
 };
@@ -141,10 +146,11 @@ __global__ __launch_bounds__(256, 2) void rows_gemm_kernel(RowsGemmParams p) {
     // bias / ReLU branch-free: a missing bias reads any valid address and is replaced by 0, no ReLU = floor -inf
     const bool has_bias = p.bias != nullptr;
     const __amdgpu_buffer_rsrc_t rb = g_rsrc(has_bias ? p.bias : p.Wp);
-    const __amdgpu_buffer_rsrc_t rr = g_rsrc(p.residual ? p.residual : (p.mask ? p.mask : p.X));
-    const int ldr = p.residual ? p.ldr : p.ldm;
+    const __amdgpu_buffer_rsrc_t rr = g_rsrc(p.residual ? p.residual : (p.mask ? p.mask : (p.bz ? p.bz : p.X)));
+    const int ldr = p.residual ? p.ldr : (p.mask ? p.ldm : p.ldbz);
     const float rfloor = p.relu ? 0.f : -__builtin_inff();
-    auto epilogue = [&](int row_w, auto full_c, auto mode_c) {      // mode 0: plain, 1: + residual, 2: masked by `mask` > 0
+    auto epilogue = [&](int row_w, auto full_c, auto mode_c) {      // mode 0: plain, 1: + residual, 2: masked by `mask` > 0,
+                                                                    // 3: BatchNorm backward sums of the producing layer
         constexpr bool FULL = decltype(full_c)::value;
         constexpr int MODE = decltype(mode_c)::value;
         constexpr bool RES = MODE != 0;
@@ -158,9 +164,11 @@ __global__ __launch_bounds__(256, 2) void rows_gemm_kernel(RowsGemmParams p) {
             // K (this lane's first value: within the column's spread), un-shifted in float64 — sum y = s + n K,
             // sum y^2 = q + 2 K s + n K^2. (Plain float32 sums of y^2 lose mean^2 / var digits in E[y^2] - mean^2: a BatchNorm over
             // a nearly constant channel then amplifies 1e-7 into 1e-4.)
-            const float kref = acc[0][u][0] + bv;               // the lane's first row: if that one is past the end, all of its rows are
+            const float kref = MODE == 3 ? 0.f : acc[0][u][0] + bv;     // the lane's first row: if that one is past the end, all of its rows are
             float s = 0.f, sq = 0.f;
             int nrows = 0;
+            float cm = 0.f, ci = 0.f, ca = 0.f, cb = 0.f;
+            if (MODE == 3) { cm = p.bmean[cn]; ci = p.binv[cn]; ca = p.ba[cn]; cb = p.bb[cn]; }
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
                 float rv[16];
@@ -178,7 +186,11 @@ __global__ __launch_bounds__(256, 2) void rows_gemm_kernel(RowsGemmParams p) {
                     const bool in = FULL || row_w + 4 * half + dr < p.rows;
                     float y = acc[rt][u][r] + bv;
                     if (MODE == 2) y = rv[r] > 0.f ? y : 0.f;
-                    if (STATS) {                                // rows past the end take no part
+                    if (STATS && MODE == 3) {                   // sum dy, sum dy * xhat of the layer this gradient flows into
+                        const float z = rv[r];
+                        const float dyv = (in && __builtin_fmaf(z, ca, cb) > 0.f) ? y : 0.f;
+                        s += dyv; sq = __builtin_fmaf(dyv, (z - cm) * ci, sq);
+                    } else if (STATS) {                         // rows past the end take no part
                         const float d = in ? y - kref : 0.f;
                         s += d; sq = __builtin_fmaf(d, d, sq);
                         if (!FULL) nrows += in ? 1 : 0;
@@ -190,7 +202,10 @@ __global__ __launch_bounds__(256, 2) void rows_gemm_kernel(RowsGemmParams p) {
                     acc[rt][u][r] = 0.f;
                 }
             }
-            if (STATS) {
+            if (STATS && MODE == 3) {
+                dsum[u] += (double)s;
+                dsq[u] += (double)sq;
+            } else if (STATS) {
                 const double K = (double)kref, S = (double)s, n = FULL ? 16.0 * RT : (double)nrows;
                 dsum[u] += S + n * K;
                 dsq[u] += (double)sq + 2.0 * K * S + n * K * K;
@@ -263,13 +278,16 @@ __global__ __launch_bounds__(256, 2) void rows_gemm_kernel(RowsGemmParams p) {
             typedef std::integral_constant<int, 0> M0;
             typedef std::integral_constant<int, 1> M1;
             typedef std::integral_constant<int, 2> M2;
+            typedef std::integral_constant<int, 3> M3;
             if (row_w + RT * 32 <= p.rows) {
                 if (p.residual) epilogue(row_w, std::true_type(), M1());
                 else if (p.mask) epilogue(row_w, std::true_type(), M2());
+                else if (STATS && p.bz) epilogue(row_w, std::true_type(), M3());
                 else epilogue(row_w, std::true_type(), M0());
             } else {
                 if (p.residual) epilogue(row_w, std::false_type(), M1());
                 else if (p.mask) epilogue(row_w, std::false_type(), M2());
+                else if (STATS && p.bz) epilogue(row_w, std::false_type(), M3());
                 else epilogue(row_w, std::false_type(), M0());
             }
         }
@@ -456,9 +474,22 @@ extern "C" int ptt_rows_gemm_stat_chunks(int rows, int K, int N) {
     return g.ok ? g.chunks : 0;
 }
 
+struct BnBwdArgs { const float* z; int ldz; const float* mean; const float* invstd; const float* a; const float* b; };
 static int rows_gemm_launch(const float* X, int rows, int K, int ldx, const float* in_scale, const float* in_shift,
                             const float* Wpacked, int N, const float* bias, int relu, const float* residual, int ldr,
-                            const float* mask, int ldm, float* out, int ldo, double* stats, size_t stats_elems, ptt_stream_t stream);
+                            const float* mask, int ldm, float* out, int ldo, double* stats, size_t stats_elems, ptt_stream_t stream,
+                            const BnBwdArgs* bn = nullptr);
+
+extern "C" int ptt_rows_gemm_bnbwd_f32(const float* X, int rows, int K, int ldx, const float* Wpacked, int N, const float* Z, int ldz,
+                                       const float* mean, const float* invstd, const float* act_scale, const float* act_shift,
+                                       float* out, int ldo, double* sums_partial, size_t partial_elems, ptt_stream_t stream) {
+    if (!Z || !mean || !invstd || !act_scale || !act_shift || !sums_partial || ldz < N)
+        return fail(PTT_EINVAL, "ptt_rows_gemm_bnbwd_f32: null pointer or ldz=%d < N=%d", ldz, N);
+    if ((long long)rows * ldz >= (1LL << 29)) return fail(PTT_EUNSUPPORTED, "ptt_rows_gemm_bnbwd_f32: rows * ldz >= 2^29");
+    const BnBwdArgs bn{Z, ldz, mean, invstd, act_scale, act_shift};
+    return rows_gemm_launch(X, rows, K, ldx, nullptr, nullptr, Wpacked, N, nullptr, 0, nullptr, 0, nullptr, 0, out, ldo, sums_partial,
+                            partial_elems, stream, &bn);
+}
 
 extern "C" int ptt_rows_gemm_f32(const float* X, int rows, int K, int ldx, const float* in_scale, const float* in_shift,
                                  const float* Wpacked, int N, const float* bias, int relu, const float* residual, int ldr,
@@ -476,7 +507,8 @@ extern "C" int ptt_rows_gemm_masked_f32(const float* X, int rows, int K, int ldx
 
 static int rows_gemm_launch(const float* X, int rows, int K, int ldx, const float* in_scale, const float* in_shift,
                             const float* Wpacked, int N, const float* bias, int relu, const float* residual, int ldr,
-                            const float* mask, int ldm, float* out, int ldo, double* stats, size_t stats_elems, ptt_stream_t stream) {
+                            const float* mask, int ldm, float* out, int ldo, double* stats, size_t stats_elems, ptt_stream_t stream,
+                            const BnBwdArgs* bn) {
     if (rows < 0 || K <= 0 || N <= 0 || ldx < K || ldo < N || (residual && ldr < N))
         return fail(PTT_EINVAL, "ptt_rows_gemm_f32: rows=%d K=%d N=%d ldx=%d ldo=%d ldr=%d", rows, K, N, ldx, ldo, ldr);
     if (rows == 0) return PTT_OK;
@@ -493,6 +525,8 @@ static int rows_gemm_launch(const float* X, int rows, int K, int ldx, const floa
     if (mask && (long long)rows * ldm >= (1LL << 29)) return fail(PTT_EUNSUPPORTED, "ptt_rows_gemm_masked_f32: rows * ldm >= 2^29");
     if (residual && (long long)rows * ldr >= (1LL << 29)) return fail(PTT_EUNSUPPORTED, "ptt_rows_gemm_f32: rows * ldr >= 2^29");
     RowsGemmParams p;
+    p.bz = bn ? bn->z : nullptr; p.ldbz = bn ? bn->ldz : 0;
+    p.bmean = bn ? bn->mean : nullptr; p.binv = bn ? bn->invstd : nullptr; p.ba = bn ? bn->a : nullptr; p.bb = bn ? bn->b : nullptr;
     p.mask = mask; p.ldm = ldm;
     p.X = X; p.Wp = Wpacked; p.bias = bias; p.residual = residual; p.out = out; p.in_a = in_scale; p.in_b = in_shift;
     p.stats = stats; p.rows = rows; p.K = K; p.ldx = ldx; p.N = N; p.NT = N / 32; p.relu = relu; p.ldr = ldr; p.ldo = ldo;

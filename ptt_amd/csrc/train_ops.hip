@@ -1230,3 +1230,31 @@ extern "C" int ptt_xcorr_z0_bwd_f32(const float* dz0, const float* cos_t, const 
     launch_wgrad_finish(static_cast<const float*>(ws), nwg, (size_t)C, 0, dw, s);
     return check_launch("xcorr_z0_bwd_kernel");
 }
+
+// BatchNorm(train) + ReLU backward when the two sums were already taken by the GEMM that produced the gradient
+// (ptt_rows_gemm_bnbwd_f32): combine its float64 partials in chunk order (-> dbeta, dgamma), then dz
+extern "C" int ptt_bn_bwd_from_partials_f32(const double* partial, int chunks, const float* G, int ldg, const float* Z, int ldz,
+                                            const float* mean, const float* invstd, const float* gamma, int R, int C, float* dZ, int ldd,
+                                            float* dgamma, float* dbeta, const float* act_scale, const float* act_shift,
+                                            ptt_stream_t stream) {
+    if (R <= 0 || C <= 0 || chunks <= 0) return fail(PTT_EINVAL, "ptt_bn_bwd_from_partials_f32: R=%d C=%d chunks=%d", R, C, chunks);
+    if (!partial || !G || !Z || !mean || !invstd || !gamma || !dZ || !dgamma || !dbeta || !act_scale || !act_shift)
+        return fail(PTT_EINVAL, "ptt_bn_bwd_from_partials_f32: null pointer");
+    if (!(vec4_ok(G, ldg, C) && vec4_ok(Z, ldz, C) && vec4_ok(dZ, ldd, C) && vec4_ok(mean, 4, 4) && vec4_ok(invstd, 4, 4) &&
+          vec4_ok(gamma, 4, 4) && vec4_ok(dgamma, 4, 4) && vec4_ok(dbeta, 4, 4) && vec4_ok(act_scale, 4, 4) && vec4_ok(act_shift, 4, 4)))
+        return fail(PTT_EUNSUPPORTED, "ptt_bn_bwd_from_partials_f32: needs C %% 4 == 0 and 16-byte aligned rows");
+    hipStream_t s = as_stream(stream);
+    hipLaunchKernelGGL((col_stats_finish2_kernel<1>), dim3(C), dim3(256), 0, s, partial, chunks, C, R, 0.f, dbeta, dgamma, nullptr);
+    const int Cq = C >> 2, RG = 256 / (Cq < 256 ? Cq : 256);
+    int grid = (R + RG * 8 - 1) / (RG * 8);
+    if (grid > 16384) grid = 16384;
+    hipLaunchKernelGGL((bn_bwd_apply4_kernel<false>), dim3(grid), dim3(256), 0, s, G, ldg, nullptr, 0, Z, ldz, mean, invstd, gamma, dbeta,
+                       dgamma, R, C, dZ, ldd, act_scale, act_shift, 1.0f / (float)R, nullptr, nullptr, 1);
+    return check_launch("ptt_bn_bwd_from_partials_f32");
+}
+
+extern "C" int ptt_bn_bwd_sums_partials_f64(const double* partial, int chunks, int C, double* sums, ptt_stream_t stream) {
+    if (chunks <= 0 || C <= 0 || !partial || !sums) return fail(PTT_EINVAL, "ptt_bn_bwd_sums_partials_f64: chunks=%d C=%d", chunks, C);
+    hipLaunchKernelGGL(col_sums_finish_kernel, dim3(C), dim3(256), 0, as_stream(stream), partial, chunks, C, sums, -1.0);
+    return check_launch("col_sums_finish_kernel");
+}

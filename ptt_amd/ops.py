@@ -880,6 +880,46 @@ def rows_gemm_masked(x, wpacked, cout, mask, want_colsum=False):
     return out
 
 
+def rows_gemm_bnbwd(x, wpacked, cout, z, mean, invstd, act_scale, act_shift):
+    """g = x @ W^T (the input gradient of a layer whose input is relu(BatchNorm(z))) and, from the same launch's epilogue, the
+    float64 partials (chunks, 2, cout) of that BatchNorm's backward sums (sum dy, sum dy * xhat) — ptt_rows_gemm_bnbwd_f32."""
+    _rows(x, "x"); _rows(z, "z")
+    rows, K = x.shape
+    cout = int(cout)
+    out = torch.empty((rows, cout), dtype=torch.float32, device=x.device)
+    chunks = _lib.lib().ptt_rows_gemm_stat_chunks(rows, K, cout)
+    part = torch.empty((max(1, chunks), 2, cout), dtype=torch.float64, device=x.device)
+    with torch.cuda.device(x.device), _timed('ptt_rows_gemm_f32'):
+        _lib.check(_lib.lib().ptt_rows_gemm_bnbwd_f32(_ptr(x), rows, K, x.stride(0), _ptr(wpacked), cout, _ptr(z), z.stride(0), _ptr(mean),
+                                                      _ptr(invstd), _ptr(act_scale), _ptr(act_shift), _ptr(out), cout, _ptr(part),
+                                                      part.numel(), _stream()), "ptt_rows_gemm_bnbwd_f32")
+    return out, part
+
+
+def bn_bwd_from_partials(part, g, z, mean, invstd, gamma, act_scale, act_shift, out=None):
+    """(dz, dgamma, dbeta) from the partial sums rows_gemm_bnbwd took — ptt_bn_bwd_from_partials_f32; `out` may alias g."""
+    R, C = z.shape
+    if out is None:
+        out = torch.empty((R, C), dtype=torch.float32, device=z.device)
+    dgamma = torch.empty((C,), dtype=torch.float32, device=z.device)
+    dbeta = torch.empty((C,), dtype=torch.float32, device=z.device)
+    with torch.cuda.device(z.device):
+        _lib.check(_lib.lib().ptt_bn_bwd_from_partials_f32(_ptr(part), part.shape[0], _ptr(g), g.stride(0), _ptr(z), z.stride(0), _ptr(mean),
+                                                           _ptr(invstd), _ptr(gamma), R, C, _ptr(out), out.stride(0), _ptr(dgamma),
+                                                           _ptr(dbeta), _ptr(act_scale), _ptr(act_shift), _stream()),
+                   "ptt_bn_bwd_from_partials_f32")
+    return out, dgamma, dbeta
+
+
+def bn_bwd_sums_from_partials(part):
+    """The (2, C) float64 sums of bn_bwd_sums from rows_gemm_bnbwd's partials (SyncBatchNorm: all-reduce them, then bn_bwd_apply)."""
+    chunks, _, C = part.shape
+    sums = torch.empty((2, C), dtype=torch.float64, device=part.device)
+    with torch.cuda.device(part.device):
+        _lib.check(_lib.lib().ptt_bn_bwd_sums_partials_f64(_ptr(part), chunks, C, _ptr(sums), _stream()), "ptt_bn_bwd_sums_partials_f64")
+    return sums
+
+
 def bn_finish_partials(partials, rows, eps):
     """(mean, biased var, invstd) from rows_gemm's partial sums (chunks, 2, C), combined in chunk order."""
     chunks, _, C = partials.shape

@@ -193,7 +193,7 @@ class _SharedMlpPool(torch.autograd.Function):
         t = ctx.saved_tensors
         arg, saved, params = t[0], t[1:1 + 9 * L], t[1 + 9 * L:]
         dpooled = dpooled.contiguous()
-        g = None
+        g, part = None, None        # part: BatchNorm backward sums of THIS layer, taken by the GEMM that produced g
         grads = [None] * (3 * L)
         for l in range(L - 1, -1, -1):
             x_in, in_a, in_b, z, mean, invstd, a, b, count = saved[9 * l:9 * l + 9]
@@ -206,6 +206,8 @@ class _SharedMlpPool(torch.autograd.Function):
                 # uses the sums of all ranks
                 if last:
                     sums = ops.bn_bwd_pooled_sums(dpooled, arg, ns, z, mean, invstd, a, b)
+                elif part is not None:
+                    sums = ops.bn_bwd_sums_from_partials(part)
                 else:
                     sums = ops.bn_bwd_sums(g, None, z, mean, invstd, act_scale=a, act_shift=b)
                 local = sums.float()
@@ -220,6 +222,8 @@ class _SharedMlpPool(torch.autograd.Function):
                                           act_scale=a, act_shift=b)
             elif last:
                 dz, dgamma, dbeta = ops.bn_bwd_pooled(dpooled, arg, ns, z, mean, invstd, gamma, a, b)
+            elif part is not None:
+                dz, dgamma, dbeta = ops.bn_bwd_from_partials(part, g, z, mean, invstd, gamma, a, b, out=g)   # in place over g
             else:
                 dz, dgamma, dbeta = ops.bn_bwd(g, None, z, mean, invstd, gamma, out=g, act_scale=a, act_shift=b)   # in place over g
             grads[3 * l + 1], grads[3 * l + 2] = dgamma, dbeta
@@ -230,8 +234,17 @@ class _SharedMlpPool(torch.autograd.Function):
             w2 = Wp.reshape(Wp.shape[0], -1)
             has_t = in_a.numel() > 0
             grads[3 * l] = ops.linear_wgrad(dz, x_in, x_scale=in_a if has_t else None, x_shift=in_b if has_t else None).view_as(W)
-            if l > 0 or ctx.needs_input_grad[0]:
-                g, _ = conv_rows(dz, w2, transpose=True)                                # w.r.t. the activated input of layer l
+            part = None
+            if l > 0:
+                # the gradient w.r.t. the activated input of layer l = the gradient BatchNorm l - 1 receives: its backward sums
+                # come out of this GEMM's epilogue where the persistent row GEMM takes the shape
+                zp, mp, ip, ap, bp = saved[9 * (l - 1) + 3], saved[9 * (l - 1) + 4], saved[9 * (l - 1) + 5], saved[9 * (l - 1) + 6], saved[9 * (l - 1) + 7]
+                if ops.rows_gemm_supported(dz.shape[0], w2.shape[0], w2.shape[1], dz.stride(0), w2.shape[1]):
+                    g, part = ops.rows_gemm_bnbwd(dz, packed(w2, True), w2.shape[1], zp, mp, ip, ap, bp)
+                else:
+                    g, _ = conv_rows(dz, w2, transpose=True)
+            elif ctx.needs_input_grad[0]:
+                g, _ = conv_rows(dz, w2, transpose=True)                                # w.r.t. the (not normalised) input rows
             else:
                 g = None
         return (g, None, None, None, None) + tuple(grads)
