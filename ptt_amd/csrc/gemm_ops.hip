@@ -78,8 +78,10 @@ struct RowsGemmParams {
 #ifndef PTT_RG_PD
 #define PTT_RG_PD 3          // weight fragments requested this many K-blocks ahead
 #endif
-template <int WR, int RT, int CT, int KC, bool STATS, bool ACT, int EXP = 0>
+// BNB: the statistics are the BatchNorm backward sums of the producing layer (p.bz ...), not those of the output
+template <int WR, int RT, int CT, int KC, bool STATS, bool ACT, int EXP = 0, bool BNB = false>
 __global__ __launch_bounds__(256, 2) void rows_gemm_kernel(RowsGemmParams p) {
+    static_assert(!BNB || (STATS && !ACT), "the backward-sums epilogue is a statistics epilogue of a plain input gradient");
     constexpr int WC = 4 / WR, TR = 32 * RT * WR, NKB = KC / 8, LDK = KC + 4, BUF = TR * LDK, QPR = KC / 4;
     constexpr int SLOTS = TR * QPR / 256, PD = PTT_RG_PD;
     constexpr int WI = SLOTS < NKB / 2 ? SLOTS : NKB / 2;       // K-blocks (the last ones of a unit) that carry a staging piece
@@ -279,15 +281,16 @@ __global__ __launch_bounds__(256, 2) void rows_gemm_kernel(RowsGemmParams p) {
             typedef std::integral_constant<int, 1> M1;
             typedef std::integral_constant<int, 2> M2;
             typedef std::integral_constant<int, 3> M3;
-            if (row_w + RT * 32 <= p.rows) {
+            if constexpr (BNB) {
+                if (row_w + RT * 32 <= p.rows) epilogue(row_w, std::true_type(), M3());
+                else epilogue(row_w, std::false_type(), M3());
+            } else if (row_w + RT * 32 <= p.rows) {
                 if (p.residual) epilogue(row_w, std::true_type(), M1());
                 else if (p.mask) epilogue(row_w, std::true_type(), M2());
-                else if (STATS && p.bz) epilogue(row_w, std::true_type(), M3());
                 else epilogue(row_w, std::true_type(), M0());
             } else {
                 if (p.residual) epilogue(row_w, std::false_type(), M1());
                 else if (p.mask) epilogue(row_w, std::false_type(), M2());
-                else if (STATS && p.bz) epilogue(row_w, std::false_type(), M3());
                 else epilogue(row_w, std::false_type(), M0());
             }
         }
@@ -520,6 +523,7 @@ static int rows_gemm_launch(const float* X, int rows, int K, int ldx, const floa
         return fail(PTT_EINVAL, "ptt_rows_gemm_f32: X / in_scale / in_shift must be 16-byte aligned");
     if ((in_scale == nullptr) != (in_shift == nullptr)) return fail(PTT_EINVAL, "ptt_rows_gemm_f32: in_scale and in_shift go together");
     const RowsGemmGeom g = rows_gemm_geom(rows, K, N);
+    if (bn && (!stats || bias || residual || mask || in_scale)) return fail(PTT_EINVAL, "ptt_rows_gemm_bnbwd_f32: plain input gradient only");
     if (stats && (bias || stats_elems < (size_t)g.chunks * 2 * N))
         return fail(PTT_EINVAL, "ptt_rows_gemm_f32: statistics need bias == NULL and %zu doubles of workspace", (size_t)g.chunks * 2 * N);
     if (mask && (long long)rows * ldm >= (1LL << 29)) return fail(PTT_EUNSUPPORTED, "ptt_rows_gemm_masked_f32: rows * ldm >= 2^29");
@@ -557,7 +561,10 @@ static int rows_gemm_launch(const float* X, int rows, int K, int ldx, const floa
     }
 #define PTT_RG_CASE(WR_, RT_, CT_, KC_)                                                                                 \
     if (g.WR == WR_ && g.RT == RT_ && g.CT == CT_ && g.KC == KC_) {                                                     \
-        if (stats && in_scale) PTT_RG_LAUNCH(WR_, RT_, CT_, KC_, true, true)                                            \
+        if (bn) {                                                                                                       \
+            if ((rc = set_lds_limit(reinterpret_cast<const void*>(rows_gemm_kernel<WR_, RT_, CT_, KC_, true, false, 0, true>), lds))) return rc; \
+            hipLaunchKernelGGL((rows_gemm_kernel<WR_, RT_, CT_, KC_, true, false, 0, true>), grid, dim3(256), lds, s, p); \
+        } else if (stats && in_scale) PTT_RG_LAUNCH(WR_, RT_, CT_, KC_, true, true)                                     \
         else if (stats) PTT_RG_LAUNCH(WR_, RT_, CT_, KC_, true, false)                                                  \
         else if (in_scale) PTT_RG_LAUNCH(WR_, RT_, CT_, KC_, false, true)                                               \
         else PTT_RG_LAUNCH(WR_, RT_, CT_, KC_, false, false)                                                            \
