@@ -156,8 +156,12 @@ def test_G10_training_step_on_the_row_kernels_matches_the_reference_gradients(de
     above = sum(1 for v in per.values() if v > 1e-3)
     print("G10 on the row kernels: worst gradient-norm error %.4f, worst cosine %.6f, %d of %d gradients more than 0.1 %% off the "
           "reference's norm" % (worst_norm, worst_cos, above, len(per)))
-    # measured on MI355X: 0.0021 / 0.999989 / 5 of 96 (round 2, before the BatchNorm variance of the fused statistics was made
-    # cancellation-free: 0.022 / 0.9990; the reference's own float32 run is 0.0028 off its float64 gradient, fixture G14)
+    # measured on MI355X: 0.0021 / 0.999989 / 6 of 96 (round 2, before the BatchNorm variance of the fused statistics was made
+    # cancellation-free: 0.022 / 0.9990; the reference's own float32 run is 0.0028 off its float64 gradient, fixture G14).
+    # How much of that is rounding luck: two numerically innocent variants of this build measured 0.0054 (short launches on the
+    # linear kernels) and 0.0075 (b = beta - mean * a as one FMA instead of a product and a difference) — every float32
+    # evaluation of this network sits 0.2 - 0.8 % from the others; the bars below are twice THIS build's figures and a
+    # change that moves them is not by itself a defect (compare against G14 before concluding anything)
     assert worst_norm < 0.004 and worst_cos > 0.99997 and above <= 12, (worst_norm, worst_cos, above)
 
 
