@@ -619,6 +619,56 @@ __global__ __launch_bounds__(256, 2) void linear_wgrad_kernel(const float* __res
         }
 }
 
+// Weight gradient of a layer with at most 4 INPUT channels (the relative-coordinate terms of the hoisted layer 0, fc_delta[0]:
+// K = 3): dW[c][k] = sum_r dZ[r][c] * X[r][k]. On the MFMA kernel above that is a 128 x 128 tile with 125 idle columns and two
+// staged operands; it is a memory-bound pass over dZ: thread = (row slot, channel quad), the K coordinates of a row are a
+// wave-uniform load, partial sums per 256-row chunk combined through LDS in slot order, chunks summed by wgrad_finish_kernel.
+constexpr int WK_ROWS = 256;
+template <int K>
+__global__ __launch_bounds__(256) void wgrad_smallk_kernel(const float* __restrict__ dZ, int ldz, const float* __restrict__ X, int ldx,
+                                                           int R, int C, float* __restrict__ partial) {
+    __shared__ float red[256][4 * K];
+    const int Cq = C >> 2, span = Cq < 256 ? Cq : 256, RG = 256 / span;
+    const int q0 = threadIdx.x % span, rg = threadIdx.x / span;
+    const int r0 = blockIdx.x * WK_ROWS, r1 = min(R, r0 + WK_ROWS);
+    for (int qb = 0; qb < Cq; qb += span) {
+        const int q = qb + q0;
+        float acc[4][K];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int k = 0; k < K; ++k) acc[j][k] = 0.f;
+        if (q < Cq && rg < RG) {
+            for (int r = r0 + rg; r < r1; r += RG) {
+                const f32x4t g = *reinterpret_cast<const f32x4t*>(dZ + (size_t)r * ldz + 4 * q);
+                float xv[K];
+#pragma unroll
+                for (int k = 0; k < K; ++k) xv[k] = X[(size_t)r * ldx + k];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int k = 0; k < K; ++k) acc[j][k] = __builtin_fmaf(g[j], xv[k], acc[j][k]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int k = 0; k < K; ++k) red[threadIdx.x][j * K + k] = acc[j][k];
+        __syncthreads();
+        if (rg == 0 && q < Cq) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    float t = 0.f;
+                    for (int g2 = 0; g2 < RG; ++g2) t += red[g2 * span + q0][j * K + k];
+                    partial[((size_t)blockIdx.x * C + 4 * q + j) * K + k] = t;
+                }
+        }
+        __syncthreads();
+    }
+}
+
 // dW = sum over chunks (fixed order); optionally accumulates into dW (beta = 1) for parameters used more than once.
 // Workgroup = 32 consecutive outputs x 8 chunk groups: group g adds the chunks g, g + 8, ... in order, the 8 group sums are
 // then added in order — a fixed summation tree, and 8x the loads in flight of a one-thread-per-output loop.
@@ -1138,8 +1188,11 @@ extern "C" int ptt_pt_attn_train_bwd_f32(const float* attn, const float* vf, con
     return check_launch("attn_bwd_kernel");
 }
 
+static inline bool wgrad_smallk_ok(int Cout, int Cin) { return Cin >= 1 && Cin <= 4 && (Cout & 3) == 0; }
+
 extern "C" size_t ptt_linear_wgrad_workspace(int R, int Cout, int Cin) {
     if (R <= 0 || Cout <= 0 || Cin <= 0) return 0;
+    if (wgrad_smallk_ok(Cout, Cin)) return (size_t)((R + WK_ROWS - 1) / WK_ROWS) * (size_t)Cout * Cin * sizeof(float);
     const int rows = wgrad_chunk_rows(R, Cout, Cin);
     return (size_t)((R + rows - 1) / rows) * (size_t)Cout * Cin * sizeof(float);
 }
@@ -1154,6 +1207,17 @@ extern "C" int ptt_linear_wgrad_f32(const float* dZ, int ldz, const float* X, in
     if (!dZ || !X || !dW) return fail(PTT_EINVAL, "ptt_linear_wgrad_f32: null pointer");
     if (!ws || ws_bytes < ptt_linear_wgrad_workspace(R, Cout, Cin))
         return fail(PTT_EWORKSPACE, "ptt_linear_wgrad_f32: workspace too small");
+    if (wgrad_smallk_ok(Cout, Cin) && !x_scale && (ldz & 3) == 0 && (reinterpret_cast<uintptr_t>(dZ) & 15) == 0) {
+        const int nch = (R + WK_ROWS - 1) / WK_ROWS;
+        hipStream_t s2 = as_stream(stream);
+        float* part = static_cast<float*>(ws);
+        if (Cin == 1) hipLaunchKernelGGL((wgrad_smallk_kernel<1>), dim3(nch), dim3(256), 0, s2, dZ, ldz, X, ldx, R, Cout, part);
+        else if (Cin == 2) hipLaunchKernelGGL((wgrad_smallk_kernel<2>), dim3(nch), dim3(256), 0, s2, dZ, ldz, X, ldx, R, Cout, part);
+        else if (Cin == 3) hipLaunchKernelGGL((wgrad_smallk_kernel<3>), dim3(nch), dim3(256), 0, s2, dZ, ldz, X, ldx, R, Cout, part);
+        else hipLaunchKernelGGL((wgrad_smallk_kernel<4>), dim3(nch), dim3(256), 0, s2, dZ, ldz, X, ldx, R, Cout, part);
+        launch_wgrad_finish(part, nch, (size_t)Cout * Cin, accumulate, dW, s2);
+        return check_launch("wgrad_smallk_kernel");
+    }
     const int rows = wgrad_chunk_rows(R, Cout, Cin);
     const int nchunks = (R + rows - 1) / rows;
     const int nbo = (Cout + 127) / 128, nbi = (Cin + 127) / 128;
