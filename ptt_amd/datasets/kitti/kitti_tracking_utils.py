@@ -225,11 +225,24 @@ def get_model(PCs, boxes, offset=0., scale=1.0, normalize=False, visual_handle=N
 
 
 def regularize_pc(pc, input_size, ratio=1, label=None, reg=None, istrain=True):
-    """:342-367 with istrain=False semantics (the tracking loop's): a fixed-size (input_size, 3) float32 cloud,
-    resampled with replacement by the index stream np.random.randint yields right after set_manual_seed(1). Returns a
-    device tensor. (istrain=True draws from numpy's running global state, a data-loader concern outside this mirror.)"""
-    if istrain or label is not None:
-        raise NotImplementedError("regularize_pc: only the evaluation form (istrain=False, no labels) is mirrored")
+    """:342-367: a fixed-size (input_size, 3) float32 cloud, resampled with replacement; returns a device tensor.
+    istrain=False (the tracking loop): the index stream np.random.randint yields right after set_manual_seed(1), reproduced on
+    the device (ptt_regularize_f32), numpy's global generator left as the reference leaves it. istrain=True (the data
+    loader's form, :349-353 without the reseed): the indices are drawn here from numpy's running global generator, exactly as
+    the reference draws them, and gathered on the device. Per-point labels (`label`, produced by crop_center_pc with a
+    ground-truth box) are not mirrored."""
+    if label is not None:
+        raise NotImplementedError("regularize_pc: per-point labels are not mirrored (crop_center_pc returns None for them)")
+    if istrain and input_size > 0:
+        size = int(input_size) // int(ratio)
+        rows = pc.points.t().contiguous()
+        n = rows.shape[0]
+        if n <= 2:
+            return torch.zeros((size, 3), dtype=torch.float32, device=rows.device)
+        if n == size:
+            return rows
+        idx = np.random.randint(low=0, high=n, size=size, dtype=np.int64)
+        return rows.index_select(0, torch.from_numpy(idx).to(rows.device))
     if input_size <= 0:
         return pc.points.t().contiguous()
     size = int(input_size) // int(ratio)

@@ -102,7 +102,7 @@ z)  # closing evidence of the round: parity tests, the default bench line (all c
     bash scripts/pmc_passes.sh $O/pmc "pair,sa0_s,sa1_s,sa2_s,sa_box" > $O/pmc.log 2>&1; tail -8 $O/pmc.log | cut -c1-300
     bash scripts/pmc_passes.sh $O/pmc_train_gemm - "python scripts/rows_gemm_bench.py --no-check --pmc" > $O/pmc_train_gemm.log 2>&1; tail -8 $O/pmc_train_gemm.log | cut -c1-300
     ;;
-r)  timeout 900 python -m pytest tests/test_gemm_gpu.py -m gpu -q 2>&1 | tail -15 | cut -c1-200
+r)  timeout 900 python -m pytest tests/test_tracking_gpu.py -m gpu -q 2>&1 | tail -15 | cut -c1-200
     ;;
 *)  echo "unknown session $S"; exit 2;;
 esac

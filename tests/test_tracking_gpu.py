@@ -88,6 +88,22 @@ def test_regularize_pc_leaves_numpys_global_generator_where_the_reference_does(d
         assert got == np.random.uniform(-1, 1), n
 
 
+def test_regularize_pc_training_form_draws_from_numpys_running_generator(dev):
+    """istrain=True (kitti_tracking_utils.py:349-353 without the reseed): the indices come from numpy's global generator in
+    whatever state it is — the mirror draws them the same way and gathers on the device."""
+    import ptt.datasets.kitti.kitti_tracking_utils as ku
+    for n in (700, 3, 5000):
+        pts = np.random.RandomState(n).standard_normal((3, n)).astype(np.float32)
+        np.random.seed(777)
+        got = ku.regularize_pc(ku.PointCloud(pts), 1024, istrain=True).cpu().numpy()
+        np.random.seed(777)
+        want = pts[:, np.random.randint(low=0, high=n, size=1024, dtype=np.int64)].T
+        np.testing.assert_array_equal(got, want)
+    same = np.random.RandomState(1).standard_normal((3, 1024)).astype(np.float32)
+    np.testing.assert_array_equal(ku.regularize_pc(ku.PointCloud(same), 1024, istrain=True).cpu().numpy(), same.T)
+    assert float(ku.regularize_pc(ku.PointCloud(same[:, :2]), 1024, istrain=True).abs().max()) == 0.0
+
+
 def test_select_box_is_first_argmax(dev):
     rs = np.random.RandomState(3)
     x = rs.standard_normal((7, 64, 5)).astype(np.float32)
