@@ -1,15 +1,23 @@
-"""N3 — the TRAINING forward and backward of the shared-MLP stages on the hand-written kernels of
-ptt_amd/csrc/train_ops.hip (+ ptt_linear_f32): the reference's SharedMLP in train mode followed by the max over the
-neighbour axis (pytorch_utils.py:12-36,94-114 + pointnet2_modules.py:84-88; similarity_modules/p2b_xcoor.py:39-41), as
-ONE autograd function over (rows, channels) activations.
+"""N3 — the TRAINING step of the tracker on the hand-written kernels of ptt_amd/csrc/gemm_ops.hip and train_ops.hip
+(+ the linear kernels of mfma_ops.hip for odd shapes). What runs through here, as torch.autograd.Functions over
+(rows, channels) activations ("point-major": one row per (centre, neighbour) / (point, neighbour) / point):
+
+  * every SharedMLP + max-pool stage — the reference's SharedMLP in train mode followed by the max over the neighbour axis
+    (pytorch_utils.py:12-36,94-114 + pointnet2_modules.py:84-88; similarity_modules/p2b_xcoor.py:39-41) — as ONE function
+    (_SharedMlpPool): per layer the 1x1 convolution on the persistent row GEMM with the BatchNorm batch statistics out of its
+    epilogue; the activation relu(z a + b) is DEFERRED (never written: the next convolution, the weight gradient, the pool and
+    the backward apply it while they load z); backward: the last layer's BatchNorm / ReLU / max-pool backward from the pooled
+    gradient, the other layers' backward sums out of the input-gradient GEMM's epilogue, weight gradients on the 256 x 256-block
+    kernel; running statistics updated as nn.BatchNorm does (momentum, unbiased variance, batch counter);
+  * the layer-0 hoist of the SA levels and of CosineSimAug (sa_level_hoisted, xcorr_hoisted);
+  * every nn.Linear of the Point-Transformer block (_RowsLinear, _RowsMlp2) and its element-wise passes (_PairInput,
+    _AttnAggregate, _KnnRel), the Conv1d stacks of the heads (conv1d_stack_rows), cov_final.
 
     y = shared_mlp_pool(grouped, mlp, pool_dim)      # grouped (B,C,M,ns) as QueryAndGroup / the fusion tensor yields it
 
 replaces `mlp(grouped).max(dim=pool_dim)[0]` (= F.max_pool2d over that axis) whenever the module is in training mode on
-a HIP device and has the plain [conv1x1 (no bias) -> BatchNorm2d -> ReLU] units every shipped config builds. Forward:
-per layer ptt_linear_f32 -> ptt_bn_stats_f32 -> ptt_bn_apply_f32, then ptt_pool_rows_f32. Backward: ptt_pool_rows_bwd_f32,
-then per layer ptt_bn_bwd_f32 -> ptt_linear_wgrad_f32 (weight gradient) -> ptt_linear_f32 on the transposed weight
-(input gradient). Running statistics are updated as nn.BatchNorm2d does (momentum, unbiased variance, batch counter).
+a HIP device and has the plain [conv1x1 (no bias) -> BatchNorm2d -> ReLU] units every shipped config builds (`usable`).
+Every reduction runs in a fixed order: a step is bit-reproducible run to run (tests/test_train_config3_gpu.py).
 """
 import weakref
 
