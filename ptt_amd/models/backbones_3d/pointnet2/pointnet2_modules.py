@@ -133,7 +133,9 @@ class PointnetSAModuleVotes(nn.Module):
                 w2 = w0.reshape(w0.shape[0], w0.shape[1]).float()
                 scale0 = layers[0][6]
                 wx = w2[:, 0:3] if scale0 is None else w2[:, 0:3] * scale0[:, None]
-                hoist = (ops.pack_weight(w2[:, 3:].contiguous()), wx.t().contiguous(), layers[0][4], layers[0][5])
+                # the BatchNorm scale folded into both halves of layer 0 (no per-value scale in the linear launch's epilogue)
+                wf = w2[:, 3:] if scale0 is None else w2[:, 3:] * scale0[:, None]
+                hoist = (ops.pack_weight(wf.contiguous()), wx.t().contiguous(), layers[0][4], layers[0][5])
         ops.publish_params(device)
         self._fused_cache = (key, (layers, hoist))
         return layers, hoist
@@ -169,7 +171,7 @@ class PointnetSAModuleVotes(nn.Module):
                 wf_packed, wx, c0, relu0 = hoist
                 rows = features.transpose(1, 2)                       # (B,N,C): contiguous when point-major
                 term = ops.linear(rows if rows.is_contiguous() else rows.contiguous(), wf_packed, c0,
-                                  layers[0][6], layers[0][2], relu=False)
+                                  None, layers[0][2], relu=False)
                 new_features = ops.sa_fused_forward(xyz, new_xyz, idx, None, [L[:6] for L in layers[1:]], self.radius, True,
                                                     self.normalize_xyz, point_major_out=True, l0=(term, wx, relu0))
             else:

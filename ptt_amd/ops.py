@@ -319,6 +319,15 @@ def linear(x, wpacked, cout, scale=None, shift=None, relu=False, residual=None, 
         r2 = residual.reshape(-1, int(cout))
         if r2.stride(1) != 1:
             r2 = r2.contiguous()
+    # above 8192 rows the persistent row GEMM is the faster launch where it takes the shape (12288 x 128 -> 128: 7.3 vs
+    # 9.2 us, 12288 x 256 -> 128: 11.0 vs 13.5; profiles/r03p_linear_infer_bench.log); below, the short-launch linear kernel
+    if (scale is None and rows > 8192 and x2.data_ptr() % 16 == 0 and o2.is_contiguous()
+            and _lib.lib().ptt_rows_gemm_supported(rows, K, int(cout), x2.stride(0), int(cout))):
+        with torch.cuda.device(x.device), _timed('ptt_linear_f32'):
+            _lib.check(_lib.lib().ptt_rows_gemm_f32(_ptr(x2), rows, K, x2.stride(0), None, None, _ptr(wpacked), int(cout), _ptr(shift),
+                                                    1 if relu else 0, _ptr(r2), r2.stride(0) if r2 is not None else int(cout),
+                                                    _ptr(o2), int(cout), None, 0, _stream()), "ptt_rows_gemm_f32")
+        return out
     with torch.cuda.device(x.device), _timed('ptt_linear_f32'):
         _lib.check(_lib.lib().ptt_linear_f32(
             _ptr(x2), rows, K, x2.stride(0) if rows > 1 else K, _ptr(wpacked), int(cout), _ptr(scale), _ptr(shift),
