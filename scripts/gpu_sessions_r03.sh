@@ -101,8 +101,14 @@ z)  # closing evidence of the round: parity tests, the default bench line (all c
     ktrace b1_kernel_stats python $REPO/scripts/tracklet_b1_profile.py
     bash scripts/pmc_passes.sh $O/pmc "pair,sa0_s,sa1_s,sa2_s,sa_box" > $O/pmc.log 2>&1; tail -8 $O/pmc.log | cut -c1-300
     bash scripts/pmc_passes.sh $O/pmc_train_gemm - "python scripts/rows_gemm_bench.py --no-check --pmc" > $O/pmc_train_gemm.log 2>&1; tail -8 $O/pmc_train_gemm.log | cut -c1-300
+    timeout 600 python scripts/fwd_precision_diag.py 2>&1 | grep -v "amdgpu.ids\|Warning" > $O/forward_precision_vs_float64.log; tail -12 $O/forward_precision_vs_float64.log
+    G14_ROWS=8 timeout 600 python scripts/g14_diag.py 2>&1 | grep -v "amdgpu.ids\|Warning\|detach\|return float" > $O/gradient_error_vs_float64.log; tail -4 $O/gradient_error_vs_float64.log
     ;;
 r)  timeout 900 python -m pytest tests/test_tracking_gpu.py -m gpu -q 2>&1 | tail -15 | cut -c1-200
+    ;;
+s)  # stability: the whole GPU suite three times in fresh processes, smoke() and build()
+    for i in 1 2 3; do timeout 1200 python -m pytest tests -m gpu -q -x 2>&1 | tail -2; done
+    timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
     ;;
 *)  echo "unknown session $S"; exit 2;;
 esac
