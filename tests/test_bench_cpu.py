@@ -33,3 +33,39 @@ def test_gpus_2_spawns_two_ranks_itself():
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert p.returncode != 0
     assert p.stderr.count("bench.py needs a HIP device") >= 2, p.stderr[-2000:]
+
+
+def test_committed_traffic_reads_the_newest_pmc_summary_and_names_its_source():
+    """roofline.traffic of the bench line: bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
+    (a process cannot PMC itself), with the file and the build it was taken from."""
+    sys.path.insert(0, ROOT)
+    import bench
+    tr, src = bench.committed_traffic("pt_attn_pair_kernel<512>")
+    assert tr is not None and src["file"].startswith("profiles/") and src["file"].endswith("pmc_summary.json")
+    assert len(src["per_launch_shape"]) == 2                                  # the N = 128 and the N = 64 launch of a step
+    per = [v["read_bytes"] + v["write_bytes"] for v in src["per_launch_shape"].values()]
+    assert abs(tr - sum(per) / 2) < 1.0
+    alg = 0.5 * (bench.pair_alg_bytes(48, 128) + bench.pair_alg_bytes(48, 64))
+    assert alg < tr < 3 * alg                                                 # measured traffic is 1.8x the compulsory bytes
+    assert bench.committed_traffic("no_such_kernel") == (None, None)
+
+
+def test_side_workload_reports_a_failing_process_instead_of_raising(monkeypatch):
+    """The default line's `workloads` entries come from child processes: a child that dies yields an `error` entry, the
+    headline line is still printed."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    class P(object):
+        returncode, stdout, stderr = 139, b"", b"Segmentation fault"
+    monkeypatch.setattr(bench.subprocess, "run", lambda *a, **k: P())
+    rec = bench.side_workload("stress", 5, 2)
+    assert "error" in rec and "139" in rec["error"]
+
+    class Q(object):
+        returncode, stderr = 0, b""
+        stdout = json.dumps({"metric": "m", "value": 1.0, "unit": "frames/s", "steps": 5, "warmup": 2, "ms_per_step": 2.0, "dtype": "f32",
+                             "roofline": {"frac": 0.5}, "config": {"workload": "w"}, "cpu_baseline": None}).encode()
+    monkeypatch.setattr(bench.subprocess, "run", lambda *a, **k: Q())
+    rec = bench.side_workload("ped", 10, 3)
+    assert rec["value"] == 1.0 and rec["config"]["ref"] == "BASELINE.json configs[2]" and "cpu_baseline" not in rec
