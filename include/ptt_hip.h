@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PTT_ABI_VERSION 13
+#define PTT_ABI_VERSION 14
 
 enum {
     PTT_OK = 0,
@@ -540,6 +540,34 @@ int ptt_xcorr_z0_f32(const float* P, const float* cos_t, const float* w_sim, int
 size_t ptt_xcorr_z0_bwd_workspace(int B, int n1, int C);
 int ptt_xcorr_z0_bwd_f32(const float* dz0, const float* cos_t, const float* w_sim, int B, int n2, int n1, int C, float* dP, float* dcos,
                          float* dw, void* workspace, size_t workspace_bytes, ptt_stream_t stream);
+/* Round 3, launch consolidation of the training step (the step is bound by device time, and ~250 of its launches were
+ * five-microsecond bookkeeping kernels):
+ *   ptt_bn_train_tail   what a training-mode BatchNorm layer does with fresh batch statistics besides normalising
+ *     (torch/nn/modules/batchnorm.py; the reference builds the layers in pytorch_utils.py:94-114), written by the SAME
+ *     launch that forms the statistics: act_a = gamma * invstd and act_b = beta - mean * act_a (the deferred activation's
+ *     constants, each operation rounded separately), running_mean / running_var updated with `momentum` and the n / (n - 1)
+ *     variance (n = R), *num_batches_tracked += 1. Null members switch a piece off; a NULL tail = the plain entry point.
+ *   ptt_pack_weights_f32  packs n_jobs weights (views by element strides: W[col * stride_out + k * stride_k], so a
+ *     transposed pack is a stride swap) into one arena in ONE launch; jobs live in DEVICE memory (a training step re-packs
+ *     every weight after each optimiser update: the table is built once, the launch repeats). out_offset: float offset
+ *     inside `arena`, a multiple of 4; each job writes ptt_packed_weight_elems(Cout, K) floats. */
+typedef struct ptt_bn_train_tail {
+    const float* gamma; const float* beta;      /* (C) affine parameters, needed for act_a / act_b */
+    float* act_a; float* act_b;                 /* (C) out, or both NULL */
+    float* running_mean; float* running_var;    /* (C) updated in place, or both NULL */
+    int64_t* num_batches_tracked;               /* incremented, or NULL */
+    float momentum;
+} ptt_bn_train_tail;
+int ptt_bn_stats_train_f32(const float* X, int R, int C, int ldx, float eps, float* mean, float* var, float* invstd,
+                           void* workspace, size_t workspace_bytes, const ptt_bn_train_tail* tail, ptt_stream_t stream);
+int ptt_bn_finish_partials_train_f32(const double* partial, int chunks, int C, int R, float eps, float* mean, float* var,
+                                     float* invstd, const ptt_bn_train_tail* tail, ptt_stream_t stream);
+typedef struct ptt_pack_job {
+    const float* W;
+    int64_t out_offset, stride_out, stride_k;
+    int32_t Cout, K;
+} ptt_pack_job;
+int ptt_pack_weights_f32(const ptt_pack_job* jobs_device, int n_jobs, float* arena, ptt_stream_t stream);
 size_t ptt_linear_wgrad2_workspace(int R, int Cout, int Cin);
 int ptt_linear_wgrad2_f32(const float* dZ, int ldz, const float* X, int ldx, int R, int Cout, int Cin, float* dW,
                           int accumulate, void* workspace, size_t workspace_bytes, const float* x_scale, const float* x_shift,

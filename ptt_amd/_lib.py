@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libptt_hip.so")
 
 PTT_SA_MAX_LAYERS = 4
-ABI_VERSION = 13            # PTT_ABI_VERSION of include/ptt_hip.h these structures mirror
+ABI_VERSION = 14            # PTT_ABI_VERSION of include/ptt_hip.h these structures mirror
 
 # every symbol include/ptt_hip.h declares (tests check the library exports all of them)
 EXPORTS = [
@@ -36,6 +36,7 @@ EXPORTS = [
     "ptt_pt_pair_input_ld_f32", "ptt_pt_attn_fwd_ld_f32",
     "ptt_rows_gemm_bnbwd_f32", "ptt_bn_bwd_from_partials_f32", "ptt_bn_bwd_sums_partials_f64",
     "ptt_bn_update_running_f32", "ptt_xcorr_z0_f32", "ptt_xcorr_z0_bwd_workspace", "ptt_xcorr_z0_bwd_f32",
+    "ptt_bn_stats_train_f32", "ptt_bn_finish_partials_train_f32", "ptt_pack_weights_f32",
 ]
 PTT_MAX_SEGMENTS = 4
 
@@ -54,6 +55,18 @@ class RegularizeJob(Structure):
                 ("seg_capacity", c_int32 * PTT_MAX_SEGMENTS), ("out", c_void_p), ("info", c_void_p),
                 ("n_seg", c_int32), ("input_size", c_int32)]
 
+
+
+class BnTrainTail(Structure):
+    """ptt_bn_train_tail: a training-mode BatchNorm's bookkeeping, done by the launch that forms the statistics."""
+    _fields_ = [("gamma", c_void_p), ("beta", c_void_p), ("act_a", c_void_p), ("act_b", c_void_p),
+                ("running_mean", c_void_p), ("running_var", c_void_p), ("num_batches_tracked", c_void_p), ("momentum", c_float)]
+
+
+class PackJob(Structure):
+    """ptt_pack_job: one weight (view) of ptt_pack_weights_f32; arrays of these are uploaded to the device."""
+    _fields_ = [("W", c_void_p), ("out_offset", c_int64), ("stride_out", c_int64), ("stride_k", c_int64),
+                ("Cout", c_int32), ("K", c_int32)]
 
 
 class SaLayer(Structure):
@@ -155,6 +168,9 @@ def _declare(lib):
         "ptt_pt_pair_input_ld_f32": [vp, i, vp, i, vp, vp, i, i, i, i, vp, vp],
         "ptt_pt_attn_fwd_ld_f32": [vp, vp, i, vp, vp, i, i, i, i, f, vp, vp, vp],
         "ptt_bn_update_running_f32": [vp, vp, vp, f, i, vp, vp, vp, vp],
+        "ptt_bn_stats_train_f32": [vp, i, i, i, f, vp, vp, vp, vp, c_size_t, vp, vp],
+        "ptt_bn_finish_partials_train_f32": [vp, i, i, i, f, vp, vp, vp, vp, vp],
+        "ptt_pack_weights_f32": [vp, i, vp, vp],
         "ptt_xcorr_z0_f32": [vp, vp, vp, i, i, i, i, vp, vp],
         "ptt_xcorr_z0_bwd_f32": [vp, vp, vp, i, i, i, i, vp, vp, vp, vp, c_size_t, vp],
         "ptt_bn_bwd_pooled_f32": [vp, i, vp, i, vp, i, vp, vp, vp, i, i, vp, i, vp, vp, vp, c_size_t, vp, vp, vp],

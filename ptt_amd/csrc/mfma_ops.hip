@@ -130,6 +130,24 @@ __global__ void pack_weight_kernel(const float* __restrict__ W, int Cout, int K,
     }
 }
 
+// Many weights in one launch (a training step re-packs all of them after every optimiser update): blockIdx.y = job.
+__global__ __launch_bounds__(256) void pack_weights_kernel(const ptt_pack_job* __restrict__ jobs, float* __restrict__ arena) {
+    const ptt_pack_job jb = jobs[blockIdx.y];
+    const int NT = (jb.Cout + 31) / 32;
+    const size_t total = (size_t)NT * (size_t)((jb.K + 7) / 8) * 256;
+    float* Pb = arena + jb.out_offset;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int j = (int)(e & 3);
+        const int lane = (int)((e >> 2) & 63);
+        const size_t tile = e >> 8;
+        const int ct = (int)(tile % NT);
+        const int kb = (int)(tile / NT);
+        const int col = ct * 32 + (lane & 31);
+        const int k = kb * 8 + 4 * (lane >> 5) + j;
+        Pb[e] = (col < jb.Cout && k < jb.K) ? jb.W[(long long)col * jb.stride_out + (long long)k * jb.stride_k] : 0.0f;
+    }
+}
+
 // One K-block: 4 * RT * CT MFMAs on the first CT column tiles of acc (ACT >= CT columns wide).
 // Weight fragments are fetched with raw buffer loads: address = descriptor base (SGPRs) + per-lane byte offset (one
 // VGPR, constant for the whole GEMM) + wave-uniform byte offset (SGPR, advanced by the scalar unit). The flat
@@ -1899,6 +1917,15 @@ extern "C" int ptt_pack_weight_strided_f32(const float* W, int Cout, int K, int6
     hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)g, (unsigned)batch), dim3(256), 0, as_stream(stream), W, Cout, K, NT, 0,
                        total, packed, (long long)stride_out, (long long)stride_k, (long long)stride_batch);
     return check_launch("pack_weight_kernel");
+}
+
+extern "C" int ptt_pack_weights_f32(const ptt_pack_job* jobs_device, int n_jobs, float* arena, ptt_stream_t stream) {
+    if (n_jobs < 0) return fail(PTT_EINVAL, "ptt_pack_weights_f32: n_jobs=%d", n_jobs);
+    if (n_jobs == 0) return PTT_OK;
+    if (!jobs_device || !arena) return fail(PTT_EINVAL, "ptt_pack_weights_f32: null pointer");
+    if (n_jobs > 65535) return fail(PTT_EUNSUPPORTED, "ptt_pack_weights_f32: n_jobs=%d exceeds one launch (65535)", n_jobs);
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(32, (unsigned)n_jobs), dim3(256), 0, as_stream(stream), jobs_device, arena);
+    return check_launch("pack_weights_kernel");
 }
 
 extern "C" int ptt_pack_weight_f32(const float* W, int Cout, int K, float* packed, ptt_stream_t stream) {

@@ -67,10 +67,36 @@ __global__ __launch_bounds__(256) void col_stats_kernel(const float* __restrict_
 
 // Combine the partials in chunk order. MODE 0: mean, biased variance, invstd = 1/sqrt(var + eps).
 //                                     MODE 1: the two sums themselves as float (out0 = sum dy, out1 = sum dy*xhat).
+// What a training-mode BatchNorm does with fresh batch statistics besides normalising, folded into the kernel that forms them
+// (31 layers x 4 five-microsecond launches per training step otherwise): the deferred activation's constants
+// a = gamma * invstd, b = beta - mean * a (two separately rounded operations, as the element-wise torch expressions they
+// replace) and nn.BatchNorm's bookkeeping (running statistics with the n / (n - 1) variance, batch counter). Null pointers
+// switch the pieces off.
+struct BnTail {
+    const float* gamma; const float* beta; float* act_a; float* act_b;
+    float* running_mean; float* running_var; long long* tracked; float momentum;
+};
+__device__ __forceinline__ void bn_tail(const BnTail& t, int c, float mean, float var, float invstd, int R) {
+#pragma clang fp contract(off)      // HIP's __fmul_rn / __fsub_rn are plain operators: hipcc's default contraction would fuse them
+    if (t.act_a) {
+        const float a = t.gamma[c] * invstd;
+        const float ma = mean * a;
+        t.act_a[c] = a;
+        t.act_b[c] = t.beta[c] - ma;
+    }
+    if (t.running_mean) {
+        const double n = (double)R;
+        const float unbias = (float)(n / (n > 1.0 ? n - 1.0 : 1.0));
+        t.running_mean[c] = (1.f - t.momentum) * t.running_mean[c] + t.momentum * mean;
+        t.running_var[c] = (1.f - t.momentum) * t.running_var[c] + t.momentum * (var * unbias);
+    }
+    if (c == 0 && t.tracked) *t.tracked += 1;
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256) void col_stats_finish_kernel(const double* __restrict__ partial, int nchunks, int C, int R,
                                                                float eps, float* __restrict__ out0, float* __restrict__ out1,
-                                                               float* __restrict__ out2) {
+                                                               float* __restrict__ out2, BnTail tail) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
     double s0 = 0.0, s1 = 0.0;
@@ -82,9 +108,11 @@ __global__ __launch_bounds__(256) void col_stats_finish_kernel(const double* __r
         const double mu = s0 / (double)R;
         double var = s1 / (double)R - mu * mu;
         if (var < 0.0) var = 0.0;
+        const float inv = (float)(1.0 / sqrt(var + (double)eps));
         out0[c] = (float)mu;
         out1[c] = (float)var;
-        out2[c] = (float)(1.0 / sqrt(var + (double)eps));
+        out2[c] = inv;
+        bn_tail(tail, c, (float)mu, (float)var, inv, R);
     } else {
         out0[c] = (float)s0;
         out1[c] = (float)s1;
@@ -160,7 +188,7 @@ __global__ __launch_bounds__(256) void col_stats4_kernel(const float* __restrict
 template <int MODE>
 __global__ __launch_bounds__(256) void col_stats_finish2_kernel(const double* __restrict__ partial, int nchunks, int C, int R,
                                                                 float eps, float* __restrict__ out0, float* __restrict__ out1,
-                                                                float* __restrict__ out2) {
+                                                                float* __restrict__ out2, BnTail tail) {
     __shared__ double t0[256], t1[256];
     const int c = blockIdx.x, t = threadIdx.x;
     double s0 = 0.0, s1 = 0.0;
@@ -179,7 +207,9 @@ __global__ __launch_bounds__(256) void col_stats_finish2_kernel(const double* __
             const double mu = t0[0] / (double)R;
             double var = t1[0] / (double)R - mu * mu;
             if (var < 0.0) var = 0.0;
-            out0[c] = (float)mu; out1[c] = (float)var; out2[c] = (float)(1.0 / sqrt(var + (double)eps));
+            const float inv = (float)(1.0 / sqrt(var + (double)eps));
+            out0[c] = (float)mu; out1[c] = (float)var; out2[c] = inv;
+            bn_tail(tail, c, (float)mu, (float)var, inv, R);
         } else {
             out0[c] = (float)t0[0]; out1[c] = (float)t1[0];
         }
@@ -861,9 +891,25 @@ extern "C" size_t ptt_bn_stats_workspace(int R, int C) {
     return (size_t)((R + ST4_ROWS - 1) / ST4_ROWS) * 2 * (size_t)C * sizeof(double);      // the finer of the two chunkings
 }
 
-extern "C" int ptt_bn_stats_f32(const float* X, int R, int C, int ldx, float eps, float* mean, float* var, float* invstd,
-                                void* ws, size_t ws_bytes, ptt_stream_t stream) {
+static int bn_tail_from(const ptt_bn_train_tail* t, int C, BnTail* out, const char* who) {
+    *out = BnTail{};
+    if (!t) return PTT_OK;
+    if ((t->act_a != nullptr) != (t->act_b != nullptr) || (t->act_a && (!t->gamma || !t->beta)))
+        return fail(PTT_EINVAL, "%s: the activation constants need gamma, beta, act_a and act_b together", who);
+    if ((t->running_mean != nullptr) != (t->running_var != nullptr))
+        return fail(PTT_EINVAL, "%s: running_mean and running_var go together", who);
+    if (t->running_mean && !(t->momentum >= 0.f && t->momentum <= 1.f)) return fail(PTT_EINVAL, "%s: momentum=%g", who, (double)t->momentum);
+    (void)C;
+    *out = BnTail{t->gamma, t->beta, t->act_a, t->act_b, t->running_mean, t->running_var,
+                  reinterpret_cast<long long*>(t->num_batches_tracked), t->momentum};
+    return PTT_OK;
+}
+
+extern "C" int ptt_bn_stats_train_f32(const float* X, int R, int C, int ldx, float eps, float* mean, float* var, float* invstd,
+                                      void* ws, size_t ws_bytes, const ptt_bn_train_tail* tail, ptt_stream_t stream) {
     if (R <= 0 || C <= 0 || ldx < C) return fail(PTT_EINVAL, "ptt_bn_stats_f32: R=%d C=%d ldx=%d", R, C, ldx);
+    BnTail bt;
+    if (int rc = bn_tail_from(tail, C, &bt, "ptt_bn_stats_train_f32")) return rc;
     if (!X || !mean || !var || !invstd) return fail(PTT_EINVAL, "ptt_bn_stats_f32: null pointer");
     if (!ws || ws_bytes < ptt_bn_stats_workspace(R, C)) return fail(PTT_EWORKSPACE, "ptt_bn_stats_f32: workspace too small");
     hipStream_t s = as_stream(stream);
@@ -872,15 +918,20 @@ extern "C" int ptt_bn_stats_f32(const float* X, int R, int C, int ldx, float eps
         hipLaunchKernelGGL((col_stats4_kernel<0>), dim3(nchunks), dim3(256), 256 * 8 * sizeof(double), s, X, nullptr, nullptr, nullptr,
                            nullptr, R, C, ldx, 0, 0, static_cast<double*>(ws), nullptr, nullptr);
         hipLaunchKernelGGL((col_stats_finish2_kernel<0>), dim3(C), dim3(256), 0, s, static_cast<const double*>(ws), nchunks, C, R, eps,
-                           mean, var, invstd);
+                           mean, var, invstd, bt);
         return check_launch("col_stats4_kernel");
     }
     const int nchunks = (R + ST_ROWS - 1) / ST_ROWS;
     hipLaunchKernelGGL((col_stats_kernel<0>), dim3(nchunks), dim3(256), 0, s, X, nullptr, nullptr, nullptr, nullptr, R, C, ldx, 0, 0,
                        static_cast<double*>(ws));
     hipLaunchKernelGGL((col_stats_finish_kernel<0>), dim3((C + 255) / 256), dim3(256), 0, s, static_cast<const double*>(ws), nchunks,
-                       C, R, eps, mean, var, invstd);
+                       C, R, eps, mean, var, invstd, bt);
     return check_launch("col_stats_kernel");
+}
+
+extern "C" int ptt_bn_stats_f32(const float* X, int R, int C, int ldx, float eps, float* mean, float* var, float* invstd,
+                                void* ws, size_t ws_bytes, ptt_stream_t stream) {
+    return ptt_bn_stats_train_f32(X, R, C, ldx, eps, mean, var, invstd, ws, ws_bytes, nullptr, stream);
 }
 
 extern "C" int ptt_bn_apply_f32(const float* Z, int ldz, const float* mean, const float* invstd, const float* gamma,
@@ -917,7 +968,7 @@ extern "C" int ptt_bn_bwd_f32(const float* G, int ldg, const float* Act, int lda
         hipLaunchKernelGGL((col_stats4_kernel<1>), dim3(nch), dim3(256), 256 * 8 * sizeof(double), s, G, Act, Z, mean, invstd, R, C, ldg,
                            lda, ldz, static_cast<double*>(ws), act_scale, act_shift);
         hipLaunchKernelGGL((col_stats_finish2_kernel<1>), dim3(C), dim3(256), 0, s, static_cast<const double*>(ws), nch, C, R, 0.f, dbeta,
-                           dgamma, nullptr);
+                           dgamma, nullptr, BnTail{});
         const int Cq = C >> 2, RG = 256 / (Cq < 256 ? Cq : 256);
         int grid = (R + RG * 8 - 1) / (RG * 8);
         if (grid > 16384) grid = 16384;
@@ -936,7 +987,7 @@ extern "C" int ptt_bn_bwd_f32(const float* G, int ldg, const float* Act, int lda
         return fail(PTT_EUNSUPPORTED, "ptt_bn_bwd_f32: relu == 0 is not instantiated (every SharedMLP unit has a ReLU)");
     }
     hipLaunchKernelGGL((col_stats_finish_kernel<1>), dim3((C + 255) / 256), dim3(256), 0, s, static_cast<const double*>(ws), nchunks,
-                       C, R, 0.f, dbeta, dgamma, nullptr);
+                       C, R, 0.f, dbeta, dgamma, nullptr, BnTail{});
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid((size_t)R * C)), dim3(256), 0, s, G, ldg, Act, lda, Z, ldz, mean, invstd,
                        gamma, dbeta, dgamma, R, C, relu, dZ, ldd);
     return check_launch("bn_bwd_kernels");
@@ -1027,7 +1078,7 @@ extern "C" int ptt_bn_bwd_pooled_f32(const float* dPooled, int ldp, const int32_
     hipLaunchKernelGGL(pool_bwd_stats_kernel, dim3(nch), dim3(256), 0, s, dPooled, ldp, arg, G, ns, Z, ldz, mean, invstd, act_scale,
                        act_shift, C, static_cast<double*>(ws), per);
     hipLaunchKernelGGL((col_stats_finish2_kernel<1>), dim3(C), dim3(256), 0, s, static_cast<const double*>(ws), nch, C, R, 0.f, dbeta,
-                       dgamma, nullptr);
+                       dgamma, nullptr, BnTail{});
     const int Cq = C >> 2, RG = 256 / (Cq < 256 ? Cq : 256);
     int grid = (R + RG * 8 - 1) / (RG * 8);
     if (grid > 16384) grid = 16384;
@@ -1240,13 +1291,20 @@ extern "C" int ptt_linear_wgrad_f32(const float* dZ, int ldz, const float* X, in
     return check_launch("linear_wgrad_kernel");
 }
 
-extern "C" int ptt_bn_finish_partials_f32(const double* partial, int chunks, int C, int R, float eps, float* mean, float* var,
-                                          float* invstd, ptt_stream_t stream) {
+extern "C" int ptt_bn_finish_partials_train_f32(const double* partial, int chunks, int C, int R, float eps, float* mean, float* var,
+                                                float* invstd, const ptt_bn_train_tail* tail, ptt_stream_t stream) {
     if (chunks <= 0 || C <= 0 || R <= 0 || !partial || !mean || !var || !invstd)
         return fail(PTT_EINVAL, "ptt_bn_finish_partials_f32: chunks=%d C=%d R=%d", chunks, C, R);
+    BnTail bt;
+    if (int rc = bn_tail_from(tail, C, &bt, "ptt_bn_finish_partials_train_f32")) return rc;
     hipLaunchKernelGGL((col_stats_finish2_kernel<0>), dim3(C), dim3(256), 0, as_stream(stream), partial, chunks, C, R, eps, mean, var,
-                       invstd);
+                       invstd, bt);
     return check_launch("col_stats_finish2_kernel");
+}
+
+extern "C" int ptt_bn_finish_partials_f32(const double* partial, int chunks, int C, int R, float eps, float* mean, float* var,
+                                          float* invstd, ptt_stream_t stream) {
+    return ptt_bn_finish_partials_train_f32(partial, chunks, C, R, eps, mean, var, invstd, nullptr, stream);
 }
 
 extern "C" int ptt_bn_sums_partials_f64(const double* partial, int chunks, int C, int R, double* sums, ptt_stream_t stream) {
@@ -1308,7 +1366,7 @@ extern "C" int ptt_bn_bwd_from_partials_f32(const double* partial, int chunks, c
           vec4_ok(gamma, 4, 4) && vec4_ok(dgamma, 4, 4) && vec4_ok(dbeta, 4, 4) && vec4_ok(act_scale, 4, 4) && vec4_ok(act_shift, 4, 4)))
         return fail(PTT_EUNSUPPORTED, "ptt_bn_bwd_from_partials_f32: needs C %% 4 == 0 and 16-byte aligned rows");
     hipStream_t s = as_stream(stream);
-    hipLaunchKernelGGL((col_stats_finish2_kernel<1>), dim3(C), dim3(256), 0, s, partial, chunks, C, R, 0.f, dbeta, dgamma, nullptr);
+    hipLaunchKernelGGL((col_stats_finish2_kernel<1>), dim3(C), dim3(256), 0, s, partial, chunks, C, R, 0.f, dbeta, dgamma, nullptr, BnTail{});
     const int Cq = C >> 2, RG = 256 / (Cq < 256 ? Cq : 256);
     int grid = (R + RG * 8 - 1) / (RG * 8);
     if (grid > 16384) grid = 16384;

@@ -622,13 +622,47 @@ def _ws(nbytes, device):
     return torch.empty((max(1, (int(nbytes) + 7) // 8),), dtype=torch.float64, device=device)
 
 
-def bn_stats(x, eps):
-    """Per-channel batch statistics of x (R,C): (mean, biased var, invstd) — ptt_bn_stats_f32."""
+def _bn_tail(bn, C, device):
+    """ptt_bn_train_tail for the training-mode BatchNorm module `bn` -> (structure, act_a, act_b): the launch that forms the
+    batch statistics also writes the deferred activation's constants a = gamma * invstd, b = beta - mean * a and does the
+    module's bookkeeping (running statistics, batch counter) in place."""
+    a, b = (torch.empty((C,), dtype=torch.float32, device=device) for _ in range(2))
+    for name in ("weight", "bias", "running_mean", "running_var"):
+        t = getattr(bn, name)
+        if t is None or t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != C or t.device != device:
+            raise RuntimeError("BatchNorm.%s must be a contiguous float32 (%d,) tensor on %s" % (name, C, device))
+    tracked = bn.num_batches_tracked
+    if tracked is not None and (tracked.dtype != torch.int64 or tracked.device != device):
+        raise RuntimeError("BatchNorm.num_batches_tracked must be an int64 tensor on %s" % device)
+    tail = _lib.BnTrainTail(gamma=bn.weight.data_ptr(), beta=bn.bias.data_ptr(), act_a=a.data_ptr(), act_b=b.data_ptr(),
+                            running_mean=bn.running_mean.data_ptr(), running_var=bn.running_var.data_ptr(),
+                            num_batches_tracked=tracked.data_ptr() if tracked is not None else None, momentum=float(bn.momentum))
+    return tail, a, b
+
+
+def _bn_tail_done(bn):
+    for t in (bn.running_mean, bn.running_var, bn.num_batches_tracked):      # the eval-mode parameter caches key on tensor versions
+        if t is not None:
+            torch.autograd.graph.increment_version(t)
+
+
+def bn_stats(x, eps, bn=None):
+    """Per-channel batch statistics of x (R,C): (mean, biased var, invstd) — ptt_bn_stats_f32. bn: the training-mode
+    BatchNorm module these statistics belong to -> (mean, var, invstd, a, b) with the deferred activation's constants, and the
+    module's running statistics / batch counter updated, all by the same two launches (ptt_bn_stats_train_f32)."""
     _rows(x, "x")
     R, C = x.shape
     mean, var, invstd = (torch.empty((C,), dtype=torch.float32, device=x.device) for _ in range(3))
     nb = _lib.lib().ptt_bn_stats_workspace(R, C)
     ws = _ws(nb, x.device)
+    if bn is not None:
+        tail, a, b = _bn_tail(bn, C, x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().ptt_bn_stats_train_f32(_ptr(x), R, C, x.stride(0), float(eps), _ptr(mean), _ptr(var), _ptr(invstd),
+                                                         _ptr(ws), ws.numel() * 8, ctypes.byref(tail), _stream()),
+                       "ptt_bn_stats_train_f32")
+        _bn_tail_done(bn)
+        return mean, var, invstd, a, b
     with torch.cuda.device(x.device):
         _lib.check(_lib.lib().ptt_bn_stats_f32(_ptr(x), R, C, x.stride(0), float(eps), _ptr(mean), _ptr(var), _ptr(invstd),
                                                _ptr(ws), ws.numel() * 8, _stream()), "ptt_bn_stats_f32")
@@ -929,10 +963,19 @@ def bn_bwd_sums_from_partials(part):
     return sums
 
 
-def bn_finish_partials(partials, rows, eps):
-    """(mean, biased var, invstd) from rows_gemm's partial sums (chunks, 2, C), combined in chunk order."""
+def bn_finish_partials(partials, rows, eps, bn=None):
+    """(mean, biased var, invstd) from rows_gemm's partial sums (chunks, 2, C), combined in chunk order. bn: as bn_stats —
+    (mean, var, invstd, a, b) plus the module's bookkeeping in the same launch (ptt_bn_finish_partials_train_f32)."""
     chunks, _, C = partials.shape
     mean, var, invstd = (torch.empty((C,), dtype=torch.float32, device=partials.device) for _ in range(3))
+    if bn is not None:
+        tail, a, b = _bn_tail(bn, C, partials.device)
+        with torch.cuda.device(partials.device):
+            _lib.check(_lib.lib().ptt_bn_finish_partials_train_f32(_ptr(partials), chunks, C, int(rows), float(eps), _ptr(mean),
+                                                                   _ptr(var), _ptr(invstd), ctypes.byref(tail), _stream()),
+                       "ptt_bn_finish_partials_train_f32")
+        _bn_tail_done(bn)
+        return mean, var, invstd, a, b
     with torch.cuda.device(partials.device):
         _lib.check(_lib.lib().ptt_bn_finish_partials_f32(_ptr(partials), chunks, C, int(rows), float(eps), _ptr(mean), _ptr(var),
                                                          _ptr(invstd), _stream()), "ptt_bn_finish_partials_f32")
@@ -986,6 +1029,24 @@ def pack_weight_strided(src, cout, k, stride_out, stride_k, batch, stride_batch)
         _lib.check(_lib.lib().ptt_pack_weight_strided_f32(_ptr(src), int(cout), int(k), int(stride_out), int(stride_k), int(batch),
                                                           int(stride_batch), _ptr(out), _stream()), "ptt_pack_weight_strided_f32")
     return out
+
+
+def pack_jobs_table(jobs, device):
+    """[(data_ptr, float offset in the arena, stride_out, stride_k, Cout, K)] -> the device job table of pack_weights."""
+    arr = (_lib.PackJob * len(jobs))()
+    for n, (ptr, off, so, sk, cout, k) in enumerate(jobs):
+        arr[n] = _lib.PackJob(W=ptr, out_offset=off, stride_out=so, stride_k=sk, Cout=cout, K=k)
+    host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+    return host.to(device)
+
+
+def pack_weights(table, n_jobs, arena):
+    """Packs the n_jobs weights of a pack_jobs_table into `arena` (float32, 1-D) in one launch — ptt_pack_weights_f32."""
+    if not arena.is_cuda or arena.dtype != torch.float32 or not arena.is_contiguous():
+        raise RuntimeError("arena must be a contiguous float32 device tensor")
+    with torch.cuda.device(arena.device):
+        _lib.check(_lib.lib().ptt_pack_weights_f32(_ptr(table), int(n_jobs), _ptr(arena), _stream()), "ptt_pack_weights_f32")
+    return arena
 
 
 def linear_batched(x, wpacked, cout, residual=None):

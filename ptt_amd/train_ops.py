@@ -68,21 +68,96 @@ def _pack_slot(base):
     return slot
 
 
+class _PackPlan:
+    """Every (weight view, transposed?) a training step has asked `packed` for, per device: after an optimiser update ALL of
+    them are stale at once, and the first miss re-packs the whole set with ONE launch (ptt_pack_weights_f32) into a fresh
+    arena instead of ~90 five-microsecond launches spread over the step. The device job table is rebuilt only when the set
+    or a parameter's address changes."""
+
+    def __init__(self):
+        self.entries = {}      # (id(base), byte offset, shape, stride, transposed) -> [weakref(base), elems]
+        self.table = None      # (device job table, [entry keys in job order], [data_ptr per job], arena elems)
+
+    def register(self, ekey, base, elems):
+        if ekey not in self.entries:
+            self.entries[ekey] = [weakref.ref(base), int(elems)]
+            self.table = None
+
+    def _build(self, device):
+        jobs, keys, ptrs, off = [], [], [], 0
+        for ekey, (ref, elems) in list(self.entries.items()):
+            base = ref()
+            if base is None or id(base) != ekey[0] or not base.is_cuda or base.device != device:
+                del self.entries[ekey]
+                continue
+            _, boff, shape, stride, transposed = ekey
+            so, sk = (stride[1], stride[0]) if transposed else (stride[0], stride[1])
+            cout, k = (shape[1], shape[0]) if transposed else (shape[0], shape[1])
+            jobs.append((base.data_ptr() + boff, off, so, sk, cout, k))
+            keys.append(ekey)
+            ptrs.append(base.data_ptr())
+            off += elems
+        self.table = (ops.pack_jobs_table(jobs, device), keys, ptrs, off) if jobs else None
+
+    def repack(self, device):
+        """Re-pack every registered weight at its current version; False when nothing is registered."""
+        if self.table is not None:
+            for ekey, ptr in zip(self.table[1], self.table[2]):
+                base = self.entries[ekey][0]()
+                if base is None or base.data_ptr() != ptr:
+                    self.table = None
+                    break
+        if self.table is None:
+            self._build(device)
+            if self.table is None:
+                return False
+        table, keys, _, total = self.table
+        arena = ops.pack_weights(table, len(keys), torch.empty((total,), dtype=torch.float32, device=device))
+        off = 0
+        for ekey in keys:
+            ref, elems = self.entries[ekey]
+            base = ref()
+            slot = _pack_slot(base)
+            version = base._version
+            for k in [k for k in slot if k[3] != version]:   # retire the previous step's packs
+                del slot[k]
+            slot[(ekey[1], ekey[2], ekey[3], version, ekey[4])] = arena[off:off + elems]
+            off += elems
+        return True
+
+
+_pack_plans = {}       # device -> _PackPlan
+PACK_PLAN = True       # False: every weight packed by its own launch (development comparisons)
+
+
 def packed(W, transpose=False):
     """ops.pack_weight(W) (or of W^T) cached per weight VERSION on the PARAMETER the view belongs to: within one training step
     a weight is packed for its forward GEMM and, transposed, for its input gradient, and the search / template branches share
     the backbone's weights; the optimiser's in-place update bumps the version. The cache lives and dies with the parameter
     object (weak references): a new model whose parameter lands on a freed one's address never sees its entries. W: a 2-D (out, in)
-    parameter, or a view / column slice of one, passed as the caller holds it (not detached: the view's base is the key)."""
+    parameter, or a view / column slice of one, passed as the caller holds it (not detached: the view's base is the key).
+    A miss on a view seen before re-packs every registered weight of the device in one launch (_PackPlan)."""
     base = W._base if W._base is not None else W
     slot = _pack_slot(base)
-    key = (W.data_ptr() - base.data_ptr(), tuple(W.shape), tuple(W.stride()), W._version, bool(transpose))
+    off = (W.data_ptr() - base.data_ptr())
+    key = (off, tuple(W.shape), tuple(W.stride()), W._version, bool(transpose))
     hit = slot.get(key)
-    if hit is None:
-        for k in [k for k in slot if k[3] != W._version]:   # retire the previous step's packs
-            del slot[k]
-        w = W.detach()
-        hit = slot[key] = ops.pack_weight((w.t() if transpose else w).contiguous())
+    if hit is not None:
+        return hit
+    ekey = (id(base), off, key[1], key[2], key[4])
+    plan = _pack_plans.setdefault(W.device, _PackPlan()) if PACK_PLAN and W.dim() == 2 else None
+    if plan is not None and ekey in plan.entries and plan.repack(W.device):
+        hit = slot.get(key)
+        if hit is not None:
+            return hit
+    for k in [k for k in slot if k[3] != W._version]:       # retire the previous step's packs
+        del slot[k]
+    w = W.detach()
+    cout, k = (w.shape[1], w.shape[0]) if transpose else w.shape
+    so, sk = (w.stride(1), w.stride(0)) if transpose else (w.stride(0), w.stride(1))
+    hit = slot[key] = ops.pack_weight_strided(w, cout, k, so, sk, 1, 0)[0]
+    if plan is not None:
+        plan.register(ekey, base, hit.numel())
     return hit
 
 
@@ -157,11 +232,13 @@ class _SharedMlpPool(torch.autograd.Function):
     xcorr_hoisted), so layer 0 is BatchNorm + ReLU only and its W entry is a placeholder that gets no gradient."""
 
     @staticmethod
-    def forward(ctx, x, ns, eps, preact, sync, *params):
+    def forward(ctx, x, ns, eps, preact, sync, bns, *params):
         """Deferred activation: a layer's output relu(BatchNorm(z)) = relu(z * a + b) is never written — the next
         convolution, its weight gradient, the max-pool and the BatchNorm backward apply it while they load z.
         sync: per layer a torch.distributed process group (nn.SyncBatchNorm: the statistics are those of the rows of ALL
-        ranks — one all-reduce of 2C + 1 float64 per layer and direction) or None."""
+        ranks — one all-reduce of 2C + 1 float64 per layer and direction) or None. bns: per layer the BatchNorm module whose
+        bookkeeping (running statistics, batch counter) the launch that forms the statistics does, with the activation
+        constants a, b (ops.bn_stats / bn_finish_partials with `bn`), or None: the caller does it (SyncBatchNorm layers)."""
         ctx.set_materialize_grads(False)          # the statistics outputs carry no gradient: no zero tensors made for them
         L = len(params) // 3
         saved, stats, counts = [], [], []
@@ -179,11 +256,14 @@ class _SharedMlpPool(torch.autograd.Function):
                 dist.all_reduce(sums, group=sync[l])
                 mean, var, invstd = ops.bn_finish(sums, eps[l])
                 count = sums[-1:].clone()                      # global row count, float64, on the device
+                a = (gamma.detach() * invstd).contiguous()
+                b = (beta.detach() - mean * a).contiguous()
             else:
-                mean, var, invstd = ops.bn_finish_partials(part, z.shape[0], eps[l]) if part is not None else ops.bn_stats(z, eps[l])
+                if part is not None:
+                    mean, var, invstd, a, b = ops.bn_finish_partials(part, z.shape[0], eps[l], bn=bns[l])
+                else:
+                    mean, var, invstd, a, b = ops.bn_stats(z, eps[l], bn=bns[l])
                 count = _row_count(z.shape[0], z.device)
-            a = (gamma.detach() * invstd).contiguous()
-            b = (beta.detach() - mean * a).contiguous()
             saved += [cur, cur_a if cur_a is not None else mean.new_empty(0), cur_b if cur_b is not None else mean.new_empty(0),
                       z, mean, invstd, a, b, count]
             stats += [mean, var, count]
@@ -255,7 +335,7 @@ class _SharedMlpPool(torch.autograd.Function):
                 g, _ = conv_rows(dz, w2, transpose=True)                                # w.r.t. the (not normalised) input rows
             else:
                 g = None
-        return (g, None, None, None, None) + tuple(grads)
+        return (g, None, None, None, None, None) + tuple(grads)
 
 
 def shared_mlp_pool(grouped, mlp, pool_dim):
@@ -289,11 +369,13 @@ def rows_mlp_pool(rows, mlp, ns, B, keep, preact):
         params += [unit.conv.weight, bn.weight, bn.bias]
         eps.append(float(bn.eps))
         sync.append(_sync_group(bn))
-    out = _SharedMlpPool.apply(rows, ns, tuple(eps), bool(preact), tuple(sync), *params)
+    bns = tuple(unit.normlayer.bn if g is None else None for unit, g in zip(mlp, sync))
+    out = _SharedMlpPool.apply(rows, ns, tuple(eps), bool(preact), tuple(sync), bns, *params)
     pooled, stats = out[0], out[1:]
-    with torch.no_grad():                                   # nn.BatchNorm's bookkeeping in training mode, one launch per layer
-        for l, unit in enumerate(mlp):
-            ops.bn_update_running(unit.normlayer.bn, stats[3 * l], stats[3 * l + 1], stats[3 * l + 2])
+    with torch.no_grad():                                   # nn.BatchNorm's bookkeeping in training mode: done by the statistics'
+        for l, unit in enumerate(mlp):                      # own launch, except for SyncBatchNorm layers (all-reduced count)
+            if bns[l] is None:
+                ops.bn_update_running(unit.normlayer.bn, stats[3 * l], stats[3 * l + 1], stats[3 * l + 2])
     return pooled.view(B, keep, -1).transpose(1, 2)         # (B, C_L, keep)
 
 

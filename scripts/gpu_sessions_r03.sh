@@ -90,6 +90,21 @@ p)  timeout 600 python scripts/linear_infer_bench.py 2>&1 | grep -v amdgpu.ids >
     ;;
 q)  timeout 600 python scripts/train_aten_ops.py 2>&1 | grep -v "amdgpu.ids\|Warning" > $O/train_aten_ops.log; cat $O/train_aten_ops.log | cut -c1-230
     ;;
+t)  timeout 600 python scripts/train_small_ops.py 2>&1 | grep -v "amdgpu.ids\|Warning" > $O/train_small_ops.log; cat $O/train_small_ops.log | cut -c1-230
+    ;;
+w)  # launch consolidation of the training step: batched weight packing, BatchNorm bookkeeping inside the statistics launch
+    timeout 1500 python -m pytest tests/test_gemm_gpu.py tests/test_train_gpu.py tests/test_train_config3_gpu.py -m gpu -q -x 2>&1 | tail -8 | cut -c1-250
+    timeout 600 python bench.py --workload train --steps 20 --warmup 5 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-400
+    ktrace train_kernel_stats python $REPO/bench.py --workload train --steps 5 --warmup 2 --no-cpu-baseline --sustain 0
+    python - <<PY
+import csv
+rows=list(csv.DictReader(open("$O/train_kernel_stats.csv")))
+tot=sum(float(r['TotalDurationNs']) for r in rows); calls=sum(int(r['Calls']) for r in rows)
+print("launches/step %.0f  device ms/step %.2f" % (calls/7, tot/7e6))
+for r in rows[:60]:
+    if int(r['Calls'])/7 >= 20: print("%7.1f/step %7.3f ms/step  %s" % (int(r['Calls'])/7, float(r['TotalDurationNs'])/7e6, r['Name'][:110]))
+PY
+    ;;
 z)  # closing evidence of the round: parity tests, the default bench line (all configs), serial + training kernel traces, PMC passes
     timeout 2400 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log; tail -3 $O/pytest_gpu.log
     SECONDS=0; timeout 1500 python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "default bench rc=$? wall ${SECONDS}s"

@@ -79,3 +79,95 @@ def test_wgrad2_values_transform_accumulate_reproducible(dev, R, Cout, Cin):
     assert float((got2.double() - ref2).abs().max()) <= 2e-6 * float(ref2.abs().max()) + 1e-6 * np.sqrt(R)
     acc = ops.linear_wgrad(dz, x, out=got.clone(), accumulate=True)
     torch.testing.assert_close(acc, 2 * got, rtol=1e-6, atol=1e-6)
+
+
+def test_bn_statistics_launch_also_writes_the_activation_constants_and_the_running_statistics(dev):
+    """ops.bn_stats / bn_finish_partials with `bn`: the launch that forms the batch statistics also writes a = gamma * invstd,
+    b = beta - mean * a (bit-equal to the element-wise expressions) and does nn.BatchNorm's training bookkeeping — compared
+    with the separate launches (ops.bn_update_running) and with torch.nn.BatchNorm1d itself."""
+    import copy
+    torch.manual_seed(5)
+    for R, C in ((4096, 128), (777, 64), (50000, 256)):
+        x = torch.randn(R, C, device=dev) * 1.7 + 0.4
+        bn = torch.nn.BatchNorm1d(C, momentum=0.1).to(dev).train()
+        with torch.no_grad():
+            bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.5, 0.5)
+            bn.running_mean.uniform_(-1, 1); bn.running_var.uniform_(0.5, 2)
+        ref, sep = copy.deepcopy(bn), copy.deepcopy(bn)
+        mean0, var0, inv0 = ops.bn_stats(x, bn.eps)
+        ops.bn_update_running(sep, mean0, var0, torch.full((1,), float(R), dtype=torch.float64, device=dev))
+        v_before = bn.running_mean._version
+        mean, var, inv, a, b = ops.bn_stats(x, bn.eps, bn=bn)
+        assert torch.equal(mean, mean0) and torch.equal(var, var0) and torch.equal(inv, inv0)
+        assert torch.equal(a, bn.weight.detach() * inv0) and torch.equal(b, bn.bias.detach() - mean0 * a)
+        assert bn.running_mean._version > v_before                         # eval-mode caches key on the version
+        assert int(bn.num_batches_tracked) == 1 == int(sep.num_batches_tracked)
+        torch.testing.assert_close(bn.running_mean, sep.running_mean, rtol=1e-6, atol=1e-7)
+        torch.testing.assert_close(bn.running_var, sep.running_var, rtol=1e-6, atol=1e-7)
+        ref(x)
+        torch.testing.assert_close(bn.running_mean, ref.running_mean, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(bn.running_var, ref.running_var, rtol=1e-5, atol=1e-6)
+        if ops.rows_gemm_supported(R, 64, C, 64, C):                        # the same tail behind the GEMM's partial sums
+            w = torch.randn(C, 64, device=dev) * 0.1
+            xin = torch.randn(R, 64, device=dev)
+            z, part = ops.rows_gemm(xin, ops.pack_weight(w), C, want_stats=True)
+            bn2 = copy.deepcopy(ref)
+            m0, v0, i0 = ops.bn_finish_partials(part, R, bn2.eps)
+            m1, v1, i1, a1, b1 = ops.bn_finish_partials(part, R, bn2.eps, bn=bn2)
+            assert torch.equal(m0, m1) and torch.equal(v0, v1) and torch.equal(i0, i1)
+            assert torch.equal(a1, bn2.weight.detach() * i0) and torch.equal(b1, bn2.bias.detach() - m0 * a1)
+            assert int(bn2.num_batches_tracked) == 2
+            n = float(R)
+            want = 0.9 * ref.running_var + 0.1 * v0 * (n / (n - 1))
+            torch.testing.assert_close(bn2.running_var, want, rtol=1e-6, atol=1e-7)
+
+
+def test_pack_plan_repacks_every_registered_weight_in_one_launch(dev):
+    """train_ops.packed: the first call per (view, transposed?) packs alone and registers; after an in-place update (version
+    bump) ONE ptt_pack_weights_f32 launch re-packs the whole registered set — bit-equal to ops.pack_weight of each view,
+    for plain, transposed, reshaped-4-D and column-sliced weights; a replaced parameter storage rebuilds the job table."""
+    from ptt_amd import train_ops
+    torch.manual_seed(6)
+    plan = train_ops._pack_plans.setdefault(dev, train_ops._PackPlan())
+    conv = torch.nn.Parameter(torch.randn(128, 67, 1, 1, device=dev))
+    lin = torch.nn.Parameter(torch.randn(512, 256, device=dev))
+    small = torch.nn.Parameter(torch.randn(64, 3, device=dev))
+
+    def views():
+        w0 = conv.reshape(128, -1)
+        return [(w0, False), (w0, True), (w0[:, 3:], False), (w0[:, 3:], True), (w0[:, 0:3], False), (lin, False), (lin, True),
+                (small, False), (small, True)]
+
+    def expect(W, tr):
+        w = W.detach()
+        return ops.pack_weight((w.t() if tr else w).contiguous())
+
+    launches = {"n": 0}
+    real = ops.pack_weights
+
+    def counting(*a):
+        launches["n"] += 1
+        return real(*a)
+
+    ops.pack_weights = counting
+    try:
+        for W, tr in views():                                            # first sight: packed one by one
+            assert torch.equal(train_ops.packed(W, tr), expect(W, tr))
+        assert launches["n"] == 0
+        for step in range(2):
+            with torch.no_grad():
+                for p in (conv, lin, small):
+                    p.add_(torch.randn_like(p) * 0.1)                   # the optimiser's in-place update
+            got = [train_ops.packed(W, tr) for W, tr in views()]
+            assert launches["n"] == step + 1, launches                   # one launch for the whole set, cache hits after it
+            for (W, tr), g in zip(views(), got):
+                assert torch.equal(g, expect(W, tr)), (tuple(W.shape), tr)
+        assert train_ops.packed(lin, False) is train_ops.packed(lin, False)
+        with torch.no_grad():
+            lin.data = lin.data.clone()                                   # new storage under the same parameter object
+            lin.add_(1.0)
+        assert torch.equal(train_ops.packed(lin, True), expect(lin, True))
+        assert torch.equal(train_ops.packed(conv.reshape(128, -1), True), expect(conv.reshape(128, -1), True))
+    finally:
+        ops.pack_weights = real
+    assert len(plan.entries) >= 9
