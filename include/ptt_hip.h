@@ -550,7 +550,17 @@ int ptt_xcorr_z0_bwd_f32(const float* dz0, const float* cos_t, const float* w_si
  *   ptt_pack_weights_f32  packs n_jobs weights (views by element strides: W[col * stride_out + k * stride_k], so a
  *     transposed pack is a stride swap) into one arena in ONE launch; jobs live in DEVICE memory (a training step re-packs
  *     every weight after each optimiser update: the table is built once, the launch repeats). out_offset: float offset
- *     inside `arena`, a multiple of 4; each job writes ptt_packed_weight_elems(Cout, K) floats. */
+ *     inside `arena`, a multiple of 4; each job writes ptt_packed_weight_elems(Cout, K) floats.
+ *   ptt_sa_z0_rows_f32  the front of one SA level in training mode with layer 0 hoisted, one pass: for row (b, m, k),
+ *     n = idx[b,m,k]: rel = (xyz[b,n] - new_xyz[b,m]) (* float(1 / radius) when normalize_xyz, as torch divides by a host
+ *     scalar) — QueryAndGroup,
+ *     pointnet2_utils.py:350-354 — and z0 = term[b,n,:] + Wx . rel, the first SharedMLP convolution (pytorch_utils.py:12-36;
+ *     channel order xyz first, pointnet2_utils.py:359-361) with its feature half `term` (B,N,C) evaluated once per point;
+ *     term NULL: a level without point features. z0 (B*M*ns, C) rows, rel_rows (B*M*ns, 3) (the weight gradient of Wx
+ *     (C,3), row stride ldw >= 3, needs them). C % 4 == 0. No gradient w.r.t. the coordinates is provided: callers with
+ *     learnable coordinates (the box head's vote aggregation) keep ptt_group_f32 + ptt_gather_rows_f32. */
+int ptt_sa_z0_rows_f32(const float* xyz, const float* new_xyz, const int32_t* idx, const float* term, const float* wx, int ldw, int B,
+                       int N, int M, int ns, int C, float radius, int normalize_xyz, float* z0, float* rel_rows, ptt_stream_t stream);
 typedef struct ptt_bn_train_tail {
     const float* gamma; const float* beta;      /* (C) affine parameters, needed for act_a / act_b */
     float* act_a; float* act_b;                 /* (C) out, or both NULL */

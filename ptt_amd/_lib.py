@@ -37,6 +37,7 @@ EXPORTS = [
     "ptt_rows_gemm_bnbwd_f32", "ptt_bn_bwd_from_partials_f32", "ptt_bn_bwd_sums_partials_f64",
     "ptt_bn_update_running_f32", "ptt_xcorr_z0_f32", "ptt_xcorr_z0_bwd_workspace", "ptt_xcorr_z0_bwd_f32",
     "ptt_bn_stats_train_f32", "ptt_bn_finish_partials_train_f32", "ptt_pack_weights_f32",
+    "ptt_sa_z0_rows_f32",
 ]
 PTT_MAX_SEGMENTS = 4
 
@@ -171,6 +172,7 @@ def _declare(lib):
         "ptt_bn_stats_train_f32": [vp, i, i, i, f, vp, vp, vp, vp, c_size_t, vp, vp],
         "ptt_bn_finish_partials_train_f32": [vp, i, i, i, f, vp, vp, vp, vp, vp],
         "ptt_pack_weights_f32": [vp, i, vp, vp],
+        "ptt_sa_z0_rows_f32": [vp, vp, vp, vp, vp, i, i, i, i, i, i, f, i, vp, vp, vp],
         "ptt_xcorr_z0_f32": [vp, vp, vp, i, i, i, i, vp, vp],
         "ptt_xcorr_z0_bwd_f32": [vp, vp, vp, i, i, i, i, vp, vp, vp, vp, c_size_t, vp],
         "ptt_bn_bwd_pooled_f32": [vp, i, vp, i, vp, i, vp, vp, vp, i, i, vp, i, vp, vp, vp, c_size_t, vp, vp, vp],

@@ -741,6 +741,46 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
     }
 }
 
+// The whole front of a hoisted SA level in training mode (train_ops.sa_level_hoisted) in one pass: per (centre m, slot k) row
+//   rel = (xyz[b, idx[b,m,k]] - new_xyz[b,m]) (* 1 / radius)        QueryAndGroup, pointnet2_utils.py:350-354; torch divides a
+//                                                                    tensor by a host scalar as a product with its float reciprocal
+//   z0  = term[b, idx[b,m,k], :] + Wx . rel                          layer 0 of the SharedMLP, its feature half hoisted per POINT
+// (term NULL: a level without point features, z0 = Wx . rel is the whole first convolution). rel rows are written too: the
+// weight gradient of Wx needs them. Replaces group(xyz) / subtract / divide / permute-copy / gather_rows / a K = 3 GEMM with
+// the gathered rows as residual — seven launches and two extra passes over the (rows, C0) tensor.
+__global__ __launch_bounds__(256) void sa_z0_rows_kernel(const float* __restrict__ xyz, const float* __restrict__ new_xyz,
+                                                         const int32_t* __restrict__ idx, const float* __restrict__ term,
+                                                         const float* __restrict__ wx, int ldw, int N, int M, int ns, int C,
+                                                         float rmul, float* __restrict__ z0, float* __restrict__ rel_out) {
+#pragma clang fp contract(off)      // the subtraction / scaling are the reference's separately rounded element-wise steps
+    const int Cq = C >> 2, span = Cq < 256 ? Cq : 256, RG = 256 / span;
+    const int q0 = threadIdx.x % span, rg = threadIdx.x / span;
+    if (rg >= RG) return;
+    const int b = blockIdx.y, E = M * ns;
+    const float* xb = xyz + (size_t)b * N * 3;
+    const float* cb = new_xyz + (size_t)b * M * 3;
+    const float* tb = term ? term + (size_t)b * N * C : nullptr;
+    const int32_t* ib = idx + (size_t)b * E;
+    float* zb = z0 + (size_t)b * E * C;
+    float* rb = rel_out + (size_t)b * E * 3;
+    for (int e = blockIdx.x * RG + rg; e < E; e += gridDim.x * RG) {
+        const int n = ib[e], m = e / ns;
+        const float rx = (xb[3 * n + 0] - cb[3 * m + 0]) * rmul, ry = (xb[3 * n + 1] - cb[3 * m + 1]) * rmul,
+                    rz = (xb[3 * n + 2] - cb[3 * m + 2]) * rmul;
+        if (q0 == 0) { rb[3 * e + 0] = rx; rb[3 * e + 1] = ry; rb[3 * e + 2] = rz; }
+        for (int q = q0; q < Cq; q += span) {
+            f32x4t v = tb ? *reinterpret_cast<const f32x4t*>(tb + (size_t)n * C + 4 * q) : f32x4t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float* w = wx + (size_t)(4 * q + j) * ldw;                 // Wx (C,3), row stride ldw
+                const float y = __builtin_fmaf(w[2], rz, __builtin_fmaf(w[1], ry, w[0] * rx));
+                v[j] = v[j] + y;
+            }
+            *reinterpret_cast<f32x4t*>(zb + (size_t)e * C + 4 * q) = v;
+        }
+    }
+}
+
 // Its backward, deterministic: out[b, n, :] = sum of g[b, e, :] over the entries e with idx[b, e] == n, in ASCENDING e
 // (order / start = the CSR scatter_csr_kernel builds). Thread = (point n, channel quad): coalesced row reads.
 __global__ __launch_bounds__(256) void scatter_rows_det_kernel(const float* __restrict__ g, const int32_t* __restrict__ order,
@@ -1157,6 +1197,24 @@ extern "C" int ptt_gather_rows_f32(const float* src, const int32_t* idx, int B, 
     if (gx > 4096) gx = 4096;
     hipLaunchKernelGGL(gather_rows_kernel, dim3(gx, B), dim3(256), 0, as_stream(stream), src, idx, N, E, C, out);
     return check_launch("gather_rows_kernel");
+}
+
+extern "C" int ptt_sa_z0_rows_f32(const float* xyz, const float* new_xyz, const int32_t* idx, const float* term, const float* wx,
+                                  int ldw, int B, int N, int M, int ns, int C, float radius, int normalize_xyz, float* z0,
+                                  float* rel_rows, ptt_stream_t stream) {
+    if (B < 0 || N <= 0 || M <= 0 || ns <= 0 || C <= 0 || (C & 3) || !(radius > 0.f) || ldw < 3)
+        return fail(PTT_EINVAL, "ptt_sa_z0_rows_f32: B=%d N=%d M=%d ns=%d C=%d (C %% 4) radius=%g", B, N, M, ns, C, (double)radius);
+    if ((long long)M * ns > 0x7fffffffLL / 4) return fail(PTT_EUNSUPPORTED, "ptt_sa_z0_rows_f32: M * ns = %lld rows per cloud", (long long)M * ns);
+    if (B == 0) return PTT_OK;
+    if (!xyz || !new_xyz || !idx || !wx || !z0 || !rel_rows ||
+        ((reinterpret_cast<uintptr_t>(z0) | reinterpret_cast<uintptr_t>(term)) & 15))
+        return fail(PTT_EINVAL, "ptt_sa_z0_rows_f32: null or unaligned pointer");
+    const int E = M * ns, Cq = C >> 2, RG = 256 / (Cq < 256 ? Cq : 256);
+    int gx = (E + RG * 4 - 1) / (RG * 4);
+    if (gx > 4096) gx = 4096;
+    hipLaunchKernelGGL(sa_z0_rows_kernel, dim3(gx, B), dim3(256), 0, as_stream(stream), xyz, new_xyz, idx, term, wx, ldw, N, M, ns,
+                       C, normalize_xyz ? 1.0f / radius : 1.0f, z0, rel_rows);
+    return check_launch("sa_z0_rows_kernel");
 }
 
 extern "C" int ptt_scatter_rows_csr_f32(const float* g, const int32_t* order, const int32_t* start, int B, int N, int E, int C,

@@ -179,13 +179,21 @@ class PointnetSAModuleVotes(nn.Module):
                                                     self.use_xyz, self.normalize_xyz, point_major_out=True)
             return new_xyz, new_features, inds64
 
+        hoist = (self.use_xyz and not self.sample_uniformly and self.nsample * npoint <= 16384
+                 and train_ops.usable(self.mlp_module, xyz if features is None else features)
+                 and self.mlp_module[0].conv.weight.shape[0] % 4 == 0)
+        if hoist and not xyz.requires_grad and inds.dtype == torch.int32:
+            # training mode on a HIP device, fixed coordinates (the backbone): centres + ball query in one launch, then
+            # layer 0 per (centre, neighbour) row in one more (train_ops.sa_level_hoisted -> ptt_sa_z0_rows_f32) — also for
+            # the level without point features, whose first convolution is the three coordinate channels alone
+            new_xyz, inds64, idx = ops.centres_ball_query(xyz.contiguous(), inds.contiguous(), npoint, self.radius, self.nsample)
+            y = train_ops.sa_level_hoisted(xyz, new_xyz, features, idx, self.mlp_module, self.radius, self.normalize_xyz)
+            return new_xyz, y, inds64
         xyz_flipped = xyz.transpose(1, 2).contiguous()
         new_xyz = pointnet2_utils.gather_operation(xyz_flipped, inds).transpose(1, 2).contiguous()
-        if (features is not None and self.use_xyz and not self.sample_uniformly
-                and self.nsample * npoint <= 16384 and train_ops.usable(self.mlp_module, features)
-                and self.mlp_module[0].conv.weight.shape[0] % 4 == 0):
-            # training mode on a HIP device, a level with point features: layer 0 hoisted to one row per POINT
-            # (ptt_amd/train_ops.py: sa_level_hoisted), the rest of the SharedMLP + max-pool on the row kernels
+        if hoist and features is not None:
+            # learnable coordinates (the box head's vote aggregation): layer 0 hoisted to one row per POINT, gradients to
+            # the coordinates through the grouping / gather operators
             idx = pointnet2_utils.ball_query(self.radius, self.nsample, xyz, new_xyz)
             y = train_ops.sa_level_hoisted(xyz, new_xyz, features, idx, self.mlp_module, self.radius, self.normalize_xyz)
             return new_xyz, y, inds.to(torch.int64)

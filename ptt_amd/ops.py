@@ -1088,6 +1088,31 @@ def gather_rows(src, idx):
     return out
 
 
+def sa_z0_rows(xyz, new_xyz, idx, term, wx, radius, normalize_xyz):
+    """Layer 0 of a hoisted SA level per (centre, neighbour) row in one pass — ptt_sa_z0_rows_f32: xyz (B,N,3), new_xyz (B,M,3),
+    idx (B,M,ns) int32, term (B,N,C) | None, wx (C,3) -> (z0 (B*M*ns, C), rel rows (B*M*ns, 3))."""
+    _chk(xyz, "xyz", torch.float32, 3)
+    _chk(new_xyz, "new_xyz", torch.float32, 3)
+    _chk(idx, "idx", torch.int32, 3)
+    if not (wx.is_cuda and wx.dtype == torch.float32 and wx.dim() == 2 and wx.stride(1) == 1):
+        raise RuntimeError("wx must be a float32 (C,3) device tensor with unit column stride (a column slice of the weight is fine)")
+    B, N, _ = xyz.shape
+    _, M, ns = idx.shape
+    C = wx.shape[0]
+    if term is not None:
+        _chk(term, "term", torch.float32, 3)
+        if tuple(term.shape) != (B, N, C):
+            raise RuntimeError("term must be (B,N,C) = %s, got %s" % ((B, N, C), tuple(term.shape)))
+    if wx.shape[1] != 3 or new_xyz.shape[1] != M:
+        raise RuntimeError("wx must be (C,3) and new_xyz (B,M,3)")
+    z0 = torch.empty((B * M * ns, C), dtype=torch.float32, device=xyz.device)
+    rel = torch.empty((B * M * ns, 3), dtype=torch.float32, device=xyz.device)
+    with torch.cuda.device(xyz.device):
+        _lib.check(_lib.lib().ptt_sa_z0_rows_f32(_ptr(xyz), _ptr(new_xyz), _ptr(idx), _ptr(term), _ptr(wx), wx.stride(0), B, N, M, ns, C, float(radius),
+                                                 int(bool(normalize_xyz)), _ptr(z0), _ptr(rel), _stream()), "ptt_sa_z0_rows_f32")
+    return z0, rel
+
+
 def scatter_rows_det(g, idx, N):
     """The adjoint of gather_rows in a fixed summation order: g (B,E,C), idx (B,E) -> (B,N,C)."""
     _chk(g, "g", torch.float32, 3)

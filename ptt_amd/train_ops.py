@@ -226,6 +226,30 @@ class _AddRelTerm(torch.autograd.Function):
         return g, d_rel, d_wx
 
 
+class _SaZ0(torch.autograd.Function):
+    """Layer 0 of a hoisted SA level, one row per (centre, neighbour), in one launch (ops.sa_z0_rows):
+    z0 = term[idx] + Wx ((xyz[idx] - centre) / radius). Coordinates carry no gradient here (asserted by the caller)."""
+
+    @staticmethod
+    def forward(ctx, xyz, new_xyz, idx, term, wx, radius, normalize_xyz):
+        z0, rel = ops.sa_z0_rows(xyz.contiguous(), new_xyz.contiguous(), idx, term.contiguous() if term is not None else None,
+                                 wx.detach(), radius, normalize_xyz)
+        ctx.save_for_backward(idx, rel)
+        ctx.N, ctx.has_term = xyz.shape[1], term is not None
+        return z0
+
+    @staticmethod
+    def backward(ctx, g):
+        idx, rel = ctx.saved_tensors
+        B, M, ns = idx.shape
+        g = g.contiguous()
+        d_term = None
+        if ctx.has_term and ctx.needs_input_grad[3]:
+            d_term = ops.scatter_rows_det(g.view(B, M * ns, -1), idx.view(B, M * ns), ctx.N)
+        d_wx = ops.linear_wgrad(g, rel) if ctx.needs_input_grad[4] else None
+        return None, None, None, d_term, d_wx, None, None
+
+
 class _SharedMlpPool(torch.autograd.Function):
     """(rows (R,C0), ns, eps per layer, preact, [W, gamma, beta] per layer) -> (pooled (R/ns, C_L), [mean, var] per layer).
     preact: `rows` already IS layer 0's convolution output (the caller hoisted that layer: train_ops.sa_level_hoisted /
@@ -390,6 +414,12 @@ def sa_level_hoisted(xyz, new_xyz, features, idx, mlp, radius, normalize_xyz):
     from .models.backbones_3d.pointnet2 import pointnet2_utils as pu
     B, M, ns = idx.shape
     w0 = mlp[0].conv.weight.reshape(mlp[0].conv.weight.shape[0], -1)                    # (C0, 3 + C): xyz first (:359-361)
+    if not (xyz.requires_grad or new_xyz.requires_grad):
+        # fixed coordinates (the backbone's levels): the whole front — relative coordinates, gather of the per-point terms,
+        # the three coordinate channels — is one launch; features None: a level without point features (layer 0 = Wx . rel)
+        term = _RowsLinear.apply(features.transpose(1, 2), w0[:, 3:], None, None) if features is not None else None
+        z0 = _SaZ0.apply(xyz, new_xyz, idx, term, w0[:, 0:3], float(radius), bool(normalize_xyz))
+        return rows_mlp_pool(z0, mlp, ns, B, M, preact=True)
     rel = pu.grouping_operation(xyz.transpose(1, 2).contiguous(), idx) - new_xyz.transpose(1, 2).unsqueeze(-1)   # (B,3,M,ns)
     if normalize_xyz:
         rel = rel / radius
