@@ -226,6 +226,19 @@ class _AddRelTerm(torch.autograd.Function):
         return g, d_rel, d_wx
 
 
+class _SplitCols(torch.autograd.Function):
+    """w (C, K) -> (w[:, :k], w[:, k:]) as views; backward = ONE concatenation instead of two zero-filled slice gradients and
+    their sum (five launches per hoisted level). The views keep the parameter as their base: `packed` keys on it."""
+
+    @staticmethod
+    def forward(ctx, w, k):
+        return w[:, :k], w[:, k:]
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        return torch.cat((ga, gb), dim=1), None
+
+
 class _SaZ0(torch.autograd.Function):
     """Layer 0 of a hoisted SA level, one row per (centre, neighbour), in one launch (ops.sa_z0_rows):
     z0 = term[idx] + Wx ((xyz[idx] - centre) / radius). Coordinates carry no gradient here (asserted by the caller)."""
@@ -414,18 +427,19 @@ def sa_level_hoisted(xyz, new_xyz, features, idx, mlp, radius, normalize_xyz):
     from .models.backbones_3d.pointnet2 import pointnet2_utils as pu
     B, M, ns = idx.shape
     w0 = mlp[0].conv.weight.reshape(mlp[0].conv.weight.shape[0], -1)                    # (C0, 3 + C): xyz first (:359-361)
+    wx, wf = _SplitCols.apply(w0, 3) if features is not None else (w0, None)
     if not (xyz.requires_grad or new_xyz.requires_grad):
         # fixed coordinates (the backbone's levels): the whole front — relative coordinates, gather of the per-point terms,
         # the three coordinate channels — is one launch; features None: a level without point features (layer 0 = Wx . rel)
-        term = _RowsLinear.apply(features.transpose(1, 2), w0[:, 3:], None, None) if features is not None else None
-        z0 = _SaZ0.apply(xyz, new_xyz, idx, term, w0[:, 0:3], float(radius), bool(normalize_xyz))
+        term = _RowsLinear.apply(features.transpose(1, 2), wf, None, None) if features is not None else None
+        z0 = _SaZ0.apply(xyz, new_xyz, idx, term, wx, float(radius), bool(normalize_xyz))
         return rows_mlp_pool(z0, mlp, ns, B, M, preact=True)
     rel = pu.grouping_operation(xyz.transpose(1, 2).contiguous(), idx) - new_xyz.transpose(1, 2).unsqueeze(-1)   # (B,3,M,ns)
     if normalize_xyz:
         rel = rel / radius
     rel_rows = rel.permute(0, 2, 3, 1).reshape(B * M * ns, 3)
-    term = _RowsLinear.apply(features.transpose(1, 2), w0[:, 3:], None, None)           # (B,N,C0), once per point
-    z0 = _AddRelTerm.apply(gather_rows(term, idx.view(B, M * ns)).view(B * M * ns, -1), rel_rows, w0[:, 0:3])
+    term = _RowsLinear.apply(features.transpose(1, 2), wf, None, None)                  # (B,N,C0), once per point
+    z0 = _AddRelTerm.apply(gather_rows(term, idx.view(B, M * ns)).view(B * M * ns, -1), rel_rows, wx)
     return rows_mlp_pool(z0, mlp, ns, B, M, preact=True)
 
 
@@ -443,8 +457,9 @@ def xcorr_hoisted(search_feats, template_feats, template_xyz, mlp, eps):
     sn = search_feats / search_feats.norm(dim=1, keepdim=True).clamp_min(eps)           # (B,C,n2)
     cos = torch.bmm(sn.transpose(1, 2), tn)                                             # (B,n2,n1)
     rows_i = torch.cat((template_xyz, template_feats.transpose(1, 2)), dim=2)           # (B,n1,3+C)
-    P = _RowsLinear.apply(rows_i, w0[:, 1:], None, None)                                # (B,n1,C0)
-    z0 = _XcorrZ0.apply(P.contiguous(), cos.contiguous(), w0[:, 0].contiguous())      # (B*n2*n1, C0) rows ordered (b, j, i)
+    wsim, wrest = _SplitCols.apply(w0, 1)
+    P = _RowsLinear.apply(rows_i, wrest, None, None)                                    # (B,n1,C0)
+    z0 = _XcorrZ0.apply(P.contiguous(), cos.contiguous(), wsim.reshape(-1).contiguous())   # (B*n2*n1, C0) rows ordered (b, j, i)
     return rows_mlp_pool(z0, mlp, n1, B, n2, preact=True)
 
 
