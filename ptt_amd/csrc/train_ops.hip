@@ -578,11 +578,15 @@ __device__ __forceinline__ void wg_act(f32x4t (&st)[4], const float* __restrict_
     }
 }
 
-template <bool VZ, bool VX>
+// NS > 1 (round 3): a layer with at most 64 output and / or input channels (SA0: 64 -> 64, 64 -> 128 over 786k rows) fills
+// one or two of the block's four 64 x 64 quadrants; instead of three (two) waves multiplying zero padding — 4x (2x) the MFMA
+// work, which made these memory-bound shapes compute-bound at 222 us — the waves that share a quadrant split the staged rows
+// (NS = 2 or 4 ways) and their accumulators are added through LDS in wave order at the end.
+template <bool VZ, bool VX, int NS = 1>
 __global__ __launch_bounds__(256, 2) void linear_wgrad_kernel(const float* __restrict__ dZ, int ldz, const float* __restrict__ X,
                                                               int ldx, int R, int Cout, int Cin, int nbi, int chunk_rows,
                                                               float* __restrict__ partial, const float* __restrict__ xa,
-                                                              const float* __restrict__ xb) {
+                                                              const float* __restrict__ xb, int narrow_o = 0, int narrow_i = 0) {
     extern __shared__ __attribute__((aligned(16))) float wg_smem[];         // As[2][32 x 132] | Bs[2][32 x 132]: 67.6 KB
     constexpr int WG_BUF = WG_KC * WG_LD;
 #define As(b) (wg_smem + (b) * WG_BUF)
@@ -591,7 +595,13 @@ __global__ __launch_bounds__(256, 2) void linear_wgrad_kernel(const float* __res
     const int bo = blockIdx.x / nbi, bi = blockIdx.x - bo * nbi;       // 128-wide output-channel / input-channel block
     const int o0 = bo * 128, i0 = bi * 128;
     const int r_begin = blockIdx.y * chunk_rows, r_end = min(R, r_begin + chunk_rows);
-    const int wo = (w >> 1) * 64, wi = (w & 1) * 64;                   // this wave's 64 x 64 quadrant
+    int wo = (w >> 1) * 64, wi = (w & 1) * 64;                         // this wave's 64 x 64 quadrant
+    int sidx = 0;                                                      // NS > 1: which share of the staged rows
+    if constexpr (NS > 1) {
+        if (narrow_o) { sidx = w >> 1; wo = 0; }
+        if (narrow_i) { sidx = sidx * 2 + (w & 1); wi = 0; }
+        sidx = __builtin_amdgcn_readfirstlane(sidx);
+    }
     f32x16t acc[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -614,10 +624,10 @@ __global__ __launch_bounds__(256, 2) void linear_wgrad_kernel(const float* __res
             wg_fetch<VX>(X, ldx, r0 + WG_KC, r_end, i0, Cin, t, sb);
             if (xa) wg_act(sb, xa, xb, i0, Cin, t);
         }
-        const float* A = As(buf) + half * WG_LD + wo + col;
-        const float* B = Bs(buf) + half * WG_LD + wi + col;
+        const float* A = As(buf) + (half + sidx * (WG_KC / NS)) * WG_LD + wo + col;
+        const float* B = Bs(buf) + (half + sidx * (WG_KC / NS)) * WG_LD + wi + col;
 #pragma unroll
-        for (int j = 0; j < WG_KC / 2; ++j) {
+        for (int j = 0; j < WG_KC / 2 / NS; ++j) {
             const float a0 = A[2 * j * WG_LD], a1 = A[2 * j * WG_LD + 32];
             const float b0 = B[2 * j * WG_LD], b1 = B[2 * j * WG_LD + 32];
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
@@ -634,6 +644,28 @@ __global__ __launch_bounds__(256, 2) void linear_wgrad_kernel(const float* __res
     }
 #undef As
 #undef Bs
+    if constexpr (NS > 1) {
+        // the shares of a quadrant, added in wave order (the loop's last barrier has released the staging buffers)
+        float* slot = wg_smem + w * 4096;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) slot[((a * 2 + b) * 16 + r) * 64 + lane] = acc[a][b][r];
+        __syncthreads();
+        if (sidx != 0) return;
+        const int step = (NS == 4) ? 1 : (narrow_i ? 1 : 2);           // the waves that share this wave's quadrant
+        for (int k = 1; k < NS; ++k) {
+            const float* other = wg_smem + (w + k * step) * 4096;
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[a][b][r] += other[((a * 2 + b) * 16 + r) * 64 + lane];
+        }
+    }
     // C/D layout: column (input channel) = lane & 31, row (output channel) = (reg & 3) + 8 * (reg >> 2) + 4 * half
     float* P = partial + (size_t)blockIdx.y * Cout * Cin;
 #pragma unroll
@@ -702,21 +734,24 @@ __global__ __launch_bounds__(256) void wgrad_smallk_kernel(const float* __restri
 // dW = sum over chunks (fixed order); optionally accumulates into dW (beta = 1) for parameters used more than once.
 // Workgroup = 32 consecutive outputs x 8 chunk groups: group g adds the chunks g, g + 8, ... in order, the 8 group sums are
 // then added in order — a fixed summation tree, and 8x the loads in flight of a one-thread-per-output loop.
+// OUT = outputs per workgroup (32, 8 or 4): many chunks over few outputs (the K = 3 gradients: 3072 chunks x 192 outputs) take
+// more groups per output — 74 us -> a few for that shape.
+template <int OUT>
 __global__ __launch_bounds__(256) void wgrad_finish_kernel(const float* __restrict__ partial, int nchunks, size_t n, int accumulate,
                                                            float* __restrict__ dW) {
-    __shared__ float part[8][32];
-    const int lane = threadIdx.x & 31, g = threadIdx.x >> 5;
-    for (size_t base = (size_t)blockIdx.x * 32; base < n; base += (size_t)gridDim.x * 32) {
+    constexpr int G = 256 / OUT;
+    __shared__ float part[G][OUT];
+    const int lane = threadIdx.x % OUT, g = threadIdx.x / OUT;
+    for (size_t base = (size_t)blockIdx.x * OUT; base < n; base += (size_t)gridDim.x * OUT) {
         const size_t e = base + lane;
         float s = 0.f;
         if (e < n)
-            for (int k = g; k < nchunks; k += 8) s += partial[(size_t)k * n + e];
+            for (int k = g; k < nchunks; k += G) s += partial[(size_t)k * n + e];
         part[g][lane] = s;
         __syncthreads();
         if (g == 0 && e < n) {
             float tot = part[0][lane];
-#pragma unroll
-            for (int q = 1; q < 8; ++q) tot += part[q][lane];
+            for (int q = 1; q < G; ++q) tot += part[q][lane];
             dW[e] = accumulate ? dW[e] + tot : tot;
         }
         __syncthreads();
@@ -912,9 +947,12 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
 }
 
 void launch_wgrad_finish(const float* partial, int nchunks, size_t n, int accumulate, float* dW, hipStream_t s) {
-    int fgrid = (int)((n + 31) / 32);
+    const int out = nchunks > 1024 ? 4 : nchunks > 256 ? 8 : 32;       // a function of the chunk count only: fixed summation tree
+    size_t fgrid = (n + out - 1) / out;
     if (fgrid > 4096) fgrid = 4096;
-    hipLaunchKernelGGL(wgrad_finish_kernel, dim3(fgrid), dim3(256), 0, s, partial, nchunks, n, accumulate, dW);
+    if (out == 4) hipLaunchKernelGGL(wgrad_finish_kernel<4>, dim3((unsigned)fgrid), dim3(256), 0, s, partial, nchunks, n, accumulate, dW);
+    else if (out == 8) hipLaunchKernelGGL(wgrad_finish_kernel<8>, dim3((unsigned)fgrid), dim3(256), 0, s, partial, nchunks, n, accumulate, dW);
+    else hipLaunchKernelGGL(wgrad_finish_kernel<32>, dim3((unsigned)fgrid), dim3(256), 0, s, partial, nchunks, n, accumulate, dW);
 }
 
 static inline int ew_grid(size_t total) {
@@ -1334,18 +1372,27 @@ extern "C" int ptt_linear_wgrad_f32(const float* dZ, int ldz, const float* X, in
     const int lds = 4 * WG_KC * WG_LD * (int)sizeof(float);
     const bool vz = (ldz & 3) == 0 && (reinterpret_cast<uintptr_t>(dZ) & 15) == 0;
     const bool vx = (ldx & 3) == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0;
+    const int narrow_o = (Cout <= 64), narrow_i = (Cin <= 64);
+    const int ns = (narrow_o ? 2 : 1) * (narrow_i ? 2 : 1);
 #define PTT_WGRAD_CASE(VZ, VX)                                                                                        \
     if (vz == VZ && vx == VX) {                                                                                       \
-        if (int rc = set_lds_limit(reinterpret_cast<const void*>(linear_wgrad_kernel<VZ, VX>), lds)) return rc;       \
-        hipLaunchKernelGGL((linear_wgrad_kernel<VZ, VX>), dim3(nbo * nbi, nchunks), dim3(256), lds, s, dZ, ldz, X, ldx, R, Cout, Cin, \
-                           nbi, rows, static_cast<float*>(ws), x_scale, x_shift);                                     \
+        if (ns == 1) {                                                                                                \
+            if (int rc = set_lds_limit(reinterpret_cast<const void*>(linear_wgrad_kernel<VZ, VX, 1>), lds)) return rc; \
+            hipLaunchKernelGGL((linear_wgrad_kernel<VZ, VX, 1>), dim3(nbo * nbi, nchunks), dim3(256), lds, s, dZ, ldz, X, ldx, R, Cout, \
+                               Cin, nbi, rows, static_cast<float*>(ws), x_scale, x_shift, 0, 0);                      \
+        } else if (ns == 2) {                                                                                         \
+            if (int rc = set_lds_limit(reinterpret_cast<const void*>(linear_wgrad_kernel<VZ, VX, 2>), lds)) return rc; \
+            hipLaunchKernelGGL((linear_wgrad_kernel<VZ, VX, 2>), dim3(nbo * nbi, nchunks), dim3(256), lds, s, dZ, ldz, X, ldx, R, Cout, \
+                               Cin, nbi, rows, static_cast<float*>(ws), x_scale, x_shift, narrow_o, narrow_i);        \
+        } else {                                                                                                      \
+            if (int rc = set_lds_limit(reinterpret_cast<const void*>(linear_wgrad_kernel<VZ, VX, 4>), lds)) return rc; \
+            hipLaunchKernelGGL((linear_wgrad_kernel<VZ, VX, 4>), dim3(nbo * nbi, nchunks), dim3(256), lds, s, dZ, ldz, X, ldx, R, Cout, \
+                               Cin, nbi, rows, static_cast<float*>(ws), x_scale, x_shift, narrow_o, narrow_i);        \
+        }                                                                                                             \
     }
     PTT_WGRAD_CASE(true, true) PTT_WGRAD_CASE(true, false) PTT_WGRAD_CASE(false, true) PTT_WGRAD_CASE(false, false)
 #undef PTT_WGRAD_CASE
-    const size_t n = (size_t)Cout * Cin;
-    int fgrid = (int)((n + 31) / 32);
-    if (fgrid > 4096) fgrid = 4096;
-    hipLaunchKernelGGL(wgrad_finish_kernel, dim3(fgrid), dim3(256), 0, s, static_cast<const float*>(ws), nchunks, n, accumulate, dW);
+    launch_wgrad_finish(static_cast<const float*>(ws), nchunks, (size_t)Cout * Cin, accumulate, dW, s);
     return check_launch("linear_wgrad_kernel");
 }
 

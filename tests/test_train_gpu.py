@@ -52,7 +52,10 @@ def test_bn_stats_apply_and_backward_kernels(dev, R, C):
 
 
 @pytest.mark.parametrize("R,Cout,Cin", [(4096, 128, 128), (10000, 64, 3), (5000, 128, 131), (9000, 256, 259), (300, 5, 256),
-                                         (40000, 512, 512)])
+                                         (40000, 512, 512),
+                                         # at most 64 channels on one or both sides: the waves split the staged rows (SA0's layers)
+                                         (50000, 64, 64), (33333, 128, 64), (20011, 64, 128), (7000, 64, 259), (6000, 260, 33),
+                                         (300000, 64, 3)])
 def test_linear_wgrad_kernel(dev, R, Cout, Cin):
     g = torch.Generator(device="cpu").manual_seed(R)
     dz = torch.randn(R, Cout, generator=g).to(dev)
