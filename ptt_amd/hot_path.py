@@ -7,8 +7,9 @@ One *frame* = one (search, template) cloud pair through
  -> TransformerBlock on the 64 proposals              (box_voting_head.py:81-86)
 with the constants of tools/cfgs/kitti_models/ptt.yaml:41-51,72-79,96-112.
 The small Conv1d heads and CosineSimAug that sit between these stages in the full tracker are
-outside the hot path; `bridge()` stands in for them with the same tensor shapes and layouts
-(votes = seeds, votes_feats = cat(score, feats) channel-major as centroids_voting_head.py:94).
+outside the hot path; `bridge()` stands in for them with the same tensor shapes (votes = seeds, votes_feats =
+cat(score, feats), (B, 1 + C, N) as centroids_voting_head.py:94 — handed over, as this build's head does, as a channel-major
+view of point-major rows).
 """
 import torch
 import torch.nn as nn
@@ -72,9 +73,11 @@ class FrameHotPath(nn.Module):
 
     @staticmethod
     def bridge(seeds, feats_bnc):
-        """Stand-in for the heads between the two transformers: votes (B,128,3), votes_feats (B,257,128)."""
+        """Stand-in for the heads between the two transformers: votes (B,128,3), votes_feats (B,257,128) — a channel-major
+        VIEW of point-major rows: the SA level that consumes it reads rows, so a channel-major copy here would be
+        transposed straight back (two 6 MB copies per step)."""
         score = torch.sigmoid(feats_bnc[:, :, :1])
-        return seeds, torch.cat((score, feats_bnc), dim=2).transpose(1, 2).contiguous()
+        return seeds, torch.cat((score, feats_bnc), dim=2).transpose(1, 2)
 
     def sample(self, search_points, template_points):
         """Level-0 furthest point sampling of both clouds -> (inds_search, inds_template) int32. Split out so
