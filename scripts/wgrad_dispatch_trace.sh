@@ -1,3 +1,6 @@
+#!/bin/bash
+# Dev tool (GPU box): per-dispatch kernel trace of a short training run, the weight-gradient / linear launches grouped by grid —
+# which shapes land on which kernel and what each costs (found SA0's 64-channel layers on zero-padded 128 x 128 blocks).
 cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/kt && timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/kt -- python $GRAFT_REPO_ROOT/bench.py --workload train --steps 3 --warmup 2 --no-cpu-baseline --sustain 0 > /dev/null 2>&1
 f=$(find /tmp/kt -name "*kernel_trace.csv" | head -1)
 python - "$f" <<'PY'
