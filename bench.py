@@ -591,8 +591,50 @@ def tracklet_loop(torch, dev, tracker, frames_b1=120, frames_b48=30):
         n = B * (T - 1)                                             # frame 0 only initialises (:96-100)
         out[key] = {"tracklets": B, "frames_tracked": n, "ms_per_step": round(dt / (T - 1) * 1e3, 4),
                     "frames_per_s": round(n / dt, 1)}
+        if B == 1:
+            # where a frame's time is (the reference prints the same split per frame: pre-process / model / post-process,
+            # tools/eval_utils/eval_tracking_utils.py:140-152, ptt/utils/timer_utils.py:104-151): a second, instrumented pass
+            # (HIP events around the frame's device work, host clocks around the host's) — its own wall time is NOT the figure above
+            runner.profile = {}
+            runner.run(tracklets[:1])
+            torch.cuda.synchronize()
+            med = lambda v: round(float(sorted(v)[len(v) // 2]), 4)
+            p = runner.profile
+            out[key].update({
+                "host_pre_ms": med(p["host_pre_ms"]), "device_ms": med(p["device_ms"]), "host_post_ms": med(p["host_post_ms"]),
+                "split": "medians over the frames of an instrumented pass: host_pre = float64 crop bounds + job-table upload + "
+                         "enqueue of the frame's launches; device = crop, resample, tracker hipGraph and read-back between "
+                         "two HIP events on the launch stream; host_post = float64 box update; the host waits for the device "
+                         "in between, so ms_per_step ~ host_pre + device + host_post minus the enqueue / execution overlap",
+                "launches_per_frame": launches_per_frame(torch, dev, tracker, runner)})
+            runner.profile = None
         del runner
     return out
+
+
+def launches_per_frame(torch, dev, tracker, runner):
+    """Kernel launches of ONE tracklet frame = the kernels of one eager tracker forward at the runner's sizes (counted by
+    torch.profiler; the same launches the runner's hipGraph replays) + crop, resample and box selection."""
+    try:
+        from torch.profiler import ProfilerActivity, profile
+        s = torch.zeros((1, runner.S, 3), device=dev)
+        t = torch.zeros((1, runner.T, 3), device=dev)
+        s[0, :, 0] = torch.linspace(0.2, 2.0, runner.S, device=dev)          # distinct, off-origin points
+        t[0, :, 1] = torch.linspace(0.2, 1.0, runner.T, device=dev)
+        with torch.no_grad():
+            for _ in range(2):
+                runner._model(s, t)
+            torch.cuda.synchronize()
+            with profile(activities=[ProfilerActivity.CUDA]) as prof:
+                runner._model(s, t)
+                torch.cuda.synchronize()
+        n = sum(1 for e in prof.events() if e.device_type.name in ("CUDA", "PrivateUse1") and "memcpy" not in e.name.lower()
+                and "memset" not in e.name.lower())
+        return {"model_graph": n, "crop_resample": 2, "copies": 3, "total": n + 5,
+                "how": "torch.profiler kernel events of one eager tracker forward + box selection at 1024 + 512 points; the "
+                       "loop adds the crop and resample launches, one job-table upload and two read-backs per frame"}
+    except Exception as e:                                  # the count is a diagnostic: never take the line down
+        return {"error": "%s: %s" % (type(e).__name__, e)}
 
 
 def run_train(args, torch, dev, dist, world, rank, ranks_seen, sync_all, B, NS, NT, W):

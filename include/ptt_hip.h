@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PTT_ABI_VERSION 14
+#define PTT_ABI_VERSION 15
 
 enum {
     PTT_OK = 0,
@@ -181,6 +181,56 @@ typedef struct ptt_sa_layer {
  * scale is folded into the weights (one instruction less per value in the epilogue). */
 int ptt_rows_mlp_f32(const float* X, int rows, int K, int ldx, const ptt_sa_layer* layers, int n_layers,
                      const float* residual, int ldr, float* out, int ldo, ptt_stream_t stream);
+
+/* ---------------------------------------------------------------------------------
+ * Row jobs (round 4): up to PTT_ROW_JOBS_MAX independent row-wise layers in ONE launch, each
+ *     out = act(A @ W^T * scale + shift) (+ residual)
+ * with the operand A formed while it is staged and the result consumed in the epilogue — the launch
+ * chain of ONE tracklet frame (tools/eval_utils/eval_tracking_utils.py:140-152: B = 1) is ~45 dependent
+ * launches of 128-2048 rows, each a few microseconds of work behind ~5 us of launch latency, so what
+ * counts is how many launches are on the chain. One job replaces one of
+ *   nn.Linear / Conv1d(k=1) forwards (transformer_block/variants.py:154-164; voting_heads/
+ *     centroids_voting_head.py:83-94 cla_layer / vote_layer; box_voting_head.py:88-90 refine_layer;
+ *     similarity_modules/p2b_xcoor.py:43-45; pointnet2_backbone.py:46),
+ * and the element-wise code around them:
+ *   prologue 0  A = [X | X2]: the columns [0,K1) from X (row stride ldx), [K1,K) from X2 (ldx2) — the
+ *               torch.cat((xyz, feats)) in front of vote_layer (centroids_voting_head.py:86-90) and of
+ *               CosineSimAug's per-template-point term without the copy (weights packed with the
+ *               matching input-channel rotation);
+ *   prologue 1  A[r,:] = relu(fc_delta[0](rel[r,:]))            variants.py:158 (first Linear + ReLU; w1 (K,4) =
+ *               [wx wy wz bias] per channel), so that fc_delta is one launch;
+ *   prologue 2  A[(i,j),:] = q_i - k[knn_ij] + pos_ij            variants.py:160 (argument of fc_gamma);
+ *   epilogue 1  res_i = sum_j softmax_j(y_ij * sm_scale) * (v[knn_ij] + pos_ij)   variants.py:161-163 — the 32 rows
+ *               of a tile are the 16 neighbours of two points, so the softmax over neighbours is local to the
+ *               accumulator tile (the per-column bias cancels and is not read); out (points, Cout).
+ *   act         0 none, 1 ReLU, 2 sigmoid (`raw`, if given, receives the value before the activation:
+ *               pred_centroids_cls beside its sigmoid, centroids_voting_head.py:84,92-94)
+ *   residual    out column c >= res_split adds res[row*ldr + c - res_split], c < res_split adds
+ *               res2[row*ldr2 + c] (either may be NULL): `vote_in + vote_layer(vote_in)` with vote_in = cat(xyz, feats)
+ *               (centroids_voting_head.py:90), `offsets[:, 0:3] + centres` (box_voting_head.py:91);
+ *   output      column c >= out_split goes to out[row*ldo + c - out_split + out_col0], c < out_split to
+ *               out2[row*ldo2 + c]: the slices / concatenations behind the heads (votes vs. votes_feats).
+ * A workgroup of 8 waves owns a 32-row x (32 * col_tiles)-column tile and splits K over 8 / col_tiles wave groups
+ * (partial sums meet in LDS): a 128-row layer is 64-192 workgroups with a 1-2 us MFMA chain each instead of 16 with 7 us.
+ * Wpacked from ptt_pack_weight_f32 (K <= 1024). Jobs of one launch must not depend on each other.
+ * ------------------------------------------------------------------------------- */
+#define PTT_ROW_JOBS_MAX 4
+typedef struct ptt_row_job {
+    const float* X; const float* X2;
+    const float* Wpacked; const float* scale; const float* shift;
+    const float* res; const float* res2;
+    float* out; float* out2; float* raw;
+    const float* rel; const float* w1;                 /* prologue 1: (rows,3), (K,4) */
+    const float* qkv; const int32_t* knn; const float* pos;   /* prologue 2 / epilogue 1: (points, ldq) rows holding q | k | v at
+                                                          column offsets q_off / k_off / v_off, (points,16) neighbour indices
+                                                          inside the point's cloud of N points, (rows, ldp) positional term */
+    int32_t rows, K, K1, ldx, ldx2, Cout;
+    int32_t act, res_split, ldr, ldr2, out_split, out_col0, ldo, ldo2, ldraw;
+    int32_t prologue, epilogue, ldq, q_off, k_off, v_off, ldp, N;
+    float sm_scale;
+    int32_t col_tiles;                                 /* 0: the library picks 1, 2 or 4 by launch size */
+} ptt_row_job;
+int ptt_row_jobs_f32(const ptt_row_job* jobs, int n_jobs, ptt_stream_t stream);
 
 typedef struct ptt_sa_desc {
     const float* xyz;     /* (B,N,3)                                                   */

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libptt_hip.so")
 
 PTT_SA_MAX_LAYERS = 4
-ABI_VERSION = 14            # PTT_ABI_VERSION of include/ptt_hip.h these structures mirror
+ABI_VERSION = 15            # PTT_ABI_VERSION of include/ptt_hip.h these structures mirror
 
 # every symbol include/ptt_hip.h declares (tests check the library exports all of them)
 EXPORTS = [
@@ -38,6 +38,7 @@ EXPORTS = [
     "ptt_bn_update_running_f32", "ptt_xcorr_z0_f32", "ptt_xcorr_z0_bwd_workspace", "ptt_xcorr_z0_bwd_f32",
     "ptt_bn_stats_train_f32", "ptt_bn_finish_partials_train_f32", "ptt_pack_weights_f32",
     "ptt_sa_z0_rows_f32",
+    "ptt_row_jobs_f32",
 ]
 PTT_MAX_SEGMENTS = 4
 
@@ -68,6 +69,18 @@ class PackJob(Structure):
     """ptt_pack_job: one weight (view) of ptt_pack_weights_f32; arrays of these are uploaded to the device."""
     _fields_ = [("W", c_void_p), ("out_offset", c_int64), ("stride_out", c_int64), ("stride_k", c_int64),
                 ("Cout", c_int32), ("K", c_int32)]
+
+
+class RowJob(Structure):
+    """ptt_row_job: one row-wise layer of ptt_row_jobs_f32 (passed by value, host memory)."""
+    _fields_ = [("X", c_void_p), ("X2", c_void_p), ("Wpacked", c_void_p), ("scale", c_void_p), ("shift", c_void_p),
+                ("res", c_void_p), ("res2", c_void_p), ("out", c_void_p), ("out2", c_void_p), ("raw", c_void_p),
+                ("rel", c_void_p), ("w1", c_void_p), ("qkv", c_void_p), ("knn", c_void_p), ("pos", c_void_p),
+                ("rows", c_int32), ("K", c_int32), ("K1", c_int32), ("ldx", c_int32), ("ldx2", c_int32), ("Cout", c_int32),
+                ("act", c_int32), ("res_split", c_int32), ("ldr", c_int32), ("ldr2", c_int32), ("out_split", c_int32),
+                ("out_col0", c_int32), ("ldo", c_int32), ("ldo2", c_int32), ("ldraw", c_int32),
+                ("prologue", c_int32), ("epilogue", c_int32), ("ldq", c_int32), ("q_off", c_int32), ("k_off", c_int32),
+                ("v_off", c_int32), ("ldp", c_int32), ("N", c_int32), ("sm_scale", c_float), ("col_tiles", c_int32)]
 
 
 class SaLayer(Structure):
@@ -178,6 +191,7 @@ def _declare(lib):
         "ptt_bn_bwd_pooled_f32": [vp, i, vp, i, vp, i, vp, vp, vp, i, i, vp, i, vp, vp, vp, c_size_t, vp, vp, vp],
         "ptt_bn_bwd_pooled_sums_f64": [vp, i, vp, i, vp, i, vp, vp, i, i, vp, vp, c_size_t, vp, vp, vp],
         "ptt_bn_bwd_pooled_apply_f32": [vp, i, vp, i, vp, i, vp, vp, vp, vp, vp, vp, i, i, vp, i, vp, vp, vp],
+        "ptt_row_jobs_f32": [POINTER(RowJob), i, vp],
     }
     for name, args in sigs.items():
         fn = getattr(lib, name)

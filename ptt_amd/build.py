@@ -13,12 +13,13 @@ CSRC = os.path.join(ROOT, "ptt_amd", "csrc")
 LIBDIR = os.path.join(ROOT, "ptt_amd", "lib")
 LIB = os.path.join(LIBDIR, "libptt_hip.so")
 
-HIP_SOURCES = ["errors.hip", "point_ops.hip", "mfma_ops.hip", "track_ops.hip", "train_ops.hip", "gemm_ops.hip"]
+HIP_SOURCES = ["errors.hip", "point_ops.hip", "mfma_ops.hip", "track_ops.hip", "train_ops.hip", "gemm_ops.hip", "rowjobs.hip"]
 # FPS / ball query / kNN index parity needs un-fused fp32 arithmetic (see point_ops.hip header)
 EXTRA_FLAGS = {"point_ops.hip": ["-ffp-contract=off"], "track_ops.hip": ["-ffp-contract=off"], # -fno-honor-nans: without it every fmaxf on an MFMA result costs a second v_max (sNaN canonicalisation), and
                # vector-ALU instructions next to fp32 MFMAs are paid in matrix time (a third of the epilogue instructions)
                "mfma_ops.hip": ["-fno-honor-nans"] + os.environ.get("PTT_MFMA_FLAGS", "").split(),
-               "gemm_ops.hip": ["-fno-honor-nans"] + os.environ.get("PTT_GEMM_FLAGS", "").split()}
+               "gemm_ops.hip": ["-fno-honor-nans"] + os.environ.get("PTT_GEMM_FLAGS", "").split(),
+               "rowjobs.hip": ["-fno-honor-nans"]}
 # build-time only: flags for every source, e.g. PTT_HIP_FLAGS="-DPTT_DEV" for a developer build that reads the PTT_*
 # A/B switches from the environment and keeps the kernels' cycle-stamp hooks (a release build has neither)
 COMMON_FLAGS = os.environ.get("PTT_HIP_FLAGS", "").split()
@@ -39,7 +40,7 @@ def build_hip(force=False, verbose=False):
     os.makedirs(LIBDIR, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(ROOT, "include", "ptt_hip.h"))
-    objs = []
+    objs, running = [], []
     for src in HIP_SOURCES:
         s = os.path.join(CSRC, src)
         if not os.path.exists(s):
@@ -51,7 +52,10 @@ def build_hip(force=False, verbose=False):
             cmd += EXTRA_FLAGS.get(src, []) + COMMON_FLAGS
             if verbose:
                 print(" ".join(cmd), flush=True)
-            subprocess.check_call(cmd)
+            running.append((cmd, subprocess.Popen(cmd)))        # the sources are independent: compile them side by side
+    for cmd, proc in running:
+        if proc.wait() != 0:
+            raise subprocess.CalledProcessError(proc.returncode, cmd)
     if force or _stale(LIB, objs):
         cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         if verbose:

@@ -25,6 +25,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include "common.h"
+#include "mfma_common.h"
 
 #ifndef PTT_PAIR_PF
 #define PTT_PAIR_PF 1
@@ -48,26 +49,6 @@ namespace ptt {
 #else
 #define PTT_STAMP(i) do { } while (0)
 #endif
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ int tile_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
-
-__device__ __forceinline__ float xor32(float v) { return __shfl_xor(v, 32, 64); }
-
-// lane <-> lane^32 combine on v_permlane32_swap (one VALU op, no LDS round trip): after the swap `lo`
-// holds the lower half-wave's values in both halves and `hi` the upper half-wave's.
-// Inline asm on purpose: with both operands holding the SAME value hipcc (ROCm 7.2) folds
-// __builtin_amdgcn_permlane32_swap's two results into one and the exchange silently disappears
-// (scripts/permlane_probe.hip). s_nop 1 = the VALU-write -> v_permlane read hazard, inside the string.
-__device__ __forceinline__ void swap_halves(float v, float& lo, float& hi) {
-    float a = v, b = v;
-    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
-    lo = a; hi = b;
-}
-__device__ __forceinline__ float max_halves(float v) { float lo, hi; swap_halves(v, lo, hi); return fmaxf(lo, hi); }
-__device__ __forceinline__ float add_halves(float v) { float lo, hi; swap_halves(v, lo, hi); return lo + hi; }
 
 // Two workgroups share each CU (and each SIMD's MFMA pipe). Launched together with identical work
 // they run in lockstep, so their non-MFMA phases (gather, epilogue, softmax) coincide and the matrix
@@ -157,13 +138,6 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const ptt_pack_job* _
 #ifndef PTT_BUFFER_WEIGHTS
 #define PTT_BUFFER_WEIGHTS 1
 #endif
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t weight_rsrc(const void* p) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);   // raw, 32-bit data format
-}
-__device__ __forceinline__ f32x4 weight_load(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
-}
-
 template <int RT, int CT, int ACT>
 __device__ __forceinline__ void gemm_mfma_block(const f32x4 (&a)[RT], const f32x4 (&b)[CT], f32x16 (&acc)[RT][ACT]) {
 #pragma unroll

@@ -170,8 +170,9 @@ class PointnetSAModuleVotes(nn.Module):
             if hoist is not None and features is not None:
                 wf_packed, wx, c0, relu0 = hoist
                 rows = features.transpose(1, 2)                       # (B,N,C): contiguous when point-major
-                term = ops.linear(rows if rows.is_contiguous() else rows.contiguous(), wf_packed, c0,
-                                  None, layers[0][2], relu=False)
+                # rows with a padded stride (the one-frame head hands over 260-float rows) are read in place
+                uniform = rows.stride(2) == 1 and rows.stride(0) == rows.shape[1] * rows.stride(1)
+                term = ops.linear(rows if uniform else rows.contiguous(), wf_packed, c0, None, layers[0][2], relu=False)
                 new_features = ops.sa_fused_forward(xyz, new_xyz, idx, None, [L[:6] for L in layers[1:]], self.radius, True,
                                                     self.normalize_xyz, point_major_out=True, l0=(term, wx, relu0))
             else:

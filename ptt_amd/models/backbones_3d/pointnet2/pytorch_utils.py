@@ -221,6 +221,24 @@ def _rows_params(seq):
     return layers
 
 
+def rows_layers(seq, rot0=0):
+    """The folded layers of an eval-mode Conv1d stack for ptt_row_jobs_f32: [(wpacked, cout, scale, shift, relu), ...].
+    rot0: the first layer's input channels rotated left by rot0 before packing — a stack whose reference input is
+    cat((xyz, feats)) (centroids_voting_head.py:86-90) then reads [feats | xyz], two tensors, no concatenation."""
+    from .... import ops
+    layers = [L[:5] for L in _rows_params(seq)]
+    if rot0:
+        cache = getattr(seq, '_rows_rot_cache', None)
+        key = (id(layers[0][0]), rot0)
+        if cache is None or cache[0] != key:
+            w = seq[0].conv.weight
+            cache = (key, ops.pack_weight(w.reshape(w.shape[0], w.shape[1]), rot0))
+            ops.publish_params(w.device)
+            object.__setattr__(seq, '_rows_rot_cache', cache)
+        layers[0] = (cache[1],) + tuple(layers[0][1:])
+    return layers
+
+
 def _one_launch(layers, rows):
     """ptt_rows_mlp_f32's envelope (at most 4 layers, K <= 264, inner widths <= 256, last <= 384) — and enough rows: the
     one-launch form runs a 32-row tile's layers back to back on ONE CU (25 us for 259 -> 256 -> 256 -> 259), while

@@ -76,7 +76,12 @@ class PointNet2BackboneLight(nn.Module):
         xyz, features, inds2 = self.SA_modules[2](xyz=xyz, features=features, npoint=npoints[2])
         point_features = self._cov_final(features)
         assert inds1.dtype == inds2.dtype == torch.int64, 'index type must be int64, not {}'.format(inds2.dtype)
-        inds = inds0.gather(1, inds1).gather(1, inds2)
+        if all(m.sample_method in ('rs', 'sequence') for m in self.SA_modules[1:]) and inds0.shape[1] >= npoints[2]:
+            # levels 1 and 2 take the FIRST npoints of the level below: the composition is a prefix of level 0's indices
+            # (same values as the two gathers of the reference, :48, without their launches)
+            inds = inds0[:, :npoints[2]]
+        else:
+            inds = inds0.gather(1, inds1).gather(1, inds2)
         return xyz, point_features, inds
 
     def sample(self, search_points, template_points):

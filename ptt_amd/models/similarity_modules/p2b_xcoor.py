@@ -86,6 +86,7 @@ class CosineSimAug(nn.Module):
             # layer 0's BatchNorm is folded into its two halves: the per-template-point term comes out of the linear
             # kernel as s0 * (W0[:,1:] . [xyz;feat]) + t0, the similarity column as s0 * w_sim
             P = dict(w_sim=(w0[:, 0].float() * s0).contiguous(), w_rest=ops.pack_weight(w0[:, 1:]), c0=w0.shape[0],
+                     w_rest_fx=ops.pack_weight(w0[:, 1:], 3),      # the same weights for rows laid out [feats | xyz]
                      scale0=s0, shift0=t0, layers=layers)
         ops.publish_params(self.conv[0].conv.weight.device)
         self._cache = (key, P)
@@ -100,8 +101,15 @@ class CosineSimAug(nn.Module):
 
         if self._fusable(search_feats, template_feats):
             P = self._params()
-            rows = torch.cat((template_xyz, template_feats.transpose(1, 2)), dim=2)          # (B,n1,3+f)
-            pre = ops.linear(rows, P['w_rest'], P['c0'], P['scale0'], P['shift0'])            # (B,n1,C0), BN folded in
+            trows = template_feats.transpose(1, 2)                                            # (B,n1,f)
+            if b * n1 <= ops.ONE_FRAME_MAX_POINTS and trows.is_contiguous():
+                # a handful of frames: the per-template-point term reads [feats | xyz] from the two tensors (no concatenation)
+                pre = torch.empty((b, n1, P['c0']), dtype=torch.float32, device=trows.device)
+                ops.row_jobs([ops.row_job(P['w_rest_fx'], P['c0'], x=trows, x2=template_xyz.contiguous(), scale=P['scale0'],
+                                          shift=P['shift0'], out=pre)])
+            else:
+                rows = torch.cat((template_xyz, trows), dim=2)                                # (B,n1,3+f)
+                pre = ops.linear(rows, P['w_rest'], P['c0'], P['scale0'], P['shift0'])        # (B,n1,C0), BN folded in
             cos_t = ops.cosine_map(search_feats, template_feats, eps=self.cosine.eps)         # (B,n2,n1), one launch
             fused, _ = ops.xcorr_fused(search_feats, template_feats, pre, P['w_sim'], None, None,
                                        P['layers'], eps=self.cosine.eps, cos_t=cos_t)         # (B,C,n2) view

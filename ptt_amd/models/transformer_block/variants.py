@@ -25,7 +25,7 @@ from ..model_utils import index_points, square_distance
 
 
 # at most this many points (B * N) take the per-layer inference form of TransformerBlock instead of the fused pair kernel
-PER_LAYER_MAX_POINTS = int(__import__("os").environ.get("PTT_PT_PER_LAYER_MAX", "512"))
+PER_LAYER_MAX_POINTS = ops.ONE_FRAME_MAX_POINTS
 
 
 def _rows2d(layers, x):
@@ -89,7 +89,8 @@ class TransformerBlock(nn.Module):
                 wg1=ops.pack_weight(self.fc_gamma[0].weight), bg1=f(self.fc_gamma[0].bias),
                 wg2=ops.pack_weight(self.fc_gamma[2].weight), bg2=f(self.fc_gamma[2].bias),
                 fc2=ops.pack_weight(self.fc2.weight), fc2_b=f(self.fc2.bias),
-                wd1_lin=ops.pack_weight(self.fc_delta[0].weight), bd1=f(self.fc_delta[0].bias))
+                wd1_lin=ops.pack_weight(self.fc_delta[0].weight), bd1=f(self.fc_delta[0].bias),
+                w1b=torch.cat((f(self.fc_delta[0].weight), f(self.fc_delta[0].bias)[:, None]), 1).contiguous())
         ops.publish_params(self.fc1.weight.device)
         self._cache = (key, P)
         return P
@@ -101,12 +102,34 @@ class TransformerBlock(nn.Module):
             D = self.d_model
             xyz = xyz.contiguous()
             knn_idx, rel = ops.knn(xyz, self.k, want_rel=True)
-            qkv = ops.linear(features, P['qkv'], 3 * D, None, P['qkv_b'])
-            if xyz.shape[0] * xyz.shape[1] <= PER_LAYER_MAX_POINTS:
+            if xyz.shape[0] * xyz.shape[1] <= PER_LAYER_MAX_POINTS and not self.materialize_attn:
                 # a handful of frames (one tracklet frame: 128 / 64 points): the fused pair kernel's one workgroup per two
                 # points is a 64-workgroup launch of three chained 512 x 512 GEMMs (106 us on 64 of the 256 CUs). Per layer,
-                # each GEMM over the (point, neighbour) rows fills the chip (256 workgroups at 2048 rows) and the
-                # intermediates (4 MB each) stay in L2: five more launches, half the time.
+                # each GEMM over the (point, neighbour) rows fills the chip, and the element-wise steps between them ride in
+                # the GEMMs' operand staging / epilogue (ptt_row_jobs_f32): kNN, then FOUR launches —
+                #   [q|k|v projection  ||  fc_delta with its first Linear + ReLU formed while the A tile is staged]
+                #   fc_gamma[0] on q_i - k_j + pos_ij gathered while the A tile is staged
+                #   fc_gamma[2] with the softmax over the 16 neighbours and the weighted sum as its epilogue
+                #   fc2 + residual
+                # instead of the nine of round 3 (a launch of this chain costs 7 - 15 us, mostly latency).
+                B, N = xyz.shape[0], xyz.shape[1]
+                dev = xyz.device
+                qkv = torch.empty((B, N, 3 * D), dtype=torch.float32, device=dev)
+                pos = torch.empty((B * N * self.k, D), dtype=torch.float32, device=dev)
+                g = torch.empty_like(pos)
+                res = torch.empty((B, N, D), dtype=torch.float32, device=dev)
+                out = torch.empty((B, N, self.d_points), dtype=torch.float32, device=dev)
+                ops.row_jobs([ops.row_job(P['qkv'], 3 * D, x=features, shift=P['qkv_b'], out=qkv),
+                              ops.row_job(P['wd2'], D, prologue=1, rel=rel.view(-1, 3), w1=P['w1b'], K=D, shift=P['bd2'], out=pos)])
+                ops.row_jobs([ops.row_job(P['wg1'], D, prologue=2, qkv=qkv, knn=knn_idx.view(-1, self.k), pos=pos, q_off=0, k_off=D,
+                                          N=N, K=D, shift=P['bg1'], act=1, out=g)])
+                ops.row_jobs([ops.row_job(P['wg2'], D, x=g, epilogue=1, qkv=qkv, knn=knn_idx.view(-1, self.k), pos=pos, v_off=2 * D,
+                                          N=N, sm_scale=1.0 / np.sqrt(D), out=res)])
+                ops.row_jobs([ops.row_job(P['fc2'], self.d_points, x=res, shift=P['fc2_b'], res=features, out=out)])
+                return out, None
+            qkv = ops.linear(features, P['qkv'], 3 * D, None, P['qkv_b'])
+            if xyz.shape[0] * xyz.shape[1] <= PER_LAYER_MAX_POINTS:
+                # the same per-layer form with the (B,N,k,D) attention tensor written out (materialize_attn)
                 pairs = rel.view(-1, 3)
                 h = ops.linear(pairs, P['wd1_lin'], D, None, P['bd1'], relu=True)
                 pos = ops.linear(h, P['wd2'], D, None, P['bd2']).view(xyz.shape[0], xyz.shape[1], self.k, D)

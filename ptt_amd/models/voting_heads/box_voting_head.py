@@ -4,7 +4,7 @@ the second Point-Track-Transformer block and a small Conv1d stack that regresses
 proposal. `vote_aggregation`, `refine_layer`, `transformer_block` are the checkpoint names."""
 import torch
 
-from ... import train_ops
+from ... import ops, train_ops
 from ..backbones_3d.pointnet2 import pointnet2_modules
 from ..backbones_3d.pointnet2 import pytorch_utils as layer_utils
 from ..transformer_block import build_transformer
@@ -60,6 +60,10 @@ class BoxVotingHead(VotingHeadTemplate):
             return train_ops.conv1d_stack_usable(self.refine_layer, feats)
         return layer_utils.rows_fusable(self.refine_layer, feats)
 
+    def _one_frame(self, rows):
+        return (rows.shape[0] * rows.shape[1] <= ops.ONE_FRAME_MAX_POINTS and len(self.refine_layer) >= 1
+                and self.refine_layer[-1].conv.weight.shape[0] >= 3)
+
     def _train_labels(self, batch_dict, centres):
         dist = torch.sqrt(torch.sum((centres - batch_dict['reg_label'][:, None, 0:3]) ** 2, dim=-1) + 1e-6)
         label = torch.zeros_like(dist, dtype=torch.float)
@@ -84,6 +88,23 @@ class BoxVotingHead(VotingHeadTemplate):
             rows = feats.transpose(1, 2)                                                         # (B,M,C)
             if hasattr(self, 'transformer_block'):
                 rows = self.transformer_block(xyz=centres, features=rows.contiguous())[0]
+            if not self.training and self._one_frame(rows):
+                # a handful of frames: one ptt_row_jobs_f32 launch per refine convolution, the last one adding the proposal
+                # centres to its first three columns (reference :91) and writing pred_box_data directly
+                L = layer_utils.rows_layers(self.refine_layer)
+                B, M, _ = rows.shape
+                x = rows.contiguous()
+                for wp, cout, scale, shift, relu in L[:-1]:
+                    h = torch.empty((B * M, cout), dtype=torch.float32, device=rows.device)
+                    ops.row_jobs([ops.row_job(wp, cout, x=x, scale=scale, shift=shift, act=1 if relu else 0, out=h)])
+                    x = h
+                wp, cout, scale, shift, relu = L[-1]
+                boxes = torch.empty((B, M, cout), dtype=torch.float32, device=rows.device)
+                ops.row_jobs([ops.row_job(wp, cout, x=x, scale=scale, shift=shift, act=1 if relu else 0, res2=centres.contiguous(),
+                                          res_split=3, out=boxes)])
+                batch_dict['pred_box_center'] = centres
+                batch_dict['pred_box_data'] = boxes
+                return batch_dict
             if self.training:
                 offsets = train_ops.conv1d_stack_rows(self.refine_layer, rows)                   # (B,M,5)
             else:

@@ -5,7 +5,7 @@ tiny (0.05 GFLOP/frame): stock torch layers in training, folded-BN linear launch
 on a HIP device; names `cla_layer`, `vote_layer`, `transformer_block` are the checkpoint contract."""
 import torch
 
-from ... import train_ops
+from ... import ops, train_ops
 from ..backbones_3d.pointnet2 import pytorch_utils as layer_utils
 from ..transformer_block import build_transformer
 from .voting_head_template import VotingHeadTemplate
@@ -84,6 +84,54 @@ class CentroidVotingHead(VotingHeadTemplate):
             }
         return batch_dict
 
+    def _forward_one_frame(self, batch_dict):
+        """The same head for a handful of frames (one tracklet frame, the reference's tracking mode): three launches of TWO
+        jobs each — cla_layer's and vote_layer's i-th convolutions side by side (ptt_row_jobs_f32) — with the concatenations,
+        the sigmoid, the residual and the output slices of reference :83-94 inside the jobs: vote_layer reads [feats | xyz]
+        from two tensors, its last convolution adds (xyz | feats) back and writes votes and votes_feats[:, 1:], cla_layer's
+        last convolution writes the raw scores and their sigmoid into votes_feats[:, 0]. Nine launches less per frame."""
+        seeds = batch_dict['search_seeds'].contiguous()                          # (B,N,3)
+        rows = batch_dict['cosine_feats'].transpose(1, 2).contiguous()            # (B,N,C): a view of point-major storage
+        if hasattr(self, 'transformer_block'):
+            rows = self.transformer_block(xyz=seeds, features=rows)[0]
+        B, N, C = rows.shape
+        dev = rows.device
+        cls_xyz = getattr(self.model_cfg, 'CLS_USE_SEARCH_XYZ', False)
+        cla = layer_utils.rows_layers(self.cla_layer, 3 if cls_xyz else 0)
+        vote = layer_utils.rows_layers(self.vote_layer, 3)
+        new = lambda c: torch.empty((B * N, c), dtype=torch.float32, device=dev)
+        hc, hv = [new(cla[0][1]), new(cla[1][1])], [new(vote[0][1]), new(vote[1][1])]
+        ld = (1 + C + 3) // 4 * 4                                               # votes_feats rows padded to 16 bytes
+        vfeats = torch.empty((B, N, ld), dtype=torch.float32, device=dev)
+        votes = torch.empty((B, N, 3), dtype=torch.float32, device=dev)
+        cls_raw = torch.empty((B * N, 1), dtype=torch.float32, device=dev)
+
+        def job(L, x, out, x2=None, **kw):
+            wp, cout, scale, shift, relu = L
+            return ops.row_job(wp, cout, x=x, x2=x2, scale=scale, shift=shift, act=1 if relu else 0, out=out, **kw)
+
+        ops.row_jobs([job(cla[0], rows, hc[0], seeds if cls_xyz else None), job(vote[0], rows, hv[0], seeds)])
+        ops.row_jobs([job(cla[1], hc[0], hc[1]), job(vote[1], hv[0], hv[1])])
+        wp, cout, scale, shift, _ = cla[2]
+        ops.row_jobs([ops.row_job(wp, cout, x=hc[1], scale=scale, shift=shift, act=2, out=vfeats.view(B * N, ld)[:, 0:1], raw=cls_raw),
+                      job(vote[2], hv[1], vfeats.view(B * N, ld), res=rows, res2=seeds, res_split=3, out_col0=1, out2=votes,
+                          out_split=3)])
+        batch_dict['pred_centroids_cls'] = cls_raw.view(B, N).squeeze(0)
+        batch_dict['pred_centroids_votes'] = votes
+        batch_dict['votes_feats'] = vfeats[:, :, :1 + C].transpose(1, 2)          # (B,1+C,N) view of point-major rows
+        return batch_dict
+
+    def _one_frame(self, feats):
+        """At most ops.ONE_FRAME_MAX_POINTS seeds in the batch, the shipped stack shapes (three convolutions, vote_layer
+        from 3 + C back to 3 + C, cla_layer to one score)."""
+        if self.training or feats.shape[0] * feats.shape[2] > ops.ONE_FRAME_MAX_POINTS:
+            return False
+        C = feats.shape[1]
+        cv, cc = [u.conv.weight.shape for u in self.vote_layer], [u.conv.weight.shape for u in self.cla_layer]
+        cls_in = C + 3 if getattr(self.model_cfg, 'CLS_USE_SEARCH_XYZ', False) else C
+        return (len(cv) == 3 and len(cc) == 3 and cv[0][1] == C + 3 and cv[2][0] == C + 3 and cc[0][1] == cls_in and cc[2][0] == 1
+                and not hasattr(self.vote_layer[2], 'activation') and not hasattr(self.cla_layer[2], 'activation'))
+
     def _fusable(self, feats):
         if self.training:
             return (train_ops.conv1d_stack_usable(self.cla_layer, feats) and train_ops.conv1d_stack_usable(self.vote_layer, feats))
@@ -91,6 +139,8 @@ class CentroidVotingHead(VotingHeadTemplate):
 
     def forward(self, batch_dict):
         if self._fusable(batch_dict['cosine_feats']):
+            if self._one_frame(batch_dict['cosine_feats']):
+                return self._forward_one_frame(batch_dict)
             return self._forward_rows(batch_dict)
         seeds_xyz = batch_dict['search_seeds'].transpose(1, 2).contiguous()      # (B,3,N)
         feats = batch_dict['cosine_feats']                                        # (B,C,N)

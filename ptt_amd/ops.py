@@ -301,6 +301,10 @@ def pack_weight(weight, rot=0):
     return out
 
 
+ROW_JOB_MAX_ROWS = 1024       # ops.linear hands launches of at most this many rows (and K >= 192) to ptt_row_jobs_f32
+ONE_FRAME_MAX_POINTS = int(os.environ.get("PTT_PT_PER_LAYER_MAX", "512"))   # B * N up to which the modules take the one-frame launch chain
+
+
 def linear(x, wpacked, cout, scale=None, shift=None, relu=False, residual=None, out=None):
     """Row-wise y = act(x @ W^T * scale + shift) (+ residual) on fp32 MFMA.
     x: (..., K) with contiguous last dim and uniform row stride; returns (..., cout)."""
@@ -327,6 +331,12 @@ def linear(x, wpacked, cout, scale=None, shift=None, relu=False, residual=None, 
             _lib.check(_lib.lib().ptt_rows_gemm_f32(_ptr(x2), rows, K, x2.stride(0), None, None, _ptr(wpacked), int(cout), _ptr(shift),
                                                     1 if relu else 0, _ptr(r2), r2.stride(0) if r2 is not None else int(cout),
                                                     _ptr(o2), int(cout), None, 0, _stream()), "ptt_rows_gemm_f32")
+        return out
+    # at most 1024 rows of >= 192 channels (the launches of ONE tracklet frame): K split over the waves of a workgroup
+    # (ptt_row_jobs_f32) — 128 x 512 -> 512: 9.0 against 12.8 us, 1024 x 512 -> 512: 10.9 against 13.1
+    # (profiles/r04a_launch_floor.log); wider or shorter-K launches stay on the kernels below
+    if rows <= ROW_JOB_MAX_ROWS and 192 <= K <= 1024 and o2.stride(1) == 1:
+        row_jobs([row_job(wpacked, cout, x=x2, scale=scale, shift=shift, act=1 if relu else 0, res=r2, out=o2)])
         return out
     with torch.cuda.device(x.device), _timed('ptt_linear_f32'):
         _lib.check(_lib.lib().ptt_linear_f32(
@@ -1182,3 +1192,88 @@ def pt_attn_train_bwd(attn, vf, knn, pos, dres, scale):
         _lib.check(_lib.lib().ptt_pt_attn_train_bwd_f32(_ptr(attn), _ptr(vf), _ptr(knn), _ptr(pos), _ptr(dres), B, N, k, D, float(scale),
                                                         _ptr(da), _ptr(dvp), _stream()), "ptt_pt_attn_train_bwd_f32")
     return da, dvp
+
+
+# --------------------------------------------------------------------------- row jobs (one tracklet frame's launch chain)
+def _rows2(t, name):
+    """(..., C) float32 device tensor -> its (rows, C) view with unit column stride and a uniform row stride."""
+    if t is None:
+        return None
+    if not t.is_cuda or t.dtype != torch.float32:
+        raise RuntimeError("%s must be a float32 device tensor" % name)
+    t2 = t.reshape(-1, t.shape[-1])
+    if t2.shape[1] > 1 and t2.stride(1) != 1:
+        raise RuntimeError("%s must have unit column stride" % name)
+    return t2
+
+
+def _ld(t2):
+    return int(t2.stride(0)) if t2.shape[0] > 1 else max(int(t2.shape[1]), int(t2.stride(0)))
+
+
+def row_job(wpacked, cout, x=None, x2=None, scale=None, shift=None, act=0, res=None, res2=None, res_split=0, out=None,
+            out2=None, out_split=0, out_col0=0, raw=None, rel=None, w1=None, qkv=None, knn=None, pos=None, q_off=0,
+            k_off=0, v_off=0, N=0, sm_scale=1.0, prologue=0, epilogue=0, K=None, col_tiles=0):
+    """One job of ptt_row_jobs_f32 (include/ptt_hip.h: ptt_row_job) from torch tensors; `out` etc. are written in place.
+    Returns (RowJob, tensors kept alive until the launch is enqueued)."""
+    j = _lib.RowJob()
+    keep = [wpacked, scale, shift]
+    j.Wpacked, j.scale, j.shift = wpacked.data_ptr(), (scale.data_ptr() if scale is not None else None), \
+        (shift.data_ptr() if shift is not None else None)
+    j.Cout, j.act, j.prologue, j.epilogue, j.col_tiles = int(cout), int(act), int(prologue), int(epilogue), int(col_tiles)
+    if prologue == 0:
+        x_ = _rows2(x, "x")
+        j.X, j.ldx, j.K1, j.rows = x_.data_ptr(), _ld(x_), x_.shape[1], x_.shape[0]
+        j.K = j.K1
+        if x2 is not None:
+            y_ = _rows2(x2, "x2")
+            if y_.shape[0] != x_.shape[0]:
+                raise RuntimeError("x and x2 must have the same number of rows")
+            j.X2, j.ldx2, j.K = y_.data_ptr(), _ld(y_), j.K1 + y_.shape[1]
+            keep.append(y_)
+        keep.append(x_)
+    elif prologue == 1:
+        r_ = _rows2(rel, "rel")
+        if r_.shape[1] != 3 or not r_.is_contiguous() or w1.shape != (int(K), 4) or not w1.is_contiguous():
+            raise RuntimeError("prologue 1: rel (rows,3) and w1 (K,4) contiguous")
+        j.rel, j.w1, j.rows, j.K, j.K1 = r_.data_ptr(), w1.data_ptr(), r_.shape[0], int(K), int(K)
+        keep += [r_, w1]
+    elif prologue == 2:
+        j.rows, j.K, j.K1 = pos.reshape(-1, pos.shape[-1]).shape[0], int(K), int(K)
+    if prologue == 2 or epilogue == 1:
+        q_, p_ = _rows2(qkv, "qkv"), _rows2(pos, "pos")
+        if knn.dtype != torch.int32 or not knn.is_contiguous() or knn.shape[-1] != 16:
+            raise RuntimeError("knn must be a contiguous (points,16) int32 tensor")
+        j.qkv, j.ldq, j.knn, j.pos, j.ldp = q_.data_ptr(), _ld(q_), knn.data_ptr(), p_.data_ptr(), _ld(p_)
+        j.q_off, j.k_off, j.v_off, j.N, j.sm_scale = int(q_off), int(k_off), int(v_off), int(N), float(sm_scale)
+        keep += [q_, p_, knn]
+    o_ = _rows2(out, "out")
+    j.out, j.ldo, j.out_split, j.out_col0 = o_.data_ptr(), _ld(o_), int(out_split), int(out_col0)
+    keep.append(o_)
+    if out2 is not None:
+        o2 = _rows2(out2, "out2")
+        j.out2, j.ldo2 = o2.data_ptr(), _ld(o2)
+        keep.append(o2)
+    if raw is not None:
+        r2 = _rows2(raw, "raw")
+        j.raw, j.ldraw = r2.data_ptr(), _ld(r2)
+        keep.append(r2)
+    j.res_split = int(res_split)
+    if res is not None:
+        r_ = _rows2(res, "res")
+        j.res, j.ldr = r_.data_ptr(), _ld(r_)
+        keep.append(r_)
+    if res2 is not None:
+        r_ = _rows2(res2, "res2")
+        j.res2, j.ldr2 = r_.data_ptr(), _ld(r_)
+        keep.append(r_)
+    return j, keep
+
+
+def row_jobs(jobs):
+    """Launch up to 4 independent row jobs (from row_job) as ONE kernel on the current stream."""
+    n = len(jobs)
+    arr = (_lib.RowJob * n)(*[j for j, _ in jobs])
+    dev = jobs[0][1][0].device
+    with torch.cuda.device(dev), _timed('ptt_linear_f32'):
+        _lib.check(_lib.lib().ptt_row_jobs_f32(arr, n, _stream()), "ptt_row_jobs_f32")

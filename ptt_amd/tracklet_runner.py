@@ -72,6 +72,7 @@ class TrackletRunner(object):
         self._graph = None
         self._done = torch.cuda.Event()
         self.stream = None                                           # run_overlapped gives every runner its own stream
+        self.profile = None       # set to {} before run(): per-frame host_pre / device / host_post milliseconds are appended
 
     # ------------------------------------------------------------------ device buffers of one group of tracklets
     def _load(self, tracklets):
@@ -170,7 +171,16 @@ class TrackletRunner(object):
         self._done.record(torch.cuda.current_stream(self.device))
         self._done.synchronize()
 
+        prof = self.profile
+        if prof is not None:
+            import time
+            for k in ('host_pre_ms', 'device_ms', 'host_post_ms', 'frame_ms'):
+                prof.setdefault(k, [])
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         for i in range(1, T):
+            if prof is not None:
+                t_a = time.perf_counter()
+                ev0.record(torch.cuda.current_stream(self.device))
             active = (i < lengths).astype(np.int32)
             # both crops of frame i are taken around the previous RESULT box (prepare_search :156-157, prepare_template
             # :189-194 with results_BBs[frame_id - 1]); a finished tracklet's later frames have n_points 0
@@ -181,8 +191,13 @@ class TrackletRunner(object):
             self.result_host.copy_(rows, non_blocking=True)
             self.info_host.copy_(self.info, non_blocking=True)
             self._done.record(torch.cuda.current_stream(self.device))
+            if prof is not None:
+                ev1.record(torch.cuda.current_stream(self.device))
+                t_b = time.perf_counter()
             yield i
             self._done.synchronize()
+            if prof is not None:
+                t_c = time.perf_counter()
             est = self.result_host.numpy()                        # (B,5) float32: x, y, z, theta (degrees), score
             info = self.info_host.numpy()
             # post_process (:266-274): box_i = get_box_by_offset(box_{i-1}, best proposal, USE_Z_AXIS). An implausibly
@@ -195,6 +210,13 @@ class TrackletRunner(object):
             rng_pos = np.where(used > 0, used, rng_pos).astype(np.int64)
             ops.track_box_by_offset(boxes, est, self.use_z, active, rng_pos)
             history.append((active, boxes['center'].copy(), boxes['quat'].copy(), est[:, 4].copy()))
+            if prof is not None:
+                t_d = time.perf_counter()
+                ev1.synchronize()
+                prof['host_pre_ms'].append((t_b - t_a) * 1e3)        # crop bounds, job upload, enqueue of the frame's launches
+                prof['device_ms'].append(ev0.elapsed_time(ev1))      # crop + resample + model graph + read-back, on the device
+                prof['host_post_ms'].append((t_d - t_c) * 1e3)       # float64 box update, history
+                prof['frame_ms'].append((t_d - t_a) * 1e3)
         # per-tracklet result lists, assembled once (three array copies per step instead of 3 x B small ones)
         results = []
         for b in range(n):

@@ -1,0 +1,46 @@
+#!/bin/bash
+# Round-4 metered GPU sessions, one function per gpurun call:  gpurun -- 'bash scripts/gpu_sessions_r04.sh <name>'
+# Everything is written under gpurun_out/r04<name>/.
+set -u
+S=${1:?session name}
+O=gpurun_out/r04$S
+mkdir -p $O
+REPO=$(pwd)
+
+ktrace() {   # ktrace <out csv> <cmd...>: rocprofv3 kernel trace + stats of a command, summary copied to $O
+    out=$1; shift
+    (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/kt_$$ && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$$ -- "$@" \
+        > $REPO/$O/$out.stdout 2> $REPO/$O/$out.stderr; f=$(find /tmp/kt_$$ -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $REPO/$O/$out.csv)
+}
+
+case $S in
+d)  # the one-frame launch chain on row jobs: parity, then where a tracklet frame's time is
+    timeout 900 python -m pytest tests -x -q -m gpu > $O/pytest.log 2>&1; tail -25 $O/pytest.log
+    timeout 300 python scripts/tracklet_b1_profile.py > $O/b1.log 2>&1; grep -v amdgpu.ids $O/b1.log
+    ktrace b1_kernel_stats python $REPO/scripts/tracklet_b1_profile.py
+    python - <<PY
+import csv
+rows = list(csv.DictReader(open("$O/b1_kernel_stats.csv")))
+tot = sum(float(r['TotalDurationNs']) for r in rows)
+for r in rows[:40]:
+    print("%-100s %6d %8.1fus %5.1f%%" % (r['Name'][:100], int(r['Calls']), float(r['AverageNs']) / 1e3, float(r['TotalDurationNs']) / tot * 100))
+PY
+    ;;
+e)  # row-job kernel after the per-launch specialisation: unit tests, launch-floor probe, one tracklet
+    timeout 600 python -m pytest tests/test_rowjobs_gpu.py tests/test_golden_gpu.py tests/test_tracking_gpu.py -x -q -m gpu > $O/pytest.log 2>&1; tail -5 $O/pytest.log
+    timeout 600 python scripts/probes/launch_floor_probe.py > $O/launch_floor.log 2>&1; grep -v amdgpu.ids $O/launch_floor.log
+    timeout 300 python scripts/tracklet_b1_profile.py > $O/b1.log 2>&1; grep -v amdgpu.ids $O/b1.log
+    ;;
+f)  # the default bench line (the driver's command), CPU baseline skipped
+    timeout 900 python bench.py --no-cpu-baseline > $O/bench.json 2> $O/bench.err; tail -3 $O/bench.err
+    python - <<PY
+import json
+d = json.load(open("$O/bench.json"))
+print(d["value"], d["ms_per_step"], d["roofline"]["frac"])
+print(json.dumps(d["latency_b1"], indent=1))
+for k, v in d.get("workloads", {}).items():
+    print(k, v.get("value"), v.get("ms_per_step"), v.get("error"))
+PY
+    ;;
+*)  echo "unknown session $S"; exit 2;;
+esac
