@@ -182,6 +182,25 @@ typedef struct ptt_sa_layer {
 int ptt_rows_mlp_f32(const float* X, int rows, int K, int ldx, const ptt_sa_layer* layers, int n_layers,
                      const float* residual, int ldr, float* out, int ldo, ptt_stream_t stream);
 
+/* Point jobs (round 4): the centre selections + ball queries of several set-abstraction levels and one kNN in ONE launch — the
+ * index ops between the level-0 furthest point sampling and the first SharedMLP of one tracklet frame
+ * (pointnet2_modules.py:68-83 for three levels, transformer_block/variants.py:150-151). Every job reads the RAW clouds
+ * xyz (B,Nraw,3): centre m of cloud b is raw[centre_sel[b][m]] (NULL: raw[m]), point k is raw[point_sel[b][k]] (NULL:
+ * raw[k]), k < Npts; with 'sequence' sampling above level 0 both selections of every level are prefixes of the level-0
+ * sample indices, so the levels do not depend on each other.
+ *   kind 0  ball query: new_xyz (B,M,3), idx64_out (B,M) = the centres' raw indices or NULL, idx_out (B,M,nsample) = positions
+ *           k inside the level's points — the results of ptt_centres_ball_query_f32 on the level's own point tensor;
+ *   kind 1  kNN of the Npts <= 128 points among themselves (M == Npts): idx_out (B,Npts,nsample), rel_out (B,Npts,nsample,3)
+ *           or NULL — the results of ptt_knn_rel_f32 on the points' own tensor. */
+#define PTT_POINT_JOBS_MAX 4
+typedef struct ptt_point_job {
+    const float* xyz; const int32_t* centre_sel; const int32_t* point_sel;
+    float* new_xyz; int64_t* idx64_out; int32_t* idx_out; float* rel_out;
+    int32_t kind, sel_ld, B, Nraw, Npts, M, nsample;
+    float radius;
+} ptt_point_job;
+int ptt_point_jobs_f32(const ptt_point_job* jobs, int n_jobs, ptt_stream_t stream);
+
 /* ---------------------------------------------------------------------------------
  * Row jobs (round 4): up to PTT_ROW_JOBS_MAX independent row-wise layers in ONE launch, each
  *     out = act(A @ W^T * scale + shift) (+ residual)
@@ -203,6 +222,14 @@ int ptt_rows_mlp_f32(const float* X, int rows, int K, int ldx, const ptt_sa_laye
  *   epilogue 1  res_i = sum_j softmax_j(y_ij * sm_scale) * (v[knn_ij] + pos_ij)   variants.py:161-163 — the 32 rows
  *               of a tile are the 16 neighbours of two points, so the softmax over neighbours is local to the
  *               accumulator tile (the per-column bias cancels and is not read); out (points, Cout).
+ *   prologue 3  A[(c,j),:] = act0(term[idx_cj,:] + Wx . (xyz[idx_cj] - centre_c)(/radius)): the grouped input of a
+ *               set-abstraction level whose first convolution is hoisted to one row per POINT (ptt_sa_desc.l0_point_term;
+ *               QueryAndGroup + SharedMLP layer 0, pointnet2_utils.py:320-361, pytorch_utils.py:12-36): X = term
+ *               (B*N rows, ldx), idx (B,M,ns) from the ball query, wx (3,K), act0 = ReLU when pro_relu;
+ *   epilogue 2  out[c,:] = act(max_j y_cj): the max-pool over the ns = 16 or 32 neighbours of a centre
+ *               (F.max_pool2d, pointnet2_modules.py:85-87), local to the 32-row accumulator tile; out (B*M, Cout).
+ *               Prologue 3 -> layer 1, then a plain layer with epilogue 2 = vote_aggregation (box_voting_head.py:75-79) in two
+ *               launches of 1024 rows over the chip, where the fused SA kernel is 16 workgroups at one frame.
  *   act         0 none, 1 ReLU, 2 sigmoid (`raw`, if given, receives the value before the activation:
  *               pred_centroids_cls beside its sigmoid, centroids_voting_head.py:84,92-94)
  *   residual    out column c >= res_split adds res[row*ldr + c - res_split], c < res_split adds
@@ -229,6 +256,9 @@ typedef struct ptt_row_job {
     int32_t prologue, epilogue, ldq, q_off, k_off, v_off, ldp, N;
     float sm_scale;
     int32_t col_tiles;                                 /* 0: the library picks 1, 2 or 4 by launch size */
+    const int32_t* idx; const float* xyz; const float* centres; const float* wx;   /* prologue 3 */
+    float radius;
+    int32_t ns, M, normalize_xyz, pro_relu;            /* prologue 3 / epilogue 2: neighbours per centre, centres per cloud */
 } ptt_row_job;
 int ptt_row_jobs_f32(const ptt_row_job* jobs, int n_jobs, ptt_stream_t stream);
 

@@ -38,7 +38,7 @@ EXPORTS = [
     "ptt_bn_update_running_f32", "ptt_xcorr_z0_f32", "ptt_xcorr_z0_bwd_workspace", "ptt_xcorr_z0_bwd_f32",
     "ptt_bn_stats_train_f32", "ptt_bn_finish_partials_train_f32", "ptt_pack_weights_f32",
     "ptt_sa_z0_rows_f32",
-    "ptt_row_jobs_f32",
+    "ptt_row_jobs_f32", "ptt_point_jobs_f32",
 ]
 PTT_MAX_SEGMENTS = 4
 
@@ -80,7 +80,16 @@ class RowJob(Structure):
                 ("act", c_int32), ("res_split", c_int32), ("ldr", c_int32), ("ldr2", c_int32), ("out_split", c_int32),
                 ("out_col0", c_int32), ("ldo", c_int32), ("ldo2", c_int32), ("ldraw", c_int32),
                 ("prologue", c_int32), ("epilogue", c_int32), ("ldq", c_int32), ("q_off", c_int32), ("k_off", c_int32),
-                ("v_off", c_int32), ("ldp", c_int32), ("N", c_int32), ("sm_scale", c_float), ("col_tiles", c_int32)]
+                ("v_off", c_int32), ("ldp", c_int32), ("N", c_int32), ("sm_scale", c_float), ("col_tiles", c_int32),
+                ("idx", c_void_p), ("xyz", c_void_p), ("centres", c_void_p), ("wx", c_void_p), ("radius", c_float),
+                ("ns", c_int32), ("M", c_int32), ("normalize_xyz", c_int32), ("pro_relu", c_int32)]
+
+
+class PointJob(Structure):
+    """ptt_point_job: one ball-query level or kNN of ptt_point_jobs_f32."""
+    _fields_ = [("xyz", c_void_p), ("centre_sel", c_void_p), ("point_sel", c_void_p), ("new_xyz", c_void_p), ("idx64_out", c_void_p),
+                ("idx_out", c_void_p), ("rel_out", c_void_p), ("kind", c_int32), ("sel_ld", c_int32), ("B", c_int32),
+                ("Nraw", c_int32), ("Npts", c_int32), ("M", c_int32), ("nsample", c_int32), ("radius", c_float)]
 
 
 class SaLayer(Structure):
@@ -192,6 +201,7 @@ def _declare(lib):
         "ptt_bn_bwd_pooled_sums_f64": [vp, i, vp, i, vp, i, vp, vp, i, i, vp, vp, c_size_t, vp, vp, vp],
         "ptt_bn_bwd_pooled_apply_f32": [vp, i, vp, i, vp, i, vp, vp, vp, vp, vp, vp, i, i, vp, i, vp, vp, vp],
         "ptt_row_jobs_f32": [POINTER(RowJob), i, vp],
+        "ptt_point_jobs_f32": [POINTER(PointJob), i, vp],
     }
     for name, args in sigs.items():
         fn = getattr(lib, name)

@@ -509,6 +509,99 @@ __global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ xyz,
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Point jobs (round 4): the ball queries of SEVERAL set-abstraction levels and a kNN in ONE launch, for the launch chain of one
+// tracklet frame. With 'sequence' sampling (tools/cfgs/kitti_models/ptt.yaml:42) the points of level l + 1 are the first
+// centres of level l, i.e. raw[sel[k]] for the level-0 sample indices `sel`: every level's centres and points can be read
+// from the RAW cloud through `sel`, so no level waits for the centre coordinates another workgroup of the same launch
+// writes. A wave owns one centre (ball query: centre selection + sweep as centres_ball_query_kernel<1>) or one query point
+// (kNN as knn_kernel); same arithmetic, same index order, same results as the per-level launches.
+// ------------------------------------------------------------------------------------------
+struct PointJobDev {
+    const float* xyz;           // raw clouds (B, Nraw, 3)
+    const int32_t* csel;        // (B, sel_ld) centre / query selection, NULL = identity
+    const int32_t* psel;        // (B, sel_ld) point selection, NULL = identity
+    float* new_xyz; long long* idx64; int32_t* idx_out; float* rel_out;
+    int kind, sel_ld, B, Nraw, Npts, M, ns, wave0;
+    float r2;
+};
+struct PointJobs { PointJobDev j[PTT_POINT_JOBS_MAX]; int n; };
+
+__global__ __launch_bounds__(256) void point_jobs_kernel(PointJobs P) {
+    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    int ji = 0;
+#pragma unroll
+    for (int i = 1; i < PTT_POINT_JOBS_MAX; ++i)
+        if (i < P.n && gw >= P.j[i].wave0) ji = i;
+    const PointJobDev& J = P.j[ji];
+    const int c = gw - J.wave0;                          // centre / query of this wave inside the job
+    if (c >= J.B * J.M) return;
+    const int lane = threadIdx.x & 63;
+    const int b = c / J.M, m = c - b * J.M;
+    const float* __restrict__ raw = J.xyz + (size_t)b * J.Nraw * 3;
+    const int32_t* __restrict__ cs = J.csel ? J.csel + (size_t)b * J.sel_ld : nullptr;
+    const int32_t* __restrict__ ps = J.psel ? J.psel + (size_t)b * J.sel_ld : nullptr;
+    const int nc = cs ? cs[m] : m;
+    const float cx = raw[3 * nc + 0], cy = raw[3 * nc + 1], cz = raw[3 * nc + 2];
+    if (J.kind == 0) {
+        if (lane == 0) {
+            J.new_xyz[(size_t)c * 3 + 0] = cx; J.new_xyz[(size_t)c * 3 + 1] = cy; J.new_xyz[(size_t)c * 3 + 2] = cz;
+            if (J.idx64) J.idx64[c] = nc;
+        }
+        int32_t* __restrict__ out = J.idx_out + (size_t)c * J.ns;
+        int cnt = 0, first = 0;
+        for (int base = 0; base < J.Npts && cnt < J.ns; base += 64) {
+            const int k = base + lane;
+            const bool in = k < J.Npts;
+            const int pi = in ? (ps ? ps[k] : k) : 0;
+            const float d = sqdist3(cx, cy, cz, raw[3 * pi + 0], raw[3 * pi + 1], raw[3 * pi + 2]);
+            const bool hit = in && d < J.r2;
+            const unsigned long long mask = __ballot(hit);
+            if (mask != 0ull) {
+                if (cnt == 0) first = base + (__ffsll((long long)mask) - 1);
+                const int pos = cnt + __popcll(mask & ((1ull << lane) - 1ull));
+                if (hit && pos < J.ns) out[pos] = k;
+                cnt += __popcll(mask);
+            }
+        }
+        const int fill = cnt > 0 ? first : 0;
+        for (int s2 = cnt + lane; s2 < J.ns; s2 += 64) out[s2] = fill;
+        return;
+    }
+    // kNN among the job's Npts (<= 128) points; the query is point m of them (M == Npts)
+    float d[2];
+    float px[2], py[2], pz[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int k = lane + i * 64;
+        const int pi = k < J.Npts ? (ps ? ps[k] : k) : 0;
+        px[i] = raw[3 * pi + 0]; py[i] = raw[3 * pi + 1]; pz[i] = raw[3 * pi + 2];
+        d[i] = k < J.Npts ? sqdist3(cx, cy, cz, px[i], py[i], pz[i]) : __builtin_inff();
+    }
+    int32_t* __restrict__ out = J.idx_out + (size_t)c * J.ns;
+    for (int r = 0; r < J.ns; ++r) {
+        float best = __builtin_inff();
+        int besti = INT_MAX;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int k = lane + i * 64;
+            if (k < J.Npts && d[i] < best) { best = d[i]; besti = k; }
+        }
+        const float wmin = wave_min_f32(best);
+        const int sel = wave_min_i32((best == wmin) ? besti : INT_MAX);
+        if (lane == 0) out[r] = sel;
+        if (J.rel_out && lane == (sel & 63)) {
+            const int i = sel >> 6;
+            float* ro = J.rel_out + ((size_t)c * J.ns + r) * 3;
+            ro[0] = cx - (i ? px[1] : px[0]); ro[1] = cy - (i ? py[1] : py[0]); ro[2] = cz - (i ? pz[1] : pz[0]);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            if (lane + i * 64 == sel) d[i] = __builtin_nanf("");
+    }
+}
+
 }  // namespace ptt
 
 using namespace ptt;
@@ -651,6 +744,36 @@ extern "C" int ptt_centres_ball_query_f32(const float* xyz, const int32_t* sel, 
         hipLaunchKernelGGL((centres_ball_query_kernel<1>), dim3((BM + 3) / 4), dim3(256), 0, as_stream(stream), xyz, sel, BM, M,
                            N, radius * radius, nsample, new_xyz, reinterpret_cast<long long*>(idx64_out), idx_out);
     return check_launch("centres_ball_query_kernel");
+}
+
+extern "C" int ptt_point_jobs_f32(const ptt_point_job* jobs, int n_jobs, ptt_stream_t stream) {
+    if (!jobs || n_jobs < 1 || n_jobs > PTT_POINT_JOBS_MAX) return fail(PTT_EINVAL, "ptt_point_jobs_f32: n_jobs=%d (1..%d)", n_jobs, PTT_POINT_JOBS_MAX);
+    PointJobs P;
+    P.n = 0;
+    int waves = 0;
+    for (int i = 0; i < n_jobs; ++i) {
+        const ptt_point_job& j = jobs[i];
+        if (j.B < 0 || j.Nraw <= 0 || j.Npts <= 0 || j.M < 0 || j.nsample <= 0 || (j.kind != 0 && j.kind != 1))
+            return fail(PTT_EINVAL, "ptt_point_jobs_f32: job %d: kind=%d B=%d Nraw=%d Npts=%d M=%d nsample=%d", i, j.kind, j.B, j.Nraw, j.Npts, j.M, j.nsample);
+        if (j.B == 0 || j.M == 0) continue;
+        if (!j.xyz || !j.idx_out || (j.kind == 0 && !j.new_xyz)) return fail(PTT_EINVAL, "ptt_point_jobs_f32: job %d: null pointer", i);
+        if ((j.centre_sel || j.point_sel) && (j.sel_ld < j.M || (j.point_sel && j.sel_ld < j.Npts)))
+            return fail(PTT_EINVAL, "ptt_point_jobs_f32: job %d: sel_ld=%d", i, j.sel_ld);
+        if ((!j.centre_sel && j.M > j.Nraw) || (!j.point_sel && j.Npts > j.Nraw))
+            return fail(PTT_EINVAL, "ptt_point_jobs_f32: job %d: identity selection past the cloud", i);
+        if (j.kind == 1 && (j.Npts > 128 || j.M != j.Npts || j.nsample > j.Npts))
+            return fail(PTT_EUNSUPPORTED, "ptt_point_jobs_f32: job %d: the kNN job takes at most 128 points, every point a query (Npts=%d M=%d k=%d)", i, j.Npts, j.M, j.nsample);
+        PointJobDev& D = P.j[P.n++];
+        D.xyz = j.xyz; D.csel = j.centre_sel; D.psel = j.point_sel; D.new_xyz = j.new_xyz;
+        D.idx64 = reinterpret_cast<long long*>(j.idx64_out); D.idx_out = j.idx_out; D.rel_out = j.rel_out;
+        D.kind = j.kind; D.sel_ld = j.sel_ld; D.B = j.B; D.Nraw = j.Nraw; D.Npts = j.Npts; D.M = j.M; D.ns = j.nsample;
+        D.r2 = j.radius * j.radius;
+        D.wave0 = waves;
+        waves += (j.B * j.M + 3) / 4 * 4;
+    }
+    if (P.n == 0) return PTT_OK;
+    hipLaunchKernelGGL(point_jobs_kernel, dim3(waves / 4), dim3(256), 0, as_stream(stream), P);
+    return check_launch("point_jobs_kernel");
 }
 
 extern "C" int ptt_group_grad_f32(const float* grad_out, const int32_t* idx, int B, int C, int N, int M, int ns,

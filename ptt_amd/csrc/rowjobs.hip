@@ -26,7 +26,7 @@ struct RowJobDev {
 };
 struct RowJobsParams { RowJobDev j[PTT_ROW_JOBS_MAX]; int n; };
 
-template <int PROS, bool EPI1, int PD>
+template <int PROS, int EPIS, int PD>
 __device__ __forceinline__ void rj_body(const RowJobDev& D, float* smem) {
     const ptt_row_job& J = D.j;
     const int t = threadIdx.x, lane = t & 63, half = lane >> 5;
@@ -111,6 +111,53 @@ __device__ __forceinline__ void rj_body(const RowJobDev& D, float* smem) {
                 *reinterpret_cast<f32x4*>(Xs + tr * ldk + c) = o0;
                 *reinterpret_cast<f32x4*>(Xs + (tr + 16) * ldk + c) = o1;
             }
+        } else if ((PROS & 8) && J.prologue == 3) {
+            // A[(c, j), :] = act0(term[n] + wx . rel), n = idx[c, j], rel = (xyz[n] - centre[c]) (/ radius): the arithmetic of
+            // sa_gather_rows (mfma_ops.hip) — true division, the three products added to the term as one fma chain x, y, z
+            const bool ok0 = gr0 < J.rows, ok1 = gr1 < J.rows;
+            const int c0 = ok0 ? gr0 / J.ns : 0, c1 = ok1 ? gr1 / J.ns : 0;
+            const size_t f0 = (size_t)(c0 / J.M) * J.N + (ok0 ? J.idx[gr0] : 0), f1 = (size_t)(c1 / J.M) * J.N + (ok1 ? J.idx[gr1] : 0);
+            float r0[3], r1[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                r0[a] = J.xyz[f0 * 3 + a] - J.centres[(size_t)c0 * 3 + a];
+                r1[a] = J.xyz[f1 * 3 + a] - J.centres[(size_t)c1 * 3 + a];
+                if (J.normalize_xyz) { r0[a] /= J.radius; r1[a] /= J.radius; }
+            }
+            const float* t0 = J.X + f0 * J.ldx;
+            const float* t1 = J.X + f1 * J.ldx;
+            const float lo = J.pro_relu ? 0.f : -__builtin_inff();
+            for (int i0 = 0; i0 < qpr; i0 += 128) {
+                f32x4 va[4][2], wv[4][3];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int c = (i0 + tc + 32 * i) << 2;
+                    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                    const bool in = c < J.K;
+                    va[i][0] = (in && ok0) ? *reinterpret_cast<const f32x4*>(t0 + c) : z;
+                    va[i][1] = (in && ok1) ? *reinterpret_cast<const f32x4*>(t1 + c) : z;
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) wv[i][a] = in ? *reinterpret_cast<const f32x4*>(J.wx + (size_t)a * J.K + c) : z;
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int s = i0 + tc + 32 * i, c = s << 2;
+                    if (s < qpr) {
+                        f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = o0;
+                        if (c < J.K) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const float y0 = __builtin_fmaf(wv[i][2][q], r0[2], __builtin_fmaf(wv[i][1][q], r0[1], __builtin_fmaf(wv[i][0][q], r0[0], va[i][0][q])));
+                                const float y1 = __builtin_fmaf(wv[i][2][q], r1[2], __builtin_fmaf(wv[i][1][q], r1[1], __builtin_fmaf(wv[i][0][q], r1[0], va[i][1][q])));
+                                o0[q] = ok0 ? fmaxf(y0, lo) : 0.f;
+                                o1[q] = ok1 ? fmaxf(y1, lo) : 0.f;
+                            }
+                        }
+                        *reinterpret_cast<f32x4*>(Xs + tr * ldk + c) = o0;
+                        *reinterpret_cast<f32x4*>(Xs + (tr + 16) * ldk + c) = o1;
+                    }
+                }
+            }
         } else if ((PROS & 4) && J.prologue == 2) {
             // A[(i, j), c] = (q_i[c] - k_{knn(i, j)}[c]) + pos_{ij}[c]   (K % 4 == 0, 16-byte aligned rows: checked by the host)
             const int p0 = gr0 >> 4, p1 = gr1 >> 4;
@@ -158,7 +205,7 @@ __device__ __forceinline__ void rj_body(const RowJobDev& D, float* smem) {
     const int col = ct * 32 + (lane & 31);
     const bool has_col = has_ct && col < J.Cout;
     float sc = 1.f, sh = 0.f, resv[16];
-    const bool plain_epi = !(EPI1 && J.epilogue == 1) && ksi == 0 && has_col;
+    const bool plain_epi = !((EPIS & 1) && J.epilogue == 1) && ksi == 0 && has_col;
     if (plain_epi) {
         if (J.scale) sc = J.scale[col];
         if (J.shift) sh = J.shift[col];
@@ -236,7 +283,7 @@ __device__ __forceinline__ void rj_body(const RowJobDev& D, float* smem) {
         }
     }
 
-    if (EPI1 && J.epilogue == 1) {
+    if ((EPIS & 1) && J.epilogue == 1) {
         // rows 0-15 of the tile are the 16 neighbours of point row0 / 16, rows 16-31 those of the next point: registers
         // 8p .. 8p+7 of a lane hold eight of point p's neighbours, lane ^ 32 the other eight. The per-column bias of the
         // layer is the same for all neighbours and cancels in the softmax: it is not read.
@@ -269,6 +316,33 @@ __device__ __forceinline__ void rj_body(const RowJobDev& D, float* smem) {
         return;
     }
     if (!has_col) return;
+    if ((EPIS & 2) && J.epilogue == 2) {
+        // max over the ns = 16 (two centres per tile) or 32 (one) neighbour rows; rows past the end do not take part
+        float best[2] = {-__builtin_inff(), -__builtin_inff()};
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int gr = row0 + tile_row(r, half);
+            const float y = gr < J.rows ? acc[r] * sc + sh : -__builtin_inff();
+            best[r >> 3] = fmaxf(best[r >> 3], y);
+        }
+        if (J.ns == 32) best[0] = fmaxf(best[0], best[1]);
+        best[0] = max_halves(best[0]);
+        best[1] = max_halves(best[1]);
+        if (half == 0) {
+            const int npc = J.ns == 32 ? 1 : 2;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int c = row0 / J.ns + p;
+                if (p < npc && c * J.ns < J.rows) {
+                    float y = best[p];
+                    if (J.act == 1) y = fmaxf(y, 0.f);
+                    else if (J.act == 2) y = 1.0f / (1.0f + __expf(-y));
+                    J.out[(size_t)c * J.ldo + col] = y;
+                }
+            }
+        }
+        return;
+    }
     float* op = col >= J.out_split ? J.out + (col - J.out_split) + J.out_col0 : J.out2 + col;
     const int ldo = col >= J.out_split ? J.ldo : J.ldo2;
 #pragma unroll
@@ -283,17 +357,17 @@ __device__ __forceinline__ void rj_body(const RowJobDev& D, float* smem) {
     }
 }
 
-// PROS: bit p set = some job of the launch has prologue p; EPI1: some job has epilogue 1; PD: weight fragments in flight per
+// PROS: bit p set = some job of the launch has prologue p; EPIS: bit e - 1 set = some job has epilogue e; PD: weight fragments in flight per
 // wave. A launch gets the instantiation that holds only what its jobs use: the all-purpose kernel is ~50 KB of code, and a
 // 5-us kernel pays for every instruction-cache line it has to pull in.
-template <int PROS, bool EPI1, int PD>
+template <int PROS, int EPIS, int PD>
 __global__ __launch_bounds__(512, 1) void rowjobs_kernel(RowJobsParams P) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int ji = 0;
 #pragma unroll
     for (int i = 1; i < PTT_ROW_JOBS_MAX; ++i)
         if (i < P.n && (int)blockIdx.x >= P.j[i].blk0) ji = i;
-    rj_body<PROS, EPI1, PD>(P.j[ji], smem);
+    rj_body<PROS, EPIS, PD>(P.j[ji], smem);
 }
 
 }  // namespace ptt
@@ -322,10 +396,17 @@ extern "C" int ptt_row_jobs_f32(const ptt_row_job* jobs, int n_jobs, ptt_stream_
             if (!j.qkv || !j.knn || !j.pos || j.N <= 0 || (j.K & 3) || (j.ldq & 3) || (j.ldp & 3) || (j.q_off & 3) || (j.k_off & 3) ||
                 !aligned16(j.qkv) || !aligned16(j.pos) || (j.rows & 15))
                 return fail(PTT_EINVAL, "ptt_row_jobs_f32: job %d: prologue 2 needs q|k|v, knn, pos, 16 rows per point and 16-byte aligned rows", i);
+        } else if (j.prologue == 3) {
+            if (!j.X || !j.idx || !j.xyz || !j.centres || !j.wx || j.N <= 0 || j.M <= 0 || j.ns <= 0 || (j.K & 3) || (j.ldx & 3) ||
+                !aligned16(j.X) || !aligned16(j.wx) || (j.normalize_xyz && !(j.radius > 0.f)))
+                return fail(PTT_EINVAL, "ptt_row_jobs_f32: job %d: prologue 3 needs term rows, idx, xyz, centres, wx (16-byte aligned, K %% 4 == 0)", i);
         } else return fail(PTT_EINVAL, "ptt_row_jobs_f32: job %d: prologue %d", i, j.prologue);
         if (j.epilogue == 1) {
             if (!j.qkv || !j.knn || !j.pos || j.N <= 0 || (j.rows & 15) || j.ldo < j.Cout || j.ldp < j.Cout)
                 return fail(PTT_EINVAL, "ptt_row_jobs_f32: job %d: epilogue 1 needs q|k|v, knn, pos and 16 rows per point", i);
+        } else if (j.epilogue == 2) {
+            if ((j.ns != 16 && j.ns != 32) || (j.rows % j.ns) || j.ldo < j.Cout || j.act < 0 || j.act > 2)
+                return fail(PTT_EINVAL, "ptt_row_jobs_f32: job %d: epilogue 2 pools ns = 16 or 32 rows per centre (ns=%d rows=%d)", i, j.ns, j.rows);
         } else if (j.epilogue == 0) {
             if (j.out_split < 0 || j.out_split > j.Cout || (j.out_split > 0 && !j.out2) || j.res_split < 0 || j.res_split > j.Cout ||
                 j.act < 0 || j.act > 2)
@@ -360,23 +441,24 @@ extern "C" int ptt_row_jobs_f32(const ptt_row_job* jobs, int n_jobs, ptt_stream_
     int pros = 0, epi1 = 0, pd = 8;
     for (int i = 0; i < P.n; ++i) {
         pros |= 1 << P.j[i].j.prologue;
-        epi1 |= P.j[i].j.epilogue == 1;
+        epi1 |= P.j[i].j.epilogue ? 1 << (P.j[i].j.epilogue - 1) : 0;
         if (P.j[i].hb & 7) pd = 4;
     }
     hipStream_t s = as_stream(stream);
     int rc = PTT_OK;
     bool done = false;
 #define PTT_RJ_CASE(PR, EP, PDV)                                                                                         \
-    if (!done && (pros & ~(PR)) == 0 && (!epi1 || (EP)) && pd == (PDV)) {                                               \
+    if (!done && (pros & ~(PR)) == 0 && (epi1 & ~(EP)) == 0 && pd == (PDV)) {                                               \
         if ((rc = set_lds_limit(reinterpret_cast<const void*>(rowjobs_kernel<PR, EP, PDV>), lds))) return rc;           \
         hipLaunchKernelGGL((rowjobs_kernel<PR, EP, PDV>), dim3(blocks), dim3(512), lds, s, P);                          \
         done = true;                                                                                                    \
     }
-    PTT_RJ_CASE(1, false, 4) PTT_RJ_CASE(1, false, 8)         // plain layers (K < 512 / K >= 512)
-    PTT_RJ_CASE(3, false, 8)                                  // q|k|v beside fc_delta
-    PTT_RJ_CASE(4, false, 8)                                  // fc_gamma[0] on the pair input
-    PTT_RJ_CASE(1, true, 8)                                   // fc_gamma[2] + softmax / weighted sum
-    PTT_RJ_CASE(7, true, 4) PTT_RJ_CASE(7, true, 8)           // anything else
+    PTT_RJ_CASE(1, 0, 4) PTT_RJ_CASE(1, 0, 8)                 // plain layers (K < 512 / K >= 512)
+    PTT_RJ_CASE(3, 0, 8)                                      // q|k|v beside fc_delta
+    PTT_RJ_CASE(4, 0, 8)                                      // fc_gamma[0] on the pair input
+    PTT_RJ_CASE(1, 1, 8)                                      // fc_gamma[2] + softmax / weighted sum
+    PTT_RJ_CASE(8, 0, 4) PTT_RJ_CASE(1, 2, 4)                 // a set-abstraction level: grouped layer 1, last layer + max-pool
+    PTT_RJ_CASE(15, 3, 4) PTT_RJ_CASE(15, 3, 8)               // anything else
 #undef PTT_RJ_CASE
     return check_launch("rowjobs_kernel");
 }

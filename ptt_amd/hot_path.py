@@ -91,7 +91,8 @@ class FrameHotPath(nn.Module):
     def forward(self, search_points, template_points, inds=None):
         d = self._backbone(search_points, template_points, inds)
         seeds = d['search_seeds']
-        fused = self.centroid_transformer(xyz=seeds, features=d['search_feats'].transpose(1, 2).contiguous())[0]
+        fused = self.centroid_transformer(xyz=seeds, features=d['search_feats'].transpose(1, 2).contiguous(),
+                                          knn=d.pop('search_seeds_knn', None))[0]
         votes, votes_feats = self.bridge(seeds, fused)
         centres, prop_feats, _ = self.vote_aggregation(xyz=votes, features=votes_feats, npoint=self.npoints_box)
         box_feats = self.box_transformer(xyz=centres, features=prop_feats.transpose(1, 2).contiguous())[0]

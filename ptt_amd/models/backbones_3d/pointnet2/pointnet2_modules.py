@@ -141,10 +141,17 @@ class PointnetSAModuleVotes(nn.Module):
         return layers, hoist
 
     # ------------------------------------------------------------------ forward (reference :57-90)
-    def forward(self, xyz: torch.Tensor, features: torch.Tensor, npoint: int, inds: torch.Tensor = None):
+    def forward(self, xyz: torch.Tensor, features: torch.Tensor, npoint: int, inds: torch.Tensor = None, pre=None):
+        """`pre` (an extension of the reference signature, eval mode on a HIP device only): (new_xyz, idx, inds64) of this level
+        already computed by the caller — the backbone forms the ball queries of all three levels of a branch in one launch
+        when it runs one tracklet frame (ops.sa_levels_point_jobs)."""
         fused = self._fusable(xyz, features)
+        if pre is not None and not fused:
+            pre = None
         prefix = inds is None and self.sample_method in ('rs', 'sequence')   # centres = the first npoint points
-        if fused and prefix:
+        if pre is not None:
+            pass
+        elif fused and prefix:
             # 'sequence' indices are constants of (B, npoint): build them once, not four tiny kernels per call
             key = (xyz.size(0), npoint, str(xyz.device))
             if self._arange_cache is None:
@@ -162,7 +169,9 @@ class PointnetSAModuleVotes(nn.Module):
 
         if fused:
             xyz = xyz.contiguous()
-            if prefix:                                   # centres + ball query in one launch
+            if pre is not None:
+                new_xyz, idx, inds64 = pre
+            elif prefix:                                 # centres + ball query in one launch
                 new_xyz, _, idx = ops.centres_ball_query(xyz, None, npoint, self.radius, self.nsample)
             else:
                 new_xyz, inds64, idx = ops.centres_ball_query(xyz, inds.contiguous(), npoint, self.radius, self.nsample)
@@ -173,6 +182,21 @@ class PointnetSAModuleVotes(nn.Module):
                 # rows with a padded stride (the one-frame head hands over 260-float rows) are read in place
                 uniform = rows.stride(2) == 1 and rows.stride(0) == rows.shape[1] * rows.stride(1)
                 term = ops.linear(rows if uniform else rows.contiguous(), wf_packed, c0, None, layers[0][2], relu=False)
+                B, M, ns = xyz.shape[0], npoint, self.nsample
+                if (B * M * ns <= ops.ONE_FRAME_MAX_SA_ROWS and ns in (16, 32) and len(layers) == 3 and c0 % 4 == 0 and c0 >= 192):
+                    # a handful of frames (vote_aggregation at one tracklet frame: 64 centres x 16 neighbours): the fused SA
+                    # kernel would be 16 workgroups with two chained 256 x 256 layers each (41 us); as two row-job launches
+                    # the 1024 grouped rows spread over the chip: layer 1 on rows built while its A tile is staged (term[idx]
+                    # + Wx . rel, ReLU), then layer 2 with the max over the neighbours as its epilogue
+                    L1, L2 = layers[1], layers[2]
+                    h = torch.empty((B * M * ns, L1[4]), dtype=torch.float32, device=xyz.device)
+                    ops.row_jobs([ops.row_job(L1[0], L1[4], prologue=3, x=term, idx=idx, xyz=xyz, centres=new_xyz, wx=wx,
+                                              radius=self.radius, ns=ns, M=M, N=xyz.shape[1], normalize_xyz=self.normalize_xyz,
+                                              pro_relu=relu0, scale=L1[1], shift=L1[2], act=1 if L1[5] else 0, out=h)])
+                    pooled = torch.empty((B, M, L2[4]), dtype=torch.float32, device=xyz.device)
+                    ops.row_jobs([ops.row_job(L2[0], L2[4], x=h, epilogue=2, ns=ns, M=M, scale=L2[1], shift=L2[2],
+                                              act=1 if L2[5] else 0, out=pooled)])
+                    return new_xyz, pooled.transpose(1, 2), inds64
                 new_features = ops.sa_fused_forward(xyz, new_xyz, idx, None, [L[:6] for L in layers[1:]], self.radius, True,
                                                     self.normalize_xyz, point_major_out=True, l0=(term, wx, relu0))
             else:

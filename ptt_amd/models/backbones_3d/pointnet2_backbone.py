@@ -35,6 +35,8 @@ class PointNet2BackboneLight(nn.Module):
         self.cov_final = nn.Conv1d(256, 256, kernel_size=1)
         self.num_point_features = sa.MLPS[-1][-1]
         self._cov_cache = None
+        self.seed_knn = 16          # neighbours of the seeds' kNN formed beside the ball queries at one frame (0: not formed);
+        #                             the tracker sets it to its centroid head's transformer's k
         self.overlap_branches = True
         self._side_stream = None
 
@@ -66,14 +68,49 @@ class PointNet2BackboneLight(nn.Module):
         out = ops.linear(rows, self._cov_cache[1], w.shape[0], None, self._cov_cache[2])
         return out.transpose(1, 2)                              # (B,C,M) view
 
-    def branch_forward(self, pts, npoints: List, inds0=None):
+    def _arange64(self, xyz, n):
+        key = (xyz.size(0), n, str(xyz.device))
+        cache = self.__dict__.setdefault('_arange_cache', {})
+        if key not in cache:
+            cache[key] = torch.arange(n, dtype=torch.int64, device=xyz.device).repeat(xyz.size(0), 1)
+            ops.publish_params(xyz.device)
+        return cache[key]
+
+    def branch_forward(self, pts, npoints: List, inds0=None, want_knn=0):
         """`inds0`: optional precomputed level-0 sample indices (B, npoints[0]) — the SA module accepts
         caller-supplied indices exactly as the reference's does (pointnet2_modules.py:60,76-77); a pipelined
         driver computes them for batch n+1 while batch n is in the dense kernels."""
         xyz, features = self._break_up_pc(pts)
-        xyz, features, inds0 = self.SA_modules[0](xyz=xyz, features=features, npoint=npoints[0], inds=inds0)
-        xyz, features, inds1 = self.SA_modules[1](xyz=xyz, features=features, npoint=npoints[1])
-        xyz, features, inds2 = self.SA_modules[2](xyz=xyz, features=features, npoint=npoints[2])
+        sa = self.model_cfg.SA_CONFIG
+        one_frame = (not self.training and xyz.is_cuda and features is None and len(self.SA_modules) == 3
+                     and xyz.shape[0] * npoints[0] <= 4 * ops.ONE_FRAME_MAX_POINTS
+                     and self.SA_modules[0].sample_method == 'fps'
+                     and all(m.sample_method in ('rs', 'sequence') for m in self.SA_modules[1:])
+                     and npoints[0] >= npoints[1] >= npoints[2] and (not want_knn or npoints[2] <= 128)
+                     and all(m._fusable(xyz, None) for m in self.SA_modules[:1]))
+        knn = None
+        if one_frame:
+            # one tracklet frame: the three ball queries (and the kNN of the seeds, which the centroid head's transformer
+            # needs) in ONE launch right behind the level-0 sampling — with 'sequence' sampling every level's centres and
+            # points are prefixes of the level-0 sample, so nothing waits for the level below (ops.sa_levels_point_jobs)
+            from .pointnet2 import pointnet2_utils
+            xyz = xyz.contiguous()
+            if inds0 is None:
+                inds0 = pointnet2_utils.furthest_point_sample(xyz, npoints[0])
+            inds0 = inds0.to(torch.int32).contiguous()
+            levels, inds64, knn = ops.sa_levels_point_jobs(xyz, inds0, list(npoints), list(sa.RADIUS), list(sa.NSAMPLE),
+                                                           knn_k=want_knn)
+            seq = [None, self._arange64(xyz, npoints[1]), self._arange64(xyz, npoints[2])]
+            xyz, features, inds0 = self.SA_modules[0](xyz=xyz, features=features, npoint=npoints[0], inds=inds0,
+                                                      pre=(levels[0][0], levels[0][1], inds64))
+            xyz, features, inds1 = self.SA_modules[1](xyz=xyz, features=features, npoint=npoints[1],
+                                                      pre=(levels[1][0], levels[1][1], seq[1]))
+            xyz, features, inds2 = self.SA_modules[2](xyz=xyz, features=features, npoint=npoints[2],
+                                                      pre=(levels[2][0], levels[2][1], seq[2]))
+        else:
+            xyz, features, inds0 = self.SA_modules[0](xyz=xyz, features=features, npoint=npoints[0], inds=inds0)
+            xyz, features, inds1 = self.SA_modules[1](xyz=xyz, features=features, npoint=npoints[1])
+            xyz, features, inds2 = self.SA_modules[2](xyz=xyz, features=features, npoint=npoints[2])
         point_features = self._cov_final(features)
         assert inds1.dtype == inds2.dtype == torch.int64, 'index type must be int64, not {}'.format(inds2.dtype)
         if all(m.sample_method in ('rs', 'sequence') for m in self.SA_modules[1:]) and inds0.shape[1] >= npoints[2]:
@@ -82,6 +119,8 @@ class PointNet2BackboneLight(nn.Module):
             inds = inds0[:, :npoints[2]]
         else:
             inds = inds0.gather(1, inds1).gather(1, inds2)
+        if want_knn:
+            return xyz, point_features, inds, knn
         return xyz, point_features, inds
 
     def sample(self, search_points, template_points):
@@ -100,7 +139,7 @@ class PointNet2BackboneLight(nn.Module):
         sa = self.model_cfg.SA_CONFIG
         i_s, i_t = inds if inds is not None else (None, None)
         if not (self.overlap_branches and search_points.is_cuda and not self.training):
-            s_seeds, s_feats, s_inds = self.branch_forward(search_points, sa.NPOINTS_SEARCH, i_s)
+            r = self.branch_forward(search_points, sa.NPOINTS_SEARCH, i_s, want_knn=self.seed_knn)
             t_seeds, t_feats, t_inds = self.branch_forward(template_points, sa.NPOINTS_TEMPLATE, i_t)
         else:
             if self._side_stream is None or self._side_stream.device != search_points.device:
@@ -109,12 +148,17 @@ class PointNet2BackboneLight(nn.Module):
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 t_seeds, t_feats, t_inds = self.branch_forward(template_points, sa.NPOINTS_TEMPLATE, i_t)
-            s_seeds, s_feats, s_inds = self.branch_forward(search_points, sa.NPOINTS_SEARCH, i_s)
+            r = self.branch_forward(search_points, sa.NPOINTS_SEARCH, i_s, want_knn=self.seed_knn)
             main.wait_stream(side)
             for t in (t_seeds, t_feats, t_inds, template_points):
                 t.record_stream(main)
-        return {'search_seeds': s_seeds, 'search_feats': s_feats, 'search_inds': s_inds,
-                'template_seeds': t_seeds, 'template_feats': t_feats, 'template_inds': t_inds}
+        s_seeds, s_feats, s_inds = r[:3]
+        s_knn = r[3] if len(r) > 3 else None
+        out = {'search_seeds': s_seeds, 'search_feats': s_feats, 'search_inds': s_inds,
+               'template_seeds': t_seeds, 'template_feats': t_feats, 'template_inds': t_inds}
+        if s_knn is not None:
+            out['search_seeds_knn'] = s_knn       # extension of the key contract: (knn_idx, rel) of the seeds for the centroid head
+        return out
 
     def forward(self, batch_dict):
         # 'fps_inds' is an extension of the key contract: level-0 sample indices computed ahead by a pipelined driver

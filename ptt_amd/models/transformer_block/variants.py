@@ -96,12 +96,17 @@ class TransformerBlock(nn.Module):
         return P
 
     # xyz: b x n x 3, features: b x n x f
-    def forward(self, xyz, features):
+    def forward(self, xyz, features, knn=None):
+        """`knn` (an extension of the reference signature, used on the fused path only): (knn_idx (B,N,k) int32, rel (B,N,k,3))
+        of `xyz` already formed by the caller — the backbone computes the seeds' neighbours beside its ball queries."""
         if self._fusable(xyz, features):
             P = self._params()
             D = self.d_model
             xyz = xyz.contiguous()
-            knn_idx, rel = ops.knn(xyz, self.k, want_rel=True)
+            if knn is not None and knn[0].shape == (xyz.shape[0], xyz.shape[1], self.k):
+                knn_idx, rel = knn
+            else:
+                knn_idx, rel = ops.knn(xyz, self.k, want_rel=True)
             if xyz.shape[0] * xyz.shape[1] <= PER_LAYER_MAX_POINTS and not self.materialize_attn:
                 # a handful of frames (one tracklet frame: 128 / 64 points): the fused pair kernel's one workgroup per two
                 # points is a 64-workgroup launch of three chained 512 x 512 GEMMs (106 us on 64 of the 256 CUs). Per layer,

@@ -91,9 +91,10 @@ class CentroidVotingHead(VotingHeadTemplate):
         from two tensors, its last convolution adds (xyz | feats) back and writes votes and votes_feats[:, 1:], cla_layer's
         last convolution writes the raw scores and their sigmoid into votes_feats[:, 0]. Nine launches less per frame."""
         seeds = batch_dict['search_seeds'].contiguous()                          # (B,N,3)
+        knn = batch_dict.pop('search_seeds_knn', None)                            # formed by the backbone beside its ball queries
         rows = batch_dict['cosine_feats'].transpose(1, 2).contiguous()            # (B,N,C): a view of point-major storage
         if hasattr(self, 'transformer_block'):
-            rows = self.transformer_block(xyz=seeds, features=rows)[0]
+            rows = self.transformer_block(xyz=seeds, features=rows, knn=knn)[0]
         B, N, C = rows.shape
         dev = rows.device
         cls_xyz = getattr(self.model_cfg, 'CLS_USE_SEARCH_XYZ', False)
@@ -141,6 +142,8 @@ class CentroidVotingHead(VotingHeadTemplate):
         if self._fusable(batch_dict['cosine_feats']):
             if self._one_frame(batch_dict['cosine_feats']):
                 return self._forward_one_frame(batch_dict)
+        batch_dict.pop('search_seeds_knn', None)             # the backbone's hand-over to the one-frame path only
+        if self._fusable(batch_dict['cosine_feats']):
             return self._forward_rows(batch_dict)
         seeds_xyz = batch_dict['search_seeds'].transpose(1, 2).contiguous()      # (B,3,N)
         feats = batch_dict['cosine_feats']                                        # (B,C,N)

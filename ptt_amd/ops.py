@@ -301,6 +301,7 @@ def pack_weight(weight, rot=0):
     return out
 
 
+ONE_FRAME_MAX_SA_ROWS = 4096   # (= 4 frames of vote_aggregation, the batch range of ONE_FRAME_MAX_POINTS) grouped rows (B * npoint * nsample) up to which a hoisted SA level runs as two row-job launches
 ROW_JOB_MAX_ROWS = 1024       # ops.linear hands launches of at most this many rows (and K >= 192) to ptt_row_jobs_f32
 ONE_FRAME_MAX_POINTS = int(os.environ.get("PTT_PT_PER_LAYER_MAX", "512"))   # B * N up to which the modules take the one-frame launch chain
 
@@ -1213,7 +1214,8 @@ def _ld(t2):
 
 def row_job(wpacked, cout, x=None, x2=None, scale=None, shift=None, act=0, res=None, res2=None, res_split=0, out=None,
             out2=None, out_split=0, out_col0=0, raw=None, rel=None, w1=None, qkv=None, knn=None, pos=None, q_off=0,
-            k_off=0, v_off=0, N=0, sm_scale=1.0, prologue=0, epilogue=0, K=None, col_tiles=0):
+            k_off=0, v_off=0, N=0, sm_scale=1.0, prologue=0, epilogue=0, K=None, col_tiles=0, idx=None, xyz=None, centres=None,
+            wx=None, radius=1.0, ns=0, M=0, normalize_xyz=False, pro_relu=False):
     """One job of ptt_row_jobs_f32 (include/ptt_hip.h: ptt_row_job) from torch tensors; `out` etc. are written in place.
     Returns (RowJob, tensors kept alive until the launch is enqueued)."""
     j = _lib.RowJob()
@@ -1240,6 +1242,16 @@ def row_job(wpacked, cout, x=None, x2=None, scale=None, shift=None, act=0, res=N
         keep += [r_, w1]
     elif prologue == 2:
         j.rows, j.K, j.K1 = pos.reshape(-1, pos.shape[-1]).shape[0], int(K), int(K)
+    elif prologue == 3:
+        x_ = _rows2(x, "x (per-point term)")
+        if (idx.dtype != torch.int32 or not idx.is_contiguous() or not xyz.is_contiguous() or not centres.is_contiguous()
+                or not wx.is_contiguous() or tuple(wx.shape) != (3, x_.shape[1])):
+            raise RuntimeError("prologue 3: idx int32, xyz / centres / wx (3,K) contiguous")
+        j.X, j.ldx, j.K, j.K1, j.rows = x_.data_ptr(), _ld(x_), x_.shape[1], x_.shape[1], idx.numel()
+        j.idx, j.xyz, j.centres, j.wx = idx.data_ptr(), xyz.data_ptr(), centres.data_ptr(), wx.data_ptr()
+        j.radius, j.normalize_xyz, j.pro_relu, j.N = float(radius), int(bool(normalize_xyz)), int(bool(pro_relu)), int(N)
+        keep += [x_, idx, xyz, centres, wx]
+    j.ns, j.M = int(ns), int(M)
     if prologue == 2 or epilogue == 1:
         q_, p_ = _rows2(qkv, "qkv"), _rows2(pos, "pos")
         if knn.dtype != torch.int32 or not knn.is_contiguous() or knn.shape[-1] != 16:
@@ -1277,3 +1289,41 @@ def row_jobs(jobs):
     dev = jobs[0][1][0].device
     with torch.cuda.device(dev), _timed('ptt_linear_f32'):
         _lib.check(_lib.lib().ptt_row_jobs_f32(arr, n, _stream()), "ptt_row_jobs_f32")
+
+
+def sa_levels_point_jobs(xyz, inds0, npoints, radii, nsamples, knn_k=0):
+    """The centre selections + ball queries of three set-abstraction levels whose levels 1 and 2 take the FIRST npoints of the
+    level below ('sequence' sampling), and optionally the kNN of the last level's centres, in ONE launch (ptt_point_jobs_f32).
+    xyz (B,N,3), inds0 (B,npoints[0]) int32 level-0 sample indices. Returns ([(new_xyz, idx), ...] per level, inds64 of level 0,
+    (knn_idx, rel) | None) — the tensors ptt_centres_ball_query_f32 / ptt_knn_rel_f32 would produce level by level."""
+    _chk(xyz, "xyz", torch.float32, 3)
+    _chk(inds0, "inds0", torch.int32, 2)
+    B, N, _ = xyz.shape
+    dev = xyz.device
+    n_jobs = len(npoints) + (1 if knn_k else 0)
+    arr = (_lib.PointJob * n_jobs)()
+    levels = []
+    inds64 = torch.empty((B, npoints[0]), dtype=torch.int64, device=dev)
+    n_pts = N
+    for l, (M, r, ns) in enumerate(zip(npoints, radii, nsamples)):
+        new_xyz = torch.empty((B, M, 3), dtype=torch.float32, device=dev)
+        idx = torch.empty((B, M, ns), dtype=torch.int32, device=dev)
+        j = arr[l]
+        j.xyz, j.centre_sel, j.point_sel = xyz.data_ptr(), inds0.data_ptr(), (inds0.data_ptr() if l > 0 else None)
+        j.new_xyz, j.idx64_out, j.idx_out = new_xyz.data_ptr(), (inds64.data_ptr() if l == 0 else None), idx.data_ptr()
+        j.kind, j.sel_ld, j.B, j.Nraw, j.Npts, j.M, j.nsample, j.radius = 0, inds0.shape[1], B, N, n_pts, M, ns, float(r)
+        levels.append((new_xyz, idx))
+        n_pts = M
+    knn = None
+    if knn_k:
+        M = npoints[-1]
+        kidx = torch.empty((B, M, knn_k), dtype=torch.int32, device=dev)
+        rel = torch.empty((B, M, knn_k, 3), dtype=torch.float32, device=dev)
+        j = arr[len(npoints)]
+        j.xyz, j.centre_sel, j.point_sel = xyz.data_ptr(), inds0.data_ptr(), inds0.data_ptr()
+        j.idx_out, j.rel_out = kidx.data_ptr(), rel.data_ptr()
+        j.kind, j.sel_ld, j.B, j.Nraw, j.Npts, j.M, j.nsample, j.radius = 1, inds0.shape[1], B, N, M, M, int(knn_k), 0.0
+        knn = (kidx, rel)
+    with torch.cuda.device(dev), _timed('ptt_ball_query_f32'):
+        _lib.check(_lib.lib().ptt_point_jobs_f32(arr, n_jobs, _stream()), "ptt_point_jobs_f32")
+    return levels, inds64, knn

@@ -42,5 +42,9 @@ for k, v in d.get("workloads", {}).items():
     print(k, v.get("value"), v.get("ms_per_step"), v.get("error"))
 PY
     ;;
+g)  # SA level as row jobs, point jobs: parity, then one tracklet
+    timeout 900 python -m pytest tests -x -q -m gpu > $O/pytest.log 2>&1; tail -25 $O/pytest.log
+    timeout 300 python scripts/tracklet_b1_profile.py > $O/b1.log 2>&1; grep -v amdgpu.ids $O/b1.log
+    ;;
 *)  echo "unknown session $S"; exit 2;;
 esac

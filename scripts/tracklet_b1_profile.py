@@ -14,8 +14,10 @@ tr = synth.tracklet(9000, T)
 runner = TrackletRunner(tracker, dev, batch=1)
 runner.run([(tr[0][:4], tr[1][:4])])
 torch.cuda.synchronize()
-t0 = time.perf_counter(); runner.run([tr]); torch.cuda.synchronize(); dt = time.perf_counter() - t0
-print("B=1 tracklet loop: %.4f ms per frame (%d frames)" % (dt / (T - 1) * 1e3, T - 1))
+loops = []
+for _ in range(5):
+    t0 = time.perf_counter(); runner.run([tr]); torch.cuda.synchronize(); loops.append((time.perf_counter() - t0) / (T - 1) * 1e3)
+print("B=1 tracklet loop: median %.4f ms per frame over 5 passes of %d frames (%s)" % (sorted(loops)[2], T - 1, " ".join("%.4f" % v for v in loops)))
 # the model graph alone, synchronised per frame
 g = runner._graph
 t0 = time.perf_counter()

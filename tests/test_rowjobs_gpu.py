@@ -137,3 +137,69 @@ def test_bad_jobs_are_refused(dev):
         ops.row_jobs([ops.row_job(wp, 32, x=x, out=out)] * 5)                       # more than PTT_ROW_JOBS_MAX
     with pytest.raises(RuntimeError):
         ops.row_jobs([ops.row_job(wp, 32, x=x, out=out, out_split=3)])              # a split without a second output
+
+
+@pytest.mark.parametrize("B,N,M,ns,C", [(1, 128, 64, 16, 256), (2, 100, 33, 16, 256), (1, 256, 40, 32, 192)])
+def test_sa_level_as_two_jobs(dev, B, N, M, ns, C):
+    """A set-abstraction level with its first convolution hoisted (pointnet2_modules.py:57-90 on per-point terms): grouped
+    layer 1 built in the A staging (term[idx] + Wx . rel, ReLU), layer 2 + max over the neighbours in the epilogue."""
+    rs = np.random.RandomState(B * 1000 + M)
+    xyz = rs.uniform(-1, 1, (B, N, 3)).astype(np.float32)
+    centres = xyz[:, :M].copy()
+    idx = rs.randint(0, N, (B, M, ns)).astype(np.int32)
+    term = rs.standard_normal((B, N, C)).astype(np.float32)
+    wx = (rs.standard_normal((3, C)) * 0.5).astype(np.float32)
+    w1, _, b1 = _layer(rs, 256, C)
+    w2, _, b2 = _layer(rs, 256, 256)
+    radius = 0.3
+    d = lambda a: torch.from_numpy(a).double()
+    bi = np.arange(B)[:, None, None]
+    rel = (d(xyz)[bi, idx] - d(centres)[:, :, None, :]) / np.float32(radius)
+    a = (d(term)[bi, idx] + rel @ d(wx)).clamp_min(0)                          # (B,M,ns,C)
+    h = (a @ d(w1).t() + d(b1)).clamp_min(0)
+    ref = (h @ d(w2).t() + d(b2)).max(dim=2)[0].clamp_min(0)                    # (B,M,256)
+    hb = torch.empty((B * M * ns, 256), device=dev)
+    ops.row_jobs([ops.row_job(ops.pack_weight(_t(w1, dev)), 256, prologue=3, x=_t(term, dev), idx=_t(idx, dev), xyz=_t(xyz, dev),
+                              centres=_t(centres, dev), wx=_t(wx, dev), radius=radius, ns=ns, M=M, N=N, normalize_xyz=True,
+                              pro_relu=True, shift=_t(b1, dev), act=1, out=hb)])
+    np.testing.assert_allclose(hb.cpu().numpy(), h.reshape(-1, 256).numpy(), atol=2e-4, rtol=1e-4)
+    out = torch.full((B, M, 256), float('nan'), device=dev)
+    ops.row_jobs([ops.row_job(ops.pack_weight(_t(w2, dev)), 256, x=_t(h.reshape(-1, 256).float().numpy(), dev), epilogue=2, ns=ns, M=M,
+                              shift=_t(b2, dev), act=1, out=out)])
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), **TOL)
+
+
+def test_tile_shape_does_not_change_a_bit(dev):
+    """The K axis is always summed as the same eight-slice tree: col_tiles 1 / 2 / 4 (K split over 8 / 4 / 2 wave groups)
+    give identical bits, so a frame's result does not depend on the batch it is evaluated in."""
+    rs = np.random.RandomState(3)
+    for rows, K, Cout in ((96, 512, 512), (40, 259, 70), (64, 256, 128)):
+        w, sc, sh = _layer(rs, Cout, K)
+        x, wp, shd = _t(rs.standard_normal((rows, K)).astype(np.float32), dev), ops.pack_weight(_t(w, dev)), _t(sh, dev)
+        outs = []
+        for cw in (1, 2, 4):
+            o = torch.empty((rows, Cout), device=dev)
+            ops.row_jobs([ops.row_job(wp, Cout, x=x, shift=shd, act=1, out=o, col_tiles=cw)])
+            outs.append(o)
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+@pytest.mark.parametrize("B,N,npoints,k", [(1, 1024, (512, 256, 128), 16), (3, 512, (256, 128, 64), 0), (2, 300, (150, 100, 40), 16)])
+def test_point_jobs_equal_the_level_by_level_launches(dev, B, N, npoints, k):
+    """ptt_point_jobs_f32 (three ball-query levels + the seeds' kNN in one launch, every level read from the raw cloud through
+    the level-0 sample) == ptt_centres_ball_query_f32 level by level + ptt_knn_rel_f32, bit for bit."""
+    rs = np.random.RandomState(B + N)
+    xyz = _t(rs.uniform(-1.5, 1.5, (B, N, 3)).astype(np.float32), dev)
+    inds0 = ops.furthest_point_sampling(xyz, npoints[0])
+    radii, ns = (0.3, 0.5, 0.7), (32, 32, 32)
+    levels, inds64, knn = ops.sa_levels_point_jobs(xyz, inds0, list(npoints), radii, ns, knn_k=k)
+    pts, sel = xyz, inds0
+    for l in range(3):
+        new_xyz, i64, idx = ops.centres_ball_query(pts, sel, npoints[l], radii[l], ns[l])
+        assert torch.equal(levels[l][0], new_xyz) and torch.equal(levels[l][1], idx)
+        if l == 0:
+            assert torch.equal(inds64, i64)
+        pts, sel = new_xyz, None
+    if k:
+        kidx, rel = ops.knn(pts, k, want_rel=True)
+        assert torch.equal(knn[0], kidx) and torch.equal(knn[1], rel)
