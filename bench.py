@@ -630,9 +630,12 @@ def launches_per_frame(torch, dev, tracker, runner):
                 torch.cuda.synchronize()
         n = sum(1 for e in prof.events() if e.device_type.name in ("CUDA", "PrivateUse1") and "memcpy" not in e.name.lower()
                 and "memset" not in e.name.lower())
-        return {"model_graph": n, "crop_resample": 2, "copies": 3, "total": n + 5,
-                "how": "torch.profiler kernel events of one eager tracker forward + box selection at 1024 + 512 points; the "
-                       "loop adds the crop and resample launches, one job-table upload and two read-backs per frame"}
+        copies = 2 if runner.few else 3
+        return {"model_graph": n, "crop_resample": 2, "copies": copies, "total": n + 2 + copies,
+                "how": "torch.profiler kernel events of one eager tracker forward at 1024 + 512 points (the launches the runner's "
+                       "hipGraph replays); the loop adds the crop and resample launches and two read-backs per frame (proposals, "
+                       "resampling counts) — the crop table rides in the crop launch's arguments and the host takes the arg-max "
+                       "of the proposal scores from the read-back"}
     except Exception as e:                                  # the count is a diagnostic: never take the line down
         return {"error": "%s: %s" % (type(e).__name__, e)}
 

@@ -192,6 +192,12 @@ int ptt_rows_mlp_f32(const float* X, int rows, int K, int ldx, const ptt_sa_laye
  *           k inside the level's points — the results of ptt_centres_ball_query_f32 on the level's own point tensor;
  *   kind 1  kNN of the Npts <= 128 points among themselves (M == Npts): idx_out (B,Npts,nsample), rel_out (B,Npts,nsample,3)
  *           or NULL — the results of ptt_knn_rel_f32 on the points' own tensor. */
+/* One launch for a small FPS-sampled set-abstraction level whose centres then meet in a TransformerBlock (vote_aggregation +
+ * the box head's transformer at one tracklet frame, box_voting_head.py:75-86): ptt_fps_f32 + ptt_centres_ball_query_f32 +
+ * ptt_knn_rel_f32 (of the CENTRES among themselves) with identical results. xyz (B,N<=256,3) -> inds (B,M) i32, inds64 (B,M)
+ * or NULL, new_xyz (B,M,3), idx (B,M,nsample), knn (B,M,k) + rel (B,M,k,3) (k = 0: neither). M <= 128. */
+int ptt_fps_ball_knn_f32(const float* xyz, int B, int N, int M, float radius, int nsample, int k, int32_t* inds,
+                         int64_t* inds64, float* new_xyz, int32_t* idx, int32_t* knn, float* rel, ptt_stream_t stream);
 #define PTT_POINT_JOBS_MAX 4
 typedef struct ptt_point_job {
     const float* xyz; const int32_t* centre_sel; const int32_t* point_sel;
@@ -244,6 +250,8 @@ int ptt_point_jobs_f32(const ptt_point_job* jobs, int n_jobs, ptt_stream_t strea
 #define PTT_ROW_JOBS_MAX 4
 typedef struct ptt_row_job {
     const float* X; const float* X2;
+    const float* Xmax;                                 /* prologue 0, optional: A = max(X, Xmax) element-wise (same rows / stride as X; needs
+                                                          K1 == K, K % 4 == 0, 16-byte aligned rows): the two halves of the split ptt_xcorr_fused_fwd_f32 */
     const float* Wpacked; const float* scale; const float* shift;
     const float* res; const float* res2;
     float* out; float* out2; float* raw;
@@ -316,6 +324,16 @@ typedef struct ptt_xcorr_desc {
     int B, Ns, Nt, C0;
     int n_layers;
     ptt_sa_layer layers[PTT_SA_MAX_LAYERS];
+    /* Split form, for a handful of frames (round 4; B * Ns search points would be as many workgroups: half the chip at one
+     * frame): split != 0 launches TWO workgroups per search point, each with half of the template points, and forms the
+     * cosines inside the kernel (cos_t is not read, ptt_cosine_map_f32 not needed). Half h writes its maxima to
+     * out + h * out_sh (same strides); the maximum over the template axis is the element-wise maximum of the two, taken by
+     * the consumer (ptt_row_job.Xmax). search_feat[b][j][:], templ_feat[b][i][:] with unit channel stride, element strides
+     * s_sb / s_sn / t_sb / t_sn, C channels (C % 4 == 0), eps of F.cosine_similarity; B * Ns % 8 == 0; sim_out NULL. */
+    int32_t split; int64_t out_sh;
+    const float* search_feat; const float* templ_feat;
+    int64_t s_sb, s_sn, t_sb, t_sn;
+    int C; float eps;
 } ptt_xcorr_desc;
 
 int ptt_xcorr_fused_fwd_f32(const ptt_xcorr_desc* d, ptt_stream_t stream);
@@ -383,6 +401,11 @@ typedef struct ptt_crop_job {
 } ptt_crop_job;
 
 int ptt_crop_compact_f32(const ptt_crop_job* jobs_device, int n_jobs, ptt_stream_t stream);
+/* The same crops with the job table in HOST memory, passed by value in the kernel arguments (n_jobs <=
+ * PTT_CROP_JOBS_BY_VALUE_MAX): one tracklet's frame is two crops, and a per-frame host-to-device copy of the table in front
+ * of the launch costs more than the launch. The table is read before the call returns. */
+#define PTT_CROP_JOBS_BY_VALUE_MAX 8
+int ptt_crop_compact_host_f32(const ptt_crop_job* jobs_host, int n_jobs, ptt_stream_t stream);
 
 /* ptt_regularize_f32 — one job = regularize_pc(pc, input_size, istrain=False) (kitti_tracking_utils.py:342-367) on the
  * concatenation of up to PTT_MAX_SEGMENTS compacted crops (get_model :219-236 concatenates the crops of several

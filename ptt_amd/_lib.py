@@ -38,7 +38,7 @@ EXPORTS = [
     "ptt_bn_update_running_f32", "ptt_xcorr_z0_f32", "ptt_xcorr_z0_bwd_workspace", "ptt_xcorr_z0_bwd_f32",
     "ptt_bn_stats_train_f32", "ptt_bn_finish_partials_train_f32", "ptt_pack_weights_f32",
     "ptt_sa_z0_rows_f32",
-    "ptt_row_jobs_f32", "ptt_point_jobs_f32",
+    "ptt_row_jobs_f32", "ptt_point_jobs_f32", "ptt_fps_ball_knn_f32", "ptt_crop_compact_host_f32",
 ]
 PTT_MAX_SEGMENTS = 4
 
@@ -73,7 +73,7 @@ class PackJob(Structure):
 
 class RowJob(Structure):
     """ptt_row_job: one row-wise layer of ptt_row_jobs_f32 (passed by value, host memory)."""
-    _fields_ = [("X", c_void_p), ("X2", c_void_p), ("Wpacked", c_void_p), ("scale", c_void_p), ("shift", c_void_p),
+    _fields_ = [("X", c_void_p), ("X2", c_void_p), ("Xmax", c_void_p), ("Wpacked", c_void_p), ("scale", c_void_p), ("shift", c_void_p),
                 ("res", c_void_p), ("res2", c_void_p), ("out", c_void_p), ("out2", c_void_p), ("raw", c_void_p),
                 ("rel", c_void_p), ("w1", c_void_p), ("qkv", c_void_p), ("knn", c_void_p), ("pos", c_void_p),
                 ("rows", c_int32), ("K", c_int32), ("K1", c_int32), ("ldx", c_int32), ("ldx2", c_int32), ("Cout", c_int32),
@@ -112,7 +112,9 @@ class XcorrDesc(Structure):
                 ("out", c_void_p), ("out_sb", c_int64), ("out_sc", c_int64), ("out_sn", c_int64),
                 ("sim_out", c_void_p),
                 ("B", c_int), ("Ns", c_int), ("Nt", c_int), ("C0", c_int),
-                ("n_layers", c_int), ("layers", SaLayer * PTT_SA_MAX_LAYERS)]
+                ("n_layers", c_int), ("layers", SaLayer * PTT_SA_MAX_LAYERS),
+                ("split", c_int32), ("out_sh", c_int64), ("search_feat", c_void_p), ("templ_feat", c_void_p),
+                ("s_sb", c_int64), ("s_sn", c_int64), ("t_sb", c_int64), ("t_sn", c_int64), ("C", c_int), ("eps", c_float)]
 
 
 class AttnDesc(Structure):
@@ -153,6 +155,7 @@ def _declare(lib):
         "ptt_cosine_map_f32": [vp, c_int64, c_int64, c_int64, vp, c_int64, c_int64, c_int64, i, i, i, i, f, vp, vp],
         "ptt_pt_attn_pair_f32": [POINTER(AttnDesc), vp],
         "ptt_crop_compact_f32": [vp, i, vp],
+        "ptt_crop_compact_host_f32": [vp, i, vp],
         "ptt_regularize_f32": [vp, i, vp, i, vp],
         "ptt_mt19937_fill": [c_uint32, vp, i],
         "ptt_select_box_f32": [vp, i, i, vp, vp, vp],
@@ -202,6 +205,7 @@ def _declare(lib):
         "ptt_bn_bwd_pooled_apply_f32": [vp, i, vp, i, vp, i, vp, vp, vp, vp, vp, vp, i, i, vp, i, vp, vp, vp],
         "ptt_row_jobs_f32": [POINTER(RowJob), i, vp],
         "ptt_point_jobs_f32": [POINTER(PointJob), i, vp],
+        "ptt_fps_ball_knn_f32": [vp, i, i, i, f, i, i, vp, vp, vp, vp, vp, vp, vp],
     }
     for name, args in sigs.items():
         fn = getattr(lib, name)

@@ -1227,6 +1227,9 @@ struct XcorrParams {
     const float* cos_t;   // (B,Ns,Nt) cosine map from cos_map_kernel
     int C0, Nt;
     SaParams sa;     // B, M (= Ns), out strides, ldk, layers (the remaining SharedMLP layers), stagger
+    // split form (a handful of frames): the features of the cosine phase and the pair workspace
+    const float* sfeat; const float* tfeat; long long s_sb, s_sn, t_sb, t_sn; int C; float eps;
+    long long out_sh;               // element offset of the second half's output
 };
 
 // Cosine map of one frame batch: cos_t[b][j][i] = <templ_i, search_j> / (max(|templ_i|, eps) * max(|search_j|, eps))
@@ -1265,13 +1268,22 @@ __global__ __launch_bounds__(256) void cos_map_kernel(CosParams q) {
     }
 }
 
+// SPLIT (a handful of frames: B * Ns <= 512 search points would be as many workgroups, half the chip at one frame): TWO
+// workgroups per search point, each with 32 of the template points (RT = 1), the cosines formed here instead of by
+// cos_map_kernel (one launch less on a latency-bound chain). Each half writes ITS maximum (out + h * out_sh); the consumer
+// takes the element-wise maximum of the two while it stages its operand (ptt_row_job.Xmax) — no atomics, no counters, and
+// relu(max(a, b)) = max(relu(a), relu(b)).
+template <int RT, bool SPLIT>
 __global__ __launch_bounds__(256, 2) void xcorr_fused_kernel(XcorrParams q) {
+    constexpr int ROWS = 32 * RT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const SaParams& p = q.sa;
-    float* Xs = smem;                        // [64][ldk]
-    float* simv = smem + 64 * p.ldk;         // [64] cosine of the current 64 template points with this search point
+    float* Xs = smem;                        // [ROWS][ldk]
+    float* simv = smem + ROWS * p.ldk;       // [ROWS] cosine of the current template points with this search point
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, half = lane >> 5;
-    const int j = logical_block();           // flat search point b*Ns + jj
+    const int npts = p.B * p.M;
+    const int j = SPLIT ? (int)blockIdx.x % npts : logical_block();           // flat search point b*Ns + jj
+    const int hsel = SPLIT ? (int)blockIdx.x / npts : 0;                        // which half of the template points (same XCD: npts % 8 == 0)
     const int b = j / p.M, jj = j - b * p.M;
     stagger_second_slot(p.first_wave, p.stagger);
     SaPre pre;
@@ -1282,16 +1294,34 @@ __global__ __launch_bounds__(256, 2) void xcorr_fused_kernel(XcorrParams q) {
     const int nlast = p.n_layers - 1;
     const SaLayerDev& LL = p.L[nlast];
 
-    for (int i0 = 0; i0 < q.Nt; i0 += 64) {
+    const int ibeg = SPLIT ? hsel * (q.Nt >> 1) : 0, iend = SPLIT ? ibeg + (q.Nt >> 1) : q.Nt;
+    for (int i0 = ibeg; i0 < iend; i0 += ROWS) {
         prefetch_first_block(p.L[0].Wp, p.L[0].scale, p.L[0].shift, p.L[0].NT, w, lane, pre);
-        if (i0) __syncthreads();             // the previous chunk's last GEMM has read Xs / simv
-        // the cosine map of the whole batch is computed once by cos_map_kernel (ptt_cosine_map_f32): 64 values to fetch
-        // here instead of ~340 vector-ALU / load instructions per wave in a phase that runs beside another workgroup's
-        // MFMA stream (and its address registers pushed this kernel over the 256-VGPR bound)
-        if (t < 64) {
-            const float cs = q.cos_t[(unsigned)((b * p.M + jj) * q.Nt + i0 + t)];
-            simv[t] = cs;
-            if (q.sim_out) q.sim_out[(unsigned)((b * q.Nt + i0 + t) * p.M + jj)] = cs;
+        if (i0 != ibeg) __syncthreads();     // the previous chunk's last GEMM has read Xs / simv
+        if constexpr (SPLIT) {
+            // cosines of this chunk's 32 template points with the search point: 8 lanes per template point, 4 channels per
+            // lane and step (unit channel stride, C % 4 == 0: checked by the host), folded with three xor-shuffles
+            const int i = t >> 3, sub = t & 7;
+            const float* a = q.tfeat + (long long)b * q.t_sb + (long long)(i0 + i) * q.t_sn;
+            const float* sv_ = q.sfeat + (long long)b * q.s_sb + (long long)jj * q.s_sn;
+            float dot = 0.f, na = 0.f, ns = 0.f;
+            for (int c = sub * 4; c < q.C; c += 32) {
+                const f32x4 av = *reinterpret_cast<const f32x4*>(a + c), sv = *reinterpret_cast<const f32x4*>(sv_ + c);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { dot += av[k] * sv[k]; na += av[k] * av[k]; ns += sv[k] * sv[k]; }
+            }
+#pragma unroll
+            for (int m = 1; m < 8; m <<= 1) { dot += __shfl_xor(dot, m, 64); na += __shfl_xor(na, m, 64); ns += __shfl_xor(ns, m, 64); }
+            if (sub == 0) simv[i] = dot / (fmaxf(sqrtf(na), q.eps) * fmaxf(sqrtf(ns), q.eps));
+        } else {
+            // the cosine map of the whole batch is computed once by cos_map_kernel (ptt_cosine_map_f32): 64 values to fetch
+            // here instead of ~340 vector-ALU / load instructions per wave in a phase that runs beside another workgroup's
+            // MFMA stream (and its address registers pushed this kernel over the 256-VGPR bound)
+            if (t < ROWS) {
+                const float cs = q.cos_t[(unsigned)((b * p.M + jj) * q.Nt + i0 + t)];
+                simv[t] = cs;
+                if (q.sim_out) q.sim_out[(unsigned)((b * q.Nt + i0 + t) * p.M + jj)] = cs;
+            }
         }
         __syncthreads();
 
@@ -1307,7 +1337,7 @@ __global__ __launch_bounds__(256, 2) void xcorr_fused_kernel(XcorrParams q) {
             const int c4 = t % nq, step = 256 / nq;
             const f32x4 w4 = *reinterpret_cast<const f32x4*>(q.wsim + c4 * 4);
             const float* prow = q.P + ((size_t)(b * q.Nt + i0) * q.C0 + c4 * 4);
-            for (int i = t / nq; i < 64; i += step) {
+            for (int i = t / nq; i < ROWS; i += step) {
                 const f32x4 pv = *reinterpret_cast<const f32x4*>(prow + (unsigned)(i * q.C0));
                 const float cs = simv[i];
                 const f32x2 c2 = {cs, cs};
@@ -1321,7 +1351,7 @@ __global__ __launch_bounds__(256, 2) void xcorr_fused_kernel(XcorrParams q) {
                 const float wsim = q.wsim[c], sc = q.scale0 ? q.scale0[c] : 1.f, sh = q.shift0 ? q.shift0[c] : 0.f;
                 const float* pr = q.P + ((long long)b * q.Nt + i0) * q.C0 + c;
 #pragma unroll 8
-                for (int i = 0; i < 64; ++i) {
+                for (int i = 0; i < ROWS; ++i) {
                     const float v = (pr[(long long)i * q.C0] + wsim * simv[i]) * sc + sh;
                     Xs[i * p.ldk + c] = fmaxf(v, 0.f);
                 }
@@ -1332,15 +1362,15 @@ __global__ __launch_bounds__(256, 2) void xcorr_fused_kernel(XcorrParams q) {
         for (int l = 0; l < nlast; ++l) {
             const SaLayerDev& L = p.L[l];
             const int ctw = (L.NT + 3) >> 2;
-            if (ctw <= 1) sa_layer<64, 1>(p, L, false, Xs, lane, w, j, 1, pre, &p.L[l + 1]);
-            else sa_layer<64, 2>(p, L, false, Xs, lane, w, j, 1, pre, &p.L[l + 1]);
+            if (ctw <= 1) sa_layer<32 * RT, 1, RT>(p, L, false, Xs, lane, w, j, 1, pre, &p.L[l + 1]);
+            else sa_layer<32 * RT, 2, RT>(p, L, false, Xs, lane, w, j, 1, pre, &p.L[l + 1]);
         }
         // ---- last layer: GEMM, then the max over this chunk's 64 template rows into the running max ----
         {
             const bool affine = LL.scale != nullptr;
-            f32x16 acc[2][2];
+            f32x16 acc[RT][2];
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt)
+            for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -1349,7 +1379,7 @@ __global__ __launch_bounds__(256, 2) void xcorr_fused_kernel(XcorrParams q) {
 #pragma unroll
             for (int u = 0; u < 2; ++u)
                 if (w + 4 * u < LL.NT) nvalid = u + 1;
-            gemm_tiles<2, 2, 0>(Xs, p.ldk, LL.nkb, reinterpret_cast<const f32x4*>(LL.Wp), LL.NT, w, nvalid, lane, acc, pre.w);
+            gemm_tiles<RT, 2, 0>(Xs, p.ldk, LL.nkb, reinterpret_cast<const f32x4*>(LL.Wp), LL.NT, w, nvalid, lane, acc, pre.w);
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 if (u >= nvalid) break;
@@ -1357,7 +1387,7 @@ __global__ __launch_bounds__(256, 2) void xcorr_fused_kernel(XcorrParams q) {
                 float sc = 1.f, sh = 0.f;
                 if (affine) { sc = LL.scale[col]; sh = LL.shift ? LL.shift[col] : 0.f; }
 #pragma unroll
-                for (int rt = 0; rt < 2; ++rt) {
+                for (int rt = 0; rt < RT; ++rt) {
                     float m = affine ? acc[rt][u][0] * sc + sh : acc[rt][u][0];
 #pragma unroll
                     for (int r = 1; r < 16; ++r) m = fmaxf(m, affine ? acc[rt][u][r] * sc + sh : acc[rt][u][r]);
@@ -1371,7 +1401,7 @@ __global__ __launch_bounds__(256, 2) void xcorr_fused_kernel(XcorrParams q) {
         for (int u = 0; u < 2; ++u) {
             if (w + 4 * u >= LL.NT) break;
             const int col = (w + 4 * u) * 32 + (lane & 31);
-            p.out[b * p.osb + col * p.osc + jj * p.osm] = LL.relu ? fmaxf(run[u], 0.f) : run[u];
+            p.out[(SPLIT ? hsel * q.out_sh : 0) + b * p.osb + col * p.osc + jj * p.osm] = LL.relu ? fmaxf(run[u], 0.f) : run[u];
         }
     }
 }
@@ -2166,8 +2196,7 @@ extern "C" int ptt_xcorr_fused_fwd_f32(const ptt_xcorr_desc* d, ptt_stream_t str
     if (d->n_layers < 2) return fail(PTT_EUNSUPPORTED, "ptt_xcorr_fused_fwd_f32: needs at least two MFMA layers after layer 0");
     if ((d->C0 % 8) != 0 || d->C0 > 256) return fail(PTT_EUNSUPPORTED, "ptt_xcorr_fused_fwd_f32: C0=%d", d->C0);
     if (d->B == 0) return PTT_OK;
-    if (!d->cos_t || !d->P || !d->w_sim || !d->out)
-        return fail(PTT_EINVAL, "ptt_xcorr_fused_fwd_f32: null pointer (cos_t comes from ptt_cosine_map_f32)");
+    if (!d->P || !d->w_sim || !d->out) return fail(PTT_EINVAL, "ptt_xcorr_fused_fwd_f32: null pointer");
     if ((unsigned long long)d->B * d->Ns * d->Nt >= 0x7fffffffull || (unsigned long long)d->B * d->Nt * d->C0 >= 0x7fffffffull)
         return fail(PTT_EUNSUPPORTED, "ptt_xcorr_fused_fwd_f32: B=%d Ns=%d Nt=%d: 32-bit element offsets — split the batch",
                     d->B, d->Ns, d->Nt);
@@ -2175,6 +2204,7 @@ extern "C" int ptt_xcorr_fused_fwd_f32(const ptt_xcorr_desc* d, ptt_stream_t str
     q.P = d->P; q.wsim = d->w_sim; q.scale0 = d->scale0;
     q.shift0 = d->shift0; q.sim_out = d->sim_out; q.cos_t = d->cos_t;
     q.C0 = d->C0; q.Nt = d->Nt;
+    q.sfeat = q.tfeat = nullptr; q.s_sb = q.s_sn = q.t_sb = q.t_sn = 0; q.C = 0; q.eps = 0.f; q.out_sh = 0;
     SaParams& p = q.sa;
     memset(&p, 0, sizeof(p));
     p.out = d->out; p.osb = d->out_sb; p.osc = d->out_sc; p.osm = d->out_sn;
@@ -2194,10 +2224,26 @@ extern "C" int ptt_xcorr_fused_fwd_f32(const ptt_xcorr_desc* d, ptt_stream_t str
     }
     p.ldk = ((maxk + 7) / 8) * 8 + 4;
     p.first_wave = 1024; p.stagger = 2;
+    if (d->split) {
+        // two workgroups per search point, cosines in the kernel: see xcorr_fused_kernel<1, true>
+        if (!d->search_feat || !d->templ_feat || d->sim_out || (d->C & 3) || (d->s_sb & 3) || (d->s_sn & 3) ||
+            (d->t_sb & 3) || (d->t_sn & 3) || ((reinterpret_cast<uintptr_t>(d->search_feat) | reinterpret_cast<uintptr_t>(d->templ_feat)) & 15) ||
+            ((d->B * d->Ns) & 7) || d->C <= 0)
+            return fail(PTT_EINVAL, "ptt_xcorr_fused_fwd_f32: the split form needs the features (unit channel stride, C %% 4 == 0, 16-byte "
+                                    "aligned rows), B * Ns %% 8 == 0 and no sim_out");
+        q.sfeat = d->search_feat; q.tfeat = d->templ_feat; q.s_sb = d->s_sb; q.s_sn = d->s_sn; q.t_sb = d->t_sb; q.t_sn = d->t_sn;
+        q.C = d->C; q.eps = d->eps; q.out_sh = d->out_sh;
+        const int lds = (32 * p.ldk + 32) * (int)sizeof(float);
+        int rc = set_lds_limit(reinterpret_cast<const void*>(xcorr_fused_kernel<1, true>), lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL((xcorr_fused_kernel<1, true>), dim3(2 * d->B * d->Ns), dim3(256), lds, as_stream(stream), q);
+        return check_launch("xcorr_fused_kernel");
+    }
+    if (!d->cos_t) return fail(PTT_EINVAL, "ptt_xcorr_fused_fwd_f32: null pointer (cos_t comes from ptt_cosine_map_f32)");
     const int lds = (64 * p.ldk + 64) * (int)sizeof(float);
-    int rc = set_lds_limit(reinterpret_cast<const void*>(xcorr_fused_kernel), lds);
+    int rc = set_lds_limit(reinterpret_cast<const void*>(xcorr_fused_kernel<2, false>), lds);
     if (rc) return rc;
-    hipLaunchKernelGGL(xcorr_fused_kernel, dim3(d->B * d->Ns), dim3(256), lds, as_stream(stream), q);
+    hipLaunchKernelGGL((xcorr_fused_kernel<2, false>), dim3(d->B * d->Ns), dim3(256), lds, as_stream(stream), q);
     return check_launch("xcorr_fused_kernel");
 }
 

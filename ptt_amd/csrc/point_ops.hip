@@ -602,6 +602,130 @@ __global__ __launch_bounds__(256) void point_jobs_kernel(PointJobs P) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// One launch for the index ops of a small set-abstraction level that samples with FPS and whose centres then meet in a
+// Point-Transformer block (vote_aggregation + the box head's transformer at one tracklet frame: 128 votes -> 64 proposals,
+// box_voting_head.py:75-86): furthest point sampling, centre selection, ball query and the kNN of the centres among
+// themselves. The cloud (<= 256 points) is copied to LDS; wave 0 of EVERY workgroup runs the cloud's FPS chain (63 dependent
+// iterations at 64 proposals — repeating it per workgroup is cheaper than a second and third launch behind it), then each of
+// the workgroup's waves takes one centre: ball query over the cloud, kNN over the centres. Same arithmetic and tie-breaks as
+// fps_kernel<64,P,true>, centres_ball_query_kernel<1> and knn_kernel: identical indices.
+// ------------------------------------------------------------------------------------------
+struct FbkParams {
+    const float* xyz; int B, N, M, ns, k; float r2;
+    int32_t* inds; long long* inds64; float* new_xyz; int32_t* idx; int32_t* knn; float* rel;
+};
+
+__global__ __launch_bounds__(256) void fps_ball_knn_kernel(FbkParams p) {
+    constexpr int P = 4;                                  // points per lane of the sampling wave: N <= 256
+    __shared__ int sel[128];
+    __shared__ float cl[256 * 3];
+    const int G = (p.M + 3) / 4;
+    const int b = blockIdx.x / G, g = blockIdx.x - b * G;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const float* __restrict__ pts = p.xyz + (size_t)b * p.N * 3;
+    for (int e = t; e < p.N * 3; e += 256) cl[e] = pts[e];
+    __syncthreads();
+    if (wv == 0) {
+        float px[P], py[P], pz[P], md[P];
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            const int kk = lane * P + i;
+            float x = 0.f, y = 0.f, z = 0.f, m = -1.0f;
+            if (kk < p.N) {
+                x = cl[3 * kk + 0]; y = cl[3 * kk + 1]; z = cl[3 * kk + 2];
+                const float mag = (x * x + y * y) + z * z;
+                m = (mag > 1e-3f) ? 1e10f : -1.0f;
+            }
+            px[i] = x; py[i] = y; pz[i] = z; md[i] = m;
+        }
+        float lx = cl[0], ly = cl[1], lz = cl[2];
+        if (lane == 0) sel[0] = 0;
+        for (int j = 1; j < p.M; ++j) {
+            float best = -1.0f;
+            int besti = 0;
+#pragma unroll
+            for (int i = 0; i < P; ++i) {
+                const float d = sqdist3(px[i], py[i], pz[i], lx, ly, lz);
+                const float m = fminf(md[i], d);
+                md[i] = m;
+                const bool take = m > best;              // strict: the lowest index wins ties inside a lane
+                best = take ? m : best;
+                besti = take ? lane * P + i : besti;
+            }
+            const float wmax = wave_max_f32_fused(best);
+            const unsigned long long winners = __ballot(best == wmax);
+            const int src = __ffsll((long long)winners) - 1;
+            int widx = __builtin_amdgcn_readlane(besti, src);
+            if (wmax < 0.f) widx = 0;
+            lx = cl[3 * widx + 0]; ly = cl[3 * widx + 1]; lz = cl[3 * widx + 2];
+            if (lane == 0) sel[j] = widx;
+        }
+    }
+    __syncthreads();
+    if (g == 0)
+        for (int j = t; j < p.M; j += 256) {
+            p.inds[(size_t)b * p.M + j] = sel[j];
+            if (p.inds64) p.inds64[(size_t)b * p.M + j] = sel[j];
+        }
+    const int m = g * 4 + wv;
+    if (m >= p.M) return;
+    const size_t c = (size_t)b * p.M + m;
+    const int nc = sel[m];
+    const float cx = cl[3 * nc + 0], cy = cl[3 * nc + 1], cz = cl[3 * nc + 2];
+    if (lane == 0) { p.new_xyz[c * 3 + 0] = cx; p.new_xyz[c * 3 + 1] = cy; p.new_xyz[c * 3 + 2] = cz; }
+    {   // ball query of centre m over the cloud
+        int32_t* __restrict__ out = p.idx + c * p.ns;
+        int cnt = 0, first = 0;
+        for (int base = 0; base < p.N && cnt < p.ns; base += 64) {
+            const int kk = base + lane;
+            const bool in = kk < p.N;
+            const int pi = in ? kk : 0;
+            const float d = sqdist3(cx, cy, cz, cl[3 * pi + 0], cl[3 * pi + 1], cl[3 * pi + 2]);
+            const bool hit = in && d < p.r2;
+            const unsigned long long mask = __ballot(hit);
+            if (mask != 0ull) {
+                if (cnt == 0) first = base + (__ffsll((long long)mask) - 1);
+                const int pos = cnt + __popcll(mask & ((1ull << lane) - 1ull));
+                if (hit && pos < p.ns) out[pos] = kk;
+                cnt += __popcll(mask);
+            }
+        }
+        const int fill = cnt > 0 ? first : 0;
+        for (int s2 = cnt + lane; s2 < p.ns; s2 += 64) out[s2] = fill;
+    }
+    if (!p.knn) return;
+    float d[2], qx[2], qy[2], qz[2];                      // kNN of centre m among the M <= 128 centres
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int kk = lane + i * 64;
+        const int pi = kk < p.M ? sel[kk] : 0;
+        qx[i] = cl[3 * pi + 0]; qy[i] = cl[3 * pi + 1]; qz[i] = cl[3 * pi + 2];
+        d[i] = kk < p.M ? sqdist3(cx, cy, cz, qx[i], qy[i], qz[i]) : __builtin_inff();
+    }
+    int32_t* __restrict__ ko = p.knn + c * p.k;
+    for (int r = 0; r < p.k; ++r) {
+        float best = __builtin_inff();
+        int besti = INT_MAX;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int kk = lane + i * 64;
+            if (kk < p.M && d[i] < best) { best = d[i]; besti = kk; }
+        }
+        const float wmin = wave_min_f32(best);
+        const int s2 = wave_min_i32((best == wmin) ? besti : INT_MAX);
+        if (lane == 0) ko[r] = s2;
+        if (p.rel && lane == (s2 & 63)) {
+            const int i = s2 >> 6;
+            float* ro = p.rel + (c * p.k + r) * 3;
+            ro[0] = cx - (i ? qx[1] : qx[0]); ro[1] = cy - (i ? qy[1] : qy[0]); ro[2] = cz - (i ? qz[1] : qz[0]);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            if (lane + i * 64 == s2) d[i] = __builtin_nanf("");
+    }
+}
+
 }  // namespace ptt
 
 using namespace ptt;
@@ -744,6 +868,20 @@ extern "C" int ptt_centres_ball_query_f32(const float* xyz, const int32_t* sel, 
         hipLaunchKernelGGL((centres_ball_query_kernel<1>), dim3((BM + 3) / 4), dim3(256), 0, as_stream(stream), xyz, sel, BM, M,
                            N, radius * radius, nsample, new_xyz, reinterpret_cast<long long*>(idx64_out), idx_out);
     return check_launch("centres_ball_query_kernel");
+}
+
+extern "C" int ptt_fps_ball_knn_f32(const float* xyz, int B, int N, int M, float radius, int nsample, int k, int32_t* inds,
+                                    int64_t* inds64, float* new_xyz, int32_t* idx, int32_t* knn, float* rel, ptt_stream_t stream) {
+    if (B < 0 || N <= 0 || M <= 0 || nsample <= 0 || k < 0) return fail(PTT_EINVAL, "ptt_fps_ball_knn_f32: B=%d N=%d M=%d nsample=%d k=%d", B, N, M, nsample, k);
+    if (N > 256 || M > 128 || M > N || k > M)
+        return fail(PTT_EUNSUPPORTED, "ptt_fps_ball_knn_f32: at most 256 points, 128 centres, k <= centres (N=%d M=%d k=%d)", N, M, k);
+    if (B == 0) return PTT_OK;
+    if (!xyz || !inds || !new_xyz || !idx || (k > 0 && !knn)) return fail(PTT_EINVAL, "ptt_fps_ball_knn_f32: null pointer");
+    FbkParams p;
+    p.xyz = xyz; p.B = B; p.N = N; p.M = M; p.ns = nsample; p.k = k; p.r2 = radius * radius;
+    p.inds = inds; p.inds64 = reinterpret_cast<long long*>(inds64); p.new_xyz = new_xyz; p.idx = idx; p.knn = k > 0 ? knn : nullptr; p.rel = rel;
+    hipLaunchKernelGGL(fps_ball_knn_kernel, dim3(B * ((M + 3) / 4)), dim3(256), 0, as_stream(stream), p);
+    return check_launch("fps_ball_knn_kernel");
 }
 
 extern "C" int ptt_point_jobs_f32(const ptt_point_job* jobs, int n_jobs, ptt_stream_t stream) {

@@ -61,6 +61,7 @@ __device__ __forceinline__ void rj_body(const RowJobDev& D, float* smem) {
             const int K1v = D.vecx ? (J.K1 & ~3) : 0, Kz = (J.K + 3) & ~3;
             const float* x0 = J.X + (size_t)gr0 * J.ldx;
             const float* x1 = J.X + (size_t)gr1 * J.ldx;
+            const long long xm = J.Xmax ? J.Xmax - J.X : 0;      // element distance to the second operand of the maximum
             for (int i0 = 0; i0 < qpr; i0 += 128) {
                 f32x4 v[4][2];
 #pragma unroll
@@ -69,6 +70,12 @@ __device__ __forceinline__ void rj_body(const RowJobDev& D, float* smem) {
                     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
                     v[i][0] = (c < K1v && gr0 < J.rows) ? *reinterpret_cast<const f32x4*>(x0 + c) : z;
                     v[i][1] = (c < K1v && gr1 < J.rows) ? *reinterpret_cast<const f32x4*>(x1 + c) : z;
+                    if (xm) {
+                        const f32x4 m0 = (c < K1v && gr0 < J.rows) ? *reinterpret_cast<const f32x4*>(x0 + xm + c) : z;
+                        const f32x4 m1 = (c < K1v && gr1 < J.rows) ? *reinterpret_cast<const f32x4*>(x1 + xm + c) : z;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { v[i][0][q] = fmaxf(v[i][0][q], m0[q]); v[i][1][q] = fmaxf(v[i][1][q], m1[q]); }
+                    }
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -390,6 +397,8 @@ extern "C" int ptt_row_jobs_f32(const ptt_row_job* jobs, int n_jobs, ptt_stream_
         if (j.prologue == 0) {
             if (!j.X || j.K1 <= 0 || j.K1 > j.K || j.ldx < j.K1 || (j.K1 < j.K && (!j.X2 || j.ldx2 < j.K - j.K1)))
                 return fail(PTT_EINVAL, "ptt_row_jobs_f32: job %d: K=%d K1=%d ldx=%d ldx2=%d", i, j.K, j.K1, j.ldx, j.ldx2);
+            if (j.Xmax && (j.K1 != j.K || (j.K & 3) || (j.ldx & 3) || !aligned16(j.X) || !aligned16(j.Xmax)))
+                return fail(PTT_EINVAL, "ptt_row_jobs_f32: job %d: Xmax needs one input of K %% 4 == 0 channels in 16-byte aligned rows", i);
         } else if (j.prologue == 1) {
             if (!j.rel || !j.w1 || !aligned16(j.w1)) return fail(PTT_EINVAL, "ptt_row_jobs_f32: job %d: prologue 1 needs rel and a 16-byte aligned w1", i);
         } else if (j.prologue == 2) {
@@ -454,7 +463,7 @@ extern "C" int ptt_row_jobs_f32(const ptt_row_job* jobs, int n_jobs, ptt_stream_
         done = true;                                                                                                    \
     }
     PTT_RJ_CASE(1, 0, 4) PTT_RJ_CASE(1, 0, 8)                 // plain layers (K < 512 / K >= 512)
-    PTT_RJ_CASE(3, 0, 8)                                      // q|k|v beside fc_delta
+    PTT_RJ_CASE(3, 0, 4) PTT_RJ_CASE(3, 0, 8)                 // q|k|v beside fc_delta
     PTT_RJ_CASE(4, 0, 8)                                      // fc_gamma[0] on the pair input
     PTT_RJ_CASE(1, 1, 8)                                      // fc_gamma[2] + softmax / weighted sum
     PTT_RJ_CASE(8, 0, 4) PTT_RJ_CASE(1, 2, 4)                 // a set-abstraction level: grouped layer 1, last layer + max-pool

@@ -64,9 +64,8 @@ __device__ __forceinline__ int block_rank(bool flag, int* wsum, int& total) {
 
 // One workgroup per crop job: a stable stream compaction over the cloud in chunks of T points.
 template <int T>
-__global__ __launch_bounds__(T) void crop_compact_kernel(const ptt_crop_job* __restrict__ jobs) {
+__device__ __forceinline__ void crop_compact_body(const ptt_crop_job& j) {
     __shared__ int wsum[T / 64];
-    const ptt_crop_job j = jobs[blockIdx.x];
     const float* px = j.points;
     const float* py = j.points + j.ld;
     const float* pz = j.points + 2 * j.ld;
@@ -103,6 +102,12 @@ __global__ __launch_bounds__(T) void crop_compact_kernel(const ptt_crop_job* __r
         written += total;
     }
     if (threadIdx.x == 0) *j.count = written;       // may exceed capacity: the caller sized `out` for n_points
+}
+
+template <int T>
+__global__ __launch_bounds__(T) void crop_compact_kernel(const ptt_crop_job* __restrict__ jobs) {
+    const ptt_crop_job j = jobs[blockIdx.x];
+    crop_compact_body<T>(j);
 }
 
 __device__ __forceinline__ void seg_point(const ptt_regularize_job& j, const int* cnt, int idx, float* dst) {
@@ -203,6 +208,22 @@ extern "C" int ptt_mt19937_fill(uint32_t seed, uint32_t* out_host, int n) {
     if (!out_host || n < 0) return fail(PTT_EINVAL, "ptt_mt19937_fill: null buffer or n=%d", n);
     mt19937_fill(seed, out_host, n);
     return PTT_OK;
+}
+
+// The same crops with the job table passed BY VALUE in the kernel arguments (a handful of jobs: one tracklet's frame is two):
+// no per-frame host-to-device copy of the table in front of the launch.
+struct CropJobsByValue { ptt_crop_job j[PTT_CROP_JOBS_BY_VALUE_MAX]; };
+__global__ __launch_bounds__(1024) void crop_compact_byvalue_kernel(CropJobsByValue P) { ptt::crop_compact_body<1024>(P.j[blockIdx.x]); }
+
+extern "C" int ptt_crop_compact_host_f32(const ptt_crop_job* jobs_host, int n_jobs, ptt_stream_t stream) {
+    if (n_jobs < 0 || n_jobs > PTT_CROP_JOBS_BY_VALUE_MAX)
+        return fail(PTT_EINVAL, "ptt_crop_compact_host_f32: n_jobs=%d (0..%d)", n_jobs, PTT_CROP_JOBS_BY_VALUE_MAX);
+    if (n_jobs == 0) return PTT_OK;
+    if (!jobs_host) return fail(PTT_EINVAL, "ptt_crop_compact_host_f32: null job array");
+    CropJobsByValue P;
+    for (int i = 0; i < n_jobs; ++i) P.j[i] = jobs_host[i];
+    hipLaunchKernelGGL(crop_compact_byvalue_kernel, dim3(n_jobs), dim3(1024), 0, as_stream(stream), P);
+    return check_launch("crop_compact_byvalue_kernel");
 }
 
 extern "C" int ptt_crop_compact_f32(const ptt_crop_job* jobs_device, int n_jobs, ptt_stream_t stream) {

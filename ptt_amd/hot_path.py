@@ -66,6 +66,7 @@ class FrameHotPath(nn.Module):
             radius=sa.RADIUS, nsample=sa.NSAMPLE, mlp=list(sa.MLPS), use_xyz=sa.get('USE_XYZ', True),
             normalize_xyz=sa.get('NORMALIZE_XYZ', True), sample_method=sa.SAMPLE_METHOD)
         self.box_transformer = build_transformer(cfg.BOX_HEAD.TRANSFORMER_BLOCK)
+        self.vote_aggregation.centres_knn_k = self.box_transformer.k
         self.npoints_box = sa.NPOINTS
         # FPS is a latency-bound chain on B workgroups; running the template branch on a second HIP
         # stream lets its kernels fill the CUs the search branch's FPS leaves idle (and vice versa).
@@ -95,7 +96,8 @@ class FrameHotPath(nn.Module):
                                           knn=d.pop('search_seeds_knn', None))[0]
         votes, votes_feats = self.bridge(seeds, fused)
         centres, prop_feats, _ = self.vote_aggregation(xyz=votes, features=votes_feats, npoint=self.npoints_box)
-        box_feats = self.box_transformer(xyz=centres, features=prop_feats.transpose(1, 2).contiguous())[0]
+        box_feats = self.box_transformer(xyz=centres, features=prop_feats.transpose(1, 2).contiguous(),
+                                         knn=self.vote_aggregation.centres_knn)[0]
         d['centroid_feats'] = fused
         d['pred_box_center'] = centres
         d['box_feats'] = box_feats

@@ -46,6 +46,8 @@ class PointnetSAModuleVotes(nn.Module):
         self.sample_method = sample_method
         self._fused_cache = None    # (key, [(wpacked, scale, shift, cin, cout, relu), ...])
         self._arange_cache = None
+        self.centres_knn_k = 0      # > 0: a caller that runs a TransformerBlock on this level's centres (the box head) wants their
+        self.centres_knn = None     #      kNN; at one frame it is formed in the sampling launch and left here (knn_idx, rel)
 
     # ------------------------------------------------------------------ sampling (reference :63-77)
     def _sample(self, xyz, features, npoint):
@@ -148,6 +150,14 @@ class PointnetSAModuleVotes(nn.Module):
         fused = self._fusable(xyz, features)
         if pre is not None and not fused:
             pre = None
+        self.centres_knn = None
+        if (fused and pre is None and inds is None and self.sample_method == 'fps' and xyz.shape[1] <= 256 and npoint <= 128
+                and xyz.shape[0] * npoint * self.nsample <= ops.ONE_FRAME_MAX_SA_ROWS and self.centres_knn_k <= npoint):
+            # a handful of frames (vote_aggregation at one tracklet frame): sampling, centre selection, ball query and the
+            # centres' kNN in ONE launch (ptt_fps_ball_knn_f32) instead of three
+            xyz = xyz.contiguous()
+            inds, inds64, new_xyz, idx, self.centres_knn = ops.fps_ball_knn(xyz, npoint, self.radius, self.nsample, self.centres_knn_k)
+            pre = (new_xyz, idx, inds64)
         prefix = inds is None and self.sample_method in ('rs', 'sequence')   # centres = the first npoint points
         if pre is not None:
             pass

@@ -110,10 +110,27 @@ class CosineSimAug(nn.Module):
             else:
                 rows = torch.cat((template_xyz, trows), dim=2)                                # (B,n1,3+f)
                 pre = ops.linear(rows, P['w_rest'], P['c0'], P['scale0'], P['shift0'])        # (B,n1,C0), BN folded in
-            cos_t = ops.cosine_map(search_feats, template_feats, eps=self.cosine.eps)         # (B,n2,n1), one launch
-            fused, _ = ops.xcorr_fused(search_feats, template_feats, pre, P['w_sim'], None, None,
-                                       P['layers'], eps=self.cosine.eps, cos_t=cos_t)         # (B,C,n2) view
-            y = layer_utils.rows_forward(self.conv, fused.transpose(1, 2))                   # both convolutions, one launch
+            if b * n2 <= ops.ONE_FRAME_MAX_POINTS:
+                # a handful of frames: two workgroups per search point, cosines formed in the kernel (one launch less)
+                fused, _ = ops.xcorr_fused(search_feats, template_feats, pre, P['w_sim'], None, None,
+                                           P['layers'], eps=self.cosine.eps, split=True)      # (B,C,n2) view
+            else:
+                cos_t = ops.cosine_map(search_feats, template_feats, eps=self.cosine.eps)     # (B,n2,n1), one launch
+                fused, _ = ops.xcorr_fused(search_feats, template_feats, pre, P['w_sim'], None, None,
+                                           P['layers'], eps=self.cosine.eps, cos_t=cos_t)     # (B,C,n2) view
+            if fused.dim() == 4:
+                # the split form's two halves: their element-wise maximum (= the max over the template axis) is taken by the
+                # first trailing convolution while it stages its operand
+                L = layer_utils.rows_layers(self.conv)
+                h0, h1 = fused[0].transpose(1, 2), fused[1].transpose(1, 2)                  # (B,n2,C) contiguous rows
+                x = None
+                for li, (wp, cout, scale, shift, relu) in enumerate(L):
+                    y = torch.empty((b, n2, cout), dtype=torch.float32, device=h0.device)
+                    ops.row_jobs([ops.row_job(wp, cout, x=h0 if li == 0 else x, xmax=h1 if li == 0 else None, scale=scale, shift=shift,
+                                              act=1 if relu else 0, out=y)])
+                    x = y
+            else:
+                y = layer_utils.rows_forward(self.conv, fused.transpose(1, 2))               # both convolutions, one launch
             batch_dict['cosine_feats'] = y.transpose(1, 2)                                    # (B,c,n2) view
             return batch_dict
 

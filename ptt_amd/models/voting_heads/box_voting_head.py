@@ -26,6 +26,7 @@ class BoxVotingHead(VotingHeadTemplate):
                              .conv1d(fc[3], activation=None))
         if self.model_cfg.TRANSFORMER_BLOCK.ENABLE:
             self.transformer_block = build_transformer(self.model_cfg.TRANSFORMER_BLOCK)
+            self.vote_aggregation.centres_knn_k = self.transformer_block.k     # the proposals' kNN beside their sampling (one frame)
 
     # ------------------------------------------------------------------ losses (reference :33-66)
     def get_cls_layer_loss(self, forward_ret_dict):
@@ -87,7 +88,7 @@ class BoxVotingHead(VotingHeadTemplate):
             # the layout the caller wants
             rows = feats.transpose(1, 2)                                                         # (B,M,C)
             if hasattr(self, 'transformer_block'):
-                rows = self.transformer_block(xyz=centres, features=rows.contiguous())[0]
+                rows = self.transformer_block(xyz=centres, features=rows.contiguous(), knn=self.vote_aggregation.centres_knn)[0]
             if not self.training and self._one_frame(rows):
                 # a handful of frames: one ptt_row_jobs_f32 launch per refine convolution, the last one adding the proposal
                 # centres to its first three columns (reference :91) and writing pred_box_data directly

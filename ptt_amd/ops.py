@@ -454,11 +454,15 @@ def rows_mlp(x, layers, residual=None):
     return out.view(*x.shape[:-1], cout)
 
 
-def xcorr_fused(search_feats, templ_feats, P, w_sim, scale0, shift0, layers, eps=1e-8, want_sim=False, cos_t=None):
+def xcorr_fused(search_feats, templ_feats, P, w_sim, scale0, shift0, layers, eps=1e-8, want_sim=False, cos_t=None, split=False):
     """Fused CosineSimAug core (similarity_modules/p2b_xcoor.py:25-42): cosine map, concat, SharedMLP, max over
     the template axis. search_feats (B,C,Ns) / templ_feats (B,C,Nt) in any strides; P (B,Nt,C0) = layer-0
     pre-activation without the similarity term; layers = remaining (wpacked, scale, shift, cin, cout, relu).
     cos_t: the (B,Ns,Nt) map of cosine_map() if the caller already has it (else computed here, one launch).
+    split: a handful of frames — two workgroups per search point, cosines inside the kernel (no cosine_map launch); needs
+    point-major features (unit channel stride), B * Ns % 8 == 0, no want_sim; silently the plain form otherwise. The split
+    form returns the two halves' maxima, out (2,B,Cout,Ns) views: the maximum over the template axis is out[0].maximum(out[1])
+    (row_job(x=..., xmax=...) takes it while it stages its operand).
     Returns (out (B,Cout,Ns) as a view of point-major storage, sim (B,Nt,Ns) | None)."""
     for t_, n_ in ((search_feats, "search_feats"), (templ_feats, "templ_feats")):
         if not t_.is_cuda or t_.dtype != torch.float32 or t_.dim() != 3:
@@ -472,22 +476,32 @@ def xcorr_fused(search_feats, templ_feats, P, w_sim, scale0, shift0, layers, eps
         raise RuntimeError("xcorr_fused: Nt=%d (ptt_xcorr_fused_fwd_f32 walks the template seeds in chunks of 64)" % Nt)
     if P.shape[0] != B or P.shape[1] != Nt or w_sim.shape[0] != C0 or templ_feats.shape[:2] != search_feats.shape[:2]:
         raise RuntimeError("xcorr_fused: inconsistent shapes")
-    if cos_t is None:
-        cos_t = cosine_map(search_feats, templ_feats, eps=eps)
-    _chk(cos_t, "cos_t", torch.float32, 3)
-    if tuple(cos_t.shape) != (B, Ns, Nt):
-        raise RuntimeError("xcorr_fused: cos_t must be (B,Ns,Nt)")
     cout = layers[-1][4]
-    store = torch.empty((B, Ns, cout), dtype=torch.float32, device=P.device)
-    out = store.transpose(1, 2)
+    split = (split and not want_sim and search_feats.stride(1) == 1 and templ_feats.stride(1) == 1 and C % 4 == 0 and (B * Ns) % 8 == 0
+             and all(st % 4 == 0 for st in (search_feats.stride(0), search_feats.stride(2), templ_feats.stride(0), templ_feats.stride(2)))
+             and search_feats.data_ptr() % 16 == 0 and templ_feats.data_ptr() % 16 == 0 and bool(layers[-1][5]))
+    if not split:
+        if cos_t is None:
+            cos_t = cosine_map(search_feats, templ_feats, eps=eps)
+        _chk(cos_t, "cos_t", torch.float32, 3)
+        if tuple(cos_t.shape) != (B, Ns, Nt):
+            raise RuntimeError("xcorr_fused: cos_t must be (B,Ns,Nt)")
+    store = torch.empty(((2, B, Ns, cout) if split else (B, Ns, cout)), dtype=torch.float32, device=P.device)
+    out = store.transpose(-1, -2)
     sim = torch.empty((B, Nt, Ns), dtype=torch.float32, device=P.device) if want_sim else None
     d = XcorrDesc()
-    d.cos_t = cos_t.data_ptr()
+    if split:
+        d.split, d.out_sh = 1, store.stride(0)
+        d.search_feat, d.templ_feat = search_feats.data_ptr(), templ_feats.data_ptr()
+        d.s_sb, d.s_sn, d.t_sb, d.t_sn = search_feats.stride(0), search_feats.stride(2), templ_feats.stride(0), templ_feats.stride(2)
+        d.C, d.eps = int(C), float(eps)
+    else:
+        d.cos_t = cos_t.data_ptr()
     d.P, d.w_sim = P.data_ptr(), w_sim.data_ptr()
     d.scale0 = scale0.data_ptr() if scale0 is not None else None
     d.shift0 = shift0.data_ptr() if shift0 is not None else None
     d.out = out.data_ptr()
-    d.out_sb, d.out_sc, d.out_sn = out.stride()
+    d.out_sb, d.out_sc, d.out_sn = out.stride()[-3:]
     d.sim_out = sim.data_ptr() if sim is not None else None
     d.B, d.Ns, d.Nt, d.C0 = B, Ns, Nt, C0
     d.n_layers = len(layers)
@@ -595,6 +609,17 @@ def crop_compact(jobs_dev, n_jobs):
     """ptt_crop_compact_f32 over a device-resident table of `n_jobs` ptt_crop_job records (uint8 tensor)."""
     with torch.cuda.device(jobs_dev.device), _timed('ptt_crop_compact_f32'):
         _lib.check(_lib.lib().ptt_crop_compact_f32(_ptr(jobs_dev), int(n_jobs), _stream()), "ptt_crop_compact_f32")
+
+
+CROP_JOBS_BY_VALUE_MAX = 8
+
+
+def crop_compact_host(jobs_np, n_jobs, device):
+    """ptt_crop_compact_host_f32: the crops of a host-resident (numpy structured) job table, passed by value with the launch —
+    at most CROP_JOBS_BY_VALUE_MAX jobs; the table may be rewritten as soon as this returns."""
+    with torch.cuda.device(device), _timed('ptt_crop_compact_f32'):
+        _lib.check(_lib.lib().ptt_crop_compact_host_f32(ctypes.c_void_p(jobs_np.ctypes.data), int(n_jobs), _stream()),
+                   "ptt_crop_compact_host_f32")
 
 
 def regularize(jobs_dev, n_jobs, draws):
@@ -1212,7 +1237,7 @@ def _ld(t2):
     return int(t2.stride(0)) if t2.shape[0] > 1 else max(int(t2.shape[1]), int(t2.stride(0)))
 
 
-def row_job(wpacked, cout, x=None, x2=None, scale=None, shift=None, act=0, res=None, res2=None, res_split=0, out=None,
+def row_job(wpacked, cout, x=None, x2=None, xmax=None, scale=None, shift=None, act=0, res=None, res2=None, res_split=0, out=None,
             out2=None, out_split=0, out_col0=0, raw=None, rel=None, w1=None, qkv=None, knn=None, pos=None, q_off=0,
             k_off=0, v_off=0, N=0, sm_scale=1.0, prologue=0, epilogue=0, K=None, col_tiles=0, idx=None, xyz=None, centres=None,
             wx=None, radius=1.0, ns=0, M=0, normalize_xyz=False, pro_relu=False):
@@ -1233,6 +1258,12 @@ def row_job(wpacked, cout, x=None, x2=None, scale=None, shift=None, act=0, res=N
                 raise RuntimeError("x and x2 must have the same number of rows")
             j.X2, j.ldx2, j.K = y_.data_ptr(), _ld(y_), j.K1 + y_.shape[1]
             keep.append(y_)
+        if xmax is not None:
+            m_ = _rows2(xmax, "xmax")
+            if m_.shape != x_.shape or _ld(m_) != _ld(x_):
+                raise RuntimeError("xmax must have x's shape and row stride")
+            j.Xmax = m_.data_ptr()
+            keep.append(m_)
         keep.append(x_)
     elif prologue == 1:
         r_ = _rows2(rel, "rel")
@@ -1327,3 +1358,22 @@ def sa_levels_point_jobs(xyz, inds0, npoints, radii, nsamples, knn_k=0):
     with torch.cuda.device(dev), _timed('ptt_ball_query_f32'):
         _lib.check(_lib.lib().ptt_point_jobs_f32(arr, n_jobs, _stream()), "ptt_point_jobs_f32")
     return levels, inds64, knn
+
+
+def fps_ball_knn(xyz, npoint, radius, nsample, k=0):
+    """ptt_fps_ball_knn_f32: furthest point sampling, centre selection, ball query and (k > 0) the kNN of the centres among
+    themselves in ONE launch; xyz (B,N<=256,3), npoint <= 128. -> (inds i32 (B,M), inds64, new_xyz, idx (B,M,nsample),
+    (knn (B,M,k) i32, rel (B,M,k,3)) | None) — bit for bit what furthest_point_sampling + centres_ball_query + knn return."""
+    _chk(xyz, "xyz", torch.float32, 3)
+    B, N, _ = xyz.shape
+    M, dev = int(npoint), xyz.device
+    inds = torch.empty((B, M), dtype=torch.int32, device=dev)
+    inds64 = torch.empty((B, M), dtype=torch.int64, device=dev)
+    new_xyz = torch.empty((B, M, 3), dtype=torch.float32, device=dev)
+    idx = torch.empty((B, M, int(nsample)), dtype=torch.int32, device=dev)
+    knn = torch.empty((B, M, int(k)), dtype=torch.int32, device=dev) if k else None
+    rel = torch.empty((B, M, int(k), 3), dtype=torch.float32, device=dev) if k else None
+    with torch.cuda.device(dev), _timed('ptt_fps_f32'):
+        _lib.check(_lib.lib().ptt_fps_ball_knn_f32(_ptr(xyz), B, N, M, float(radius), int(nsample), int(k), _ptr(inds), _ptr(inds64),
+                                                   _ptr(new_xyz), _ptr(idx), _ptr(knn), _ptr(rel), _stream()), "ptt_fps_ball_knn_f32")
+    return inds, inds64, new_xyz, idx, ((knn, rel) if k else None)

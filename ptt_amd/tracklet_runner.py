@@ -31,14 +31,18 @@ from .hot_path import GraphedHotPath, TrackerThroughput
 
 
 class _BoxedForward(object):
-    """tracker forward + best-proposal selection as ONE capturable callable: (search, template) -> (B,5) rows."""
+    """tracker forward + best-proposal selection as ONE capturable callable: (search, template) -> (B,5) rows, the best
+    proposal of each frame picked on the device (ptt_select_box_f32) — or, select=False, all (B,P,5) proposals: at a handful of
+    tracklets the host takes the arg-max itself from the one read-back it makes anyway (np.argmax, the reference's own
+    post_process, eval_tracking_utils.py:267-269): one launch less on a chain where launches are what a frame costs."""
 
-    def __init__(self, tracker):
+    def __init__(self, tracker, select=True):
         self.fwd = TrackerThroughput(tracker)
+        self.select = select
 
     def __call__(self, search, template):
-        out = self.fwd(search, template)
-        return ops.select_box(out['pred_box_data'].contiguous())
+        boxes = self.fwd(search, template)['pred_box_data'].contiguous()
+        return ops.select_box(boxes) if self.select else boxes
 
 
 class TrackletRunner(object):
@@ -66,9 +70,12 @@ class TrackletRunner(object):
         #                                                                           before it rewrites the table
         self.reg_jobs_dev = torch.zeros(2 * B * ops.REGULARIZE_JOB.itemsize, dtype=torch.uint8, device=dev)
         self.draws = ops.mt19937_draws(dev, max(8192, 4 * max(self.S, self.T) + 1024))
-        self.result_host = torch.empty((B, 5), dtype=torch.float32).pin_memory()
+        # a handful of tracklets: the crop table rides in the crop launch's arguments (no upload), and the host picks the best
+        # proposal itself from the (B,P,5) read-back — two launches less per frame of a chain that is launches
+        self.few = 2 * B <= ops.CROP_JOBS_BY_VALUE_MAX
+        self.result_host = None if self.few else torch.empty((B, 5), dtype=torch.float32).pin_memory()
         self.info_host = torch.empty((B, 2, 2), dtype=torch.int32).pin_memory()
-        self._model = _BoxedForward(tracker)
+        self._model = _BoxedForward(tracker, select=not self.few)
         self._graph = None
         self._done = torch.cuda.Event()
         self.stream = None                                           # run_overlapped gives every runner its own stream
@@ -138,7 +145,11 @@ class TrackletRunner(object):
                 continue
             half['points'], half['ld'], half['n_points'] = self.ptr[frame], self.ld[frame], self.npts[frame]
             ops.track_crop_bounds(self.boxes, cfg[0], cfg[1], cfg[2], half, job_stride=2)
-        self.crop_jobs_dev.copy_(self.crop_jobs_host, non_blocking=True)
+        if self.few:
+            ops.crop_compact_host(jobs, 2 * self.B, self.device)
+        else:
+            self.crop_jobs_dev.copy_(self.crop_jobs_host, non_blocking=True)
+            ops.crop_compact(self.crop_jobs_dev, 2 * self.B)
 
     # ------------------------------------------------------------------ one group in lockstep
     def _steps(self, tracklets):
@@ -165,7 +176,6 @@ class TrackletRunner(object):
 
         # frame 0: the first-frame template crop (get_model's first segment) is fixed for the whole tracklet
         self._crop_jobs(0, 1, model_cfg, None, 2, model_cfg)
-        ops.crop_compact(self.crop_jobs_dev, 2 * B)
         # the job table travels through ONE pinned staging buffer: its copy must have left the host before frame 1's
         # table is written into it (every later frame waits for its boxes anyway)
         self._done.record(torch.cuda.current_stream(self.device))
@@ -185,11 +195,12 @@ class TrackletRunner(object):
             # both crops of frame i are taken around the previous RESULT box (prepare_search :156-157, prepare_template
             # :189-194 with results_BBs[frame_id - 1]); a finished tracklet's later frames have n_points 0
             self._crop_jobs(i, 0, (self.search_offset, self.search_scale, gt_wlh1[i] * 0.6), i - 1, 2, model_cfg)
-            ops.crop_compact(self.crop_jobs_dev, 2 * B)
             ops.regularize(self.reg_jobs_dev, 2 * B, self.draws)
+            self.info_host.copy_(self.info, non_blocking=True)       # behind the resampling, ahead of the model: off the frame's tail
             rows = self._forward()
+            if self.result_host is None or self.result_host.shape != rows.shape:
+                self.result_host = torch.empty(tuple(rows.shape), dtype=torch.float32).pin_memory()
             self.result_host.copy_(rows, non_blocking=True)
-            self.info_host.copy_(self.info, non_blocking=True)
             self._done.record(torch.cuda.current_stream(self.device))
             if prof is not None:
                 ev1.record(torch.cuda.current_stream(self.device))
@@ -199,6 +210,8 @@ class TrackletRunner(object):
             if prof is not None:
                 t_c = time.perf_counter()
             est = self.result_host.numpy()                        # (B,5) float32: x, y, z, theta (degrees), score
+            if est.ndim == 3:                                     # (B,P,5): the first arg-max of the scores, as post_process takes it (:267-269)
+                est = est[np.arange(B), np.argmax(est[:, :, 4], axis=1)]
             info = self.info_host.numpy()
             # post_process (:266-274): box_i = get_box_by_offset(box_{i-1}, best proposal, USE_Z_AXIS). An implausibly
             # large x / y offset is redrawn from numpy's GLOBAL generator (:205-208), whose state then is "seeded with 1

@@ -46,5 +46,18 @@ g)  # SA level as row jobs, point jobs: parity, then one tracklet
     timeout 900 python -m pytest tests -x -q -m gpu > $O/pytest.log 2>&1; tail -25 $O/pytest.log
     timeout 300 python scripts/tracklet_b1_profile.py > $O/b1.log 2>&1; grep -v amdgpu.ids $O/b1.log
     ;;
+h)  # kernel trace of one tracklet (per-kernel time and launch count per frame)
+    timeout 300 python scripts/tracklet_b1_profile.py > $O/b1.log 2>&1; grep -v amdgpu.ids $O/b1.log
+    ktrace b1_kernel_stats python $REPO/scripts/tracklet_b1_profile.py
+    python - <<PY
+import csv
+rows = list(csv.DictReader(open("$O/b1_kernel_stats.csv")))
+tot = sum(float(r['TotalDurationNs']) for r in rows)
+frames = 199 * 5 + 3 + 400
+print("device time per frame ~ %.1f us, launches per frame ~ %.1f" % (tot / frames / 1e3, sum(int(r['Calls']) for r in rows) / frames))
+for r in rows[:30]:
+    print("%-100s %6d %8.1fus %5.1f%% %6.2f/frame" % (r['Name'][:100], int(r['Calls']), float(r['AverageNs']) / 1e3, float(r['TotalDurationNs']) / tot * 100, int(r['Calls']) / frames))
+PY
+    ;;
 *)  echo "unknown session $S"; exit 2;;
 esac

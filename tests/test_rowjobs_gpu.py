@@ -203,3 +203,32 @@ def test_point_jobs_equal_the_level_by_level_launches(dev, B, N, npoints, k):
     if k:
         kidx, rel = ops.knn(pts, k, want_rel=True)
         assert torch.equal(knn[0], kidx) and torch.equal(knn[1], rel)
+
+
+@pytest.mark.parametrize("B,N,M,k", [(1, 128, 64, 16), (3, 128, 64, 16), (2, 200, 50, 16), (1, 64, 64, 0), (2, 256, 128, 16)])
+def test_fps_ball_knn_equals_the_three_launches(dev, B, N, M, k):
+    """ptt_fps_ball_knn_f32 == ptt_fps_f32 + ptt_centres_ball_query_f32 + ptt_knn_rel_f32 on the centres, bit for bit — with
+    duplicated points (exact distance ties) and points inside the 1e-3 origin ball in the cloud."""
+    rs = np.random.RandomState(B * 31 + N)
+    x = rs.uniform(-1.0, 1.0, (B, N, 3)).astype(np.float32)
+    x[:, 5] = x[:, 3]; x[:, N // 2] = x[:, 1]; x[:, 7] = 0.001
+    xyz = _t(x, dev)
+    inds, inds64, new_xyz, idx, knn = ops.fps_ball_knn(xyz, M, 0.3, 16, k)
+    ref_inds = ops.furthest_point_sampling(xyz, M)
+    assert torch.equal(inds, ref_inds) and torch.equal(inds64, ref_inds.long())
+    ref_xyz, _, ref_idx = ops.centres_ball_query(xyz, ref_inds, M, 0.3, 16)
+    assert torch.equal(new_xyz, ref_xyz) and torch.equal(idx, ref_idx)
+    if k:
+        kidx, rel = ops.knn(ref_xyz, k, want_rel=True)
+        assert torch.equal(knn[0], kidx) and torch.equal(knn[1], rel)
+
+
+def test_xmax_operand(dev):
+    rs = np.random.RandomState(9)
+    a, b2 = rs.standard_normal((128, 256)).astype(np.float32), rs.standard_normal((128, 256)).astype(np.float32)
+    w, sc, sh = _layer(rs, 256, 256)
+    ref = torch.from_numpy(np.maximum(a, b2)).double() @ torch.from_numpy(w).double().t() + torch.from_numpy(sh).double()
+    out = torch.empty((128, 256), device=dev)
+    both = _t(np.stack([a, b2]), dev)
+    ops.row_jobs([ops.row_job(ops.pack_weight(_t(w, dev)), 256, x=both[0], xmax=both[1], shift=_t(sh, dev), out=out)])
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), **TOL)
