@@ -102,12 +102,50 @@ def _free_port():
 
 
 def spawn_ranks(n):
-    """WORLD_SIZE unset and --gpus n > 1: run this very command line as n ranks under torch.distributed.run."""
+    """WORLD_SIZE unset and --gpus n > 1: run this very command line as n ranks under torch.distributed.run — and, for the
+    default car line, run the n ranks a SECOND time on `--workload train` (BASELINE.json configs[3]: the DDP step whose
+    gradient all-reduce over RCCL / xGMI is the only collective of the whole path, tools/train_tracking.py:158-159,
+    scripts/train_ddp.sh:9) and carry that line as `workloads.train` of the one JSON line printed: the car workload
+    shards frames with no data-path collective, so without the second launch the one command a driver runs at N > 1 would
+    never meet RCCL beyond a barrier."""
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this host driver (RCCL needs it)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
-           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.call(cmd, env=env)
+
+    def launch(extra, capture):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + extra
+        print("[bench] spawn: %d ranks: bench.py %s" % (n, " ".join(extra)), file=sys.stderr, flush=True)
+        if not capture:
+            return subprocess.call(cmd, env=env), None
+        p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+        lines = [l for l in p.stdout.decode(errors="replace").splitlines() if l.startswith("{")]
+        try:
+            return p.returncode, (json.loads(lines[-1]) if lines else None)
+        except ValueError:
+            return p.returncode, None
+
+    argv = sys.argv[1:]
+    args = parse_args()
+    with_train = (args.workload == "car" and not args.no_workloads and "train" in args.workloads.split(",") and args.batch is None
+                  and args.ns is None and args.nt is None and not args.serial and not args.no_graph)
+    if not with_train:
+        return launch(argv, False)[0]
+    rc, line = launch(argv, True)
+    # the DDP step of configs[3] on the same n ranks; a failure here must not take the headline line down
+    rc2, train = launch(["--gpus", str(n), "--workload", "train", "--steps", "5", "--warmup", "2", "--sustain", "0",
+                         "--no-cpu-baseline", "--no-workloads"], True)
+    if line is not None:
+        keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "dtype", "scaling", "roofline", "loss",
+                "rccl_ranks_seen", "grad_bytes_allreduced_per_step", "allreduce")
+        if train is not None and rc2 == 0:
+            rec = {k: train[k] for k in keep if train.get(k) is not None}
+            rec["config"] = {"workload": train["config"]["workload"], "name": "train", "ref": WORKLOADS["train"]["ref"],
+                             "sharding": train["config"].get("sharding")}
+        else:
+            rec = {"error": "the train launch on %d ranks exited with code %d" % (n, rc2)}
+        line.setdefault("workloads", {})["train"] = rec
+        print(json.dumps(line), flush=True)
+    return rc
 
 
 def pair_kernel_flops(B, N, k=16, D=512):
@@ -664,6 +702,20 @@ def run_train(args, torch, dev, dist, world, rank, ranks_seen, sync_all, B, NS, 
         sustained = {"steps": n_sus, "seconds": round(dt, 3), "value": round(B * world * n_sus / dt, 2),
                      "ms_per_step": round(dt / n_sus * 1e3, 4)}
     value = B * world * args.steps / elapsed
+    allreduce = None
+    if world > 1:
+        # what the gradient all-reduce costs the step: the same steps with DDP's synchronisation switched off
+        # (model.no_sync(): gradients stay local; the replicas drift apart, which is why this runs last)
+        def step_local():
+            with trainer.model.no_sync():
+                last["loss"] = trainer.step(batch)
+        for _ in range(2):
+            step_local()
+        local = reduce_max(torch, dist, dev, timed_loop(step_local, args.steps, sync_all))
+        allreduce = {"ms_per_step_without_allreduce": round(local / args.steps * 1e3, 4),
+                     "exposed_ms_per_step": round((elapsed - local) / args.steps * 1e3, 4),
+                     "how": "step time minus the same steps under DistributedDataParallel.no_sync(); DDP overlaps the one "
+                            "%.1f MB bucket with the tail of the backward pass, so this is what is NOT hidden" % (GRAD_ELEMS * 4 / 1e6)}
     # dense FLOPs of one training step: forward 12.3 GFLOP per frame at 1024+512 (SURVEY.md §8a totals) x 3 (the
     # backward of a linear layer is two GEMMs of the forward's size)
     flops = 3.0 * 12.3e9 * B
@@ -690,6 +742,7 @@ def run_train(args, torch, dev, dist, world, rank, ranks_seen, sync_all, B, NS, 
         "sustained": sustained,
         "loss": float(last["loss"].detach()),
         "grad_bytes_allreduced_per_step": GRAD_ELEMS * 4 if world > 1 else 0,
+        "allreduce": allreduce,
     }
 
 

@@ -28,11 +28,26 @@ def test_workloads_cover_the_baseline_configs():
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="only meaningful where no HIP device is visible")
 def test_gpus_2_spawns_two_ranks_itself():
+    """`python bench.py --gpus 2` (what a driver runs at N > 1) launches the 2 ranks TWICE: the car headline, then the DDP
+    training step of configs[3] whose line rides as workloads.train — on a GPU-less host every rank of both launches stops
+    at "needs a HIP device", which is the observable proof that 2 x 2 ranks were started."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
-                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert p.returncode != 0
-    assert p.stderr.count("bench.py needs a HIP device") >= 2, p.stderr[-2000:]
+    spawns = [l for l in p.stderr.splitlines() if "spawn: 2 ranks" in l]
+    assert len(spawns) == 2 and "--workload train" in spawns[1] and "--workload train" not in spawns[0], p.stderr[-2000:]
+    assert p.stderr.count("bench.py needs a HIP device") >= 4, p.stderr[-2000:]
+
+
+def test_gpus_2_with_another_workload_is_one_launch():
+    """Only the default car line carries the train launch: `--workload train --gpus 2` itself is a single launch."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    if torch.cuda.is_available():
+        pytest.skip("only meaningful where no HIP device is visible")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "train", "--steps", "1",
+                        "--warmup", "0"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert p.returncode != 0 and sum("spawn: 2 ranks" in l for l in p.stderr.splitlines()) == 1
 
 
 def test_committed_traffic_reads_the_newest_pmc_summary_and_names_its_source():
