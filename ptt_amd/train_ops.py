@@ -28,6 +28,19 @@ import torch.nn as nn
 from . import ops
 
 
+def _raw_pointer_ready(conv, bn, device):
+    """The row kernels read the convolution weight and the BatchNorm's parameters / buffers through raw pointers (and update the
+    running statistics in place): contiguous float32 on the activations' device, an int64 batch counter. Anything else (a
+    module cast to float64, a channels-last experiment, parameters left on another device) takes the stock torch path."""
+    ts = [conv.weight] + ([conv.bias] if conv.bias is not None else [])
+    if bn is not None:
+        ts += [bn.weight, bn.bias, bn.running_mean, bn.running_var]
+        nbt = bn.num_batches_tracked
+        if nbt is not None and (nbt.dtype != torch.int64 or nbt.device != device):
+            return False
+    return all(t is not None and t.dtype == torch.float32 and t.device == device and t.is_contiguous() for t in ts)
+
+
 def usable(mlp, x):
     """Plain SharedMLP units, float32 on a HIP device, training mode."""
     if not (mlp.training and x.is_cuda and x.dtype == torch.float32 and len(mlp) > 0):
@@ -48,6 +61,8 @@ def usable(mlp, x):
         if not isinstance(getattr(unit, 'activation', None), nn.ReLU):
             return False
         if list(unit._modules.keys()) != ['conv', 'normlayer', 'activation']:
+            return False
+        if not _raw_pointer_ready(conv, bn, x.device):
             return False
     return True
 
@@ -645,7 +660,9 @@ def conv1d_stack_usable(seq, x):
                 return False
             if not isinstance(getattr(unit, 'activation', None), nn.ReLU) or list(unit._modules.keys()) != ['conv', 'normlayer', 'activation']:
                 return False
-        elif k != len(units) - 1 or list(unit._modules.keys()) != ['conv']:
+            if not _raw_pointer_ready(conv, bn, x.device):
+                return False
+        elif k != len(units) - 1 or list(unit._modules.keys()) != ['conv'] or not _raw_pointer_ready(conv, None, x.device):
             return False
     return True
 

@@ -59,5 +59,9 @@ for r in rows[:30]:
     print("%-100s %6d %8.1fus %5.1f%% %6.2f/frame" % (r['Name'][:100], int(r['Calls']), float(r['AverageNs']) / 1e3, float(r['TotalDurationNs']) / tot * 100, int(r['Calls']) / frames))
 PY
     ;;
+i)  # the review's small parity gaps: shim, frozen BatchNorm, draw-table exhaustion, G15, ped at 2048 + 1024
+    timeout 1200 python -m pytest tests/test_round4_gaps_gpu.py tests/test_train_gpu.py tests/test_hot_path_gpu.py -x -q -m gpu -s > $O/pytest.log 2>&1
+    grep -E "G15|G10|G14|passed|failed|Error|error" $O/pytest.log | tail -30
+    ;;
 *)  echo "unknown session $S"; exit 2;;
 esac

@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 TOL = dict(atol=1e-4, rtol=1e-4)
 
 
-@pytest.mark.parametrize("kind,NS,NT", [("car", 1024, 512), ("ped", 1024, 512), ("car", 2048, 1024)])
+@pytest.mark.parametrize("kind,NS,NT", [("car", 1024, 512), ("ped", 1024, 512), ("car", 2048, 1024), ("ped", 2048, 1024)])
 def test_frame_hot_path_matches_oracle(dev, kind, NS, NT):
     cfg = kitti_model_cfg()
     model = randomize_(FrameHotPath(cfg), seed=3).eval()
