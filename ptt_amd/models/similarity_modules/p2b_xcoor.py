@@ -135,7 +135,7 @@ class CosineSimAug(nn.Module):
             return batch_dict
 
         if (train_ops.usable(self.mlp, search_feats) and self.mlp[0].conv.weight.shape[1] == f + 4
-                and self.mlp[0].conv.weight.shape[0] % 4 == 0):
+                and self.mlp[0].conv.weight.shape[0] % 4 == 0 and self.mlp[0].conv.weight.shape[0] <= 256):   # ptt_xcorr_z0_bwd_f32: C0 <= 256
             # training on a HIP device: layer 0 split per template point + similarity term (train_ops.xcorr_hoisted),
             # the remaining SharedMLP layers and the max over the template axis on the row kernels
             fused = train_ops.xcorr_hoisted(search_feats, template_feats, template_xyz, self.mlp, self.cosine.eps)   # (B,C,n2) view

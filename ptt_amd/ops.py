@@ -907,8 +907,12 @@ def linear_act_in(x, in_scale, in_shift, wpacked, cout):
     return out
 
 
-def rows_gemm_supported(rows, K, N, ldx=None, ldo=None):
-    """True when ptt_rows_gemm_f32 takes the shape (K and N multiples of 64, ...): the persistent row GEMM of the training step."""
+def rows_gemm_supported(rows, K, N, ldx=None, ldo=None, x=None):
+    """True when ptt_rows_gemm_f32 takes the shape (K and N multiples of 64, ...): the persistent row GEMM of the training step.
+    `x`: the input tensor, when the caller has it — the entry point also wants 16-byte aligned rows, and a caller that asks here
+    first falls back to the linear kernel instead of meeting PTT_EINVAL."""
+    if x is not None and x.data_ptr() % 16:
+        return False
     return bool(_lib.lib().ptt_rows_gemm_supported(int(rows), int(K), int(N), int(ldx if ldx is not None else K),
                                                    int(ldo if ldo is not None else N)))
 
@@ -1037,7 +1041,11 @@ def linear_wgrad(dz, x, out=None, accumulate=False, x_scale=None, x_shift=None):
     Cin = x.shape[1]
     if out is None:
         out = torch.empty((Cout, Cin), dtype=torch.float32, device=dz.device)
-    nb2 = _lib.lib().ptt_linear_wgrad2_workspace(R, Cout, Cin) if (dz.stride(0) % 4 == 0 and x.stride(0) % 4 == 0) else 0
+    # ptt_linear_wgrad2_f32's own entry checks, asked here so that a shape / layout it refuses goes to the older kernel:
+    # float4 rows (stride % 4, 16-byte aligned) and 32-bit element offsets (R * stride < 2^29)
+    ok2 = (dz.stride(0) % 4 == 0 and x.stride(0) % 4 == 0 and dz.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0
+           and R * max(dz.stride(0), x.stride(0)) < (1 << 29))
+    nb2 = _lib.lib().ptt_linear_wgrad2_workspace(R, Cout, Cin) if ok2 else 0
     if nb2 and WGRAD2:
         ws = _ws(nb2, dz.device)
         with torch.cuda.device(dz.device), _timed('ptt_linear_wgrad_f32'):

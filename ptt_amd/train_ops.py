@@ -133,7 +133,7 @@ class _PackPlan:
             ref, elems = self.entries[ekey]
             base = ref()
             slot = _pack_slot(base)
-            version = base._version
+            version = (base._version, base.data_ptr())
             for k in [k for k in slot if k[3] != version]:   # retire the previous step's packs
                 del slot[k]
             slot[(ekey[1], ekey[2], ekey[3], version, ekey[4])] = arena[off:off + elems]
@@ -151,11 +151,13 @@ def packed(W, transpose=False):
     the backbone's weights; the optimiser's in-place update bumps the version. The cache lives and dies with the parameter
     object (weak references): a new model whose parameter lands on a freed one's address never sees its entries. W: a 2-D (out, in)
     parameter, or a view / column slice of one, passed as the caller holds it (not detached: the view's base is the key).
-    A miss on a view seen before re-packs every registered weight of the device in one launch (_PackPlan)."""
+    A miss on a view seen before re-packs every registered weight of the device in one launch (_PackPlan).
+    What the key cannot see: an update made through `.data` (p.data.copy_(ema), fastai-style master copies) changes neither the
+    version nor the address — call invalidate_packed() after such an update."""
     base = W._base if W._base is not None else W
     slot = _pack_slot(base)
     off = (W.data_ptr() - base.data_ptr())
-    key = (off, tuple(W.shape), tuple(W.stride()), W._version, bool(transpose))
+    key = (off, tuple(W.shape), tuple(W.stride()), (W._version, base.data_ptr()), bool(transpose))
     hit = slot.get(key)
     if hit is not None:
         return hit
@@ -165,7 +167,7 @@ def packed(W, transpose=False):
         hit = slot.get(key)
         if hit is not None:
             return hit
-    for k in [k for k in slot if k[3] != W._version]:       # retire the previous step's packs
+    for k in [k for k in slot if k[3] != key[3]]:           # retire the previous step's packs
         del slot[k]
     w = W.detach()
     cout, k = (w.shape[1], w.shape[0]) if transpose else w.shape
@@ -176,6 +178,13 @@ def packed(W, transpose=False):
     return hit
 
 
+def invalidate_packed():
+    """Forget every packed weight (and the re-pack plans): needed after parameter updates the version counter does not see,
+    i.e. anything written through `.data` (EMA / master-copy schemes: `p.data.copy_(master)`)."""
+    _pack_cache.clear()
+    _pack_plans.clear()
+
+
 def conv_rows(x, W2d, in_a=None, in_b=None, want_stats=False, transpose=False):
     """z = act_in(x) @ W2d^T over (rows, K) activations, act_in = relu(x * in_a + in_b) when given (the deferred BatchNorm +
     ReLU of the producing layer). On the persistent row GEMM (ptt_rows_gemm_f32) where the shape allows, else on the linear
@@ -183,7 +192,7 @@ def conv_rows(x, W2d, in_a=None, in_b=None, want_stats=False, transpose=False):
     caller then takes the statistics in a pass of their own). transpose: multiply by W2d instead of W2d^T (input gradients)."""
     cout, K = (W2d.shape[1], W2d.shape[0]) if transpose else W2d.shape
     wp = packed(W2d, transpose)
-    if ops.rows_gemm_supported(x.shape[0], K, cout, x.stride(0), cout):
+    if ops.rows_gemm_supported(x.shape[0], K, cout, x.stride(0), cout, x=x):
         if want_stats:
             return ops.rows_gemm(x, wp, cout, in_scale=in_a, in_shift=in_b, want_stats=True)
         return ops.rows_gemm(x, wp, cout, in_scale=in_a, in_shift=in_b), None
@@ -379,7 +388,7 @@ class _SharedMlpPool(torch.autograd.Function):
                 # the gradient w.r.t. the activated input of layer l = the gradient BatchNorm l - 1 receives: its backward sums
                 # come out of this GEMM's epilogue where the persistent row GEMM takes the shape
                 zp, mp, ip, ap, bp = saved[9 * (l - 1) + 3], saved[9 * (l - 1) + 4], saved[9 * (l - 1) + 5], saved[9 * (l - 1) + 6], saved[9 * (l - 1) + 7]
-                if ops.rows_gemm_supported(dz.shape[0], w2.shape[0], w2.shape[1], dz.stride(0), w2.shape[1]):
+                if ops.rows_gemm_supported(dz.shape[0], w2.shape[0], w2.shape[1], dz.stride(0), w2.shape[1], x=dz):
                     g, part = ops.rows_gemm_bnbwd(dz, packed(w2, True), w2.shape[1], zp, mp, ip, ap, bp)
                 else:
                     g, _ = conv_rows(dz, w2, transpose=True)
@@ -566,7 +575,7 @@ def lin_rows(x2, W, b=None, relu=False, residual=None, transpose=False):
     shape allows, else the linear kernel (K = 3, N = 1 / 5 / 259, ...)."""
     cout, K = (W.shape[1], W.shape[0]) if transpose else W.shape
     wp = packed(W, transpose)
-    if ops.rows_gemm_supported(x2.shape[0], K, cout, x2.stride(0), cout):
+    if ops.rows_gemm_supported(x2.shape[0], K, cout, x2.stride(0), cout, x=x2):
         return ops.rows_gemm(x2, wp, cout, bias=b, relu=relu, residual=residual)
     return ops.linear(x2, wp, cout, None, b, relu, residual)
 
@@ -581,8 +590,9 @@ class _RowsLinear(torch.autograd.Function):
     def forward(ctx, x, W, b, residual):
         x2 = x.reshape(-1, x.shape[-1]).contiguous()
         assert W.dim() == 2
-        ctx.save_for_backward(x2)
-        ctx.W = W                                            # as passed (a parameter or a view of one): key of the pack cache
+        ctx.save_for_backward(x2, W)                         # W too: autograd's version check then catches an in-place update
+        ctx.W = W                                            # between forward and backward (backward re-packs the weight).
+        #                                                      ctx.W = the object as passed (a parameter or a view of one): key of the pack cache
         ctx.shape = x.shape
         r2 = residual.reshape(-1, W.shape[0]).contiguous() if residual is not None else None
         y = lin_rows(x2, W, b.detach() if b is not None else None, residual=r2)
@@ -590,7 +600,7 @@ class _RowsLinear(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        (x2,) = ctx.saved_tensors
+        x2, _ = ctx.saved_tensors
         g2 = g.reshape(-1, g.shape[-1]).contiguous()
         dx = lin_rows(g2, ctx.W, transpose=True).view(ctx.shape) if ctx.needs_input_grad[0] else None
         dW = ops.linear_wgrad(g2, x2) if ctx.needs_input_grad[1] else None
@@ -615,20 +625,20 @@ class _RowsMlp2(torch.autograd.Function):
         x2 = x.reshape(-1, x.shape[-1]).contiguous()
         h = lin_rows(x2, W1, b1.detach(), relu=True)
         y = lin_rows(h, W2, b2.detach())
-        ctx.save_for_backward(x2, h)
+        ctx.save_for_backward(x2, h, W1, W2)                 # the weights too: see _RowsLinear
         ctx.Ws = (W1, W2)
         ctx.shape = x.shape
         return y.view(*x.shape[:-1], W2.shape[0])
 
     @staticmethod
     def backward(ctx, dy):
-        x2, h = ctx.saved_tensors
+        x2, h, _, _ = ctx.saved_tensors
         W1, W2 = ctx.Ws
         dy2 = dy.reshape(-1, dy.shape[-1]).contiguous()
         rows, D1 = h.shape
         dW2 = ops.linear_wgrad(dy2, h)
         db2 = dy2.sum(0)
-        if ops.rows_gemm_supported(rows, W2.shape[0], D1, dy2.stride(0), D1):
+        if ops.rows_gemm_supported(rows, W2.shape[0], D1, dy2.stride(0), D1, x=dy2):
             dz1, db1 = ops.rows_gemm_masked(dy2, packed(W2, True), D1, h, want_colsum=True)
         else:
             dz1 = lin_rows(dy2, W2, transpose=True) * (h > 0)

@@ -63,5 +63,10 @@ i)  # the review's small parity gaps: shim, frozen BatchNorm, draw-table exhaust
     timeout 1200 python -m pytest tests/test_round4_gaps_gpu.py tests/test_train_gpu.py tests/test_hot_path_gpu.py -x -q -m gpu -s > $O/pytest.log 2>&1
     grep -E "G15|G10|G14|passed|failed|Error|error" $O/pytest.log | tail -30
     ;;
+j)  # split-bf16 GEMM probe beside the exact-fp32 row GEMM on the same shapes
+    hipcc --offload-arch=gfx950 -O3 scripts/probes/bf16x3_gemm_probe.hip -o /tmp/bf16x3 2> $O/bf16x3_build.log && timeout 600 /tmp/bf16x3 > $O/bf16x3_probe.log 2>&1
+    cat $O/bf16x3_probe.log
+    timeout 900 python scripts/rows_gemm_bench.py > $O/rows_gemm.log 2>&1; grep -v amdgpu.ids $O/rows_gemm.log | cut -c1-300
+    ;;
 *)  echo "unknown session $S"; exit 2;;
 esac
