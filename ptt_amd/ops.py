@@ -622,6 +622,13 @@ def crop_compact_host(jobs_np, n_jobs, device):
                    "ptt_crop_compact_host_f32")
 
 
+def crop_compact_pinned(jobs_pinned, n_jobs, device):
+    """ptt_crop_compact_f32 reading its job table straight from PINNED host memory (device-visible under unified addressing):
+    the launch can then sit inside a hipGraph whose table the host rewrites between replays — no upload, no per-frame launch."""
+    with torch.cuda.device(device), _timed('ptt_crop_compact_f32'):
+        _lib.check(_lib.lib().ptt_crop_compact_f32(ctypes.c_void_p(jobs_pinned.data_ptr()), int(n_jobs), _stream()), "ptt_crop_compact_f32")
+
+
 def regularize(jobs_dev, n_jobs, draws):
     """ptt_regularize_f32 over a device-resident table of ptt_regularize_job records."""
     with torch.cuda.device(jobs_dev.device), _timed('ptt_regularize_f32'):

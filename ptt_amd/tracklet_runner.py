@@ -77,6 +77,7 @@ class TrackletRunner(object):
         self.info_host = torch.empty((B, 2, 2), dtype=torch.int32).pin_memory()
         self._model = _BoxedForward(tracker, select=not self.few)
         self._graph = None
+        self._frame = None                                           # few tracklets: crops + resampling + model + read-backs, one graph
         self._done = torch.cuda.Event()
         self.stream = None                                           # run_overlapped gives every runner its own stream
         self.profile = None       # set to {} before run(): per-frame host_pre / device / host_post milliseconds are appended
@@ -131,7 +132,7 @@ class TrackletRunner(object):
         t['info'] = self.info.data_ptr() + np.arange(B) * 16 + 8
         ops.upload_jobs(rj, self.reg_jobs_dev)
 
-    def _crop_jobs(self, frame_a, slot_a, cfg_a, frame_b, slot_b, cfg_b):
+    def _crop_jobs(self, frame_a, slot_a, cfg_a, frame_b, slot_b, cfg_b, launch=True):
         """The 2B-entry crop table of one step, built in the pinned staging buffer and copied to the device: job 2b =
         cloud `frame_a` of tracklet b cropped around the tracklet's current box into slot_a, job 2b+1 likewise (frame
         None / past the tracklet's end: an empty job -> count 0 -> an all-zero resampled cloud). cfg = (offset, scale,
@@ -145,6 +146,8 @@ class TrackletRunner(object):
                 continue
             half['points'], half['ld'], half['n_points'] = self.ptr[frame], self.ld[frame], self.npts[frame]
             ops.track_crop_bounds(self.boxes, cfg[0], cfg[1], cfg[2], half, job_stride=2)
+        if self.few and self.use_graph and launch is False:
+            return                                   # the frame graph reads the pinned table itself
         if self.few:
             ops.crop_compact_host(jobs, 2 * self.B, self.device)
         else:
@@ -194,13 +197,21 @@ class TrackletRunner(object):
             active = (i < lengths).astype(np.int32)
             # both crops of frame i are taken around the previous RESULT box (prepare_search :156-157, prepare_template
             # :189-194 with results_BBs[frame_id - 1]); a finished tracklet's later frames have n_points 0
-            self._crop_jobs(i, 0, (self.search_offset, self.search_scale, gt_wlh1[i] * 0.6), i - 1, 2, model_cfg)
-            ops.regularize(self.reg_jobs_dev, 2 * B, self.draws)
-            self.info_host.copy_(self.info, non_blocking=True)       # behind the resampling, ahead of the model: off the frame's tail
-            rows = self._forward()
-            if self.result_host is None or self.result_host.shape != rows.shape:
-                self.result_host = torch.empty(tuple(rows.shape), dtype=torch.float32).pin_memory()
-            self.result_host.copy_(rows, non_blocking=True)
+            if self.few and self.use_graph:
+                # a handful of tracklets: the WHOLE frame is one hipGraph replay — crops (their table read from pinned host
+                # memory, rewritten here), resampling, read-back of the draw counts, tracker, read-back of the proposals
+                self._crop_jobs(i, 0, (self.search_offset, self.search_scale, gt_wlh1[i] * 0.6), i - 1, 2, model_cfg, launch=False)
+                if self._frame is None:
+                    self._capture_frame()
+                self._frame.replay()
+            else:
+                self._crop_jobs(i, 0, (self.search_offset, self.search_scale, gt_wlh1[i] * 0.6), i - 1, 2, model_cfg)
+                ops.regularize(self.reg_jobs_dev, 2 * B, self.draws)
+                self.info_host.copy_(self.info, non_blocking=True)   # behind the resampling, ahead of the model: off the frame's tail
+                rows = self._forward()
+                if self.result_host is None or self.result_host.shape != rows.shape:
+                    self.result_host = torch.empty(tuple(rows.shape), dtype=torch.float32).pin_memory()
+                self.result_host.copy_(rows, non_blocking=True)
             self._done.record(torch.cuda.current_stream(self.device))
             if prof is not None:
                 ev1.record(torch.cuda.current_stream(self.device))
@@ -248,9 +259,34 @@ class TrackletRunner(object):
             except StopIteration as stop:
                 return stop.value
 
+    def _frame_body(self):
+        ops.crop_compact_pinned(self.crop_jobs_host, 2 * self.B, self.device)
+        ops.regularize(self.reg_jobs_dev, 2 * self.B, self.draws)
+        self.info_host.copy_(self.info, non_blocking=True)
+        return self._model(self.search, self.template)
+
+    def _capture_frame(self):
+        """One frame of a handful of tracklets as ONE hipGraph: called at the first tracked frame of the first group, when the
+        job tables hold valid pointers (the warm-up runs execute them)."""
+        with torch.no_grad():
+            cur = torch.cuda.current_stream(self.device)
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                for _ in range(3):                           # weight packing / LDS attributes happen here, not in capture
+                    rows = self._frame_body()
+            cur.wait_stream(side)
+            torch.cuda.synchronize(self.device)
+            self.result_host = torch.empty(tuple(rows.shape), dtype=torch.float32).pin_memory()
+            self._frame = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._frame):
+                self.result_host.copy_(self._frame_body(), non_blocking=True)
+
     def _ensure_graph(self):
         """The tracker forward + box selection for B frames as a hipGraph whose static inputs ARE the buffers the
         resampling kernel writes (no staging copy)."""
+        if self.few:
+            return                                           # the frame graph (_capture_frame) holds the model
         if self.use_graph and self._graph is None:
             with torch.no_grad():
                 self._graph = GraphedHotPath(self._model, self.search, self.template)

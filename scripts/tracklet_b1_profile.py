@@ -19,7 +19,8 @@ for _ in range(5):
     t0 = time.perf_counter(); runner.run([tr]); torch.cuda.synchronize(); loops.append((time.perf_counter() - t0) / (T - 1) * 1e3)
 print("B=1 tracklet loop: median %.4f ms per frame over 5 passes of %d frames (%s)" % (sorted(loops)[2], T - 1, " ".join("%.4f" % v for v in loops)))
 # the model graph alone, synchronised per frame
-g = runner._graph
+g = runner._frame if runner._frame is not None else runner._graph      # the whole-frame graph (crops + resampling + model + read-backs)
+g = g.replay if hasattr(g, "replay") else g
 t0 = time.perf_counter()
 for _ in range(T):
     g(); torch.cuda.synchronize()
