@@ -428,6 +428,12 @@ typedef struct ptt_regularize_job {
 
 int ptt_regularize_f32(const ptt_regularize_job* jobs_device, int n_jobs, const uint32_t* draws, int n_draws,
                        ptt_stream_t stream);
+/* ptt_crop_compact_f32 + ptt_regularize_f32 of one frame in ONE launch: workgroup w runs crop job w and then resampling job w
+ * (whose segments are that crop's output and, for a template, crops of earlier launches) — identical results. crop_jobs may
+ * live in device memory or in PINNED host memory (read through unified addressing: the launch can sit in a hipGraph whose
+ * table the host rewrites between replays); reg_jobs_device as for ptt_regularize_f32. */
+int ptt_crop_regularize_f32(const ptt_crop_job* crop_jobs, const ptt_regularize_job* reg_jobs_device, int n_jobs,
+                            const uint32_t* draws, int n_draws, ptt_stream_t stream);
 
 /* First n outputs of MT19937 seeded with init_genrand(seed) (what np.random.seed(seed) followed by 32-bit draws
  * yields) into a HOST buffer — the one entry point that takes a host pointer. */

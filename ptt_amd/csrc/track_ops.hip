@@ -119,8 +119,7 @@ __device__ __forceinline__ void seg_point(const ptt_regularize_job& j, const int
 
 // One workgroup per output cloud.
 template <int T>
-__global__ __launch_bounds__(T) void regularize_kernel(const ptt_regularize_job* __restrict__ jobs,
-                                                       const uint32_t* __restrict__ draws, int n_draws) {
+__device__ __forceinline__ void regularize_body(const ptt_regularize_job* __restrict__ jobs, const uint32_t* __restrict__ draws, int n_draws) {
     __shared__ int wsum[T / 64];
     // the job and the segment sizes live in LDS: seg_point() indexes them with a run-time segment number, which as
     // private arrays meant 112 B of scratch per lane
@@ -179,6 +178,25 @@ __global__ __launch_bounds__(T) void regularize_kernel(const ptt_regularize_job*
     }
 }
 
+template <int T>
+__global__ __launch_bounds__(T) void regularize_kernel(const ptt_regularize_job* __restrict__ jobs,
+                                                       const uint32_t* __restrict__ draws, int n_draws) {
+    regularize_body<T>(jobs, draws, n_draws);
+}
+
+// Crop and resampling of one frame in ONE launch: workgroup w runs crop job w, then resampling job w, whose segments are that
+// crop's output (and, for a template, crops of earlier launches: the first frame's). What the tracking loop launches per
+// frame for a handful of tracklets (prepare_search / prepare_template, eval_tracking_utils.py:155-229): job 2b = tracklet b's
+// search cloud, job 2b + 1 = its previous-frame template crop followed by get_model + regularize_pc.
+__global__ __launch_bounds__(1024) void crop_regularize_kernel(const ptt_crop_job* __restrict__ cjobs, const ptt_regularize_job* __restrict__ rjobs,
+                                                               const uint32_t* __restrict__ draws, int n_draws) {
+    const ptt_crop_job j = cjobs[blockIdx.x];
+    crop_compact_body<1024>(j);
+    __threadfence();                                 // the crop's points and count are read back by this workgroup below
+    __syncthreads();
+    regularize_body<1024>(rjobs, draws, n_draws);
+}
+
 // One wave per frame: first arg-max of column 4 over the P proposals (np.argmax: lowest index among equal maxima).
 __global__ __launch_bounds__(256) void select_box_kernel(const float* __restrict__ boxes, int B, int P, float* __restrict__ out,
                                                          int32_t* __restrict__ idx_out) {
@@ -232,6 +250,15 @@ extern "C" int ptt_crop_compact_f32(const ptt_crop_job* jobs_device, int n_jobs,
     if (!jobs_device) return fail(PTT_EINVAL, "ptt_crop_compact_f32: null job array");
     hipLaunchKernelGGL((crop_compact_kernel<1024>), dim3(n_jobs), dim3(1024), 0, as_stream(stream), jobs_device);
     return check_launch("crop_compact_kernel");
+}
+
+extern "C" int ptt_crop_regularize_f32(const ptt_crop_job* crop_jobs, const ptt_regularize_job* reg_jobs_device, int n_jobs,
+                                       const uint32_t* draws, int n_draws, ptt_stream_t stream) {
+    if (n_jobs < 0 || n_draws < 0) return fail(PTT_EINVAL, "ptt_crop_regularize_f32: n_jobs=%d n_draws=%d", n_jobs, n_draws);
+    if (n_jobs == 0) return PTT_OK;
+    if (!crop_jobs || !reg_jobs_device || !draws) return fail(PTT_EINVAL, "ptt_crop_regularize_f32: null pointer");
+    hipLaunchKernelGGL(crop_regularize_kernel, dim3(n_jobs), dim3(1024), 0, as_stream(stream), crop_jobs, reg_jobs_device, draws, n_draws);
+    return check_launch("crop_regularize_kernel");
 }
 
 extern "C" int ptt_regularize_f32(const ptt_regularize_job* jobs_device, int n_jobs, const uint32_t* draws, int n_draws,

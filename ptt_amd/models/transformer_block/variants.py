@@ -124,8 +124,9 @@ class TransformerBlock(nn.Module):
                 g = torch.empty_like(pos)
                 res = torch.empty((B, N, D), dtype=torch.float32, device=dev)
                 out = torch.empty((B, N, self.d_points), dtype=torch.float32, device=dev)
-                ops.row_jobs([ops.row_job(P['qkv'], 3 * D, x=features, shift=P['qkv_b'], out=qkv),
-                              ops.row_job(P['wd2'], D, prologue=1, rel=rel.view(-1, 3), w1=P['w1b'], K=D, shift=P['bd2'], out=pos)])
+                # (the long job first: its workgroups take the CUs at once, the projection's short ones fill in behind them)
+                ops.row_jobs([ops.row_job(P['wd2'], D, prologue=1, rel=rel.view(-1, 3), w1=P['w1b'], K=D, shift=P['bd2'], out=pos),
+                              ops.row_job(P['qkv'], 3 * D, x=features, shift=P['qkv_b'], out=qkv)])
                 ops.row_jobs([ops.row_job(P['wg1'], D, prologue=2, qkv=qkv, knn=knn_idx.view(-1, self.k), pos=pos, q_off=0, k_off=D,
                                           N=N, K=D, shift=P['bg1'], act=1, out=g)])
                 ops.row_jobs([ops.row_job(P['wg2'], D, x=g, epilogue=1, qkv=qkv, knn=knn_idx.view(-1, self.k), pos=pos, v_off=2 * D,

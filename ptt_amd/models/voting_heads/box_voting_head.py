@@ -100,7 +100,11 @@ class BoxVotingHead(VotingHeadTemplate):
                     ops.row_jobs([ops.row_job(wp, cout, x=x, scale=scale, shift=shift, act=1 if relu else 0, out=h)])
                     x = h
                 wp, cout, scale, shift, relu = L[-1]
-                boxes = torch.empty((B, M, cout), dtype=torch.float32, device=rows.device)
+                # pred_box_out (set by a driver: ptt_amd.tracklet_runner): a preallocated (B,M,5) buffer to write the proposals
+                # into, so that its one read-back per frame needs no gathering copy
+                boxes = getattr(self, 'pred_box_out', None)
+                if boxes is None or tuple(boxes.shape) != (B, M, cout) or boxes.device != rows.device:
+                    boxes = torch.empty((B, M, cout), dtype=torch.float32, device=rows.device)
                 ops.row_jobs([ops.row_job(wp, cout, x=x, scale=scale, shift=shift, act=1 if relu else 0, res2=centres.contiguous(),
                                           res_split=3, out=boxes)])
                 batch_dict['pred_box_center'] = centres

@@ -629,6 +629,13 @@ def crop_compact_pinned(jobs_pinned, n_jobs, device):
         _lib.check(_lib.lib().ptt_crop_compact_f32(ctypes.c_void_p(jobs_pinned.data_ptr()), int(n_jobs), _stream()), "ptt_crop_compact_f32")
 
 
+def crop_regularize_pinned(crop_jobs_pinned, reg_jobs_dev, n_jobs, draws):
+    """ptt_crop_regularize_f32: crop job w then resampling job w per workgroup, the crop table read from pinned host memory."""
+    with torch.cuda.device(reg_jobs_dev.device), _timed('ptt_crop_compact_f32'):
+        _lib.check(_lib.lib().ptt_crop_regularize_f32(ctypes.c_void_p(crop_jobs_pinned.data_ptr()), _ptr(reg_jobs_dev), int(n_jobs),
+                                                      _ptr(draws), draws.numel(), _stream()), "ptt_crop_regularize_f32")
+
+
 def regularize(jobs_dev, n_jobs, draws):
     """ptt_regularize_f32 over a device-resident table of ptt_regularize_job records."""
     with torch.cuda.device(jobs_dev.device), _timed('ptt_regularize_f32'):

@@ -73,6 +73,13 @@ class TrackletRunner(object):
         # a handful of tracklets: the crop table rides in the crop launch's arguments (no upload), and the host picks the best
         # proposal itself from the (B,P,5) read-back — two launches less per frame of a chain that is launches
         self.few = 2 * B <= ops.CROP_JOBS_BY_VALUE_MAX
+        if self.few and use_graph:
+            # one read-back buffer: (B,P,5) proposals, then the (B,2,2) resampling counts
+            self.P = int(tracker.box_voting_head.model_cfg.SA_CONFIG.NPOINTS)
+            self.n_box = B * self.P * 5
+            self.readback = torch.zeros(self.n_box + B * 4, dtype=torch.float32, device=dev)
+            self.readback_host = torch.zeros(self.n_box + B * 4, dtype=torch.float32).pin_memory()
+            self.info = self.readback[self.n_box:].view(torch.int32).view(B, 2, 2)
         self.result_host = None if self.few else torch.empty((B, 5), dtype=torch.float32).pin_memory()
         self.info_host = torch.empty((B, 2, 2), dtype=torch.int32).pin_memory()
         self._model = _BoxedForward(tracker, select=not self.few)
@@ -220,10 +227,14 @@ class TrackletRunner(object):
             self._done.synchronize()
             if prof is not None:
                 t_c = time.perf_counter()
-            est = self.result_host.numpy()                        # (B,5) float32: x, y, z, theta (degrees), score
+            if self.few and self.use_graph:                      # one buffer: (B,P,5) proposals, then the resampling counts
+                host = self.readback_host.numpy()
+                est, info = host[:self.n_box].reshape(B, self.P, 5), host[self.n_box:].view(np.int32).reshape(B, 2, 2)
+            else:
+                est = self.result_host.numpy()                    # (B,5) float32: x, y, z, theta (degrees), score
+                info = self.info_host.numpy()
             if est.ndim == 3:                                     # (B,P,5): the first arg-max of the scores, as post_process takes it (:267-269)
                 est = est[np.arange(B), np.argmax(est[:, :, 4], axis=1)]
-            info = self.info_host.numpy()
             # post_process (:266-274): box_i = get_box_by_offset(box_{i-1}, best proposal, USE_Z_AXIS). An implausibly
             # large x / y offset is redrawn from numpy's GLOBAL generator (:205-208), whose state then is "seeded with 1
             # and advanced by the template's (else the search's) resampling draws" — the draw counts come back with the boxes
@@ -260,27 +271,35 @@ class TrackletRunner(object):
                 return stop.value
 
     def _frame_body(self):
-        ops.crop_compact_pinned(self.crop_jobs_host, 2 * self.B, self.device)
-        ops.regularize(self.reg_jobs_dev, 2 * self.B, self.draws)
-        self.info_host.copy_(self.info, non_blocking=True)
-        return self._model(self.search, self.template)
+        ops.crop_regularize_pinned(self.crop_jobs_host, self.reg_jobs_dev, 2 * self.B, self.draws)     # crop w, then resampling w
+        rows = self._model(self.search, self.template)
+        if rows.data_ptr() != self.readback.data_ptr():      # a box head that did not take the preallocated output: one copy
+            self.readback[:self.n_box].view(self.B, self.P, 5).copy_(rows)
+        return rows
 
     def _capture_frame(self):
         """One frame of a handful of tracklets as ONE hipGraph: called at the first tracked frame of the first group, when the
-        job tables hold valid pointers (the warm-up runs execute them)."""
+        job tables hold valid pointers (the warm-up runs execute them). The box head writes its proposals straight into the
+        read-back buffer whose tail the resampling kernel fills with its draw counts (`self.info` lives there): ONE device-to-
+        host copy per frame."""
+        head = self.tracker.box_voting_head
         with torch.no_grad():
             cur = torch.cuda.current_stream(self.device)
             side = torch.cuda.Stream(device=self.device)
             side.wait_stream(cur)
-            with torch.cuda.stream(side):
-                for _ in range(3):                           # weight packing / LDS attributes happen here, not in capture
-                    rows = self._frame_body()
-            cur.wait_stream(side)
-            torch.cuda.synchronize(self.device)
-            self.result_host = torch.empty(tuple(rows.shape), dtype=torch.float32).pin_memory()
-            self._frame = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._frame):
-                self.result_host.copy_(self._frame_body(), non_blocking=True)
+            head.pred_box_out = self.readback[:self.n_box].view(self.B, self.P, 5)
+            try:
+                with torch.cuda.stream(side):
+                    for _ in range(3):                       # weight packing / LDS attributes happen here, not in capture
+                        rows = self._frame_body()
+                cur.wait_stream(side)
+                torch.cuda.synchronize(self.device)
+                self._frame = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self._frame):
+                    self._frame_body()
+                    self.readback_host.copy_(self.readback, non_blocking=True)
+            finally:
+                head.pred_box_out = None                     # the tracker may be shared: the hook is only live during capture
 
     def _ensure_graph(self):
         """The tracker forward + box selection for B frames as a hipGraph whose static inputs ARE the buffers the

@@ -1,10 +1,13 @@
 #!/bin/bash
-# Copies the merged output of the closing GPU session (gpurun_out/r03z, scripts/gpu_sessions_r03.sh z) into profiles/r03z_*.
+# Copies the merged output of a closing GPU session (gpurun_out/r04<S>, scripts/gpu_sessions_r04.sh z) into profiles/r04<S>_*.
+#   bash scripts/copy_closing_evidence.sh z
 set -e
-O=gpurun_out/r03z
+S=${1:-z}
+O=gpurun_out/r04$S
 for f in pytest_gpu.log bench_default.json bench_train.json serial_kernel_stats.csv serial_bench_line.json train_kernel_stats.csv \
-         train_profiled_bench_line.json b1_kernel_stats.csv forward_precision_vs_float64.log gradient_error_vs_float64.log; do
-    cp $O/$f profiles/r03z_$f
+         train_profiled_bench_line.json b1_kernel_stats.csv; do
+    [ -f $O/$f ] && cp $O/$f profiles/r04${S}_$f
 done
-cp $O/pmc/*.csv $O/pmc/pmc_summary.json profiles/r03z_pmc/
-cp $O/pmc_train_gemm/*.csv $O/pmc_train_gemm/pmc_summary.json profiles/r03z_pmc_train_gemm/
+for d in pmc pmc_stress pmc_train_gemm; do
+    if [ -f $O/$d/pmc_summary.json ]; then mkdir -p profiles/r04${S}_$d; cp $O/$d/*.csv $O/$d/pmc_summary.json profiles/r04${S}_$d/; fi
+done

@@ -68,5 +68,30 @@ j)  # split-bf16 GEMM probe beside the exact-fp32 row GEMM on the same shapes
     cat $O/bf16x3_probe.log
     timeout 900 python scripts/rows_gemm_bench.py > $O/rows_gemm.log 2>&1; grep -v amdgpu.ids $O/rows_gemm.log | cut -c1-300
     ;;
+z)  # closing evidence of the round: parity tests, the default bench line (all configs), serial / training / one-tracklet kernel
+    # traces, PMC passes over the kernels the steps launch NOW (incl. the row jobs and the stress-size pair launch)
+    timeout 2400 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log; tail -3 $O/pytest_gpu.log
+    SECONDS=0; timeout 1500 python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "default bench rc=$? wall ${SECONDS}s"
+    timeout 600 python bench.py --workload train --steps 20 --warmup 5 > $O/bench_train.json 2> $O/bench_train.err
+    ktrace serial_kernel_stats python $REPO/bench.py --serial --steps 10 --warmup 3 --no-cpu-baseline --sustain 0 --no-workloads
+    cp $O/serial_kernel_stats.stdout $O/serial_bench_line.json 2>/dev/null
+    ktrace train_kernel_stats python $REPO/bench.py --workload train --steps 5 --warmup 2 --sustain 0
+    cp $O/train_kernel_stats.stdout $O/train_profiled_bench_line.json 2>/dev/null
+    ktrace b1_kernel_stats python $REPO/scripts/tracklet_b1_profile.py
+    bash scripts/pmc_passes.sh $O/pmc "pair,sa0_s,sa1_s,sa2_s,sa_box,xcorr,lin_,rj" > $O/pmc.log 2>&1; tail -12 $O/pmc.log | cut -c1-300
+    bash scripts/pmc_passes.sh $O/pmc_stress "pair" "" "--batch 32 --pair-n 2048,64" > $O/pmc_stress.log 2>&1; tail -4 $O/pmc_stress.log | cut -c1-300
+    bash scripts/pmc_passes.sh $O/pmc_train_gemm - "python scripts/rows_gemm_bench.py --no-check --pmc" > $O/pmc_train_gemm.log 2>&1; tail -4 $O/pmc_train_gemm.log | cut -c1-300
+    python - <<PY
+import json
+d = json.load(open("$O/bench_default.json"))
+print("car", d["value"], d["ms_per_step"], d["roofline"]["frac"], "b1 loop", d["latency_b1"]["tracklet_loop"]["b1"])
+for k, v in d.get("workloads", {}).items():
+    print(k, v.get("value"), v.get("ms_per_step"), v.get("error"))
+PY
+    ;;
+s)  # stability: the whole GPU suite three times in fresh processes, smoke()
+    for i in 1 2 3; do timeout 1200 python -m pytest tests -m gpu -q -x 2>&1 | tail -2; done
+    timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+    ;;
 *)  echo "unknown session $S"; exit 2;;
 esac

@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--batch", type=int, default=48)
+    ap.add_argument("--pair-n", default="128,64", help="points per frame of the pair-kernel cases (stress: --batch 32 --pair-n 2048,64)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     B = a.batch
@@ -39,7 +40,7 @@ def main():
     rs = np.random.RandomState(0)
 
     # ---- pair kernel ----
-    for N in (128, 64):
+    for N in [int(v) for v in a.pair_n.split(",")]:
         name = "pair_N%d" % N
         if not want(name):
             continue
@@ -110,7 +111,7 @@ def main():
         print("%-14s %8.4f ms  %7.2f TFLOP/s   (cosine map %.4f ms)" % ("xcorr", ms, fl / ms / 1e9, timeit(lambda: ops.cosine_map(sf, tf), a.iters)))
 
     # ---- linear ----
-    for name, rows, K, Cout in (("lin_qkvf", B * 128, 256, 1536), ("lin_qkvf64", B * 64, 256, 1536), ("lin_fc1", B * 128, 256, 512), ("lin_qkv", B * 128, 512, 1536), ("lin_fc2", B * 128, 512, 256),
+    for name, rows, K, Cout in (("lin_hoist1", B * 512, 128, 128), ("lin_hoist2", B * 256, 256, 128), ("lin_qkvf", B * 128, 256, 1536), ("lin_qkvf64", B * 64, 256, 1536), ("lin_fc1", B * 128, 256, 512), ("lin_qkv", B * 128, 512, 1536), ("lin_fc2", B * 128, 512, 256),
                                 ("lin_cov", B * 128, 256, 256), ("lin_qkv64", B * 64, 512, 1536), ("lin_fc2_64", B * 64, 512, 256)):
         if not want(name):
             continue
@@ -126,6 +127,34 @@ def main():
                 ms = timeit(fn, a.iters)
                 print("   tile RT,CT=%s %8.4f ms  %7.2f TFLOP/s" % (tile, ms, 2.0 * rows * K * Cout / ms / 1e9))
             os.environ.pop("PTT_LINEAR_TILE")
+
+    # ---- the row jobs of ONE tracklet frame (ptt_row_jobs_f32; independent of --batch) ----
+    if want("rj"):
+        D, N = 512, 128
+        qkv = torch.randn((N, 3 * D), device=dev)
+        knn1 = torch.stack([torch.randperm(N)[:16] for _ in range(N)]).to(torch.int32).to(dev)
+        pos = torch.randn((N * 16, D), device=dev)
+        rel = torch.randn((N * 16, 3), device=dev)
+        w1 = torch.randn((D, 4), device=dev)
+        wp = ops.pack_weight(torch.randn((D, D), device=dev) / 22.6)
+        wq = ops.pack_weight(torch.randn((3 * D, 256), device=dev) / 16)
+        b = torch.zeros(3 * D, device=dev)
+        feats = torch.randn((N, 256), device=dev)
+        g = torch.empty((N * 16, D), device=dev)
+        res = torch.empty((N, D), device=dev)
+        o = torch.empty((N, D), device=dev)
+        q2 = torch.empty((N, 3 * D), device=dev)
+        cases = (("rj_qkv_delta", lambda: ops.row_jobs([ops.row_job(wq, 3 * D, x=feats, shift=b, out=q2),
+                                                         ops.row_job(wp, D, prologue=1, rel=rel, w1=w1, K=D, shift=b[:D], out=g)]),
+                  2.0 * (N * 256 * 3 * D + N * 16 * D * D)),
+                 ("rj_gamma0", lambda: ops.row_jobs([ops.row_job(wp, D, prologue=2, qkv=qkv, knn=knn1, pos=pos, k_off=D, N=N, K=D, shift=b[:D], act=1, out=g)]),
+                  2.0 * N * 16 * D * D),
+                 ("rj_gamma2", lambda: ops.row_jobs([ops.row_job(wp, D, x=g, epilogue=1, qkv=qkv, knn=knn1, pos=pos, v_off=2 * D, N=N, sm_scale=0.0442, out=res)]),
+                  2.0 * N * 16 * D * D),
+                 ("rj_plain", lambda: ops.row_jobs([ops.row_job(wp, D, x=res, shift=b[:D], out=o)]), 2.0 * N * D * D))
+        for name, fn, fl in cases:
+            ms = timeit(fn, a.iters)
+            print("%-14s %8.4f ms  %7.2f TFLOP/s" % (name, ms, fl / ms / 1e9))
 
     # ---- FPS ----
     for name, N, m in (("fps_2048", 2048, 512), ("fps_1024", 1024, 256), ("fps_128", 128, 64)):

@@ -9,6 +9,8 @@ ONLY=${2:-pair,sa0_s,sa1_s,sa2_s,sa_box}
 # optional third argument: another command to profile instead of scripts/kernel_bench.py (e.g. the training row GEMMs:
 #   bash scripts/pmc_passes.sh gpurun_out/x_pmc - "python scripts/rows_gemm_bench.py --no-check --pmc")
 CMD=${3:-}
+# optional fourth argument: extra arguments for scripts/kernel_bench.py (e.g. "--batch 32 --pair-n 2048,64": the stress shapes)
+KB_ARGS=${4:-}
 mkdir -p "$OUT"
 REPO=$(pwd)
 cd /tmp && export TMPDIR=/tmp
@@ -19,11 +21,11 @@ pass() {
         (cd "$REPO" && timeout 600 rocprofv3 --pmc "$@" --output-format csv -d /tmp/pmc_$name -- $CMD > /tmp/pmc_$name.log 2>&1)
     else
         timeout 300 rocprofv3 --pmc "$@" --output-format csv -d /tmp/pmc_$name -- \
-            python "$REPO/scripts/kernel_bench.py" --only "$ONLY" --iters 4 > /tmp/pmc_$name.log 2>&1
+            python "$REPO/scripts/kernel_bench.py" --only "$ONLY" --iters 4 $KB_ARGS > /tmp/pmc_$name.log 2>&1
     fi
     f=$(find /tmp/pmc_$name -name "*counter_collection.csv" | head -1)
     if [ -n "$f" ]; then
-        grep -E "Counter_Name|pt_attn_pair|sa_fused_kernel|sa_wave_kernel|sa_stream_kernel|sa_lds_kernel|linear_kernel|linear_small_kernel|xcorr_fused|rows_gemm_kernel|wgrad2_kernel|linear_wgrad_kernel" "$f" > "$REPO/$OUT/pmc_$name.csv"
+        grep -E "Counter_Name|pt_attn_pair|sa_fused_kernel|sa_wave_kernel|sa_stream_kernel|sa_lds_kernel|linear_kernel|linear_small_kernel|xcorr_fused|rows_gemm_kernel|wgrad2_kernel|linear_wgrad_kernel|rowjobs_kernel" "$f" > "$REPO/$OUT/pmc_$name.csv"
     else
         tail -5 /tmp/pmc_$name.log > "$REPO/$OUT/pmc_$name.err"
     fi
