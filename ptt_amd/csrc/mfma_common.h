@@ -17,7 +17,7 @@ __device__ __forceinline__ float xor32(float v) { return __shfl_xor(v, 32, 64); 
 // holds the lower half-wave's values in both halves and `hi` the upper half-wave's.
 // Inline asm on purpose: with both operands holding the SAME value hipcc (ROCm 7.2) folds
 // __builtin_amdgcn_permlane32_swap's two results into one and the exchange silently disappears
-// (scripts/permlane_probe.hip). s_nop 1 = the VALU-write -> v_permlane read hazard, inside the string.
+// (scripts/probes/permlane_probe.hip). s_nop 1 = the VALU-write -> v_permlane read hazard, inside the string.
 __device__ __forceinline__ void swap_halves(float v, float& lo, float& hi) {
     float a = v, b = v;
     asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));

@@ -41,7 +41,7 @@ __device__ __forceinline__ float lane_bcast(float v, int src_lane) {
 // the squared distances are formed two points at a time with packed fp32 instructions (v_pk_add / v_pk_mul: the same
 // IEEE operations, no FMA) — 8 instead of 15 vector-ALU instructions per point. It is every instruction of this
 // kernel, not its 0.4 ms, that the pipelined step pays for: the FPS of the next batch runs beside the MFMA kernels
-// and costs them 0.14 ms per step (scripts/fps_interference_probe.py, fps_vs_pair_probe.py; 0.07 with LX). LX needs
+// and costs them 0.14 ms per step (scripts/probes/fps_interference_probe.py, fps_vs_pair_probe.py; 0.07 with LX). LX needs
 // 12 N bytes of LDS beside the index buffer: clouds up to ~4096 points; larger ones keep the coordinates in the selects.
 typedef float fps_f2 __attribute__((ext_vector_type(2)));
 

@@ -212,7 +212,7 @@ class InterleavedHotPath(object):
     """Throughput mode with `ways` independent batches in flight: `ways` PipelinedHotPath graphs, each on its own HIP
     stream, replayed round-robin. The tail of one batch's kernels (the last workgroups of a launch, the launch gaps
     between ~55 dependent kernels) is filled by the other batch's kernels; every batch still executes every kernel.
-    Measured on the KITTI-Car workload (scripts/dual_pipeline_probe.py): 3.18 -> 3.11 ms per 48-frame step with two
+    Measured on the KITTI-Car workload (scripts/probes/dual_pipeline_probe.py): 3.18 -> 3.11 ms per 48-frame step with two
     ways, nothing more with three or four.
 
         pipe = InterleavedHotPath(model, search0, template0)        # ways = 2

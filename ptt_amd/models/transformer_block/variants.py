@@ -31,7 +31,7 @@ PER_LAYER_MAX_POINTS = ops.ONE_FRAME_MAX_POINTS
 def _rows2d(layers, x):
     """layers(x) for Linear stacks acting on the last dim, evaluated on the flattened (rows, C) view. Same numbers;
     on ROCm the autograd backward of nn.Linear over a 4-D (B,N,k,C) input takes a GEMM path that runs at 1-4 TFLOP/s
-    (scripts/linear_train_probe.py: 14 ms vs 1.6 ms for forward + backward of one 512x512 layer at B=48)."""
+    (scripts/probes/linear_train_probe.py: 14 ms vs 1.6 ms for forward + backward of one 512x512 layer at B=48)."""
     return layers(x.reshape(-1, x.shape[-1])).reshape(*x.shape[:-1], -1)
 
 

@@ -332,7 +332,7 @@ def run_overlapped(runners, tracklets):
     """Throughput form of the tracking loop: the tracklets are dealt to `len(runners)` TrackletRunners (each with its own
     buffers, model graph and HIP stream) whose lockstep groups advance ALTERNATELY — while the host waits for group A's
     boxes and computes its next crop bounds, group B's frame is on the device. Same per-tracklet results as
-    runner.run(). Measured on one MI355X (round 3, scripts/tracklet_groups_probe.py): 96 tracklets as 2 x 48 alternating
+    runner.run(). Measured on one MI355X (round 3, scripts/probes/tracklet_groups_probe.py): 96 tracklets as 2 x 48 alternating
     10.7k frames/s against 9.8-10.3k one group after the other (144 / 192 tracklets as 3 / 4 groups: 10.7k / 10.5k) — the
     model graph of a 48-wide group fills the chip, so what overlaps is the host bubble (~0.5 ms per step) and the
     latency-bound sampling; splitting 48 tracklets into 2 x 24 loses more in half-filled graphs than it hides (round 2:

@@ -28,7 +28,7 @@ c)  timeout 900 python scripts/rows_gemm_bench.py > $O/rows_gemm.log 2>&1; cat $
     ;;
 d)  timeout 900 python scripts/rows_gemm_exp.py > $O/rows_gemm_exp.log 2>&1; cat $O/rows_gemm_exp.log | cut -c1-420
     ;;
-e)  hipcc --offload-arch=gfx950 -O2 scripts/buffer_range_probe.hip -o /tmp/brp && /tmp/brp > $O/buffer_range_probe.log 2>&1; cat $O/buffer_range_probe.log
+e)  hipcc --offload-arch=gfx950 -O2 scripts/probes/buffer_range_probe.hip -o /tmp/brp && /tmp/brp > $O/buffer_range_probe.log 2>&1; cat $O/buffer_range_probe.log
     timeout 900 python scripts/rows_gemm_bench.py > $O/rows_gemm.log 2>&1; grep -v amdgpu.ids $O/rows_gemm.log | cut -c1-420
     timeout 900 python scripts/rows_gemm_exp.py > $O/rows_gemm_exp.log 2>&1; grep -v amdgpu.ids $O/rows_gemm_exp.log | cut -c1-420
     ;;

@@ -1,6 +1,6 @@
 """Probe: with three batches in flight, does the template branch still need its own stream inside a batch?"""
 import os, sys, time, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from ptt_amd import synth
 from ptt_amd.hot_path import FrameHotPath, InterleavedHotPath, kitti_model_cfg, randomize_
 dev = torch.device("cuda:0")

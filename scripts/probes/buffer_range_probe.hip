@@ -1,6 +1,6 @@
 // Does the range check of a raw buffer load (stride 0) on gfx950 see the SGPR offset? Prints, for a 1024-byte buffer of
 // ones followed by twos, what loads at (voffset, soffset) return: 0 = clipped by the descriptor, 2 = read past it.
-//   hipcc --offload-arch=gfx950 -O2 scripts/buffer_range_probe.hip -o /tmp/brp && /tmp/brp
+//   hipcc --offload-arch=gfx950 -O2 scripts/probes/buffer_range_probe.hip -o /tmp/brp && /tmp/brp
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 __global__ void probe(const float* base, float* out) {

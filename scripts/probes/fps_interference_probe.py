@@ -1,7 +1,7 @@
 """Probe: what the side-stream FPS of the next batch costs the step — the same two-way pipelined replay with the sampling
 stage replaced by a copy of cached indices (wrong for new inputs: timing only)."""
 import os, sys, time, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from ptt_amd import synth
 from ptt_amd.hot_path import FrameHotPath, InterleavedHotPath, kitti_model_cfg, randomize_
 dev = torch.device("cuda:0")

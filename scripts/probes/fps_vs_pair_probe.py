@@ -1,6 +1,6 @@
 """Probe: how much a concurrent FPS launch (48 clouds, one workgroup each) slows the pair kernel on another stream."""
 import os, sys, time, numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from ptt_amd import ops, synth
 from tests.util import transformer_params
 dev = torch.device("cuda:0"); B, N = 48, 128

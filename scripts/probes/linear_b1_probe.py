@@ -1,6 +1,6 @@
 """Dev: per-launch time of the small linear launches of one tracklet frame, inside a hipGraph of 20 dependent launches."""
 import os, sys, time, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from ptt_amd import ops
 dev = torch.device("cuda:0")
 for rows, K, C in ((128, 256, 256), (128, 256, 1536), (64, 512, 256), (512, 128, 128), (6144, 256, 256)):

@@ -2,7 +2,7 @@
 """Dev: where do the slow GEMMs of the TransformerBlock training path come from? Times fwd / dX / dW formulations of a
 (98304 x 512) @ (512 x 512) linear layer in fp32."""
 import os, sys, torch, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from ptt_amd import ops
 dev = torch.device("cuda:0")
 B, N, k, D = 48, 128, 16, 512

@@ -1,5 +1,5 @@
 // Dev probe: what limits the fp32-MFMA K-loop? Variants: MFMA only / + global B loads / + LDS A reads.
-// hipcc --offload-arch=gfx950 -O3 scripts/mfma_loop_probe.hip -o /tmp/probe && /tmp/probe
+// hipcc --offload-arch=gfx950 -O3 scripts/probes/mfma_loop_probe.hip -o /tmp/probe && /tmp/probe
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 typedef float f32x16 __attribute__((ext_vector_type(16)));

@@ -1,7 +1,7 @@
 """Dev probe: is ptt_sa_z0_rows_f32 bit-identical to the launches it replaces (group / subtract / divide / gather_rows / K = 3
 linear with residual)?"""
 import os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from ptt_amd import ops, synth, train_ops
 from ptt_amd.models.backbones_3d.pointnet2 import pointnet2_utils as pu
 dev = torch.device("cuda:0")

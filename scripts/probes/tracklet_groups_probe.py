@@ -1,7 +1,7 @@
 """Dev probe: tracking throughput with G lockstep groups of 48 tracklets advancing alternately (run_overlapped) against
 one group after the other (TrackletRunner.run) — same tracklets, same results."""
 import os, sys, time, torch, numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from ptt_amd import synth
 from ptt_amd.config import StubDataset, ptt_model_cfg
 from ptt_amd.hot_path import randomize_

@@ -1,7 +1,7 @@
 // Dev probe: how fast does a wave issue VALU / LDS / readlane work while ANOTHER wave on the same SIMD streams
 // fp32 MFMAs? One workgroup of 512 threads per CU: waves 0-3 (one per SIMD) run the test loop, waves 4-7 either
 // idle or run a dense v_mfma_f32_32x32x2_f32 loop. Cycles per instruction of the test loop are reported.
-// hipcc --offload-arch=gfx950 -O3 scripts/valu_under_mfma_probe.hip -o /tmp/vprobe && /tmp/vprobe
+// hipcc --offload-arch=gfx950 -O3 scripts/probes/valu_under_mfma_probe.hip -o /tmp/vprobe && /tmp/vprobe
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #pragma clang diagnostic ignored "-Wunused-value"
