@@ -766,8 +766,9 @@ extern "C" int ptt_fps_f32(const float* xyz, int B, int N, int npoint, int32_t* 
     if (N <= 4096) return launch_fps<512, 8>(xyz, B, N, npoint, idx_out, s);
     if (N <= 8192) return launch_fps<1024, 8>(xyz, B, N, npoint, idx_out, s);
     if (N <= 16384) return launch_fps<1024, 16>(xyz, B, N, npoint, idx_out, s);
-    if (N <= 32768) return launch_fps<1024, 32>(xyz, B, N, npoint, idx_out, s);
-    return fail(PTT_EUNSUPPORTED, "ptt_fps_f32: N=%d exceeds the register-resident limit 32768", N);
+    // 32 points per thread (clouds up to 32768 points) is the whole 128-register budget of a 1024-thread workgroup and spilled
+    // 164-180 bytes per lane: no BASELINE config reaches it (the largest is 16384), so it is refused rather than shipped slow
+    return fail(PTT_EUNSUPPORTED, "ptt_fps_f32: N=%d exceeds the register-resident limit 16384", N);
 }
 
 // centres per wave of the ball-query kernels: 4 when the launch still has at least two waves per SIMD of the device and
