@@ -551,6 +551,10 @@ int ptt_gather_rows_f32(const float* src, const int32_t* idx, int B, int N, int 
 int ptt_scatter_csr_i32(const int32_t* idx, int B, int N, int E, int32_t* order, int32_t* start, ptt_stream_t stream);
 int ptt_scatter_rows_csr_f32(const float* g, const int32_t* order, const int32_t* start, int B, int N, int E, int C,
                              float* out, ptt_stream_t stream);
+/* out[c] = sum over the R rows of X[r][c] — the bias gradient of a row-wise layer (nn.Linear / Conv1d(k=1) backward,
+ * transformer_block/variants.py:154-164 in training) — in a fixed order: bit-reproducible. C % 4 == 0, 16-byte aligned rows. */
+size_t ptt_colsum_workspace(int R, int C);
+int ptt_colsum_f32(const float* X, int R, int C, int ldx, float* out, void* workspace, size_t workspace_bytes, ptt_stream_t stream);
 size_t ptt_linear_wgrad_workspace(int R, int Cout, int Cin);
 int ptt_linear_wgrad_f32(const float* dZ, int ldz, const float* X, int ldx, int R, int Cout, int Cin, float* dW,
                          int accumulate, void* workspace, size_t workspace_bytes, const float* x_scale, const float* x_shift,

@@ -734,6 +734,45 @@ __global__ __launch_bounds__(256) void wgrad_smallk_kernel(const float* __restri
 // dW = sum over chunks (fixed order); optionally accumulates into dW (beta = 1) for parameters used more than once.
 // Workgroup = 32 consecutive outputs x 8 chunk groups: group g adds the chunks g, g + 8, ... in order, the 8 group sums are
 // then added in order — a fixed summation tree, and 8x the loads in flight of a one-thread-per-output loop.
+// Column sums of a (rows, C) tensor — the bias gradient of a row-wise layer (sum over the rows of dY; torch's reduce takes 27 us for
+// the 6144-row layers of a step). One workgroup per (row chunk, block of 64 channel quads): 4 row lanes stride the chunk's rows with
+// coalesced float4 loads, combined through LDS in lane order; the chunk partials are summed in chunk order by wgrad_finish_kernel
+// (deterministic, as every reduction of the training step).
+constexpr int CS_ROWS = 128;          // rows per chunk at least
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ X, int ldx, int R, int C, int rows_per_chunk,
+                                                             float* __restrict__ partial) {
+    __shared__ f32x4t red[4][64];
+    const int q = blockIdx.y * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+    const int r0 = blockIdx.x * rows_per_chunk, r1 = min(R, r0 + rows_per_chunk);
+    f32x4t acc = {0.f, 0.f, 0.f, 0.f};
+    if (4 * q < C) {
+        int r = r0 + rg;
+        for (; r + 12 < r1; r += 16) {
+            const f32x4t a = *reinterpret_cast<const f32x4t*>(X + (size_t)r * ldx + 4 * q);
+            const f32x4t b = *reinterpret_cast<const f32x4t*>(X + (size_t)(r + 4) * ldx + 4 * q);
+            const f32x4t c = *reinterpret_cast<const f32x4t*>(X + (size_t)(r + 8) * ldx + 4 * q);
+            const f32x4t d = *reinterpret_cast<const f32x4t*>(X + (size_t)(r + 12) * ldx + 4 * q);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k] = (((acc[k] + a[k]) + b[k]) + c[k]) + d[k];
+        }
+        for (; r < r1; r += 4) {
+            const f32x4t a = *reinterpret_cast<const f32x4t*>(X + (size_t)r * ldx + 4 * q);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k] += a[k];
+        }
+    }
+    red[rg][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (rg == 0 && 4 * q < C) {
+        f32x4t t = red[0][threadIdx.x];
+#pragma unroll
+        for (int g = 1; g < 4; ++g)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) t[k] += red[g][threadIdx.x][k];
+        *reinterpret_cast<f32x4t*>(partial + (size_t)blockIdx.x * C + 4 * q) = t;
+    }
+}
+
 // OUT = outputs per workgroup (32, 8 or 4): many chunks over few outputs (the K = 3 gradients: 3072 chunks x 192 outputs) take
 // more groups per output — 74 us -> a few for that shape.
 template <int OUT>
@@ -1336,6 +1375,36 @@ extern "C" int ptt_pt_attn_train_bwd_f32(const float* attn, const float* vf, con
 }
 
 static inline bool wgrad_smallk_ok(int Cout, int Cin) { return Cin >= 1 && Cin <= 4 && (Cout & 3) == 0; }
+
+static inline int colsum_rows_per_chunk(int R, int C) {
+    const int colblocks = (C / 4 + 63) / 64;
+    int chunks = 512 / colblocks;                       // about two workgroups per CU in all
+    int rows = (R + chunks - 1) / chunks;
+    if (rows < CS_ROWS) rows = CS_ROWS;
+    return (rows + 3) / 4 * 4;
+}
+extern "C" size_t ptt_colsum_workspace(int R, int C) {
+    if (R <= 0 || C <= 0) return 0;
+    const int rows = colsum_rows_per_chunk(R, C);
+    return (size_t)((R + rows - 1) / rows) * (size_t)C * sizeof(float);
+}
+extern "C" int ptt_colsum_f32(const float* X, int R, int C, int ldx, float* out, void* ws, size_t ws_bytes, ptt_stream_t stream) {
+    if (R <= 0 || C <= 0 || (C & 3) || ldx < C || (ldx & 3) || (reinterpret_cast<uintptr_t>(X) & 15) || (reinterpret_cast<uintptr_t>(out) & 15))
+        return fail(PTT_EINVAL, "ptt_colsum_f32: R=%d C=%d ldx=%d (C %% 4 == 0, 16-byte aligned rows)", R, C, ldx);
+    if (!X || !out) return fail(PTT_EINVAL, "ptt_colsum_f32: null pointer");
+    const int rows = colsum_rows_per_chunk(R, C), nch = (R + rows - 1) / rows;
+    hipStream_t s2 = as_stream(stream);
+    const dim3 grid(nch, (C / 4 + 63) / 64);
+    if (nch == 1) {
+        hipLaunchKernelGGL(colsum_partial_kernel, grid, dim3(256), 0, s2, X, ldx, R, C, rows, out);
+        return check_launch("colsum_partial_kernel");
+    }
+    if (!ws || ws_bytes < ptt_colsum_workspace(R, C)) return fail(PTT_EWORKSPACE, "ptt_colsum_f32: workspace too small");
+    float* part = static_cast<float*>(ws);
+    hipLaunchKernelGGL(colsum_partial_kernel, grid, dim3(256), 0, s2, X, ldx, R, C, rows, part);
+    launch_wgrad_finish(part, nch, (size_t)C, 0, out, s2);
+    return check_launch("colsum_partial_kernel");
+}
 
 extern "C" size_t ptt_linear_wgrad_workspace(int R, int Cout, int Cin) {
     if (R <= 0 || Cout <= 0 || Cin <= 0) return 0;

@@ -164,9 +164,11 @@ class TransformerBlock(nn.Module):
             x = train_ops.rows_linear(self.fc1, features)
             q, kf, vf = (train_ops.rows_linear(m, x) for m in (self.w_qs, self.w_ks, self.w_vs))
             pos_enc = train_ops.rows_mlp2(self.fc_delta, rel)                          # (B,N,k,D)
-            t = train_ops._PairInput.apply(q, kf, knn_idx, pos_enc)
+            # the backward scatters of k and v run over the same neighbour indices: their (bin, entry) order is formed once
+            order, start = ops.scatter_csr(knn_idx.view(knn_idx.shape[0], -1), knn_idx.shape[1])
+            t = train_ops._PairInput.apply(q, kf, knn_idx, pos_enc, order, start)
             a = train_ops.rows_mlp2(self.fc_gamma, t)
-            res, attn = train_ops._AttnAggregate.apply(a, vf, knn_idx, pos_enc, 1.0 / np.sqrt(self.d_model))
+            res, attn = train_ops._AttnAggregate.apply(a, vf, knn_idx, pos_enc, 1.0 / np.sqrt(self.d_model), order, start)
             res = train_ops.rows_linear(self.fc2, res, residual=features)
             return res, attn
 

@@ -1046,6 +1046,20 @@ def bn_sums_partials(partials, rows):
     return sums
 
 
+def colsum(x):
+    """(rows, C) -> (C,) column sums in a fixed order (ptt_colsum_f32): the bias gradient of a row-wise layer. Falls back to
+    torch's sum for layouts the kernel does not take (C % 4, unaligned rows)."""
+    _rows(x, "x")
+    R, C = x.shape
+    if R == 0 or C % 4 or x.stride(0) % 4 or x.data_ptr() % 16:
+        return x.sum(0)
+    out = torch.empty((C,), dtype=torch.float32, device=x.device)
+    ws = _ws(_lib.lib().ptt_colsum_workspace(R, C), x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().ptt_colsum_f32(_ptr(x), R, C, x.stride(0), _ptr(out), _ptr(ws), ws.numel() * 8, _stream()), "ptt_colsum_f32")
+    return out
+
+
 def linear_wgrad(dz, x, out=None, accumulate=False, x_scale=None, x_shift=None):
     """dW (Cout,Cin) = dz^T x over the rows, on fp32 MFMA — ptt_linear_wgrad2_f32 (up to 256 x 256 outputs per workgroup)
     where it applies, else ptt_linear_wgrad_f32; with x_scale / x_shift the rows of x are relu(x * scale + shift), applied
@@ -1171,16 +1185,27 @@ def sa_z0_rows(xyz, new_xyz, idx, term, wx, radius, normalize_xyz):
     return z0, rel
 
 
-def scatter_rows_det(g, idx, N):
-    """The adjoint of gather_rows in a fixed summation order: g (B,E,C), idx (B,E) -> (B,N,C)."""
+def scatter_csr(idx, N):
+    """(order (B,E), start (B,N+1)) of ptt_scatter_csr_i32 for idx (B,E) into N bins: the entries of every cloud sorted by (bin,
+    entry). Reusable by every scatter_rows_det over the same indices (the k and v gathers of a TransformerBlock share its kNN)."""
+    _chk(idx, "idx", torch.int32, 2)
+    B, E = idx.shape
+    order = torch.empty((B, E), dtype=torch.int32, device=idx.device)
+    start = torch.empty((B, int(N) + 1), dtype=torch.int32, device=idx.device)
+    with torch.cuda.device(idx.device):
+        _lib.check(_lib.lib().ptt_scatter_csr_i32(_ptr(idx), B, int(N), E, _ptr(order), _ptr(start), _stream()), "ptt_scatter_csr_i32")
+    return order, start
+
+
+def scatter_rows_det(g, idx, N, csr=None):
+    """The adjoint of gather_rows in a fixed summation order: g (B,E,C), idx (B,E) -> (B,N,C). csr: scatter_csr(idx, N) if the
+    caller already has it."""
     _chk(g, "g", torch.float32, 3)
     _chk(idx, "idx", torch.int32, 2)
     B, E, C = g.shape
-    order = torch.empty((B, E), dtype=torch.int32, device=g.device)
-    start = torch.empty((B, int(N) + 1), dtype=torch.int32, device=g.device)
+    order, start = csr if csr is not None else scatter_csr(idx, N)
     out = torch.empty((B, int(N), C), dtype=torch.float32, device=g.device)
     with torch.cuda.device(g.device):
-        _lib.check(_lib.lib().ptt_scatter_csr_i32(_ptr(idx), B, int(N), E, _ptr(order), _ptr(start), _stream()), "ptt_scatter_csr_i32")
         _lib.check(_lib.lib().ptt_scatter_rows_csr_f32(_ptr(g), _ptr(order), _ptr(start), B, int(N), E, C, _ptr(out), _stream()),
                    "ptt_scatter_rows_csr_f32")
     return out

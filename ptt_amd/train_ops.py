@@ -528,18 +528,20 @@ class _PairInput(torch.autograd.Function):
     dkf = -(deterministic row scatter-add of dt over knn)."""
 
     @staticmethod
-    def forward(ctx, q, kf, knn, pos):
-        ctx.save_for_backward(knn)
+    def forward(ctx, q, kf, knn, pos, order=None, start=None):
+        # order / start: ops.scatter_csr(knn) when the caller shares it with _AttnAggregate (the two scatters of a block sort the
+        # same indices)
+        ctx.save_for_backward(knn, *((order, start) if order is not None else ()))
         return ops.pt_pair_input(q.contiguous(), kf.contiguous(), knn, pos.contiguous())
 
     @staticmethod
     def backward(ctx, dt):
-        (knn,) = ctx.saved_tensors
+        knn, csr = ctx.saved_tensors[0], (tuple(ctx.saved_tensors[1:]) or None)
         B, N, k, D = dt.shape
         dt = dt.contiguous()
         dq = dt.sum(dim=2) if ctx.needs_input_grad[0] else None
-        dkf = ops.scatter_rows_det(dt.view(B, N * k, D), knn.view(B, N * k), N).neg_() if ctx.needs_input_grad[1] else None
-        return dq, dkf, None, dt
+        dkf = ops.scatter_rows_det(dt.view(B, N * k, D), knn.view(B, N * k), N, csr).neg_() if ctx.needs_input_grad[1] else None
+        return dq, dkf, None, dt, None, None
 
 
 class _AttnAggregate(torch.autograd.Function):
@@ -547,22 +549,23 @@ class _AttnAggregate(torch.autograd.Function):
     Returns (res, attn); attn is returned for the caller's benefit only (both heads drop it) and carries no gradient."""
 
     @staticmethod
-    def forward(ctx, a, vf, knn, pos, scale):
+    def forward(ctx, a, vf, knn, pos, scale, order=None, start=None):
         ctx.set_materialize_grads(False)
         a, vf, pos = a.contiguous(), vf.contiguous(), pos.contiguous()
         attn, res = ops.pt_attn_train_fwd(a, vf, knn, pos, scale)
-        ctx.save_for_backward(attn, vf, knn, pos)
+        ctx.save_for_backward(attn, vf, knn, pos, *((order, start) if order is not None else ()))
         ctx.scale = float(scale)
         ctx.mark_non_differentiable(attn)
         return res, attn
 
     @staticmethod
     def backward(ctx, dres, _dattn):
-        attn, vf, knn, pos = ctx.saved_tensors
+        attn, vf, knn, pos = ctx.saved_tensors[:4]
+        csr = tuple(ctx.saved_tensors[4:]) or None
         B, N, k, D = attn.shape
         da, dvp = ops.pt_attn_train_bwd(attn, vf, knn, pos, dres.contiguous(), ctx.scale)
-        dvf = ops.scatter_rows_det(dvp.view(B, N * k, D), knn.view(B, N * k), N) if ctx.needs_input_grad[1] else None
-        return da, dvf, None, dvp, None
+        dvf = ops.scatter_rows_det(dvp.view(B, N * k, D), knn.view(B, N * k), N, csr) if ctx.needs_input_grad[1] else None
+        return da, dvf, None, dvp, None, None, None
 
 
 def pt_block_usable(block, xyz, features):
@@ -604,7 +607,7 @@ class _RowsLinear(torch.autograd.Function):
         g2 = g.reshape(-1, g.shape[-1]).contiguous()
         dx = lin_rows(g2, ctx.W, transpose=True).view(ctx.shape) if ctx.needs_input_grad[0] else None
         dW = ops.linear_wgrad(g2, x2) if ctx.needs_input_grad[1] else None
-        db = g2.sum(0) if ctx.needs_input_grad[2] else None
+        db = ops.colsum(g2) if ctx.needs_input_grad[2] else None
         return dx, dW, db, (g if ctx.needs_input_grad[3] else None)
 
 
@@ -637,7 +640,7 @@ class _RowsMlp2(torch.autograd.Function):
         dy2 = dy.reshape(-1, dy.shape[-1]).contiguous()
         rows, D1 = h.shape
         dW2 = ops.linear_wgrad(dy2, h)
-        db2 = dy2.sum(0)
+        db2 = ops.colsum(dy2)
         if ops.rows_gemm_supported(rows, W2.shape[0], D1, dy2.stride(0), D1, x=dy2):
             dz1, db1 = ops.rows_gemm_masked(dy2, packed(W2, True), D1, h, want_colsum=True)
         else:

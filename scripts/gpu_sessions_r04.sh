@@ -93,5 +93,11 @@ s)  # stability: the whole GPU suite three times in fresh processes, smoke()
     for i in 1 2 3; do timeout 1200 python -m pytest tests -m gpu -q -x 2>&1 | tail -2; done
     timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
     ;;
+t)  # the training step after a change: gradient parity (G10 / G14 / G15, reproducibility), then the step time
+    timeout 1500 python -m pytest tests/test_train_gpu.py tests/test_train_config3_gpu.py tests/test_gemm_gpu.py -x -q -m gpu -s > $O/pytest.log 2>&1
+    grep -E "G15 \(|G10 on|G14:|passed|failed|Error" $O/pytest.log | tail -12
+    timeout 600 python bench.py --workload train --steps 20 --warmup 5 > $O/bench_train.json 2> $O/bench_train.err
+    python -c "import json;d=json.load(open('$O/bench_train.json'));print('train', d['ms_per_step'], d['value'], d['sustained'])"
+    ;;
 *)  echo "unknown session $S"; exit 2;;
 esac
