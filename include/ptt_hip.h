@@ -551,6 +551,19 @@ int ptt_gather_rows_f32(const float* src, const int32_t* idx, int B, int N, int 
 int ptt_scatter_csr_i32(const int32_t* idx, int B, int N, int E, int32_t* order, int32_t* start, ptt_stream_t stream);
 int ptt_scatter_rows_csr_f32(const float* g, const int32_t* order, const int32_t* start, int B, int N, int E, int C,
                              float* out, ptt_stream_t stream);
+/* The last layer of a SharedMLP + max-pool stage in training (pytorch_utils.py:12-36 + F.max_pool2d, pointnet2_modules.py:84-88)
+ * without the pooling pass over its (rows, N) output: ptt_rows_gemm_f32 with statistics whose epilogue ALSO takes, per group of
+ * `ns` consecutive rows and per column, the largest and the smallest output with the first row (inside the group) holding it —
+ * pmax / pmin (rows / ns, N) float, amax / amin (rows / ns, N) int32. Once the batch statistics (summed by the same launch) give
+ * the BatchNorm's a = gamma * invstd and b = beta - mean * a, ptt_pool_select_f32 forms the pooled relu(a y + b) and its arg-max:
+ * relu(a y + b) is monotone in y, the sign of a picks max or min. in_scale / in_shift (the producing layer's deferred activation)
+ * are required; shapes: ptt_rows_gemm_pool_supported (K, N multiples of 128 with ns 16 / 32 / 64, or K % 64 == 0, N % 128 == 0 with ns 32). */
+int ptt_rows_gemm_pool_supported(int rows, int K, int N, int ldx, int ns);
+int ptt_rows_gemm_pool_f32(const float* X, int rows, int K, int ldx, const float* in_scale, const float* in_shift,
+                           const float* Wpacked, int N, float* out, int ldo, double* stats, size_t stats_elems, int ns,
+                           float* pmax, float* pmin, int32_t* amax, int32_t* amin, ptt_stream_t stream);
+int ptt_pool_select_f32(const float* pmax, const float* pmin, const int32_t* amax, const int32_t* amin, const float* act_scale,
+                        const float* act_shift, int G, int C, float* out, int32_t* arg, ptt_stream_t stream);
 /* out[c] = sum over the R rows of X[r][c] — the bias gradient of a row-wise layer (nn.Linear / Conv1d(k=1) backward,
  * transformer_block/variants.py:154-164 in training) — in a fixed order: bit-reproducible. C % 4 == 0, 16-byte aligned rows. */
 size_t ptt_colsum_workspace(int R, int C);

@@ -38,7 +38,7 @@ EXPORTS = [
     "ptt_bn_update_running_f32", "ptt_xcorr_z0_f32", "ptt_xcorr_z0_bwd_workspace", "ptt_xcorr_z0_bwd_f32",
     "ptt_bn_stats_train_f32", "ptt_bn_finish_partials_train_f32", "ptt_pack_weights_f32",
     "ptt_sa_z0_rows_f32",
-    "ptt_row_jobs_f32", "ptt_point_jobs_f32", "ptt_fps_ball_knn_f32", "ptt_crop_compact_host_f32", "ptt_crop_regularize_f32", "ptt_colsum_workspace", "ptt_colsum_f32",
+    "ptt_row_jobs_f32", "ptt_point_jobs_f32", "ptt_fps_ball_knn_f32", "ptt_crop_compact_host_f32", "ptt_crop_regularize_f32", "ptt_colsum_workspace", "ptt_colsum_f32", "ptt_rows_gemm_pool_supported", "ptt_rows_gemm_pool_f32", "ptt_pool_select_f32",
 ]
 PTT_MAX_SEGMENTS = 4
 
@@ -158,6 +158,9 @@ def _declare(lib):
         "ptt_crop_compact_host_f32": [vp, i, vp],
         "ptt_crop_regularize_f32": [vp, vp, i, vp, i, vp],
         "ptt_colsum_f32": [vp, i, i, i, vp, vp, c_size_t, vp],
+        "ptt_rows_gemm_pool_supported": [i, i, i, i, i],
+        "ptt_rows_gemm_pool_f32": [vp, i, i, i, vp, vp, vp, i, vp, i, vp, c_size_t, i, vp, vp, vp, vp, vp],
+        "ptt_pool_select_f32": [vp, vp, vp, vp, vp, vp, i, i, vp, vp, vp],
         "ptt_regularize_f32": [vp, i, vp, i, vp],
         "ptt_mt19937_fill": [c_uint32, vp, i],
         "ptt_select_box_f32": [vp, i, i, vp, vp, vp],

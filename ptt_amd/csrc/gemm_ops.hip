@@ -48,6 +48,14 @@ __device__ __forceinline__ float g_add_halves(float v) {
     asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
     return a + b;
 }
+// (value, row) of lane ^ 32 beside this lane's: lo = the lower half-wave's pair in both halves, hi = the upper half-wave's
+__device__ __forceinline__ void g_swap_pair(float v, int i, float& lo_v, int& lo_i, float& hi_v, int& hi_i) {
+    float a = v, b = v;
+    int c = i, d = i;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(c), "+v"(d));
+    lo_v = a; hi_v = b; lo_i = c; hi_i = d;
+}
 // the dispatcher places block b on XCD b % 8: consecutive LOGICAL blocks share an XCD (and its L2)
 __device__ __forceinline__ int g_logical_block() {
     const int bid = blockIdx.x, per = (int)gridDim.x >> 3;
@@ -69,6 +77,10 @@ struct RowsGemmParams {
                                                 // xhat = (bz - bmean) * binv), instead of the statistics of the output
     double* stats;                              // optional [chunks][2][N] partial column sums / sums of squares of Y
     int rows, K, ldx, N, NT, relu, ldr, ldo, ntiles, G, ncg, nchunks;
+    // POOL instantiations: per group of POOL consecutive rows and column the largest and the smallest y with the FIRST row (inside
+    // the group) that holds it — what the max-pool of relu(BatchNorm(y)) needs once the batch statistics (which this same launch
+    // sums) are known: the sign of gamma * invstd picks max or min (ptt_pool_select_f32)
+    float* pmax; float* pmin; int* amax; int* amin;
 };
 
 // WR x WC waves (WR * WC = 4): wave (wr, wc) owns row tiles wr*RT .. wr*RT+RT-1 of the workgroup's 32*RT*WR rows and the
@@ -79,9 +91,10 @@ struct RowsGemmParams {
 #define PTT_RG_PD 3          // weight fragments requested this many K-blocks ahead
 #endif
 // BNB: the statistics are the BatchNorm backward sums of the producing layer (p.bz ...), not those of the output
-template <int WR, int RT, int CT, int KC, bool STATS, bool ACT, int EXP = 0, bool BNB = false>
+template <int WR, int RT, int CT, int KC, bool STATS, bool ACT, int EXP = 0, bool BNB = false, int POOL = 0>
 __global__ __launch_bounds__(256, 2) void rows_gemm_kernel(RowsGemmParams p) {
     static_assert(!BNB || (STATS && !ACT), "the backward-sums epilogue is a statistics epilogue of a plain input gradient");
+    static_assert(POOL == 0 || (STATS && !BNB && (POOL == 16 || POOL == 32 || (POOL == 64 && RT % 2 == 0))), "pooled statistics epilogue");
     constexpr int WC = 4 / WR, TR = 32 * RT * WR, NKB = KC / 8, LDK = KC + 4, BUF = TR * LDK, QPR = KC / 4;
     constexpr int SLOTS = TR * QPR / 256, PD = PTT_RG_PD;
     constexpr int WI = SLOTS < NKB / 2 ? SLOTS : NKB / 2;       // K-blocks (the last ones of a unit) that carry a staging piece
@@ -169,6 +182,8 @@ __global__ __launch_bounds__(256, 2) void rows_gemm_kernel(RowsGemmParams p) {
             const float kref = MODE == 3 ? 0.f : acc[0][u][0] + bv;     // the lane's first row: if that one is past the end, all of its rows are
             float s = 0.f, sq = 0.f;
             int nrows = 0;
+            float p64max = 0.f, p64min = 0.f;
+            int p64imax = 0, p64imin = 0;
             float cm = 0.f, ci = 0.f, ca = 0.f, cb = 0.f;
             if (MODE == 3) { cm = p.bmean[cn]; ci = p.binv[cn]; ca = p.ba[cn]; cb = p.bb[cn]; }
 #pragma unroll
@@ -182,12 +197,20 @@ __global__ __launch_bounds__(256, 2) void rows_gemm_kernel(RowsGemmParams p) {
                         rv[r] = g_load1(rr, rbase + (dr + grc) * (ldr * 4), 0);        // rows past the end: clamped, never stored
                     }
                 }
+                float pv_max[2] = {-__builtin_inff(), -__builtin_inff()}, pv_min[2] = {__builtin_inff(), __builtin_inff()};
+                int pi_max[2] = {0, 0}, pi_min[2] = {0, 0};
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int dr = rt * 32 + (r & 3) + 8 * (r >> 2);
                     const bool in = FULL || row_w + 4 * half + dr < p.rows;
                     float y = acc[rt][u][r] + bv;
                     if (MODE == 2) y = rv[r] > 0.f ? y : 0.f;
+                    if (POOL > 0 && MODE == 0) {                // rows ascend with r inside a lane: strict comparisons keep the first
+                        const int gq = POOL == 16 ? (r >> 3) : 0;
+                        const int rowg = (dr + 4 * half) % (POOL > 0 ? POOL : 1);
+                        if (in && y > pv_max[gq]) { pv_max[gq] = y; pi_max[gq] = rowg; }
+                        if (in && y < pv_min[gq]) { pv_min[gq] = y; pi_min[gq] = rowg; }
+                    }
                     if (STATS && MODE == 3) {                   // sum dy, sum dy * xhat of the layer this gradient flows into
                         const float z = rv[r];
                         const float dyv = (in && __builtin_fmaf(z, ca, cb) > 0.f) ? y : 0.f;
@@ -202,6 +225,31 @@ __global__ __launch_bounds__(256, 2) void rows_gemm_kernel(RowsGemmParams p) {
                     if (!(EXP & 1) || r == 15)
                         if (in) g_store1(y, ro, obase + dr * (p.ldo * 4), 0);
                     acc[rt][u][r] = 0.f;
+                }
+                if constexpr (POOL > 0 && MODE == 0) {
+                    // the other half-wave holds the group's other rows; a 64-row group spans two row tiles of this wave
+                    constexpr int NG = POOL == 16 ? 2 : 1;
+#pragma unroll
+                    for (int gq = 0; gq < NG; ++gq) {
+                        float lv, hv; int li, hi;
+                        g_swap_pair(pv_max[gq], pi_max[gq], lv, li, hv, hi);
+                        const bool th = hv > lv || (hv == lv && hi < li);
+                        float mx = th ? hv : lv; int mxi = th ? hi : li;
+                        g_swap_pair(pv_min[gq], pi_min[gq], lv, li, hv, hi);
+                        const bool tl = hv < lv || (hv == lv && hi < li);
+                        float mn = tl ? hv : lv; int mni = tl ? hi : li;
+                        if (POOL == 64) {
+                            if ((rt & 1) == 0) { p64max = mx; p64min = mn; p64imax = mxi; p64imin = mni; continue; }
+                            // second tile of the group: its rows come later, so ties stay with the first tile
+                            if (!(mx > p64max)) { mx = p64max; mxi = p64imax; }
+                            if (!(mn < p64min)) { mn = p64min; mni = p64imin; }
+                        }
+                        const int row_g = row_w + rt * 32 - (POOL == 64 ? 32 : 0) + gq * 16;      // first row of the group
+                        if (half == 0 && row_g < p.rows) {
+                            const size_t o = (size_t)(row_g / POOL) * p.N + cn;
+                            p.pmax[o] = mx; p.pmin[o] = mn; p.amax[o] = mxi; p.amin[o] = mni;
+                        }
+                    }
                 }
             }
             if (STATS && MODE == 3) {
@@ -478,10 +526,11 @@ extern "C" int ptt_rows_gemm_stat_chunks(int rows, int K, int N) {
 }
 
 struct BnBwdArgs { const float* z; int ldz; const float* mean; const float* invstd; const float* a; const float* b; };
+struct PoolArgs { float* pmax; float* pmin; int32_t* amax; int32_t* amin; int ns; };
 static int rows_gemm_launch(const float* X, int rows, int K, int ldx, const float* in_scale, const float* in_shift,
                             const float* Wpacked, int N, const float* bias, int relu, const float* residual, int ldr,
                             const float* mask, int ldm, float* out, int ldo, double* stats, size_t stats_elems, ptt_stream_t stream,
-                            const BnBwdArgs* bn = nullptr);
+                            const BnBwdArgs* bn = nullptr, const PoolArgs* pool = nullptr);
 
 extern "C" int ptt_rows_gemm_bnbwd_f32(const float* X, int rows, int K, int ldx, const float* Wpacked, int N, const float* Z, int ldz,
                                        const float* mean, const float* invstd, const float* act_scale, const float* act_shift,
@@ -492,6 +541,21 @@ extern "C" int ptt_rows_gemm_bnbwd_f32(const float* X, int rows, int K, int ldx,
     const BnBwdArgs bn{Z, ldz, mean, invstd, act_scale, act_shift};
     return rows_gemm_launch(X, rows, K, ldx, nullptr, nullptr, Wpacked, N, nullptr, 0, nullptr, 0, nullptr, 0, out, ldo, sums_partial,
                             partial_elems, stream, &bn);
+}
+
+extern "C" int ptt_rows_gemm_pool_supported(int rows, int K, int N, int ldx, int ns) {
+    if (!ptt_rows_gemm_supported(rows, K, N, ldx, N) || ns <= 0 || rows % ns) return 0;
+    const RowsGemmGeom g = rows_gemm_geom(rows, K, N);
+    return ((g.WR == 1 && g.RT == 2 && g.CT == 2 && g.KC == 128 && (ns == 16 || ns == 32 || ns == 64)) ||
+            (g.WR == 1 && g.RT == 4 && g.CT == 1 && g.KC == 64 && ns == 32)) ? 1 : 0;
+}
+
+extern "C" int ptt_rows_gemm_pool_f32(const float* X, int rows, int K, int ldx, const float* in_scale, const float* in_shift,
+                                      const float* Wpacked, int N, float* out, int ldo, double* stats, size_t stats_elems, int ns,
+                                      float* pmax, float* pmin, int32_t* amax, int32_t* amin, ptt_stream_t stream) {
+    const PoolArgs pool{pmax, pmin, amax, amin, ns};
+    return rows_gemm_launch(X, rows, K, ldx, in_scale, in_shift, Wpacked, N, nullptr, 0, nullptr, 0, nullptr, 0, out, ldo, stats,
+                            stats_elems, stream, nullptr, &pool);
 }
 
 extern "C" int ptt_rows_gemm_f32(const float* X, int rows, int K, int ldx, const float* in_scale, const float* in_shift,
@@ -511,7 +575,7 @@ extern "C" int ptt_rows_gemm_masked_f32(const float* X, int rows, int K, int ldx
 static int rows_gemm_launch(const float* X, int rows, int K, int ldx, const float* in_scale, const float* in_shift,
                             const float* Wpacked, int N, const float* bias, int relu, const float* residual, int ldr,
                             const float* mask, int ldm, float* out, int ldo, double* stats, size_t stats_elems, ptt_stream_t stream,
-                            const BnBwdArgs* bn) {
+                            const BnBwdArgs* bn, const PoolArgs* pool) {
     if (rows < 0 || K <= 0 || N <= 0 || ldx < K || ldo < N || (residual && ldr < N))
         return fail(PTT_EINVAL, "ptt_rows_gemm_f32: rows=%d K=%d N=%d ldx=%d ldo=%d ldr=%d", rows, K, N, ldx, ldo, ldr);
     if (rows == 0) return PTT_OK;
@@ -524,6 +588,12 @@ static int rows_gemm_launch(const float* X, int rows, int K, int ldx, const floa
     if ((in_scale == nullptr) != (in_shift == nullptr)) return fail(PTT_EINVAL, "ptt_rows_gemm_f32: in_scale and in_shift go together");
     const RowsGemmGeom g = rows_gemm_geom(rows, K, N);
     if (bn && (!stats || bias || residual || mask || in_scale)) return fail(PTT_EINVAL, "ptt_rows_gemm_bnbwd_f32: plain input gradient only");
+    if (pool && (!stats || bias || residual || mask || bn || !in_scale || relu || !pool->pmax || !pool->pmin || !pool->amax || !pool->amin ||
+                 rows % pool->ns))
+        return fail(PTT_EINVAL, "ptt_rows_gemm_pool_f32: a statistics launch with a deferred-activation input, whole groups of rows");
+    if (pool && !((g.WR == 1 && g.RT == 2 && g.CT == 2 && g.KC == 128 && (pool->ns == 16 || pool->ns == 32 || pool->ns == 64)) ||
+                  (g.WR == 1 && g.RT == 4 && g.CT == 1 && g.KC == 64 && pool->ns == 32)))
+        return fail(PTT_EUNSUPPORTED, "ptt_rows_gemm_pool_f32: K=%d N=%d ns=%d is not an instantiated shape (ptt_rows_gemm_pool_supported)", K, N, pool->ns);
     if (stats && (bias || stats_elems < (size_t)g.chunks * 2 * N))
         return fail(PTT_EINVAL, "ptt_rows_gemm_f32: statistics need bias == NULL and %zu doubles of workspace", (size_t)g.chunks * 2 * N);
     if (mask && (long long)rows * ldm >= (1LL << 29)) return fail(PTT_EUNSUPPORTED, "ptt_rows_gemm_masked_f32: rows * ldm >= 2^29");
@@ -535,6 +605,7 @@ static int rows_gemm_launch(const float* X, int rows, int K, int ldx, const floa
     p.X = X; p.Wp = Wpacked; p.bias = bias; p.residual = residual; p.out = out; p.in_a = in_scale; p.in_b = in_shift;
     p.stats = stats; p.rows = rows; p.K = K; p.ldx = ldx; p.N = N; p.NT = N / 32; p.relu = relu; p.ldr = ldr; p.ldo = ldo;
     p.ntiles = g.ntiles; p.G = g.G; p.ncg = g.ncg; p.nchunks = K / g.KC;
+    p.pmax = pool ? pool->pmax : nullptr; p.pmin = pool ? pool->pmin : nullptr; p.amax = pool ? pool->amax : nullptr; p.amin = pool ? pool->amin : nullptr;
     const int lds = 2 * g.TR * (g.KC + 4) * (int)sizeof(float);
     const dim3 grid(g.G * g.ncg);
     hipStream_t s = as_stream(stream);
@@ -554,6 +625,16 @@ static int rows_gemm_launch(const float* X, int rows, int K, int ldx, const floa
         }
     }
 #endif
+    if (pool) {
+#define PTT_RG_POOL(WR_, RT_, CT_, KC_, NS_)                                                                            \
+        if (g.WR == WR_ && g.RT == RT_ && g.CT == CT_ && g.KC == KC_ && pool->ns == NS_) {                              \
+            if ((rc = set_lds_limit(reinterpret_cast<const void*>(rows_gemm_kernel<WR_, RT_, CT_, KC_, true, true, 0, false, NS_>), lds))) return rc; \
+            hipLaunchKernelGGL((rows_gemm_kernel<WR_, RT_, CT_, KC_, true, true, 0, false, NS_>), grid, dim3(256), lds, s, p); \
+        }
+        PTT_RG_POOL(1, 2, 2, 128, 16) PTT_RG_POOL(1, 2, 2, 128, 32) PTT_RG_POOL(1, 2, 2, 128, 64) PTT_RG_POOL(1, 4, 1, 64, 32)
+#undef PTT_RG_POOL
+        return check_launch("rows_gemm_kernel(pool)");
+    }
 #define PTT_RG_LAUNCH(WR_, RT_, CT_, KC_, ST_, AC_)                                                                     \
     {                                                                                                                   \
         if ((rc = set_lds_limit(reinterpret_cast<const void*>(rows_gemm_kernel<WR_, RT_, CT_, KC_, ST_, AC_>), lds))) return rc; \

@@ -511,6 +511,23 @@ __global__ __launch_bounds__(256) void pool_rows_kernel(const float* __restrict_
     }
 }
 
+// The max-pool of relu(y * a + b) over groups of rows from the per-group extrema the GEMM's epilogue took (ptt_rows_gemm_pool_f32):
+// relu(a y + b) is monotone in y — increasing for a > 0, decreasing for a < 0 — so its maximum over a group is at the group's
+// largest / smallest y, and the first row holding that extremum is the first arg-max (a == 0: every row ties, row 0). Same
+// value and the same gradient routing as pool_rows_kernel (an arg-max whose activation is 0 gets no gradient either way).
+__global__ __launch_bounds__(256) void pool_select_kernel(const float* __restrict__ pmax, const float* __restrict__ pmin,
+                                                          const int32_t* __restrict__ amax, const int32_t* __restrict__ amin,
+                                                          const float* __restrict__ act_a, const float* __restrict__ act_b, size_t total,
+                                                          int C, float* __restrict__ out, int32_t* __restrict__ arg) {
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const int c = (int)(e % C);
+        const float a = act_a[c], b = act_b[c];
+        const float y = a > 0.f ? pmax[e] : pmin[e];
+        out[e] = fmaxf(__builtin_fmaf(y, a, b), 0.f);
+        arg[e] = a > 0.f ? amax[e] : (a < 0.f ? amin[e] : 0);
+    }
+}
+
 // dX[g*ns + k, c] = dOut[g, c] if k == arg[g, c] else 0 (every element of dX is written).
 __global__ __launch_bounds__(256) void pool_rows_bwd_kernel(const float* __restrict__ dOut, int ldo, const int32_t* __restrict__ arg,
                                                             int G, int ns, int C, float* __restrict__ dX, int ldx) {
@@ -1241,6 +1258,15 @@ extern "C" int ptt_pool_rows_f32(const float* X, int ldx, int G, int ns, int C, 
     hipLaunchKernelGGL(pool_rows_kernel, dim3(ew_grid((size_t)G * C)), dim3(256), 0, as_stream(stream), X, ldx, G, ns, C, out, ldo, arg,
                        act_scale, act_scale ? act_shift : nullptr);
     return check_launch("pool_rows_kernel");
+}
+
+extern "C" int ptt_pool_select_f32(const float* pmax, const float* pmin, const int32_t* amax, const int32_t* amin, const float* act_scale,
+                                   const float* act_shift, int G, int C, float* out, int32_t* arg, ptt_stream_t stream) {
+    if (G <= 0 || C <= 0) return fail(PTT_EINVAL, "ptt_pool_select_f32: G=%d C=%d", G, C);
+    if (!pmax || !pmin || !amax || !amin || !act_scale || !act_shift || !out || !arg) return fail(PTT_EINVAL, "ptt_pool_select_f32: null pointer");
+    hipLaunchKernelGGL(pool_select_kernel, dim3(ew_grid((size_t)G * C)), dim3(256), 0, as_stream(stream), pmax, pmin, amax, amin, act_scale,
+                       act_shift, (size_t)G * C, C, out, arg);
+    return check_launch("pool_select_kernel");
 }
 
 extern "C" int ptt_pool_rows_bwd_f32(const float* dOut, int ldo, const int32_t* arg, int G, int ns, int C, float* dX, int ldx,

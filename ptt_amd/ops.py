@@ -956,6 +956,46 @@ def rows_gemm(x, wpacked, cout, in_scale=None, in_shift=None, bias=None, relu=Fa
     return (out, stats) if want_stats else out
 
 
+def rows_gemm_pool_supported(rows, K, N, ldx, ns, x=None):
+    if x is not None and x.data_ptr() % 16:
+        return False
+    return bool(_lib.lib().ptt_rows_gemm_pool_supported(int(rows), int(K), int(N), int(ldx), int(ns)))
+
+
+def rows_gemm_pool(x, wpacked, cout, in_scale, in_shift, ns):
+    """ptt_rows_gemm_pool_f32: z = relu(x * in_scale + in_shift) @ W^T with the float64 statistics partials of z AND, per group of
+    `ns` rows and column, (max z, min z, first row of each) — the last layer of a SharedMLP + max-pool stage without a pooling
+    pass over z. -> (z, stats partials, (pmax, pmin, amax, amin)); pool_select() finishes once a, b of z's BatchNorm exist."""
+    _rows(x, "x")
+    rows, K = x.shape
+    cout, ns = int(cout), int(ns)
+    G = rows // ns
+    out = torch.empty((rows, cout), dtype=torch.float32, device=x.device)
+    chunks = _lib.lib().ptt_rows_gemm_stat_chunks(rows, K, cout)
+    stats = torch.empty((max(1, chunks), 2, cout), dtype=torch.float64, device=x.device)
+    pmax = torch.empty((G, cout), dtype=torch.float32, device=x.device)
+    pmin = torch.empty((G, cout), dtype=torch.float32, device=x.device)
+    amax = torch.empty((G, cout), dtype=torch.int32, device=x.device)
+    amin = torch.empty((G, cout), dtype=torch.int32, device=x.device)
+    with torch.cuda.device(x.device), _timed('ptt_rows_gemm_f32'):
+        _lib.check(_lib.lib().ptt_rows_gemm_pool_f32(_ptr(x), rows, K, x.stride(0), _ptr(in_scale), _ptr(in_shift), _ptr(wpacked), cout,
+                                                     _ptr(out), cout, _ptr(stats), stats.numel(), ns, _ptr(pmax), _ptr(pmin), _ptr(amax),
+                                                     _ptr(amin), _stream()), "ptt_rows_gemm_pool_f32")
+    return out, stats, (pmax, pmin, amax, amin)
+
+
+def pool_select(extrema, act_scale, act_shift):
+    """(pmax, pmin, amax, amin) of rows_gemm_pool + the BatchNorm's a, b -> (pooled relu(a z + b) (G,C), arg-max (G,C) int32)."""
+    pmax, pmin, amax, amin = extrema
+    G, C = pmax.shape
+    out = torch.empty((G, C), dtype=torch.float32, device=pmax.device)
+    arg = torch.empty((G, C), dtype=torch.int32, device=pmax.device)
+    with torch.cuda.device(pmax.device):
+        _lib.check(_lib.lib().ptt_pool_select_f32(_ptr(pmax), _ptr(pmin), _ptr(amax), _ptr(amin), _ptr(act_scale), _ptr(act_shift), G, C,
+                                                  _ptr(out), _ptr(arg), _stream()), "ptt_pool_select_f32")
+    return out, arg
+
+
 def rows_gemm_masked(x, wpacked, cout, mask, want_colsum=False):
     """out = (mask > 0) ? x @ W^T : 0 — the input gradient of the layer behind a ReLU whose output is `mask`
     (ptt_rows_gemm_masked_f32). want_colsum: also the column sums of the masked result (float32 (cout,)), i.e. the bias

@@ -141,6 +141,7 @@ class _PackPlan:
         return True
 
 
+POOL_EPILOGUE = True   # the last layer's max-pool from the extrema its GEMM's epilogue takes (False: a pooling pass over z)
 _pack_plans = {}       # device -> _PackPlan
 PACK_PLAN = True       # False: every weight packed by its own launch (development comparisons)
 
@@ -307,9 +308,14 @@ class _SharedMlpPool(torch.autograd.Function):
         for l in range(L):
             W, gamma, beta = params[3 * l], params[3 * l + 1], params[3 * l + 2]
             cout = gamma.shape[0]
-            part = None
+            part, extrema = None, None
             if preact and l == 0:
                 z = cur
+            elif (l == L - 1 and ns > 1 and POOL_EPILOGUE and sync[l] is None and cur_a is not None
+                  and ops.rows_gemm_pool_supported(cur.shape[0], cur.shape[1], cout, cur.stride(0), ns, x=cur)):
+                # the last layer: its GEMM's epilogue also takes the per-group extrema of z, so that the max-pool needs no pass
+                # over z once the statistics (summed by the same launch) are finished
+                z, part, extrema = ops.rows_gemm_pool(cur, packed(W.reshape(cout, -1)), cout, cur_a, cur_b, ns)
             else:       # the statistics of z come out of the GEMM's epilogue where the persistent row GEMM runs
                 z, part = conv_rows(cur, W.reshape(cout, -1), cur_a, cur_b, want_stats=True)
             if sync[l] is not None:
@@ -329,7 +335,7 @@ class _SharedMlpPool(torch.autograd.Function):
                       z, mean, invstd, a, b, count]
             stats += [mean, var, count]
             cur, cur_a, cur_b = z, a, b
-        pooled, arg = ops.pool_rows(cur, ns, cur_a, cur_b)
+        pooled, arg = ops.pool_select(extrema, cur_a, cur_b) if extrema is not None else ops.pool_rows(cur, ns, cur_a, cur_b)
         ctx.save_for_backward(arg, *saved, *[p.detach() for p in params])
         ctx.weights = tuple(params[3 * l] for l in range(L))     # the parameter objects themselves: keys of the pack cache
         ctx.L, ctx.ns, ctx.preact, ctx.sync = L, int(ns), bool(preact), tuple(sync)

@@ -171,3 +171,35 @@ def test_pack_plan_repacks_every_registered_weight_in_one_launch(dev):
     finally:
         ops.pack_weights = real
     assert len(plan.entries) >= 9
+
+
+@pytest.mark.parametrize("rows,K,N,ns", [(4096, 128, 256, 32), (70016, 256, 256, 16), (8192, 256, 256, 64), (49152 + 64, 64, 128, 32),
+                                         (3 * 64 * 7, 128, 256, 64)])
+def test_pool_epilogue_equals_the_pooling_pass(dev, rows, K, N, ns):
+    """ptt_rows_gemm_pool_f32 + ptt_pool_select_f32 (the max-pool from the extrema the GEMM's epilogue takes) against
+    ptt_rows_gemm_f32 + ptt_pool_rows_f32 (a pooling pass over z): the same z and statistics bit for bit, the same pooled values
+    bit for bit (relu(a z + b) is monotone in z), and an arg-max that holds the pooled value — for positive, negative and zero
+    BatchNorm scales, with duplicated rows (exact ties) in the input."""
+    g = torch.Generator().manual_seed(rows + K + ns)
+    x = torch.randn(rows, K, generator=g)
+    x[5::7] = x[3::7][:x[5::7].shape[0]]                      # duplicated rows: ties inside groups
+    x = x.to(dev)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
+    ia, ib = (torch.rand(K, generator=g) + 0.5).to(dev), (torch.randn(K, generator=g) * 0.1).to(dev)
+    a = torch.randn(N, generator=g).to(dev)
+    a[::5] = 0.0
+    b = (torch.randn(N, generator=g) * 0.3).to(dev)
+    wp = ops.pack_weight(w)
+    z0, st0 = ops.rows_gemm(x, wp, N, in_scale=ia, in_shift=ib, want_stats=True)
+    assert ops.rows_gemm_pool_supported(rows, K, N, x.stride(0), ns, x=x)
+    z1, st1, ext = ops.rows_gemm_pool(x, wp, N, ia, ib, ns)
+    assert torch.equal(z0, z1) and torch.equal(st0, st1)
+    p0, arg0 = ops.pool_rows(z0, ns, a, b)
+    p1, arg1 = ops.pool_select(ext, a, b)
+    assert torch.equal(p0, p1)
+    act = torch.relu(z1 * a + b).view(rows // ns, ns, N)
+    picked = act.gather(1, arg1.long().unsqueeze(1)).squeeze(1)
+    assert torch.equal(picked, act.max(dim=1)[0])            # the arg-max holds the maximum
+    pos = (a > 0)
+    first = (z1.view(rows // ns, ns, N) == ext[0].unsqueeze(1)).float().argmax(dim=1)
+    assert torch.equal(arg1[:, pos], first[:, pos].int())    # and is the FIRST row of the extremum
