@@ -99,5 +99,18 @@ t)  # the training step after a change: gradient parity (G10 / G14 / G15, reprod
     timeout 600 python bench.py --workload train --steps 20 --warmup 5 > $O/bench_train.json 2> $O/bench_train.err
     python -c "import json;d=json.load(open('$O/bench_train.json'));print('train', d['ms_per_step'], d['value'], d['sustained'])"
     ;;
+u)  # kernel trace of the training step
+    ktrace train_kernel_stats python $REPO/bench.py --workload train --steps 5 --warmup 2 --sustain 0
+    python - <<PY
+import csv
+rows = list(csv.DictReader(open("$O/train_kernel_stats.csv")))
+tot = sum(float(r['TotalDurationNs']) for r in rows)
+steps = 7
+ptt = sum(float(r['TotalDurationNs']) for r in rows if 'ptt::' in r['Name'])
+print("device ms/step %.2f launches/step %.0f ptt share %.3f" % (tot / steps / 1e6, sum(int(r['Calls']) for r in rows) / steps, ptt / tot))
+for r in rows[:45]:
+    print("%-110s %6.1f %8.1fus %8.1fus/step" % (r['Name'][:110], int(r['Calls']) / steps, float(r['AverageNs']) / 1e3, float(r['TotalDurationNs']) / steps / 1e3))
+PY
+    ;;
 *)  echo "unknown session $S"; exit 2;;
 esac
