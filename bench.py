@@ -336,7 +336,7 @@ def main():
     if (args.workload == "car" and world == 1 and not args.no_workloads and not args.serial and not args.no_graph
             and args.batch is None and args.ns is None and args.nt is None):
         out["workloads"] = {}
-        for name, steps, warm in (("ped", 20, 5), ("stress", 8, 3), ("train", 8, 3)):
+        for name, steps, warm in (("ped", 20, 5), ("stress", 8, 3), ("train", 20, 5)):
             if name not in args.workloads.split(","):
                 continue
             note("workload %s" % name)
