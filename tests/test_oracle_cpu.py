@@ -299,3 +299,29 @@ def test_checkpoint_helpers_partial_and_full_load(tmp_path):
     it, epoch = dst2.load_params_with_optimizer(str(ck), to_cpu=True, optimizer=opt2, logger=logging.getLogger("ckpt"))
     assert (it, epoch) == (17, 3) and opt2.param_groups[0]['lr'] == 1e-3
     assert all(torch.equal(a, b) for a, b in zip(dst2.state_dict().values(), src.state_dict().values()))
+
+
+def test_ctypes_structures_match_the_c_header(tmp_path):
+    """Every structure ptt_amd/_lib.py mirrors from include/ptt_hip.h has the size and the field offsets the C compiler gives it:
+    a probe compiled here with gcc prints sizeof / offsetof, ctypes must agree (a drifted field would only show up as wrong
+    results on the GPU box)."""
+    import subprocess
+    from ptt_amd import _lib
+    pairs = [("ptt_row_job", _lib.RowJob), ("ptt_point_job", _lib.PointJob), ("ptt_xcorr_desc", _lib.XcorrDesc), ("ptt_sa_desc", _lib.SaDesc),
+             ("ptt_attn_desc", _lib.AttnDesc), ("ptt_sa_layer", _lib.SaLayer), ("ptt_crop_job", _lib.CropJob),
+             ("ptt_regularize_job", _lib.RegularizeJob), ("ptt_pack_job", _lib.PackJob), ("ptt_bn_train_tail", _lib.BnTrainTail)]
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "ptt_hip.h"', 'int main(void) {']
+    for cname, st in pairs:
+        lines.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
+        for fname, *_ in st._fields_:
+            lines.append('printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (cname, fname, cname, fname))
+    lines += ['return 0;', '}']
+    src = tmp_path / "abi_probe.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "abi_probe"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = dict(l.split() for l in subprocess.check_output([str(exe)]).decode().splitlines())
+    for cname, st in pairs:
+        assert int(got[cname]) == ctypes.sizeof(st), (cname, got[cname], ctypes.sizeof(st))
+        for fname, *_ in st._fields_:
+            assert int(got["%s.%s" % (cname, fname)]) == getattr(st, fname).offset, (cname, fname)
