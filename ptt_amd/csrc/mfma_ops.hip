@@ -1512,8 +1512,9 @@ void sa_lds_kernel(SaParams p) {
         const f32x4* g2 = reinterpret_cast<const f32x4*>(p.L[2].Wp);
         f32x4* s1 = reinterpret_cast<f32x4*>(W1);
         f32x4* s2 = reinterpret_cast<f32x4*>(W2);
-        for (int i = t; i < 1024; i += 64 * PTT_SAL_WAVES) s1[i] = g1[i];
-        for (int i = t; i < 2048; i += 64 * PTT_SAL_WAVES) s2[i] = g2[i];
+        const int nthr = (int)blockDim.x;                    // 12 waves for full launches, 4 for a handful of frames (see the host)
+        for (int i = t; i < 1024; i += nthr) s1[i] = g1[i];
+        for (int i = t; i < 2048; i += nthr) s2[i] = g2[i];
     }
     // per-lane constants, parked in LDS (10 registers less: four waves per SIMD fit without a spill). Layer 0's weights
     // and shift as A operands: lane (channel c, half h) supplies W0[c][h] for step 0 and (h ? shift0[c] : W0[c][2]) for
@@ -1532,7 +1533,7 @@ void sa_lds_kernel(SaParams p) {
     const float one_zero = half ? 0.f : 1.f, one_hi = 1.f;
     __syncthreads();
     const int total = p.B * p.M, M = p.M, N = p.N;           // one tile per centre
-    const int gw = logical_block() * PTT_SAL_WAVES + w;
+    const int gw = logical_block() * ((int)blockDim.x >> 6) + w;
     const int c0 = gw * p.chunk, c1 = min(total, c0 + p.chunk);
     if (c0 >= c1) return;
     const float rdiv = p.normalize ? p.radius : 1.0f;        // x / 1 is exact: one code path
@@ -2127,10 +2128,13 @@ extern "C" int ptt_sa_fused_fwd_f32(const ptt_sa_desc* d, ptt_stream_t stream) {
         // short-lived workgroups (2 centres per wave) instead of one pass per wave: in the graphed step the CUs that also run
         // the next batch's FPS are slower, and dynamically scheduled workgroups go where the time is (3.18 -> 3.14 ms)
         if (dev_switches().sa_lds_chunk > 0 && p.chunk > dev_switches().sa_lds_chunk) p.chunk = dev_switches().sa_lds_chunk;
-        int wgs = (total_centres + p.chunk * PTT_SAL_WAVES - 1) / (p.chunk * PTT_SAL_WAVES);
+        // a handful of frames (one tracklet frame: 512 centres): with 12 waves per workgroup that is 43 workgroups whose SIMDs run
+        // three centres' 198 MFMAs one after the other (16 us); four waves per workgroup put one centre on every SIMD of 128 CUs
+        const int nw = total_centres * 3 <= 256 * PTT_SAL_WAVES ? 4 : PTT_SAL_WAVES;
+        int wgs = (total_centres + p.chunk * nw - 1) / (p.chunk * nw);
         const int lds = (4096 + 8192 + PTT_SAL_WAVES * 640) * (int)sizeof(float);
         if ((rc = set_lds_limit(reinterpret_cast<const void*>(sa_lds_kernel), lds))) return rc;
-        hipLaunchKernelGGL(sa_lds_kernel, dim3(wgs), dim3(64 * PTT_SAL_WAVES), lds, s, p);
+        hipLaunchKernelGGL(sa_lds_kernel, dim3(wgs), dim3(64 * nw), lds, s, p);
         return check_launch("sa_lds_kernel");
     }
     // small weight set (fits L1/L2 comfortably) and <= 4 column tiles everywhere: barrier-free wave-private kernel
