@@ -159,17 +159,19 @@ def _cfg5():
     return cfg
 
 
-def test_config5_stress_shapes_match_oracle(dev):
-    """Largest configuration (register-resident FPS at N=16384, kNN at N=2048, 2048-seed transformer) vs the oracle."""
+@pytest.mark.parametrize("B", [1, 2])
+def test_config5_stress_shapes_match_oracle(dev, B):
+    """Largest configuration (register-resident FPS at N=16384, kNN at N=2048, 2048-seed transformer) vs the oracle — one frame and
+    a batch of two (the bench runs 32)."""
     cfg = _cfg5()
     model = randomize_(FrameHotPath(cfg), seed=11).eval()
-    s, t = synth.frames(31, 1, 16384, 4096, kind="dense")
+    s, t = synth.frames(31, B, 16384, 4096, kind="dense")
     with torch.no_grad():
         ref = frame_ref.frame(model.state_dict(), cfg, torch.from_numpy(s), torch.from_numpy(t))
         got = model.to(dev)(torch.from_numpy(s).to(dev), torch.from_numpy(t).to(dev))
     for k in ("search_inds", "template_inds"):
         np.testing.assert_array_equal(got[k].cpu().numpy(), ref[k].numpy())
-    assert tuple(got["search_feats"].shape) == (1, 256, 2048)
+    assert tuple(got["search_feats"].shape) == (B, 256, 2048)
     for k in ("search_feats", "template_feats", "centroid_feats", "box_feats"):
         np.testing.assert_allclose(got[k].cpu().numpy(), ref[k].numpy(), err_msg=k, **TOL)
 
