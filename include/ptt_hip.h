@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PTT_ABI_VERSION 15
+#define PTT_ABI_VERSION 16
 
 enum {
     PTT_OK = 0,
@@ -687,6 +687,13 @@ int ptt_xcorr_z0_bwd_f32(const float* dz0, const float* cos_t, const float* w_si
  *     learnable coordinates (the box head's vote aggregation) keep ptt_group_f32 + ptt_gather_rows_f32. */
 int ptt_sa_z0_rows_f32(const float* xyz, const float* new_xyz, const int32_t* idx, const float* term, const float* wx, int ldw, int B,
                        int N, int M, int ns, int C, float radius, int normalize_xyz, float* z0, float* rel_rows, ptt_stream_t stream);
+/* The same launch also summing the BatchNorm statistics of layer 0 (the float64 column sums / sums of squares of z0) as
+ * partials (chunks, 2, C), chunks = ptt_sa_z0_rows_stat_chunks(B, M, ns, C), for ptt_bn_finish_partials_f32 (or its _train form) — no
+ * statistics pass over z0. C <= 1024. */
+int ptt_sa_z0_rows_stat_chunks(int B, int M, int ns, int C);
+int ptt_sa_z0_rows_stats_f32(const float* xyz, const float* new_xyz, const int32_t* idx, const float* term, const float* wx, int ldw, int B,
+                             int N, int M, int ns, int C, float radius, int normalize_xyz, float* z0, float* rel_rows,
+                             double* stats_partial, size_t partial_elems, ptt_stream_t stream);
 typedef struct ptt_bn_train_tail {
     const float* gamma; const float* beta;      /* (C) affine parameters, needed for act_a / act_b */
     float* act_a; float* act_b;                 /* (C) out, or both NULL */
@@ -708,6 +715,54 @@ size_t ptt_linear_wgrad2_workspace(int R, int Cout, int Cin);
 int ptt_linear_wgrad2_f32(const float* dZ, int ldz, const float* X, int ldx, int R, int Cout, int Cin, float* dW,
                           int accumulate, void* workspace, size_t workspace_bytes, const float* x_scale, const float* x_shift,
                           ptt_stream_t stream);
+
+/* The four tracking losses of a training step with their gradients, in two launches (reference
+ * ptt/models/voting_heads/centroids_voting_head.py:29-62: BCEWithLogits (mean) over the seed scores + masked smooth-L1 of the votes;
+ * box_voting_head.py:33-66: masked BCEWithLogits of the proposal scores + label-weighted smooth-L1 of the 4 box numbers; the
+ * proposal labels / masks of box_voting_head.py:96-104 are formed in the kernels from the proposal centres).
+ *   seed_cls (B,N) logits; cls_label (B,Ns) per search POINT with search_inds (B,N) int64 the seeds' point indices, or
+ *   search_inds NULL and cls_label (B,N) per seed; votes (B,N,3); reg_label (B, ld_reg >= 4): gt centre + angle;
+ *   box_data (B,M,5) = (x, y, z, angle, score logit); centres (B,M,3); pos_weight_*: device scalars (the modules' buffers).
+ * out8: [0] the weighted total, [1..4] the un-weighted losses (seed cls, seed reg, proposal cls, proposal reg), [5..7] the sums
+ * of the seed labels / proposal masks / proposal labels (the backward's denominators). Reductions in float64, fixed order.
+ * ptt_track_losses_bwd_f32: d total / d (seed_cls, votes, box_data) times upstream[0] (device scalar; NULL: 1). */
+typedef struct ptt_track_loss_desc {
+    const float* seed_cls;
+    const float* cls_label;
+    const int64_t* search_inds;
+    const float* votes;
+    const float* reg_label;
+    const float* box_data;
+    const float* centres;
+    const float* pos_weight_seed;
+    const float* pos_weight_box;
+    int32_t B, N, Ns, M, ld_reg;
+    float w_seed_cls, w_seed_reg, w_box_cls, w_box_reg;
+} ptt_track_loss_desc;
+int ptt_track_losses_f32(const ptt_track_loss_desc* desc, float* out8, float* total /* optional: out8[0] once more */, ptt_stream_t stream);
+int ptt_track_losses_bwd_f32(const ptt_track_loss_desc* desc, const float* out8, const float* upstream, float* d_seed_cls,
+                             float* d_votes, float* d_box_data, ptt_stream_t stream);
+/* torch.nn.utils.clip_grad_norm_(params, max_norm) + torch.optim.Adam.step() (tools/train_utils/train_utils.py:48-51,
+ * optimization/__init__.py:12-14) over a device table of tensors in two launches. The caller cuts every tensor into chunks of
+ * ptt_adam_chunk_elems() elements: chunk_tensor[w] = table index, chunk_first[w] = first element. hyper: step_size =
+ * lr / (1 - beta1^t), bias2_sqrt = sqrt(1 - beta2^t); max_norm <= 0: no clipping (partial may be NULL); write_clipped: also
+ * scale .grad in place as clip_grad_norm_ leaves it. partial: n_chunks doubles of workspace; norm_out (optional): the total norm. */
+typedef struct ptt_adam_tensor {
+    float* param;
+    float* grad;
+    float* exp_avg;
+    float* exp_avg_sq;
+    int64_t n;
+} ptt_adam_tensor;
+typedef struct ptt_adam_hyper {
+    float beta1, beta2, one_minus_beta1, one_minus_beta2 /* formed in double by the caller, as torch does */, eps, step_size, bias2_sqrt,
+          weight_decay, max_norm;
+    int32_t write_clipped;
+} ptt_adam_hyper;
+int ptt_adam_chunk_elems(void);
+int ptt_adam_clip_step_f32(const ptt_adam_tensor* tensors_device, const int32_t* chunk_tensor_device, const int64_t* chunk_first_device,
+                           int n_chunks, const ptt_adam_hyper* hyper, double* partial, size_t partial_elems, float* norm_out,
+                           ptt_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libptt_hip.so")
 
 PTT_SA_MAX_LAYERS = 4
-ABI_VERSION = 15            # PTT_ABI_VERSION of include/ptt_hip.h these structures mirror
+ABI_VERSION = 16            # PTT_ABI_VERSION of include/ptt_hip.h these structures mirror
 
 # every symbol include/ptt_hip.h declares (tests check the library exports all of them)
 EXPORTS = [
@@ -38,7 +38,8 @@ EXPORTS = [
     "ptt_bn_update_running_f32", "ptt_xcorr_z0_f32", "ptt_xcorr_z0_bwd_workspace", "ptt_xcorr_z0_bwd_f32",
     "ptt_bn_stats_train_f32", "ptt_bn_finish_partials_train_f32", "ptt_pack_weights_f32",
     "ptt_sa_z0_rows_f32",
-    "ptt_row_jobs_f32", "ptt_point_jobs_f32", "ptt_fps_ball_knn_f32", "ptt_crop_compact_host_f32", "ptt_crop_regularize_f32", "ptt_colsum_workspace", "ptt_colsum_f32", "ptt_rows_gemm_pool_supported", "ptt_rows_gemm_pool_f32", "ptt_pool_select_f32",
+    "ptt_row_jobs_f32", "ptt_point_jobs_f32", "ptt_fps_ball_knn_f32", "ptt_crop_compact_host_f32", "ptt_crop_regularize_f32", "ptt_colsum_workspace", "ptt_colsum_f32", "ptt_rows_gemm_pool_supported", "ptt_rows_gemm_pool_f32", "ptt_pool_select_f32", "ptt_sa_z0_rows_stat_chunks", "ptt_sa_z0_rows_stats_f32",
+    "ptt_track_losses_f32", "ptt_track_losses_bwd_f32", "ptt_adam_chunk_elems", "ptt_adam_clip_step_f32",
 ]
 PTT_MAX_SEGMENTS = 4
 
@@ -90,6 +91,25 @@ class PointJob(Structure):
     _fields_ = [("xyz", c_void_p), ("centre_sel", c_void_p), ("point_sel", c_void_p), ("new_xyz", c_void_p), ("idx64_out", c_void_p),
                 ("idx_out", c_void_p), ("rel_out", c_void_p), ("kind", c_int32), ("sel_ld", c_int32), ("B", c_int32),
                 ("Nraw", c_int32), ("Npts", c_int32), ("M", c_int32), ("nsample", c_int32), ("radius", c_float)]
+
+
+class TrackLossDesc(Structure):
+    """ptt_track_loss_desc: the inputs of the four tracking losses (passed by value, host memory)."""
+    _fields_ = [("seed_cls", c_void_p), ("cls_label", c_void_p), ("search_inds", c_void_p), ("votes", c_void_p), ("reg_label", c_void_p),
+                ("box_data", c_void_p), ("centres", c_void_p), ("pos_weight_seed", c_void_p), ("pos_weight_box", c_void_p),
+                ("B", c_int32), ("N", c_int32), ("Ns", c_int32), ("M", c_int32), ("ld_reg", c_int32),
+                ("w_seed_cls", c_float), ("w_seed_reg", c_float), ("w_box_cls", c_float), ("w_box_reg", c_float)]
+
+
+class AdamTensor(Structure):
+    """ptt_adam_tensor: one parameter with its gradient and moments; arrays of these are uploaded to the device."""
+    _fields_ = [("param", c_void_p), ("grad", c_void_p), ("exp_avg", c_void_p), ("exp_avg_sq", c_void_p), ("n", c_int64)]
+
+
+class AdamHyper(Structure):
+    """ptt_adam_hyper (passed by value, host memory)."""
+    _fields_ = [("beta1", c_float), ("beta2", c_float), ("one_minus_beta1", c_float), ("one_minus_beta2", c_float), ("eps", c_float), ("step_size", c_float), ("bias2_sqrt", c_float),
+                ("weight_decay", c_float), ("max_norm", c_float), ("write_clipped", c_int32)]
 
 
 class SaLayer(Structure):
@@ -161,6 +181,11 @@ def _declare(lib):
         "ptt_rows_gemm_pool_supported": [i, i, i, i, i],
         "ptt_rows_gemm_pool_f32": [vp, i, i, i, vp, vp, vp, i, vp, i, vp, c_size_t, i, vp, vp, vp, vp, vp],
         "ptt_pool_select_f32": [vp, vp, vp, vp, vp, vp, i, i, vp, vp, vp],
+        "ptt_sa_z0_rows_stat_chunks": [i, i, i, i],
+        "ptt_sa_z0_rows_stats_f32": [vp, vp, vp, vp, vp, i, i, i, i, i, i, f, i, vp, vp, vp, c_size_t, vp],
+        "ptt_track_losses_f32": [vp, vp, vp, vp],
+        "ptt_track_losses_bwd_f32": [vp, vp, vp, vp, vp, vp, vp],
+        "ptt_adam_clip_step_f32": [vp, vp, vp, i, vp, vp, c_size_t, vp, vp],
         "ptt_regularize_f32": [vp, i, vp, i, vp],
         "ptt_mt19937_fill": [c_uint32, vp, i],
         "ptt_select_box_f32": [vp, i, i, vp, vp, vp],
@@ -226,6 +251,8 @@ def _declare(lib):
     lib.ptt_linear_wgrad_workspace.argtypes = [i, i, i]
     lib.ptt_xcorr_z0_bwd_workspace.restype = c_size_t
     lib.ptt_xcorr_z0_bwd_workspace.argtypes = [i, i, i]
+    lib.ptt_adam_chunk_elems.restype = c_int
+    lib.ptt_adam_chunk_elems.argtypes = []
     lib.ptt_colsum_workspace.restype = c_size_t
     lib.ptt_colsum_workspace.argtypes = [i, i]
     lib.ptt_linear_wgrad2_workspace.restype = c_size_t

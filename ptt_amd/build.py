@@ -13,7 +13,7 @@ CSRC = os.path.join(ROOT, "ptt_amd", "csrc")
 LIBDIR = os.path.join(ROOT, "ptt_amd", "lib")
 LIB = os.path.join(LIBDIR, "libptt_hip.so")
 
-HIP_SOURCES = ["errors.hip", "point_ops.hip", "mfma_ops.hip", "track_ops.hip", "train_ops.hip", "gemm_ops.hip", "rowjobs.hip"]
+HIP_SOURCES = ["errors.hip", "point_ops.hip", "mfma_ops.hip", "track_ops.hip", "train_ops.hip", "gemm_ops.hip", "rowjobs.hip", "step_ops.hip"]
 # FPS / ball query / kNN index parity needs un-fused fp32 arithmetic (see point_ops.hip header)
 EXTRA_FLAGS = {"point_ops.hip": ["-ffp-contract=off"], "track_ops.hip": ["-ffp-contract=off"], # -fno-honor-nans: without it every fmaxf on an MFMA result costs a second v_max (sNaN canonicalisation), and
                # vector-ALU instructions next to fp32 MFMAs are paid in matrix time (a third of the epilogue instructions)

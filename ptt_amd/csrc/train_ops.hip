@@ -842,11 +842,15 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
 __global__ __launch_bounds__(256) void sa_z0_rows_kernel(const float* __restrict__ xyz, const float* __restrict__ new_xyz,
                                                          const int32_t* __restrict__ idx, const float* __restrict__ term,
                                                          const float* __restrict__ wx, int ldw, int N, int M, int ns, int C,
-                                                         float rmul, float* __restrict__ z0, float* __restrict__ rel_out) {
+                                                         float rmul, float* __restrict__ z0, float* __restrict__ rel_out,
+                                                         double* __restrict__ stats) {
 #pragma clang fp contract(off)      // the subtraction / scaling are the reference's separately rounded element-wise steps
+    // stats (optional, C <= 1024): the float64 column sums / sums of squares of the rows this workgroup writes, partial
+    // [workgroup][2][C] (workgroup = blockIdx.y * gridDim.x + blockIdx.x), the format ptt_bn_finish_partials_* combine in order:
+    // the BatchNorm statistics of layer 0 without a pass of their own over z0
+    __shared__ double red[2][256][4];
     const int Cq = C >> 2, span = Cq < 256 ? Cq : 256, RG = 256 / span;
     const int q0 = threadIdx.x % span, rg = threadIdx.x / span;
-    if (rg >= RG) return;
     const int b = blockIdx.y, E = M * ns;
     const float* xb = xyz + (size_t)b * N * 3;
     const float* cb = new_xyz + (size_t)b * M * 3;
@@ -854,20 +858,37 @@ __global__ __launch_bounds__(256) void sa_z0_rows_kernel(const float* __restrict
     const int32_t* ib = idx + (size_t)b * E;
     float* zb = z0 + (size_t)b * E * C;
     float* rb = rel_out + (size_t)b * E * 3;
-    for (int e = blockIdx.x * RG + rg; e < E; e += gridDim.x * RG) {
-        const int n = ib[e], m = e / ns;
-        const float rx = (xb[3 * n + 0] - cb[3 * m + 0]) * rmul, ry = (xb[3 * n + 1] - cb[3 * m + 1]) * rmul,
-                    rz = (xb[3 * n + 2] - cb[3 * m + 2]) * rmul;
-        if (q0 == 0) { rb[3 * e + 0] = rx; rb[3 * e + 1] = ry; rb[3 * e + 2] = rz; }
-        for (int q = q0; q < Cq; q += span) {
-            f32x4t v = tb ? *reinterpret_cast<const f32x4t*>(tb + (size_t)n * C + 4 * q) : f32x4t{0.f, 0.f, 0.f, 0.f};
+    double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+    if (rg < RG) {
+        for (int e = blockIdx.x * RG + rg; e < E; e += gridDim.x * RG) {
+            const int n = ib[e], m = e / ns;
+            const float rx = (xb[3 * n + 0] - cb[3 * m + 0]) * rmul, ry = (xb[3 * n + 1] - cb[3 * m + 1]) * rmul,
+                        rz = (xb[3 * n + 2] - cb[3 * m + 2]) * rmul;
+            if (q0 == 0) { rb[3 * e + 0] = rx; rb[3 * e + 1] = ry; rb[3 * e + 2] = rz; }
+            for (int q = q0; q < Cq; q += span) {
+                f32x4t v = tb ? *reinterpret_cast<const f32x4t*>(tb + (size_t)n * C + 4 * q) : f32x4t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float* w = wx + (size_t)(4 * q + j) * ldw;                 // Wx (C,3), row stride ldw
-                const float y = __builtin_fmaf(w[2], rz, __builtin_fmaf(w[1], ry, w[0] * rx));
-                v[j] = v[j] + y;
+                for (int j = 0; j < 4; ++j) {
+                    const float* w = wx + (size_t)(4 * q + j) * ldw;                 // Wx (C,3), row stride ldw
+                    const float y = __builtin_fmaf(w[2], rz, __builtin_fmaf(w[1], ry, w[0] * rx));
+                    v[j] = v[j] + y;
+                    if (stats) { s1[j] += (double)v[j]; s2[j] += (double)v[j] * (double)v[j]; }
+                }
+                *reinterpret_cast<f32x4t*>(zb + (size_t)e * C + 4 * q) = v;
             }
-            *reinterpret_cast<f32x4t*>(zb + (size_t)e * C + 4 * q) = v;
+        }
+    }
+    if (!stats) return;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { red[0][threadIdx.x][j] = s1[j]; red[1][threadIdx.x][j] = s2[j]; }
+    __syncthreads();
+    if (rg == 0) {                                   // the row groups' sums in group order (span == Cq here: one quad per thread)
+        double* sp = stats + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 * C;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            double t1 = 0.0, t2 = 0.0;
+            for (int g = 0; g < RG; ++g) { t1 += red[0][g * span + q0][j]; t2 += red[1][g * span + q0][j]; }
+            sp[4 * q0 + j] = t1; sp[C + 4 * q0 + j] = t2;
         }
     }
 }
@@ -1302,22 +1323,45 @@ extern "C" int ptt_gather_rows_f32(const float* src, const int32_t* idx, int B, 
     return check_launch("gather_rows_kernel");
 }
 
-extern "C" int ptt_sa_z0_rows_f32(const float* xyz, const float* new_xyz, const int32_t* idx, const float* term, const float* wx,
-                                  int ldw, int B, int N, int M, int ns, int C, float radius, int normalize_xyz, float* z0,
-                                  float* rel_rows, ptt_stream_t stream) {
+// with statistics the grid is also the number of partial sums the finishing pass walks per channel: about 4096 over the batch
+// (16 workgroups per CU) instead of one workgroup per 4 row groups
+static inline int sa_z0_grid(int B, int M, int ns, int C, bool stats) {
+    const int E = M * ns, Cq = C >> 2, RG = 256 / (Cq < 256 ? Cq : 256);
+    int gx = (E + RG * 4 - 1) / (RG * 4);
+    if (gx > 4096) gx = 4096;
+    if (stats) { const int cap = (4096 + B - 1) / B; if (gx > cap) gx = cap; }
+    return gx;
+}
+extern "C" int ptt_sa_z0_rows_stat_chunks(int B, int M, int ns, int C) {
+    if (B <= 0 || M <= 0 || ns <= 0 || C <= 0 || (C & 3) || C > 1024) return 0;
+    return sa_z0_grid(B, M, ns, C, true) * B;
+}
+static int sa_z0_rows_launch(const float* xyz, const float* new_xyz, const int32_t* idx, const float* term, const float* wx,
+                             int ldw, int B, int N, int M, int ns, int C, float radius, int normalize_xyz, float* z0,
+                             float* rel_rows, double* stats, ptt_stream_t stream) {
     if (B < 0 || N <= 0 || M <= 0 || ns <= 0 || C <= 0 || (C & 3) || !(radius > 0.f) || ldw < 3)
         return fail(PTT_EINVAL, "ptt_sa_z0_rows_f32: B=%d N=%d M=%d ns=%d C=%d (C %% 4) radius=%g", B, N, M, ns, C, (double)radius);
     if ((long long)M * ns > 0x7fffffffLL / 4) return fail(PTT_EUNSUPPORTED, "ptt_sa_z0_rows_f32: M * ns = %lld rows per cloud", (long long)M * ns);
+    if (stats && C > 1024) return fail(PTT_EUNSUPPORTED, "ptt_sa_z0_rows_stats_f32: C=%d (at most 1024 channels)", C);
     if (B == 0) return PTT_OK;
     if (!xyz || !new_xyz || !idx || !wx || !z0 || !rel_rows ||
         ((reinterpret_cast<uintptr_t>(z0) | reinterpret_cast<uintptr_t>(term)) & 15))
         return fail(PTT_EINVAL, "ptt_sa_z0_rows_f32: null or unaligned pointer");
-    const int E = M * ns, Cq = C >> 2, RG = 256 / (Cq < 256 ? Cq : 256);
-    int gx = (E + RG * 4 - 1) / (RG * 4);
-    if (gx > 4096) gx = 4096;
-    hipLaunchKernelGGL(sa_z0_rows_kernel, dim3(gx, B), dim3(256), 0, as_stream(stream), xyz, new_xyz, idx, term, wx, ldw, N, M, ns,
-                       C, normalize_xyz ? 1.0f / radius : 1.0f, z0, rel_rows);
+    hipLaunchKernelGGL(sa_z0_rows_kernel, dim3(sa_z0_grid(B, M, ns, C, stats != nullptr), B), dim3(256), 0, as_stream(stream), xyz, new_xyz, idx, term, wx, ldw,
+                       N, M, ns, C, normalize_xyz ? 1.0f / radius : 1.0f, z0, rel_rows, stats);
     return check_launch("sa_z0_rows_kernel");
+}
+extern "C" int ptt_sa_z0_rows_f32(const float* xyz, const float* new_xyz, const int32_t* idx, const float* term, const float* wx,
+                                  int ldw, int B, int N, int M, int ns, int C, float radius, int normalize_xyz, float* z0,
+                                  float* rel_rows, ptt_stream_t stream) {
+    return sa_z0_rows_launch(xyz, new_xyz, idx, term, wx, ldw, B, N, M, ns, C, radius, normalize_xyz, z0, rel_rows, nullptr, stream);
+}
+extern "C" int ptt_sa_z0_rows_stats_f32(const float* xyz, const float* new_xyz, const int32_t* idx, const float* term, const float* wx,
+                                        int ldw, int B, int N, int M, int ns, int C, float radius, int normalize_xyz, float* z0,
+                                        float* rel_rows, double* stats_partial, size_t partial_elems, ptt_stream_t stream) {
+    if (!stats_partial || partial_elems < (size_t)ptt_sa_z0_rows_stat_chunks(B, M, ns, C) * 2 * (size_t)C)
+        return fail(PTT_EWORKSPACE, "ptt_sa_z0_rows_stats_f32: the partial sums need %d x 2 x %d doubles", ptt_sa_z0_rows_stat_chunks(B, M, ns, C), C);
+    return sa_z0_rows_launch(xyz, new_xyz, idx, term, wx, ldw, B, N, M, ns, C, radius, normalize_xyz, z0, rel_rows, stats_partial, stream);
 }
 
 extern "C" int ptt_scatter_rows_csr_f32(const float* g, const int32_t* order, const int32_t* start, int B, int N, int E, int C,

@@ -31,6 +31,7 @@ class BoxVotingHead(VotingHeadTemplate):
     # ------------------------------------------------------------------ losses (reference :33-66)
     def get_cls_layer_loss(self, forward_ret_dict):
         weights = self.model_cfg.LOSS_CONFIG.LOSS_WEIGHTS
+        forward_ret_dict = self._proposal_labels(forward_ret_dict)
         mask = forward_ret_dict['mask']
         loss = self.cls_loss_func(forward_ret_dict['pred_boxes_cls'], forward_ret_dict['cls_label'])
         loss = torch.sum(loss * mask) / (torch.sum(mask) + 1e-6)
@@ -39,7 +40,7 @@ class BoxVotingHead(VotingHeadTemplate):
 
     def get_reg_layer_loss(self, forward_ret_dict):
         weights = self.model_cfg.LOSS_CONFIG.LOSS_WEIGHTS
-        mask = forward_ret_dict['cls_label']
+        mask = self._proposal_labels(forward_ret_dict)['cls_label']
         pred = forward_ret_dict['pred_boxes_reg']
         target = forward_ret_dict['reg_label'][:, None, :].expand_as(pred)
         loss = self.reg_loss_func(pred, target)
@@ -66,17 +67,22 @@ class BoxVotingHead(VotingHeadTemplate):
                 and self.refine_layer[-1].conv.weight.shape[0] >= 3)
 
     def _train_labels(self, batch_dict, centres):
-        dist = torch.sqrt(torch.sum((centres - batch_dict['reg_label'][:, None, 0:3]) ** 2, dim=-1) + 1e-6)
-        label = torch.zeros_like(dist, dtype=torch.float)
-        mask = torch.zeros_like(label, dtype=torch.float)
-        label[dist < 0.3] = 1
-        mask[dist < 0.3] = 1
-        mask[dist > 0.6] = 1
-        self.forward_ret_dict = {
-            'pred_boxes_cls': batch_dict['pred_box_data'][:, :, -1],
-            'pred_boxes_reg': batch_dict['pred_box_data'][:, :, :-1],
-            'mask': mask, 'cls_label': label, 'reg_label': batch_dict['reg_label'],
-        }
+        """What the losses need (reference :96-110). The proposal labels and the score / box slices are formed when a loss asks
+        for them (_proposal_labels): the one-launch loss path (train_ops.track_losses) forms them inside its kernel."""
+        self.forward_ret_dict = {'pred_box_data': batch_dict['pred_box_data'], 'centres': centres, 'reg_label': batch_dict['reg_label']}
+
+    @staticmethod
+    def _proposal_labels(d):
+        if 'mask' not in d:
+            dist = torch.sqrt(torch.sum((d['centres'] - d['reg_label'][:, None, 0:3]) ** 2, dim=-1) + 1e-6)
+            label = torch.zeros_like(dist, dtype=torch.float)
+            mask = torch.zeros_like(label, dtype=torch.float)
+            label[dist < 0.3] = 1
+            mask[dist < 0.3] = 1
+            mask[dist > 0.6] = 1
+            d.update({'pred_boxes_cls': d['pred_box_data'][:, :, -1], 'pred_boxes_reg': d['pred_box_data'][:, :, :-1],
+                      'mask': mask, 'cls_label': label})
+        return d
 
     def forward(self, batch_dict):
         centres, feats, _ = self.vote_aggregation(xyz=batch_dict['pred_centroids_votes'],

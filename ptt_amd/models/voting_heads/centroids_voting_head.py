@@ -27,8 +27,17 @@ class CentroidVotingHead(VotingHeadTemplate):
             self.transformer_block = build_transformer(self.model_cfg.TRANSFORMER_BLOCK)
 
     # ------------------------------------------------------------------ losses (reference :29-62)
+    @staticmethod
+    def _seed_labels(d):
+        """The seeds' labels, gathered from the per-point labels when first needed (the one-launch loss path of
+        train_ops.track_losses gathers them itself)."""
+        if 'cls_label' not in d:
+            d['cls_label'] = d['cls_label_points'].gather(1, d['search_inds'])
+        return d
+
     def get_cls_layer_loss(self, forward_ret_dict):
         weights = self.model_cfg.LOSS_CONFIG.LOSS_WEIGHTS
+        forward_ret_dict = self._seed_labels(forward_ret_dict)
         loss = self.cls_loss_func(forward_ret_dict['pred_centroids_cls'].view(-1),
                                   forward_ret_dict['cls_label'].view(-1))
         tb_dict = {'centroids_cls_loss': loss.item()}
@@ -36,7 +45,7 @@ class CentroidVotingHead(VotingHeadTemplate):
 
     def get_reg_layer_loss(self, forward_ret_dict):
         weights = self.model_cfg.LOSS_CONFIG.LOSS_WEIGHTS
-        mask = forward_ret_dict['cls_label']
+        mask = self._seed_labels(forward_ret_dict)['cls_label']
         pred = forward_ret_dict['pred_centroids_votes']
         target = forward_ret_dict['reg_label'][:, None, :3].expand_as(pred)
         loss = self.reg_loss_func(pred, target)
@@ -79,7 +88,7 @@ class CentroidVotingHead(VotingHeadTemplate):
             self.forward_ret_dict = {
                 'pred_centroids_cls': batch_dict['pred_centroids_cls'],
                 'pred_centroids_votes': batch_dict['pred_centroids_votes'],
-                'cls_label': batch_dict['cls_label'].gather(1, batch_dict['search_inds']),
+                'cls_label_points': batch_dict['cls_label'], 'search_inds': batch_dict['search_inds'],
                 'reg_label': batch_dict['reg_label'],
             }
         return batch_dict

@@ -1200,9 +1200,10 @@ def gather_rows(src, idx):
     return out
 
 
-def sa_z0_rows(xyz, new_xyz, idx, term, wx, radius, normalize_xyz):
+def sa_z0_rows(xyz, new_xyz, idx, term, wx, radius, normalize_xyz, want_stats=False):
     """Layer 0 of a hoisted SA level per (centre, neighbour) row in one pass — ptt_sa_z0_rows_f32: xyz (B,N,3), new_xyz (B,M,3),
-    idx (B,M,ns) int32, term (B,N,C) | None, wx (C,3) -> (z0 (B*M*ns, C), rel rows (B*M*ns, 3))."""
+    idx (B,M,ns) int32, term (B,N,C) | None, wx (C,3) -> (z0 (B*M*ns, C), rel rows (B*M*ns, 3)[, stats partials (chunks,2,C) f64 —
+    want_stats: the BatchNorm statistics of z0 summed by the same launch, for bn_finish_partials; None when C > 1024])."""
     _chk(xyz, "xyz", torch.float32, 3)
     _chk(new_xyz, "new_xyz", torch.float32, 3)
     _chk(idx, "idx", torch.int32, 3)
@@ -1219,10 +1220,18 @@ def sa_z0_rows(xyz, new_xyz, idx, term, wx, radius, normalize_xyz):
         raise RuntimeError("wx must be (C,3) and new_xyz (B,M,3)")
     z0 = torch.empty((B * M * ns, C), dtype=torch.float32, device=xyz.device)
     rel = torch.empty((B * M * ns, 3), dtype=torch.float32, device=xyz.device)
+    chunks = _lib.lib().ptt_sa_z0_rows_stat_chunks(B, M, ns, C) if want_stats else 0
+    if chunks:
+        part = torch.empty((chunks, 2, C), dtype=torch.float64, device=xyz.device)
+        with torch.cuda.device(xyz.device):
+            _lib.check(_lib.lib().ptt_sa_z0_rows_stats_f32(_ptr(xyz), _ptr(new_xyz), _ptr(idx), _ptr(term), _ptr(wx), wx.stride(0), B, N, M, ns, C,
+                                                           float(radius), int(bool(normalize_xyz)), _ptr(z0), _ptr(rel), _ptr(part), part.numel(),
+                                                           _stream()), "ptt_sa_z0_rows_stats_f32")
+        return z0, rel, part
     with torch.cuda.device(xyz.device):
         _lib.check(_lib.lib().ptt_sa_z0_rows_f32(_ptr(xyz), _ptr(new_xyz), _ptr(idx), _ptr(term), _ptr(wx), wx.stride(0), B, N, M, ns, C, float(radius),
                                                  int(bool(normalize_xyz)), _ptr(z0), _ptr(rel), _stream()), "ptt_sa_z0_rows_f32")
-    return z0, rel
+    return (z0, rel, None) if want_stats else (z0, rel)
 
 
 def scatter_csr(idx, N):
@@ -1464,3 +1473,97 @@ def fps_ball_knn(xyz, npoint, radius, nsample, k=0):
         _lib.check(_lib.lib().ptt_fps_ball_knn_f32(_ptr(xyz), B, N, M, float(radius), int(nsample), int(k), _ptr(inds), _ptr(inds64),
                                                    _ptr(new_xyz), _ptr(idx), _ptr(knn), _ptr(rel), _stream()), "ptt_fps_ball_knn_f32")
     return inds, inds64, new_xyz, idx, ((knn, rel) if k else None)
+
+
+# --------------------------------------------------------------------------- the ends of the training step
+def _track_loss_desc(seed_cls, cls_label, search_inds, votes, reg_label, box_data, centres, pw_seed, pw_box, weights):
+    B, N = seed_cls.shape
+    M = box_data.shape[1]
+    for t, name, dt in ((seed_cls, "seed_cls", torch.float32), (cls_label, "cls_label", torch.float32), (votes, "votes", torch.float32),
+                        (reg_label, "reg_label", torch.float32), (box_data, "box_data", torch.float32), (centres, "centres", torch.float32),
+                        (pw_seed, "pos_weight_seed", torch.float32), (pw_box, "pos_weight_box", torch.float32)):
+        if t.dtype != dt or not t.is_cuda or not t.is_contiguous():
+            raise ValueError("%s: contiguous %s tensor on a HIP device expected" % (name, dt))
+    if search_inds is not None and (search_inds.dtype != torch.int64 or not search_inds.is_contiguous() or tuple(search_inds.shape) != (B, N)):
+        raise ValueError("search_inds: contiguous (B,N) int64 expected")
+    if tuple(votes.shape) != (B, N, 3) or tuple(box_data.shape) != (B, M, 5) or tuple(centres.shape) != (B, M, 3) or reg_label.shape[0] != B \
+            or reg_label.dim() != 2 or reg_label.shape[1] < 4 or cls_label.shape[0] != B or (search_inds is None and cls_label.shape[1] != N):
+        raise ValueError("track losses: seed_cls (B,N), votes (B,N,3), box_data (B,M,5), centres (B,M,3), reg_label (B,>=4)")
+    d = _lib.TrackLossDesc()
+    d.seed_cls, d.cls_label, d.search_inds, d.votes = seed_cls.data_ptr(), cls_label.data_ptr(), (search_inds.data_ptr() if search_inds is not None else None), votes.data_ptr()
+    d.reg_label, d.box_data, d.centres = reg_label.data_ptr(), box_data.data_ptr(), centres.data_ptr()
+    d.pos_weight_seed, d.pos_weight_box = pw_seed.data_ptr(), pw_box.data_ptr()
+    d.B, d.N, d.Ns, d.M, d.ld_reg = B, N, cls_label.shape[1], M, reg_label.shape[1]
+    d.w_seed_cls, d.w_seed_reg, d.w_box_cls, d.w_box_reg = (float(w) for w in weights)
+    return d
+
+
+def track_losses(seed_cls, cls_label, search_inds, votes, reg_label, box_data, centres, pw_seed, pw_box, weights):
+    """The four tracking losses of a training step in one launch (ptt_track_losses_f32; reference centroids_voting_head.py:29-62,
+    box_voting_head.py:33-66,96-104) -> (total (), out (8,): [total, seed cls, seed reg, proposal cls, proposal reg, three label sums]).
+    weights = (centroids_cls_weight, centroids_reg_weight, boxes_cls_weight, boxes_reg_weight)."""
+    d = _track_loss_desc(seed_cls, cls_label, search_inds, votes, reg_label, box_data, centres, pw_seed, pw_box, weights)
+    out = torch.empty((8,), dtype=torch.float32, device=seed_cls.device)
+    total = torch.empty((), dtype=torch.float32, device=seed_cls.device)
+    with torch.cuda.device(seed_cls.device):
+        _lib.check(_lib.lib().ptt_track_losses_f32(ctypes.byref(d), _ptr(out), _ptr(total), _stream()), "ptt_track_losses_f32")
+    return total, out
+
+
+def track_losses_bwd(out8, upstream, seed_cls, cls_label, search_inds, votes, reg_label, box_data, centres, pw_seed, pw_box, weights):
+    """d total / d (seed_cls, votes, box_data) times the scalar tensor `upstream` (None: 1), one launch."""
+    d = _track_loss_desc(seed_cls, cls_label, search_inds, votes, reg_label, box_data, centres, pw_seed, pw_box, weights)
+    if upstream is not None and (upstream.dtype != torch.float32 or upstream.numel() != 1 or not upstream.is_cuda):
+        raise ValueError("upstream: one float32 on the device expected")
+    g_cls, g_votes, g_box = torch.empty_like(seed_cls), torch.empty_like(votes), torch.empty_like(box_data)
+    with torch.cuda.device(seed_cls.device):
+        _lib.check(_lib.lib().ptt_track_losses_bwd_f32(ctypes.byref(d), _ptr(out8), _ptr(upstream), _ptr(g_cls), _ptr(g_votes), _ptr(g_box),
+                                                       _stream()), "ptt_track_losses_bwd_f32")
+    return g_cls, g_votes, g_box
+
+
+class AdamTable(object):
+    """The device table ptt_adam_clip_step_f32 walks: parameters, their moments and the chunk map are fixed, the gradient
+    pointers are refreshed every step (autograd allocates new .grad tensors after zero_grad(set_to_none=True)) through one
+    pinned host copy of the table."""
+
+    def __init__(self, params, exp_avgs, exp_avg_sqs):
+        self.device = params[0].device
+        chunk = _lib.lib().ptt_adam_chunk_elems()
+        n = len(params)
+        self.host = torch.zeros((n, ctypes.sizeof(_lib.AdamTensor)), dtype=torch.uint8).pin_memory()
+        self.rows = (_lib.AdamTensor * n).from_address(self.host.data_ptr())
+        which, first = [], []
+        for k, (p, m, v) in enumerate(zip(params, exp_avgs, exp_avg_sqs)):
+            for t in (p, m, v):
+                if t.dtype != torch.float32 or not t.is_contiguous() or t.device != self.device:
+                    raise ValueError("AdamTable: contiguous float32 tensors on one device expected")
+            r = self.rows[k]
+            r.param, r.exp_avg, r.exp_avg_sq, r.n = p.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel()
+            for e in range(0, p.numel(), chunk):
+                which.append(k)
+                first.append(e)
+        self.n_chunks = len(which)
+        self.which = torch.tensor(which, dtype=torch.int32, device=self.device)
+        self.first = torch.tensor(first, dtype=torch.int64, device=self.device)
+        self.table = torch.empty_like(self.host, device=self.device)
+        self.partial = torch.empty((max(1, self.n_chunks),), dtype=torch.float64, device=self.device)
+        self.norm = torch.zeros((1,), dtype=torch.float32, device=self.device)
+        self.keep = (list(params), list(exp_avgs), list(exp_avg_sqs))
+        self.uploaded = torch.cuda.Event()
+
+    def step(self, grads, beta1, beta2, eps, step_size, bias2_sqrt, weight_decay=0.0, max_norm=0.0, write_clipped=True):
+        self.uploaded.synchronize()                            # the previous step's upload has left the pinned table
+        for r, g, p in zip(self.rows, grads, self.keep[0]):
+            if g.dtype != torch.float32 or not g.is_contiguous() or g.numel() != p.numel() or g.device != self.device:
+                raise ValueError("AdamTable.step: contiguous float32 gradients of the parameters' sizes expected")
+            r.grad = g.data_ptr()
+        self.table.copy_(self.host, non_blocking=True)
+        self.uploaded.record()
+        h = _lib.AdamHyper(float(beta1), float(beta2), 1.0 - float(beta1), 1.0 - float(beta2), float(eps), float(step_size), float(bias2_sqrt), float(weight_decay), float(max_norm),
+                           1 if write_clipped else 0)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().ptt_adam_clip_step_f32(_ptr(self.table), _ptr(self.which), _ptr(self.first), self.n_chunks, ctypes.byref(h),
+                                                         _ptr(self.partial), self.partial.numel(), _ptr(self.norm), _stream()),
+                       "ptt_adam_clip_step_f32")
+        return self.norm

@@ -270,14 +270,19 @@ class _SaZ0(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, xyz, new_xyz, idx, term, wx, radius, normalize_xyz):
-        z0, rel = ops.sa_z0_rows(xyz.contiguous(), new_xyz.contiguous(), idx, term.contiguous() if term is not None else None,
-                                 wx.detach(), radius, normalize_xyz)
+        """-> (z0, the float64 partial sums of z0's BatchNorm statistics (or an empty tensor), summed by the same launch)."""
+        ctx.set_materialize_grads(False)
+        z0, rel, part = ops.sa_z0_rows(xyz.contiguous(), new_xyz.contiguous(), idx, term.contiguous() if term is not None else None,
+                                       wx.detach(), radius, normalize_xyz, want_stats=True)
         ctx.save_for_backward(idx, rel)
         ctx.N, ctx.has_term = xyz.shape[1], term is not None
-        return z0
+        if part is None:
+            part = z0.new_empty(0, dtype=torch.float64)
+        ctx.mark_non_differentiable(part)
+        return z0, part
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, _unused=None):
         idx, rel = ctx.saved_tensors
         B, M, ns = idx.shape
         g = g.contiguous()
@@ -294,7 +299,7 @@ class _SharedMlpPool(torch.autograd.Function):
     xcorr_hoisted), so layer 0 is BatchNorm + ReLU only and its W entry is a placeholder that gets no gradient."""
 
     @staticmethod
-    def forward(ctx, x, ns, eps, preact, sync, bns, *params):
+    def forward(ctx, x, ns, eps, preact, sync, bns, z0_part, *params):
         """Deferred activation: a layer's output relu(BatchNorm(z)) = relu(z * a + b) is never written — the next
         convolution, its weight gradient, the max-pool and the BatchNorm backward apply it while they load z.
         sync: per layer a torch.distributed process group (nn.SyncBatchNorm: the statistics are those of the rows of ALL
@@ -310,7 +315,7 @@ class _SharedMlpPool(torch.autograd.Function):
             cout = gamma.shape[0]
             part, extrema = None, None
             if preact and l == 0:
-                z = cur
+                z, part = cur, z0_part                     # the caller's launch summed the statistics of its rows (or None)
             elif (l == L - 1 and ns > 1 and POOL_EPILOGUE and sync[l] is None and cur_a is not None
                   and ops.rows_gemm_pool_supported(cur.shape[0], cur.shape[1], cout, cur.stride(0), ns, x=cur)):
                 # the last layer: its GEMM's epilogue also takes the per-group extrema of z, so that the max-pool needs no pass
@@ -402,7 +407,7 @@ class _SharedMlpPool(torch.autograd.Function):
                 g, _ = conv_rows(dz, w2, transpose=True)                                # w.r.t. the (not normalised) input rows
             else:
                 g = None
-        return (g, None, None, None, None, None) + tuple(grads)
+        return (g, None, None, None, None, None, None) + tuple(grads)
 
 
 def shared_mlp_pool(grouped, mlp, pool_dim):
@@ -427,9 +432,10 @@ def _sync_group(bn):
     return group if dist.get_world_size(group) > 1 else None
 
 
-def rows_mlp_pool(rows, mlp, ns, B, keep, preact):
+def rows_mlp_pool(rows, mlp, ns, B, keep, preact, z0_part=None):
     """The row form: rows (B * keep * ns, C) ordered (frame, kept position, pooled position) -> (B, C_L, keep).
-    preact: rows are layer 0's convolution output already (hoisted by the caller)."""
+    preact: rows are layer 0's convolution output already (hoisted by the caller); z0_part: its BatchNorm statistics as float64
+    partial sums (chunks, 2, C), when the launch that built the rows summed them (ops.sa_z0_rows)."""
     params, eps, sync = [], [], []
     for unit in mlp:
         bn = unit.normlayer.bn
@@ -437,7 +443,7 @@ def rows_mlp_pool(rows, mlp, ns, B, keep, preact):
         eps.append(float(bn.eps))
         sync.append(_sync_group(bn))
     bns = tuple(unit.normlayer.bn if g is None else None for unit, g in zip(mlp, sync))
-    out = _SharedMlpPool.apply(rows, ns, tuple(eps), bool(preact), tuple(sync), bns, *params)
+    out = _SharedMlpPool.apply(rows, ns, tuple(eps), bool(preact), tuple(sync), bns, z0_part, *params)
     pooled, stats = out[0], out[1:]
     with torch.no_grad():                                   # nn.BatchNorm's bookkeeping in training mode: done by the statistics'
         for l, unit in enumerate(mlp):                      # own launch, except for SyncBatchNorm layers (all-reduced count)
@@ -462,8 +468,8 @@ def sa_level_hoisted(xyz, new_xyz, features, idx, mlp, radius, normalize_xyz):
         # fixed coordinates (the backbone's levels): the whole front — relative coordinates, gather of the per-point terms,
         # the three coordinate channels — is one launch; features None: a level without point features (layer 0 = Wx . rel)
         term = _RowsLinear.apply(features.transpose(1, 2), wf, None, None) if features is not None else None
-        z0 = _SaZ0.apply(xyz, new_xyz, idx, term, wx, float(radius), bool(normalize_xyz))
-        return rows_mlp_pool(z0, mlp, ns, B, M, preact=True)
+        z0, z0_part = _SaZ0.apply(xyz, new_xyz, idx, term, wx, float(radius), bool(normalize_xyz))
+        return rows_mlp_pool(z0, mlp, ns, B, M, preact=True, z0_part=z0_part if z0_part.numel() else None)
     rel = pu.grouping_operation(xyz.transpose(1, 2).contiguous(), idx) - new_xyz.transpose(1, 2).unsqueeze(-1)   # (B,3,M,ns)
     if normalize_xyz:
         rel = rel / radius
@@ -702,3 +708,88 @@ def conv1d_stack_rows(seq, rows, residual=None):
         return rows_linear(last, x, res2).view(B, N, -1)
     assert residual is None
     return x.reshape(B, N, -1)
+
+
+# --------------------------------------------------------------------------- the four tracking losses, one launch each way
+class LossValues(object):
+    """The un-weighted loss values a training forward reports (tb_dict / disp_dict of reference ptt.py:44-60) as numbers that
+    are fetched from the device when first LOOKED at: the reference calls .item() four times inside the forward pass (four
+    host-device synchronisations before the backward pass can be queued); here the four values live in one device tensor and
+    one copy serves all of them, at the time a logger formats or adds them — never, if nobody looks."""
+
+    class Value(object):
+        __slots__ = ("owner", "k")
+
+        def __init__(self, owner, k):
+            self.owner, self.k = owner, k
+
+        def __float__(self):
+            return self.owner.fetch()[self.k]
+
+        def item(self):
+            return float(self)
+
+        def __repr__(self):
+            return repr(float(self))
+
+        __str__ = __repr__
+
+        def __format__(self, spec):
+            return format(float(self), spec)
+
+        def __add__(self, o): return float(self) + o
+        def __radd__(self, o): return o + float(self)
+        def __sub__(self, o): return float(self) - o
+        def __rsub__(self, o): return o - float(self)
+        def __mul__(self, o): return float(self) * o
+        def __rmul__(self, o): return o * float(self)
+        def __truediv__(self, o): return float(self) / o
+        def __rtruediv__(self, o): return o / float(self)
+        def __lt__(self, o): return float(self) < o
+        def __le__(self, o): return float(self) <= o
+        def __gt__(self, o): return float(self) > o
+        def __ge__(self, o): return float(self) >= o
+        def __eq__(self, o): return float(self) == o
+        def __hash__(self): return hash((id(self.owner), self.k))
+
+    def __init__(self, device_values):
+        self.device_values, self.host = device_values, None
+
+    def fetch(self):
+        if self.host is None:
+            self.host = self.device_values.tolist()
+        return self.host
+
+    def __getitem__(self, k):
+        return LossValues.Value(self, k)
+
+
+class _TrackLosses(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, seed_cls, votes, box_data, centres, cls_label, search_inds, reg_label, pw_seed, pw_box, weights):
+        args = (seed_cls.contiguous(), cls_label.contiguous(), search_inds.contiguous() if search_inds is not None else None,
+                votes.contiguous(), reg_label.contiguous(), box_data.contiguous(), centres.detach().contiguous(), pw_seed, pw_box)
+        total, out = ops.track_losses(*args, weights)
+        ctx.save_for_backward(out, *[a for a in args if a is not None])
+        ctx.has_inds, ctx.weights = search_inds is not None, tuple(weights)
+        ctx.mark_non_differentiable(out)
+        return total, out
+
+    @staticmethod
+    def backward(ctx, g_total, _g_out):
+        out, t = ctx.saved_tensors[0], list(ctx.saved_tensors[1:])
+        if not ctx.has_inds:
+            t.insert(2, None)
+        g = g_total.contiguous().float() if g_total is not None else None
+        g_cls, g_votes, g_box = ops.track_losses_bwd(out, g, *t, ctx.weights)
+        return g_cls, g_votes, g_box, None, None, None, None, None, None, None
+
+
+def track_losses_usable(*tensors):
+    return all(t is not None and t.is_cuda and t.dtype == torch.float32 for t in tensors)
+
+
+def track_losses(seed_cls, votes, box_data, centres, cls_label, search_inds, reg_label, pw_seed, pw_box, weights):
+    """-> (total loss (scalar tensor with the graph), LossValues of [total, seed cls, seed reg, proposal cls, proposal reg])."""
+    total, out = _TrackLosses.apply(seed_cls, votes, box_data, centres, cls_label, search_inds, reg_label, pw_seed, pw_box, tuple(weights))
+    return total, LossValues(out.detach())

@@ -16,6 +16,7 @@ import torch
 import torch.distributed as dist
 
 from . import synth
+from .optim import ClipAdam
 
 GRAD_ELEMS = 4903113            # parameters of the shipped PTT model
 
@@ -55,7 +56,8 @@ class DataParallelTrainer(object):
             self.model = torch.nn.parallel.DistributedDataParallel(model, device_ids=ids, bucket_cap_mb=bucket_cap_mb)
         else:
             self.model = model
-        self.optimizer = torch.optim.Adam(self.model.parameters(), lr=lr, betas=betas, eps=eps)
+        # torch.optim.Adam with clip_grad_norm_ folded into step(): two launches on a HIP device, the stock path elsewhere
+        self.optimizer = ClipAdam(self.model.parameters(), lr=lr, betas=betas, eps=eps)
         self.clip = clip
 
     def forward_backward(self, batch):
@@ -68,9 +70,7 @@ class DataParallelTrainer(object):
 
     def step(self, batch):
         loss = self.forward_backward(batch)
-        if self.clip:
-            torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.clip)
-        self.optimizer.step()
+        self.optimizer.step(max_norm=self.clip if self.clip else None)
         self.tracker.update_global_step()
         return loss
 

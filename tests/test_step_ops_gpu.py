@@ -1,0 +1,149 @@
+"""The ends of the training step on the GPU (ptt_amd/csrc/step_ops.hip): the one-launch tracking losses against the heads' own
+stock-torch losses (the mirror of reference centroids_voting_head.py:29-62 / box_voting_head.py:33-66,96-104) — values and every
+gradient — and ClipAdam against torch.nn.utils.clip_grad_norm_ + torch.optim.Adam (tools/train_utils/train_utils.py:47-51)."""
+import numpy as np
+import pytest
+import torch
+
+from ptt_amd import ops, train_ops
+from ptt_amd.optim import ClipAdam
+
+pytestmark = pytest.mark.gpu
+
+
+def _loss_inputs(dev, B, N, Ns, M, seed, near):
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s: torch.randn(*s, generator=g)
+    reg = torch.cat((r(B, 3) * 0.5, r(B, 1)), dim=1)
+    votes = reg[:, None, :3] + r(B, N, 3) * 0.8                          # residuals on both sides of smooth-L1's knee
+    centres = reg[:, None, :3] + r(B, M, 3) * near                       # proposals inside 0.3, between, and beyond 0.6
+    box = torch.cat((centres + r(B, M, 3) * 0.7, reg[:, None, 3:] + r(B, M, 1) * 1.5, r(B, M, 1) * 3), dim=2)
+    cls_points = (torch.rand(B, Ns, generator=g) > 0.6).float()
+    inds = torch.stack([torch.randperm(Ns, generator=g)[:N] for _ in range(B)])
+    t = [r(B, N) * 3, votes, box, centres, cls_points, inds, reg]
+    return [x.to(dev).contiguous() for x in t]
+
+
+def _stock_losses(seed_cls, votes, box, centres, cls_points, inds, reg, pw_s, pw_b, w):
+    """The heads' op sequences (ptt_amd/models/voting_heads/*.py get_*_loss, _proposal_labels) written out."""
+    bce = lambda pw, red: torch.nn.BCEWithLogitsLoss(pos_weight=pw, reduction=red)
+    sl1 = torch.nn.SmoothL1Loss(reduction='none')
+    label = cls_points.gather(1, inds)
+    l1 = bce(pw_s, 'mean')(seed_cls.view(-1), label.view(-1))
+    l2 = (sl1(votes, reg[:, None, :3].expand_as(votes)).mean(2) * label).sum() / (label.sum() + 1e-06)
+    dist = torch.sqrt(torch.sum((centres - reg[:, None, 0:3]) ** 2, dim=-1) + 1e-6)
+    y = torch.zeros_like(dist); m = torch.zeros_like(dist)
+    y[dist < 0.3] = 1; m[dist < 0.3] = 1; m[dist > 0.6] = 1
+    l3 = torch.sum(bce(pw_b, 'none')(box[:, :, -1], y) * m) / (torch.sum(m) + 1e-6)
+    pred = box[:, :, :-1]
+    l4 = (sl1(pred, reg[:, None, :].expand_as(pred)).mean(2) * y).sum() / (y.sum() + 1e-06)
+    total = (l1.float() * w[0] + l2.float() * w[1]).float() + (l3.float() * w[2] + l4.float() * w[3]).float()
+    return total, (l1, l2, l3, l4), (y, m)
+
+
+@pytest.mark.parametrize("B,N,Ns,M,near", [(48, 128, 1024, 64, 0.3), (3, 128, 1024, 64, 0.25), (2, 37, 50, 5, 0.4), (4, 16, 16, 8, 5.0)])
+def test_one_launch_losses_equal_the_heads_stock_losses(dev, B, N, Ns, M, near):
+    """near = 5.0: no proposal within 0.3 of the box centre — the label sum is zero and the box regression loss 0 / 1e-6 = 0."""
+    seed_cls, votes, box, centres, cls_points, inds, reg = _loss_inputs(dev, B, N, Ns, M, 11 + B, near)
+    pw_s, pw_b = torch.tensor([1.0], device=dev), torch.tensor([2.0], device=dev)
+    w = (0.2, 1.0, 1.5, 0.2)
+    leaves = [t.clone().requires_grad_(True) for t in (seed_cls, votes, box)]
+    ref_total, ref_parts, (y, m) = _stock_losses(leaves[0], leaves[1], leaves[2], centres, cls_points, inds, reg, pw_s, pw_b, w)
+    (ref_total * 0.75).backward()
+    mine = [t.clone().requires_grad_(True) for t in (seed_cls, votes, box)]
+    total, vals = train_ops.track_losses(mine[0], mine[1], mine[2], centres, cls_points, inds, reg, pw_s, pw_b, w)
+    (total * 0.75).backward()
+    assert abs(float(total) - float(ref_total)) <= 2e-6 * max(1.0, abs(float(ref_total)))
+    for k, r in enumerate(ref_parts):
+        assert abs(float(vals[1 + k]) - float(r)) <= 2e-6 * max(1.0, abs(float(r))), k
+    out = vals.device_values
+    assert float(out[5]) == float(cls_points.gather(1, inds).sum()) and float(out[6]) == float(m.sum()) and float(out[7]) == float(y.sum())
+    for a, b in zip(mine, leaves):
+        scale = float(b.grad.abs().max()) + 1e-12
+        assert float((a.grad - b.grad).abs().max()) <= 2e-6 * scale + 1e-10
+    # labels given per seed (no index list)
+    t2, v2 = train_ops.track_losses(seed_cls, votes, box, centres, cls_points.gather(1, inds).contiguous(), None, reg, pw_s, pw_b, w)
+    assert float(t2) == float(total)
+
+
+def test_loss_values_are_fetched_once_and_only_when_read(dev):
+    dv = torch.arange(8, dtype=torch.float32, device=dev)
+    vals = train_ops.LossValues(dv)
+    a, b = vals[1], vals[3]
+    assert vals.host is None                                        # nothing copied yet
+    assert float(a) == 1.0 and vals.host is not None
+    assert "%.1f" % b == "3.0" and a + b == 4.0 and b.item() == 3.0 and repr(a) == "1.0" and b > a
+
+
+def test_full_model_training_loss_takes_the_one_launch_path_and_matches_the_stock_losses(dev):
+    from ptt_amd.config import StubDataset, ptt_model_cfg
+    from ptt_amd.models import build_network
+    from ptt_amd.train_step import synthetic_train_batch
+    torch.manual_seed(3)
+    model = build_network(ptt_model_cfg(), 1, StubDataset(training=True)).to(dev).train()
+    batch = synthetic_train_batch(5, 4, dev)
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    ret, tb, disp = model(dict(batch))
+    assert isinstance(tb['centroids_cls_loss'], train_ops.LossValues.Value) and set(tb) == set(disp) == {
+        'centroids_cls_loss', 'centroids_reg_loss', 'boxes_cls_loss', 'boxes_reg_loss'}
+    ret['loss'].mean().backward()
+    g1 = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+    model.load_state_dict(state)
+    model.zero_grad(set_to_none=True)
+    model._one_launch_losses = lambda: None                          # the heads' own losses (the mirror of the reference's)
+    ret2, tb2, _ = model(dict(batch))
+    assert isinstance(tb2['centroids_cls_loss'], float)
+    ret2['loss'].mean().backward()
+    assert abs(float(ret['loss']) - float(ret2['loss'])) <= 2e-6 * abs(float(ret2['loss']))
+    for k in tb2:
+        assert abs(float(tb[k]) - tb2[k]) <= 2e-6 * max(1.0, abs(tb2[k])), k
+    named = dict(model.named_parameters())
+    assert set(g1) == {k for k, p in named.items() if p.grad is not None}
+    for k, g in g1.items():
+        ref = named[k].grad
+        assert float((g - ref).norm()) <= 2e-5 * float(ref.norm()) + 1e-9, k
+
+
+@pytest.mark.parametrize("max_norm,scale", [(10.0, 1.0), (10.0, 300.0), (None, 1.0)])
+def test_clip_adam_equals_clip_grad_norm_then_torch_adam(dev, max_norm, scale):
+    """Three steps on the same gradients: parameters, both moments, the clipped .grad and the reported norm; scale = 300: the
+    clip is active. Different lr / step counts exercise the bias corrections; weight_decay = 0.01 the L2 term."""
+    g = torch.Generator().manual_seed(5)
+    shapes = [(64, 67), (4100,), (1,), (3, 5, 7), (256, 256), (9000,)]
+    mk = lambda: [torch.nn.Parameter(torch.randn(*s, generator=g).to(dev)) for s in shapes]
+    g = torch.Generator().manual_seed(5); pa = mk()
+    g = torch.Generator().manual_seed(5); pb = mk()
+    kw = dict(lr=1e-3, betas=(0.5, 0.999), eps=1e-6, weight_decay=0.01)
+    oa, ob = ClipAdam(pa, **kw), torch.optim.Adam(pb, foreach=True, **kw)
+    gg = torch.Generator().manual_seed(9)
+    for step in range(3):
+        grads = [torch.randn(*s, generator=gg).to(dev) * scale * (1 + step) for s in shapes]
+        for p, q, gr in zip(pa, pb, grads):
+            p.grad, q.grad = gr.clone(), gr.clone()
+        oa.step(max_norm=max_norm)
+        if max_norm is not None:
+            norm = torch.nn.utils.clip_grad_norm_(pb, max_norm)
+            assert abs(float(oa.last_norm) - float(norm)) <= 2e-6 * float(norm)
+        ob.step()
+        for p, q in zip(pa, pb):
+            assert float((p - q).abs().max()) <= 1e-6 * float(q.abs().max()) + 2e-9, step
+            assert float((p.grad - q.grad).abs().max()) <= 2e-6 * float(q.grad.abs().max()) + 1e-12
+            for key in ('exp_avg', 'exp_avg_sq'):
+                a, b = oa.state[p][key], ob.state[q][key]
+                # a moment of a single element can cancel: the bar is relative to the gradients that went into it
+                ref_scale = max(float(b.abs().max()), float(q.grad.abs().max()) ** (2 if key == 'exp_avg_sq' else 1) * 1e-3)
+                assert float((a - b).abs().max()) <= 2e-6 * ref_scale + 1e-12, (step, key)
+            assert float(oa.state[p]['step']) == float(ob.state[q]['step']) == step + 1
+    # the state dict of one loads into the other
+    ob.load_state_dict(oa.state_dict())
+    oa.load_state_dict(ob.state_dict())
+
+
+def test_clip_adam_takes_the_stock_path_for_what_the_table_does_not_hold(dev):
+    p_gpu = torch.nn.Parameter(torch.ones(10, device=dev))
+    p_half = torch.nn.Parameter(torch.ones(10, device=dev, dtype=torch.float64))
+    o = ClipAdam([p_gpu, p_half], lr=0.1)
+    p_gpu.grad, p_half.grad = torch.ones_like(p_gpu), torch.ones_like(p_half)
+    o.step(max_norm=1.0)
+    ref_g = 1.0 / (20 ** 0.5)
+    assert abs(float(p_gpu.grad[0]) - ref_g) < 1e-6 and abs(float(p_gpu[0]) - 0.9) < 1e-5 and abs(float(p_half[0]) - 0.9) < 1e-5

@@ -324,9 +324,9 @@ def test_sa_level_with_fixed_coordinates_one_launch_front_equals_the_reference_o
     calls = {"z0": 0}
     real = ops.sa_z0_rows
 
-    def counting(*k):
+    def counting(*k, **kw):
         calls["z0"] += 1
-        return real(*k)
+        return real(*k, **kw)
 
     ops.sa_z0_rows = counting
     try:
