@@ -763,6 +763,18 @@ int ptt_adam_chunk_elems(void);
 int ptt_adam_clip_step_f32(const ptt_adam_tensor* tensors_device, const int32_t* chunk_tensor_device, const int64_t* chunk_first_device,
                            int n_chunks, const ptt_adam_hyper* hyper, double* partial, size_t partial_elems, float* norm_out,
                            ptt_stream_t stream);
+/* The two element-wise ends of CosineSimAug's cosine map in training (p2b_xcoor.py:35-42 via nn.CosineSimilarity); the map
+ * itself is a batched product of unit rows.
+ *   ptt_unit_rows_f32     x addressed as x[b * sb + j * sn + c * sc] (any layout) -> unit (B,n,C) rows x / max(|x|, eps) and
+ *                         nrm (B,n) = max(|x|, eps), stored NEGATIVE where the clamp is active
+ *   ptt_cos_bwd_rows_f32  dx[b,j,:] = (A[b,j,:] - (sum_i G[b,j,i] cos[b,j,i]) unit[b,j,:]) / |nrm[b,j]| (no projection term where
+ *                         nrm < 0), A (B,n,C) = the caller's product of G with the OTHER side's unit rows; G / cos addressed as
+ *                         [b * map_sb + j * own + i * other], i < m; dx written as dx[b * sb + j * sn + c * sc] */
+int ptt_unit_rows_f32(const float* x, long long sb, long long sn, long long sc, int B, int n, int C, float eps, float* unit, float* nrm,
+                      ptt_stream_t stream);
+int ptt_cos_bwd_rows_f32(const float* A, const float* unit, const float* nrm, const float* G, const float* cosm, long long map_sb,
+                         long long own, long long other, int m, int B, int n, int C, float* dx, long long sb, long long sn, long long sc,
+                         ptt_stream_t stream);
 
 #ifdef __cplusplus
 }

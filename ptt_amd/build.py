@@ -13,13 +13,15 @@ CSRC = os.path.join(ROOT, "ptt_amd", "csrc")
 LIBDIR = os.path.join(ROOT, "ptt_amd", "lib")
 LIB = os.path.join(LIBDIR, "libptt_hip.so")
 
-HIP_SOURCES = ["errors.hip", "point_ops.hip", "mfma_ops.hip", "track_ops.hip", "train_ops.hip", "gemm_ops.hip", "rowjobs.hip", "step_ops.hip"]
+HIP_SOURCES = ["errors.hip", "point_ops.hip", "mfma_ops.hip", "track_ops.hip", "train_ops.hip", "gemm_ops.hip", "rowjobs.hip", "step_ops.hip", "wgrad_stream.hip"]
 # FPS / ball query / kNN index parity needs un-fused fp32 arithmetic (see point_ops.hip header)
 EXTRA_FLAGS = {"point_ops.hip": ["-ffp-contract=off"], "track_ops.hip": ["-ffp-contract=off"], # -fno-honor-nans: without it every fmaxf on an MFMA result costs a second v_max (sNaN canonicalisation), and
                # vector-ALU instructions next to fp32 MFMAs are paid in matrix time (a third of the epilogue instructions)
                "mfma_ops.hip": ["-fno-honor-nans"] + os.environ.get("PTT_MFMA_FLAGS", "").split(),
                "gemm_ops.hip": ["-fno-honor-nans"] + os.environ.get("PTT_GEMM_FLAGS", "").split(),
-               "rowjobs.hip": ["-fno-honor-nans"]}
+               "rowjobs.hip": ["-fno-honor-nans"],
+               # accumulators in vector registers: see the file's header (one wave per SIMD otherwise)
+               "wgrad_stream.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 # build-time only: flags for every source, e.g. PTT_HIP_FLAGS="-DPTT_DEV" for a developer build that reads the PTT_*
 # A/B switches from the environment and keeps the kernels' cycle-stamp hooks (a release build has neither)
 COMMON_FLAGS = os.environ.get("PTT_HIP_FLAGS", "").split()

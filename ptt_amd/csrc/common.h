@@ -48,6 +48,12 @@ const DevSwitches& dev_switches();
 // call this on every launch and it is a table lookup after the first.
 int set_lds_limit(const void* fn, int bytes);
 
+// wgrad_stream.hip: the weight gradient of narrow layers (Cin = 64, Cout = 64 / 128) over many rows, partial[chunk][Cout][Cin]
+bool wgrad_stream_ok(int R, int Cout, int Cin, int ldz, int ldx);
+int wgrad_stream_rows(int R);
+int launch_wgrad_stream(const float* dZ, int ldz, const float* X, int ldx, int R, int Cout, int Cin, int rows, float* partial,
+                        const float* x_scale, const float* x_shift, hipStream_t s);
+
 // ---- wave64 cross-lane reductions on DPP (no LDS traffic) -------------------------
 // After 4 row-local butterfly steps every lane of a 16-lane row holds the row result;
 // row_bcast:15 / row_bcast:31 then fold the four rows into lane 63.

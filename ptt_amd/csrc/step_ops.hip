@@ -199,6 +199,52 @@ __global__ __launch_bounds__(256) void adam_update_kernel(const ptt_adam_tensor*
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// The cosine map of CosineSimAug in training (reference ptt/models/similarity_modules/p2b_xcoor.py:35-42 through
+// nn.CosineSimilarity: cos(s_j, t_i) = s_j . t_i / (max(|s_j|, eps) max(|t_i|, eps))): the map itself is a batched matrix product
+// of UNIT rows; these two kernels are everything around it. Wave = one point, lanes over channels.
+//   unit_rows:     u = x / max(|x|, eps) as point-major rows, nrm = max(|x|, eps) (negative when the clamp is active: no
+//                  gradient flows through a clamped norm)
+//   cos_bwd_rows:  dx = (A - (sum_i G_i cos_i) u) / nrm with A = sum_i G_i u'_i (the caller's matrix product), written in the
+//                  input's own layout
+// ------------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void unit_rows_kernel(const float* __restrict__ x, long long sb, long long sn, long long sc, int n, int C,
+                                                        long long points, float eps, float* __restrict__ unit, float* __restrict__ nrm) {
+    const int lane = threadIdx.x & 63;
+    const long long p = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= points) return;
+    const long long b = p / n, j = p - b * n;
+    const float* row = x + b * sb + j * sn;
+    float ss = 0.f;
+    for (int c = lane; c < C; c += 64) { const float v = row[c * sc]; ss = __builtin_fmaf(v, v, ss); }
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
+    const float norm = sqrtf(ss), d = fmaxf(norm, eps);
+    for (int c = lane; c < C; c += 64) unit[p * C + c] = row[c * sc] / d;
+    if (lane == 0) nrm[p] = norm < eps ? -d : d;
+}
+
+__global__ __launch_bounds__(256) void cos_bwd_rows_kernel(const float* __restrict__ A, const float* __restrict__ unit,
+                                                           const float* __restrict__ nrm, const float* __restrict__ G,
+                                                           const float* __restrict__ cosm, long long map_sb, long long own, long long other,
+                                                           int m, int n, int C, long long points, float* __restrict__ dx, long long sb,
+                                                           long long sn, long long sc) {
+    const int lane = threadIdx.x & 63;
+    const long long p = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= points) return;
+    const long long b = p / n, j = p - b * n;
+    const float d = nrm[p];
+    float r = 0.f;
+    if (d > 0.f) {                                                         // the projection term exists only where the norm is not clamped
+        const float* g = G + b * map_sb + j * own;
+        const float* c = cosm + b * map_sb + j * own;
+        for (int i = lane; i < m; i += 64) r = __builtin_fmaf(g[i * other], c[i * other], r);
+        for (int off = 32; off > 0; off >>= 1) r += __shfl_xor(r, off, 64);
+    }
+    const float inv = 1.f / fabsf(d);
+    float* out = dx + b * sb + j * sn;
+    for (int c = lane; c < C; c += 64) out[c * sc] = (A[p * C + c] - r * unit[p * C + c]) * inv;
+}
+
 }  // namespace ptt
 
 using namespace ptt;
@@ -237,4 +283,25 @@ extern "C" int ptt_adam_clip_step_f32(const ptt_adam_tensor* tensors_device, con
     hipLaunchKernelGGL(adam_update_kernel, dim3(n_chunks), dim3(256), 0, s, tensors_device, chunk_tensor_device, chunk_first_device, partial,
                        n_chunks, *hyper, norm_out);
     return check_launch("adam_update_kernel");
+}
+
+extern "C" int ptt_unit_rows_f32(const float* x, long long sb, long long sn, long long sc, int B, int n, int C, float eps, float* unit,
+                                 float* nrm, ptt_stream_t stream) {
+    if (B <= 0 || n <= 0 || C <= 0 || !(eps > 0.f)) return fail(PTT_EINVAL, "ptt_unit_rows_f32: B=%d n=%d C=%d eps=%g", B, n, C, (double)eps);
+    if (!x || !unit || !nrm) return fail(PTT_EINVAL, "ptt_unit_rows_f32: null pointer");
+    const long long points = (long long)B * n;
+    hipLaunchKernelGGL(unit_rows_kernel, dim3((unsigned)((points + 3) / 4)), dim3(256), 0, as_stream(stream), x, sb, sn, sc, n, C, points, eps,
+                       unit, nrm);
+    return check_launch("unit_rows_kernel");
+}
+
+extern "C" int ptt_cos_bwd_rows_f32(const float* A, const float* unit, const float* nrm, const float* G, const float* cosm, long long map_sb,
+                                    long long own, long long other, int m, int B, int n, int C, float* dx, long long sb, long long sn,
+                                    long long sc, ptt_stream_t stream) {
+    if (B <= 0 || n <= 0 || C <= 0 || m <= 0) return fail(PTT_EINVAL, "ptt_cos_bwd_rows_f32: B=%d n=%d C=%d m=%d", B, n, C, m);
+    if (!A || !unit || !nrm || !G || !cosm || !dx) return fail(PTT_EINVAL, "ptt_cos_bwd_rows_f32: null pointer");
+    const long long points = (long long)B * n;
+    hipLaunchKernelGGL(cos_bwd_rows_kernel, dim3((unsigned)((points + 3) / 4)), dim3(256), 0, as_stream(stream), A, unit, nrm, G, cosm, map_sb,
+                       own, other, m, n, C, points, dx, sb, sn, sc);
+    return check_launch("cos_bwd_rows_kernel");
 }

@@ -698,6 +698,21 @@ __global__ __launch_bounds__(256, 2) void linear_wgrad_kernel(const float* __res
         }
 }
 
+// the same for rows that are not float4-addressable (C % 4, row stride % 4 or an unaligned base: the 3 + 256 = 259-channel rows of
+// the vote layer): thread = (row group, column), scalar loads, the same chunking and combination order
+__global__ __launch_bounds__(256) void colsum_partial_scalar_kernel(const float* __restrict__ X, int ldx, int R, int C, int rows_per_chunk,
+                                                                    float* __restrict__ partial) {
+    __shared__ float red[4][64];
+    const int c = blockIdx.y * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+    const int r0 = blockIdx.x * rows_per_chunk, r1 = min(R, r0 + rows_per_chunk);
+    float acc = 0.f;
+    if (c < C)
+        for (int r = r0 + rg; r < r1; r += 4) acc += X[(size_t)r * ldx + c];
+    red[rg][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (rg == 0 && c < C) partial[(size_t)blockIdx.x * C + c] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+}
+
 // Weight gradient of a layer with at most 4 INPUT channels (the relative-coordinate terms of the hoisted layer 0, fc_delta[0]:
 // K = 3): dW[c][k] = sum_r dZ[r][c] * X[r][k]. On the MFMA kernel above that is a 128 x 128 tile with 125 idle columns and two
 // staged operands; it is a memory-bound pass over dZ: thread = (row slot, channel quad), the K coordinates of a row are a
@@ -1447,7 +1462,7 @@ extern "C" int ptt_pt_attn_train_bwd_f32(const float* attn, const float* vf, con
 static inline bool wgrad_smallk_ok(int Cout, int Cin) { return Cin >= 1 && Cin <= 4 && (Cout & 3) == 0; }
 
 static inline int colsum_rows_per_chunk(int R, int C) {
-    const int colblocks = (C / 4 + 63) / 64;
+    const int colblocks = (C + 255) / 256;
     int chunks = 512 / colblocks;                       // about two workgroups per CU in all
     int rows = (R + chunks - 1) / chunks;
     if (rows < CS_ROWS) rows = CS_ROWS;
@@ -1459,27 +1474,23 @@ extern "C" size_t ptt_colsum_workspace(int R, int C) {
     return (size_t)((R + rows - 1) / rows) * (size_t)C * sizeof(float);
 }
 extern "C" int ptt_colsum_f32(const float* X, int R, int C, int ldx, float* out, void* ws, size_t ws_bytes, ptt_stream_t stream) {
-    if (R <= 0 || C <= 0 || (C & 3) || ldx < C || (ldx & 3) || (reinterpret_cast<uintptr_t>(X) & 15) || (reinterpret_cast<uintptr_t>(out) & 15))
-        return fail(PTT_EINVAL, "ptt_colsum_f32: R=%d C=%d ldx=%d (C %% 4 == 0, 16-byte aligned rows)", R, C, ldx);
+    if (R <= 0 || C <= 0 || ldx < C) return fail(PTT_EINVAL, "ptt_colsum_f32: R=%d C=%d ldx=%d", R, C, ldx);
     if (!X || !out) return fail(PTT_EINVAL, "ptt_colsum_f32: null pointer");
+    const bool vec = !(C & 3) && !(ldx & 3) && !((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(out)) & 15);
     const int rows = colsum_rows_per_chunk(R, C), nch = (R + rows - 1) / rows;
     hipStream_t s2 = as_stream(stream);
-    const dim3 grid(nch, (C / 4 + 63) / 64);
-    if (nch == 1) {
-        hipLaunchKernelGGL(colsum_partial_kernel, grid, dim3(256), 0, s2, X, ldx, R, C, rows, out);
-        return check_launch("colsum_partial_kernel");
-    }
-    if (!ws || ws_bytes < ptt_colsum_workspace(R, C)) return fail(PTT_EWORKSPACE, "ptt_colsum_f32: workspace too small");
-    float* part = static_cast<float*>(ws);
-    hipLaunchKernelGGL(colsum_partial_kernel, grid, dim3(256), 0, s2, X, ldx, R, C, rows, part);
-    launch_wgrad_finish(part, nch, (size_t)C, 0, out, s2);
+    if (nch > 1 && (!ws || ws_bytes < ptt_colsum_workspace(R, C))) return fail(PTT_EWORKSPACE, "ptt_colsum_f32: workspace too small");
+    float* part = nch == 1 ? out : static_cast<float*>(ws);
+    if (vec) hipLaunchKernelGGL(colsum_partial_kernel, dim3(nch, (C / 4 + 63) / 64), dim3(256), 0, s2, X, ldx, R, C, rows, part);
+    else hipLaunchKernelGGL(colsum_partial_scalar_kernel, dim3(nch, (C + 63) / 64), dim3(256), 0, s2, X, ldx, R, C, rows, part);
+    if (nch > 1) launch_wgrad_finish(part, nch, (size_t)C, 0, out, s2);
     return check_launch("colsum_partial_kernel");
 }
 
 extern "C" size_t ptt_linear_wgrad_workspace(int R, int Cout, int Cin) {
     if (R <= 0 || Cout <= 0 || Cin <= 0) return 0;
     if (wgrad_smallk_ok(Cout, Cin)) return (size_t)((R + WK_ROWS - 1) / WK_ROWS) * (size_t)Cout * Cin * sizeof(float);
-    const int rows = wgrad_chunk_rows(R, Cout, Cin);
+    const int rows = wgrad_stream_ok(R, Cout, Cin, Cout, Cin) ? wgrad_stream_rows(R) : wgrad_chunk_rows(R, Cout, Cin);   // the finer chunking
     return (size_t)((R + rows - 1) / rows) * (size_t)Cout * Cin * sizeof(float);
 }
 
@@ -1503,6 +1514,13 @@ extern "C" int ptt_linear_wgrad_f32(const float* dZ, int ldz, const float* X, in
         else hipLaunchKernelGGL((wgrad_smallk_kernel<4>), dim3(nch), dim3(256), 0, s2, dZ, ldz, X, ldx, R, Cout, part);
         launch_wgrad_finish(part, nch, (size_t)Cout * Cin, accumulate, dW, s2);
         return check_launch("wgrad_smallk_kernel");
+    }
+    if (wgrad_stream_ok(R, Cout, Cin, ldz, ldx)) {       // narrow layers over many rows: the streaming form (wgrad_stream.hip)
+        const int rows = wgrad_stream_rows(R), nch = (R + rows - 1) / rows;
+        hipStream_t s2 = as_stream(stream);
+        if (int rc = launch_wgrad_stream(dZ, ldz, X, ldx, R, Cout, Cin, rows, static_cast<float*>(ws), x_scale, x_shift, s2)) return rc;
+        launch_wgrad_finish(static_cast<const float*>(ws), nch, (size_t)Cout * Cin, accumulate, dW, s2);
+        return check_launch("wgrad_stream_kernel");
     }
     const int rows = wgrad_chunk_rows(R, Cout, Cin);
     const int nchunks = (R + rows - 1) / rows;

@@ -1087,11 +1087,11 @@ def bn_sums_partials(partials, rows):
 
 
 def colsum(x):
-    """(rows, C) -> (C,) column sums in a fixed order (ptt_colsum_f32): the bias gradient of a row-wise layer. Falls back to
-    torch's sum for layouts the kernel does not take (C % 4, unaligned rows)."""
+    """(rows, C) -> (C,) column sums in a fixed order (ptt_colsum_f32): the bias gradient of a row-wise layer (float4 loads where
+    the rows allow them, scalar loads otherwise)."""
     _rows(x, "x")
     R, C = x.shape
-    if R == 0 or C % 4 or x.stride(0) % 4 or x.data_ptr() % 16:
+    if R == 0:
         return x.sum(0)
     out = torch.empty((C,), dtype=torch.float32, device=x.device)
     ws = _ws(_lib.lib().ptt_colsum_workspace(R, C), x.device)
@@ -1567,3 +1567,36 @@ class AdamTable(object):
                                                          _ptr(self.partial), self.partial.numel(), _ptr(self.norm), _stream()),
                        "ptt_adam_clip_step_f32")
         return self.norm
+
+
+def unit_rows_eps(x, eps):
+    """(B,C,n) float32 in any strides -> (unit (B,n,C) = x / max(|x|, eps) over the channel axis as point-major rows,
+    nrm (B,n) = max(|x|, eps), negative where the clamp is active) — ptt_unit_rows_f32."""
+    if x.dtype != torch.float32 or not x.is_cuda or x.dim() != 3:
+        raise ValueError("x: (B,C,n) float32 on a HIP device expected")
+    B, C, n = x.shape
+    unit = torch.empty((B, n, C), dtype=torch.float32, device=x.device)
+    nrm = torch.empty((B, n), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().ptt_unit_rows_f32(_ptr(x), x.stride(0), x.stride(2), x.stride(1), B, n, C, float(eps), _ptr(unit), _ptr(nrm),
+                                                _stream()), "ptt_unit_rows_f32")
+    return unit, nrm
+
+
+def cos_bwd_rows(A, unit, nrm, G, cosm, own_is_row, like):
+    """The gradient of the cosine map w.r.t. one side's features, in the layout of `like` ((B,C,n), any strides):
+    dx[b,:,j] = (A[b,j,:] - (sum_i G cos) unit[b,j,:]) / |nrm[b,j]|. G / cos (B,n2,n1) contiguous; own_is_row: this side indexes
+    the maps' rows (the search side), else their columns (the template side); like = (size, strides) of the (B,C,n) input — ptt_cos_bwd_rows_f32."""
+    B, n, C = unit.shape
+    n2, n1 = G.shape[1], G.shape[2]
+    for t in (A, unit, nrm, G, cosm):
+        if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous():
+            raise ValueError("cos_bwd_rows: contiguous float32 device tensors expected")
+    if n != (n2 if own_is_row else n1) or tuple(A.shape) != (B, n, C) or tuple(cosm.shape) != tuple(G.shape):
+        raise ValueError("cos_bwd_rows: shapes")
+    dx = torch.empty_strided(like[0], like[1], dtype=torch.float32, device=unit.device)
+    own, other, m = (n1, 1, n1) if own_is_row else (1, n1, n2)
+    with torch.cuda.device(unit.device):
+        _lib.check(_lib.lib().ptt_cos_bwd_rows_f32(_ptr(A), _ptr(unit), _ptr(nrm), _ptr(G), _ptr(cosm), n2 * n1, own, other, m, B, n, C, _ptr(dx),
+                                                   dx.stride(0), dx.stride(2), dx.stride(1), _stream()), "ptt_cos_bwd_rows_f32")
+    return dx

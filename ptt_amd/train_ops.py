@@ -489,14 +489,38 @@ def xcorr_hoisted(search_feats, template_feats, template_xyz, mlp, eps):
     B, C, n2 = search_feats.shape
     n1 = template_feats.shape[-1]
     w0 = mlp[0].conv.weight.reshape(mlp[0].conv.weight.shape[0], -1)                    # (C0, 1 + 3 + C)
-    tn = template_feats / template_feats.norm(dim=1, keepdim=True).clamp_min(eps)       # (B,C,n1)
-    sn = search_feats / search_feats.norm(dim=1, keepdim=True).clamp_min(eps)           # (B,C,n2)
-    cos = torch.bmm(sn.transpose(1, 2), tn)                                             # (B,n2,n1)
+    cos = _CosMap.apply(search_feats, template_feats, float(eps))                       # (B,n2,n1)
     rows_i = torch.cat((template_xyz, template_feats.transpose(1, 2)), dim=2)           # (B,n1,3+C)
     wsim, wrest = _SplitCols.apply(w0, 1)
     P = _RowsLinear.apply(rows_i, wrest, None, None)                                    # (B,n1,C0)
     z0 = _XcorrZ0.apply(P.contiguous(), cos.contiguous(), wsim.reshape(-1).contiguous())   # (B*n2*n1, C0) rows ordered (b, j, i)
     return rows_mlp_pool(z0, mlp, n1, B, n2, preact=True)
+
+
+class _CosMap(torch.autograd.Function):
+    """cos[b,j,i] = s_j . t_i / (max(|s_j|, eps) max(|t_i|, eps)) for search features s (B,C,n2) and template features t (B,C,n1)
+    in any layout: unit rows (one launch per side), one batched product; backward: two batched products and one launch per side
+    (ops.cos_bwd_rows) — 3 + 4 launches for the ~40 of the element-wise formulation (norm, clamp, divide and their adjoints)."""
+
+    @staticmethod
+    def forward(ctx, s, t, eps):
+        us, ns = ops.unit_rows_eps(s, eps)
+        ut, nt = ops.unit_rows_eps(t, eps)
+        cos = torch.bmm(us, ut.transpose(1, 2))
+        ctx.save_for_backward(us, ns, ut, nt, cos)
+        ctx.like = ((tuple(s.shape), tuple(s.stride())), (tuple(t.shape), tuple(t.stride())))    # the gradients' layouts
+        return cos
+
+    @staticmethod
+    def backward(ctx, g):
+        us, ns, ut, nt, cos = ctx.saved_tensors
+        g = g.contiguous()
+        ds = dt = None
+        if ctx.needs_input_grad[0]:
+            ds = ops.cos_bwd_rows(torch.bmm(g, ut), us, ns, g, cos, True, ctx.like[0])
+        if ctx.needs_input_grad[1]:
+            dt = ops.cos_bwd_rows(torch.bmm(g.transpose(1, 2), us), ut, nt, g, cos, False, ctx.like[1])
+        return ds, dt, None
 
 
 class _XcorrZ0(torch.autograd.Function):

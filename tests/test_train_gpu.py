@@ -55,7 +55,9 @@ def test_bn_stats_apply_and_backward_kernels(dev, R, C):
                                          (40000, 512, 512),
                                          # at most 64 channels on one or both sides: the waves split the staged rows (SA0's layers)
                                          (50000, 64, 64), (33333, 128, 64), (20011, 64, 128), (7000, 64, 259), (6000, 260, 33),
-                                         (300000, 64, 3)])
+                                         (300000, 64, 3),
+                                         # the streaming form (>= 65536 rows, 64 inputs, 64 / 128 outputs): ragged chunk ends, odd rows
+                                         (786432, 64, 64), (393216, 128, 64), (65537, 64, 64), (100001, 128, 64)])
 def test_linear_wgrad_kernel(dev, R, Cout, Cin):
     g = torch.Generator(device="cpu").manual_seed(R)
     dz = torch.randn(R, Cout, generator=g).to(dev)
@@ -66,6 +68,15 @@ def test_linear_wgrad_kernel(dev, R, Cout, Cin):
     assert torch.equal(got, ops.linear_wgrad(dz, x))                     # fixed summation order
     acc = ops.linear_wgrad(dz, x, out=got.clone(), accumulate=True)
     torch.testing.assert_close(acc, 2 * got, rtol=1e-6, atol=1e-6)
+    if Cin % 4 == 0 and R >= 20000:
+        # the deferred activation of the layer input: x = relu(z * a + b) applied while the rows are staged, also on row views
+        # of a wider buffer (row stride > channels)
+        a, b = torch.randn(Cin, generator=g).to(dev), torch.randn(Cin, generator=g).to(dev)
+        wide = torch.randn(R, Cin + 8, generator=g).to(dev)
+        zv = wide[:, :Cin]
+        got2 = ops.linear_wgrad(dz, zv, x_scale=a, x_shift=b)
+        ref2 = dz.double().t() @ torch.relu(zv.double() * a.double() + b.double())
+        assert float((got2.double() - ref2).abs().max()) <= 1e-5 * float(ref2.abs().max()) + 1e-4 * np.sqrt(R) * 1e-2
 
 
 @pytest.mark.parametrize("G,ns,C", [(100, 32, 128), (77, 16, 256), (10, 64, 33)])
