@@ -420,6 +420,88 @@ __global__ __launch_bounds__(1024) void scatter_csr_kernel(const int32_t* __rest
     }
 }
 
+// The same CSR by a stable COUNTING sort (N <= 2048 bins), ~6x faster than the bitonic network at E = 16384: wave w owns the
+// contiguous entries [w * per, (w + 1) * per); (1) every wave histograms its range into its own row of counters, (2) per bin the
+// rows become exclusive offsets (wave order) and the bin totals are scanned into `start`, (3) every wave walks its range in
+// rounds of 64 entries, in order: the lanes of a round that share a bin rank themselves with a ballot (ascending lane = ascending
+// e), place their entries at start[bin] + offset[w][bin] + rank and advance the offset. Ascending e inside every bin, as the
+// sort gives it; no atomics decide an order.
+__global__ __launch_bounds__(1024) void scatter_csr_count_kernel(const int32_t* __restrict__ idx, int N, int E, int32_t* __restrict__ order,
+                                                                 int32_t* __restrict__ start) {
+    extern __shared__ unsigned csr_smem[];              // off[16][N] | binstart[N + 1] | wave_tot[16]
+    unsigned* off = csr_smem;
+    unsigned* binstart = csr_smem + 16 * N;
+    unsigned* wave_tot = binstart + N + 1;
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int32_t* ib = idx + (size_t)b * E;
+    for (int i = t; i < 16 * N; i += 1024) off[i] = 0u;
+    __syncthreads();
+    const int per = ((E + 15) / 16 + 63) / 64 * 64;
+    const int e0 = w * per, e1 = min(E, e0 + per);
+    for (int e = e0 + lane; e < e1; e += 64) {
+        const unsigned n = (unsigned)ib[e];
+        if (n < (unsigned)N) atomicAdd(&off[w * N + n], 1u);              // a count: the order of the additions is immaterial
+    }
+    __syncthreads();
+    // per bin: exclusive offsets over the waves; bins 2t, 2t + 1 (N <= 2048) of thread t, then a scan of the bin totals
+    unsigned tot[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int n = 2 * t + u;
+        unsigned run = 0;
+        if (n < N)
+            for (int k = 0; k < 16; ++k) { const unsigned c = off[k * N + n]; off[k * N + n] = run; run += c; }
+        tot[u] = run;
+    }
+    unsigned incl = tot[0] + tot[1];
+    for (int d = 1; d < 64; d <<= 1) { const unsigned v = __shfl_up(incl, d, 64); if (lane >= d) incl += v; }
+    if (lane == 63) wave_tot[w] = incl;
+    __syncthreads();
+    unsigned base = 0;
+    for (int k = 0; k < w; ++k) base += wave_tot[k];
+    const unsigned excl = base + incl - (tot[0] + tot[1]);
+    if (2 * t < N) binstart[2 * t] = excl;
+    if (2 * t + 1 < N) binstart[2 * t + 1] = excl + tot[0];
+    if (t == 1023) binstart[N] = base + incl;
+    __syncthreads();
+    for (int n = t; n <= N; n += 1024) start[(size_t)b * (N + 1) + n] = (int32_t)binstart[n];
+    for (int r0 = e0; r0 < e1; r0 += 64) {
+        const int e = r0 + lane;
+        const unsigned n = e < e1 ? (unsigned)ib[e] : 0xffffffffu;
+        const bool valid = n < (unsigned)N;
+        unsigned long long todo = __ballot(valid);
+        unsigned rank = 0, cnt = 0;
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const unsigned lb = (unsigned)__builtin_amdgcn_readlane((int)n, leader);
+            const unsigned long long same = __ballot(valid && n == lb);
+            if (valid && n == lb) {
+                rank = (unsigned)__popcll(same & ((1ull << lane) - 1ull));
+                cnt = (unsigned)__popcll(same);
+            }
+            todo &= ~same;
+        }
+        if (valid) {
+            const unsigned o = off[w * N + n];                            // read by all lanes of the bin before its last lane writes
+            order[(size_t)b * E + binstart[n] + o + rank] = e;
+            __builtin_amdgcn_wave_barrier();
+            if (rank + 1 == cnt) off[w * N + n] = o + cnt;
+        }
+    }
+}
+static int launch_scatter_csr(const int32_t* idx, int B, int N, int E, int32_t* order, int32_t* start, hipStream_t s) {
+    if (N <= 2048) {
+        const int lds = (16 * N + N + 1 + 16) * (int)sizeof(unsigned);
+        if (int rc = set_lds_limit(reinterpret_cast<const void*>(scatter_csr_count_kernel), lds)) return rc;
+        hipLaunchKernelGGL(scatter_csr_count_kernel, dim3(B), dim3(1024), lds, s, idx, N, E, order, start);
+        return check_launch("scatter_csr_count_kernel");
+    }
+    int Epad = 2;
+    while (Epad < E) Epad <<= 1;
+    hipLaunchKernelGGL(scatter_csr_kernel, dim3(B), dim3(1024), (size_t)Epad * sizeof(unsigned), s, idx, N, E, Epad, order, start);
+    return check_launch("scatter_csr_kernel");
+}
+
 __global__ __launch_bounds__(512) void scatter_add_det_kernel(const float* __restrict__ src, const int32_t* __restrict__ order,
                                                               const int32_t* __restrict__ start, int C, int N, int E,
                                                               int CC, int nchunks, float* __restrict__ out) {
@@ -962,13 +1044,9 @@ extern "C" int ptt_scatter_add_det_f32(const float* src, const int32_t* idx, int
     const size_t need = ptt_scatter_add_det_workspace(B, N, E);
     if (!workspace || workspace_bytes < need)
         return fail(PTT_EWORKSPACE, "ptt_scatter_add_det_f32: workspace of %zu bytes, %zu needed", workspace_bytes, need);
-    int Epad = 2;
-    while (Epad < E) Epad <<= 1;
     int32_t* order = static_cast<int32_t*>(workspace);
     int32_t* start = order + (size_t)B * E;
-    hipLaunchKernelGGL(scatter_csr_kernel, dim3(B), dim3(1024), (size_t)Epad * sizeof(unsigned), s, idx, N, E, Epad, order,
-                       start);
-    int rc = check_launch("scatter_csr_kernel");
+    int rc = launch_scatter_csr(idx, B, N, E, order, start, s);
     if (rc) return rc;
     const int CC = 8, nchunks = (C + CC - 1) / CC;
     const size_t lds = (size_t)E * (sizeof(float) + sizeof(int));
@@ -984,11 +1062,7 @@ extern "C" int ptt_scatter_csr_i32(const int32_t* idx, int B, int N, int E, int3
     if (!idx || !order || !start) return fail(PTT_EINVAL, "ptt_scatter_csr_i32: null pointer");
     if (E > 16384 || (unsigned long long)N * 16384ull > 0xffffffffull)
         return fail(PTT_EUNSUPPORTED, "ptt_scatter_csr_i32: E=%d N=%d (at most 16384 entries per cloud)", E, N);
-    int Epad = 2;
-    while (Epad < E) Epad <<= 1;
-    hipLaunchKernelGGL(scatter_csr_kernel, dim3(B), dim3(1024), (size_t)Epad * sizeof(unsigned), as_stream(stream), idx, N, E, Epad,
-                       order, start);
-    return check_launch("scatter_csr_kernel");
+    return launch_scatter_csr(idx, B, N, E, order, start, as_stream(stream));
 }
 
 extern "C" int ptt_knn_rel_f32(const float* xyz, int B, int N, int k, int32_t* idx_out, float* rel_out,

@@ -63,7 +63,7 @@ class DataParallelTrainer(object):
     def forward_backward(self, batch):
         """loss.mean() and its gradients (averaged over ranks by DDP); no optimiser step."""
         ret, _, _ = self.model(dict(batch))
-        loss = ret['loss'].mean()
+        loss = ret['loss'] if ret['loss'].dim() == 0 else ret['loss'].mean()
         self.optimizer.zero_grad(set_to_none=True)
         loss.backward()
         return loss

@@ -55,7 +55,7 @@ def test_one_launch_losses_equal_the_heads_stock_losses(dev, B, N, Ns, M, near):
     (total * 0.75).backward()
     assert abs(float(total.detach()) - float(ref_total.detach())) <= 2e-6 * max(1.0, abs(float(ref_total.detach())))
     for k, r in enumerate(ref_parts):
-        assert abs(float(vals[1 + k]) - float(r)) <= 2e-6 * max(1.0, abs(float(r))), k
+        assert abs(float(vals[1 + k]) - float(r.detach())) <= 2e-6 * max(1.0, abs(float(r.detach()))), k
     out = vals.device_values
     assert float(out[5]) == float(cls_points.gather(1, inds).sum()) and float(out[6]) == float(m.sum()) and float(out[7]) == float(y.sum())
     for a, b in zip(mine, leaves):
@@ -196,3 +196,20 @@ def test_cos_map_function_equals_the_elementwise_formulation(dev):
             assert float((za - zb).abs().max()) <= 1e-5 * float(zb.abs().max()), "ds of the clamped column"
             a, b = a[:, :, keep], b[:, :, keep]
         assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()) + 1e-7, name
+
+
+@pytest.mark.parametrize("B,N,E,hot", [(48, 1024, 16384, False), (3, 512, 8192, True), (2, 100, 37, False), (1, 16, 16384, True),
+                                       (2, 2048, 4096, False), (2, 3000, 5000, False), (4, 128, 2048, True), (1, 1, 700, False)])
+def test_scatter_csr_is_the_stable_sort_by_bin(dev, B, N, E, hot):
+    """ptt_scatter_csr_i32 (counting sort up to 2048 bins, bitonic above): order = the entries sorted by (bin, entry) — exactly
+    numpy's stable argsort — and start = the bins' first slots; hot: most entries in a few bins (ball-query padding repeats a
+    group's first index)."""
+    rs = np.random.RandomState(E + N)
+    idx = rs.randint(0, N, size=(B, E))
+    if hot:
+        idx[:, ::2] = idx[:, :1] % max(1, N // 8)
+    order, start = ops.scatter_csr(torch.from_numpy(idx.astype(np.int32)).to(dev), N)
+    order, start = order.cpu().numpy(), start.cpu().numpy()
+    for b in range(B):
+        assert np.array_equal(order[b], np.argsort(idx[b], kind="stable"))
+        assert np.array_equal(start[b], np.searchsorted(np.sort(idx[b]), np.arange(N + 1), side="left"))
