@@ -663,6 +663,10 @@ int ptt_bn_update_running_f32(const float* mean, const float* var, const double*
  * backward in one pass over dz0: dP[b,i,:] = sum_j dz0, dcos[b,j,i] = <dz0[b,j,i,:], w_sim>, dw[:] = sum dz0 * cos_t
  * (fixed summation order). C % 4 == 0; the backward needs C <= 256. */
 int ptt_xcorr_z0_f32(const float* P, const float* cos_t, const float* w_sim, int B, int n2, int n1, int C, float* z0, ptt_stream_t stream);
+/* the same launch also sums z0's BatchNorm statistics: float64 partials (chunks, 2, C), chunks = ptt_xcorr_z0_stat_chunks(...) */
+int ptt_xcorr_z0_stat_chunks(int B, int n2, int n1, int C);
+int ptt_xcorr_z0_stats_f32(const float* P, const float* cos_t, const float* w_sim, int B, int n2, int n1, int C, float* z0,
+                           double* stats_partial, size_t partial_elems, ptt_stream_t stream);
 size_t ptt_xcorr_z0_bwd_workspace(int B, int n1, int C);
 int ptt_xcorr_z0_bwd_f32(const float* dz0, const float* cos_t, const float* w_sim, int B, int n2, int n1, int C, float* dP, float* dcos,
                          float* dw, void* workspace, size_t workspace_bytes, ptt_stream_t stream);

@@ -331,9 +331,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const float* __restr
 // (group, channel), so s0 = sum_g dy and s1 = sum_g dy * xhat run over G x C entries instead of R x C. One workgroup per
 // chunk of PB_GROUPS groups, thread = channel (coalesced dP / arg rows; z is gathered at the arg-max row), float64 partials
 // [chunk][2][C] in group order, combined by col_stats_finish2_kernel<1> / col_sums_finish_kernel as the dense form's.
-constexpr int PB_GROUPS = 64;
-// groups per workgroup: PB_GROUPS, but never more chunks than ptt_bn_stats_workspace(R, C) holds (one per ST4_ROWS rows)
-static inline int pool_bwd_groups_per_chunk(int ns) { const int m = (ST4_ROWS + ns - 1) / ns; return m > PB_GROUPS ? m : PB_GROUPS; }
+constexpr int PB_GROUPS = 8;        // (64 until round 4: 24 workgroups for the vote aggregation's 3072 groups, 70 us of gathers each)
+// groups per workgroup: PB_GROUPS, but never more chunks than ptt_bn_stats_workspace(R, C) holds (one per ST4_ROWS rows, at least
+// STATS_MIN_CHUNKS); a small problem (the Conv1d stacks of the heads: 6144 rows, "groups" of one row) is cut into ~512 chunks
+// anyway — 24 workgroups walking 256 dependent gathers each took 69 us
+constexpr int STATS_MIN_CHUNKS = 512;
+static inline int pool_bwd_groups_per_chunk(int G, int ns) {
+    const int m = (ST4_ROWS + ns - 1) / ns;
+    int per = m > PB_GROUPS ? m : PB_GROUPS;
+    if ((G + per - 1) / per < STATS_MIN_CHUNKS / 2) per = (G + STATS_MIN_CHUNKS - 1) / STATS_MIN_CHUNKS;
+    return per < 1 ? 1 : per;
+}
 __global__ __launch_bounds__(256) void pool_bwd_stats_kernel(const float* __restrict__ dP, int ldp, const int32_t* __restrict__ arg,
                                                              int G, int ns, const float* __restrict__ Z, int ldz,
                                                              const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -395,24 +403,45 @@ __global__ __launch_bounds__(256) void bn_running_update_kernel(const float* __r
 //   z0[b, j, i, :] = P[b, i, :] + cos[b, j, i] * w[:]          (j search point, i template point)
 // forward: one pass that writes z0 (rows ordered (b, j, i)); backward: ONE pass over dz0 gives dP[b,i,:] = sum_j dz0,
 // dcos[b,j,i] = <dz0[b,j,i,:], w> and the per-workgroup partials of dw[:] = sum dz0 * cos (summed in workgroup order).
+// stats (optional, C <= 1024): the float64 column sums / sums of squares of the rows this workgroup writes, partial
+// [workgroup][2][C] as sa_z0_rows_kernel's: layer 0's BatchNorm statistics without a pass of their own over z0
 __global__ __launch_bounds__(256) void xcorr_z0_kernel(const float* __restrict__ P, const float* __restrict__ cosm,
                                                        const float* __restrict__ w, int n2, int n1, int C, long long total_rows,
-                                                       float* __restrict__ z0) {
+                                                       float* __restrict__ z0, double* __restrict__ stats) {
+    __shared__ double red[2][256][4];
     const int Cq = C >> 2, span = Cq < 256 ? Cq : 256, RG = 256 / span;
     const int q0 = threadIdx.x % span, rg = threadIdx.x / span;
-    if (rg >= RG) return;
-    for (int q = q0; q < Cq; q += span) {
-        const f32x4t w4 = *reinterpret_cast<const f32x4t*>(w + 4 * q);
-        for (long long r = (long long)blockIdx.x * RG + rg; r < total_rows; r += (long long)gridDim.x * RG) {
-            const long long bj = r / n1;                       // (b, j)
-            const int i = (int)(r - bj * n1);
-            const long long b = bj / n2;
-            const float cv = cosm[r];
-            const f32x4t pv = *reinterpret_cast<const f32x4t*>(P + (b * n1 + i) * C + 4 * q);
-            f32x4t o;
+    double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+    if (rg < RG) {
+        for (int q = q0; q < Cq; q += span) {
+            const f32x4t w4 = *reinterpret_cast<const f32x4t*>(w + 4 * q);
+            for (long long r = (long long)blockIdx.x * RG + rg; r < total_rows; r += (long long)gridDim.x * RG) {
+                const long long bj = r / n1;                       // (b, j)
+                const int i = (int)(r - bj * n1);
+                const long long b = bj / n2;
+                const float cv = cosm[r];
+                const f32x4t pv = *reinterpret_cast<const f32x4t*>(P + (b * n1 + i) * C + 4 * q);
+                f32x4t o;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) o[k] = __builtin_fmaf(cv, w4[k], pv[k]);
-            *reinterpret_cast<f32x4t*>(z0 + r * C + 4 * q) = o;
+                for (int k = 0; k < 4; ++k) {
+                    o[k] = __builtin_fmaf(cv, w4[k], pv[k]);
+                    if (stats) { s1[k] += (double)o[k]; s2[k] += (double)o[k] * (double)o[k]; }
+                }
+                *reinterpret_cast<f32x4t*>(z0 + r * C + 4 * q) = o;
+            }
+        }
+    }
+    if (!stats) return;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { red[0][threadIdx.x][k] = s1[k]; red[1][threadIdx.x][k] = s2[k]; }
+    __syncthreads();
+    if (rg == 0) {                                   // the row groups' sums in group order (span == Cq: one quad per thread)
+        double* sp = stats + (size_t)blockIdx.x * 2 * C;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            double t1 = 0.0, t2 = 0.0;
+            for (int g = 0; g < RG; ++g) { t1 += red[0][g * span + q0][k]; t2 += red[1][g * span + q0][k]; }
+            sp[4 * q0 + k] = t1; sp[C + 4 * q0 + k] = t2;
         }
     }
 }
@@ -432,7 +461,30 @@ __global__ __launch_bounds__(256) void xcorr_z0_bwd_kernel(const float* __restri
         const int b = bi / n1, i = bi - b * n1;
         f32x4t w4 = {0.f, 0.f, 0.f, 0.f};
         if (on) w4 = *reinterpret_cast<const f32x4t*>(w + 4 * lane);
-        for (int j = 0; j < n2; ++j) {
+        int j = 0;
+        for (; j + 3 < n2; j += 4) {                       // four rows in flight; the sums keep the order of the single-row loop
+            f32x4t v[4];
+            float cv[4], dot[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long long r = ((long long)b * n2 + j + u) * n1 + i;
+                v[u] = f32x4t{0.f, 0.f, 0.f, 0.f};
+                if (on) v[u] = *reinterpret_cast<const f32x4t*>(dz0 + r * C + 4 * lane);
+                cv[u] = cosm[r];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                dot[u] = 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { accP[k] += v[u][k]; accW[k] = __builtin_fmaf(v[u][k], cv[u], accW[k]); dot[u] = __builtin_fmaf(v[u][k], w4[k], dot[u]); }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) dot[u] += __shfl_xor(dot[u], off, 64);
+            if (lane < 4) dcos[((long long)b * n2 + j + lane) * n1 + i] = lane == 0 ? dot[0] : lane == 1 ? dot[1] : lane == 2 ? dot[2] : dot[3];
+        }
+        for (; j < n2; ++j) {
             const long long r = ((long long)b * n2 + j) * n1 + i;
             f32x4t v = {0.f, 0.f, 0.f, 0.f};
             if (on) v = *reinterpret_cast<const f32x4t*>(dz0 + r * C + 4 * lane);
@@ -924,7 +976,17 @@ __global__ __launch_bounds__(256) void scatter_rows_det_kernel(const float* __re
         const int k0 = st[n], k1 = st[n + 1];
         for (int q = q0; q < Cq; q += span) {
             f32x4t acc = {0.f, 0.f, 0.f, 0.f};
-            for (int k = k0; k < k1; ++k) {
+            int k = k0;
+            for (; k + 3 < k1; k += 4) {                 // four rows in flight, added in entry order
+                const int e0 = ob[k], e1 = ob[k + 1], e2 = ob[k + 2], e3 = ob[k + 3];
+                const f32x4t v0 = *reinterpret_cast<const f32x4t*>(gb + (size_t)e0 * C + 4 * q);
+                const f32x4t v1 = *reinterpret_cast<const f32x4t*>(gb + (size_t)e1 * C + 4 * q);
+                const f32x4t v2 = *reinterpret_cast<const f32x4t*>(gb + (size_t)e2 * C + 4 * q);
+                const f32x4t v3 = *reinterpret_cast<const f32x4t*>(gb + (size_t)e3 * C + 4 * q);
+#pragma unroll
+                for (int x = 0; x < 4; ++x) acc[x] = (((acc[x] + v0[x]) + v1[x]) + v2[x]) + v3[x];
+            }
+            for (; k < k1; ++k) {
                 const f32x4t v = *reinterpret_cast<const f32x4t*>(gb + (size_t)ob[k] * C + 4 * q);
                 acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
             }
@@ -1058,7 +1120,8 @@ using namespace ptt;
 
 extern "C" size_t ptt_bn_stats_workspace(int R, int C) {
     if (R <= 0 || C <= 0) return 0;
-    return (size_t)((R + ST4_ROWS - 1) / ST4_ROWS) * 2 * (size_t)C * sizeof(double);      // the finer of the two chunkings
+    const int chunks = (R + ST4_ROWS - 1) / ST4_ROWS;                                       // the finer of the two chunkings
+    return (size_t)(chunks > STATS_MIN_CHUNKS ? chunks : STATS_MIN_CHUNKS) * 2 * (size_t)C * sizeof(double);
 }
 
 static int bn_tail_from(const ptt_bn_train_tail* t, int C, BnTail* out, const char* who) {
@@ -1244,7 +1307,7 @@ extern "C" int ptt_bn_bwd_pooled_f32(const float* dPooled, int ldp, const int32_
         return fail(PTT_EINVAL, "ptt_bn_bwd_pooled_f32: bad output / gamma pointer");
     if (!ws || ws_bytes < ptt_bn_stats_workspace(R, C)) return fail(PTT_EWORKSPACE, "ptt_bn_bwd_pooled_f32: workspace too small");
     hipStream_t s = as_stream(stream);
-    const int G = R / ns, per = pool_bwd_groups_per_chunk(ns), nch = (G + per - 1) / per;
+    const int G = R / ns, per = pool_bwd_groups_per_chunk(G, ns), nch = (G + per - 1) / per;
     hipLaunchKernelGGL(pool_bwd_stats_kernel, dim3(nch), dim3(256), 0, s, dPooled, ldp, arg, G, ns, Z, ldz, mean, invstd, act_scale,
                        act_shift, C, static_cast<double*>(ws), per);
     hipLaunchKernelGGL((col_stats_finish2_kernel<1>), dim3(C), dim3(256), 0, s, static_cast<const double*>(ws), nch, C, R, 0.f, dbeta,
@@ -1264,7 +1327,7 @@ extern "C" int ptt_bn_bwd_pooled_sums_f64(const float* dPooled, int ldp, const i
     if (!sums) return fail(PTT_EINVAL, "ptt_bn_bwd_pooled_sums_f64: null pointer");
     if (!ws || ws_bytes < ptt_bn_stats_workspace(R, C)) return fail(PTT_EWORKSPACE, "ptt_bn_bwd_pooled_sums_f64: workspace too small");
     hipStream_t s = as_stream(stream);
-    const int G = R / ns, per = pool_bwd_groups_per_chunk(ns), nch = (G + per - 1) / per;
+    const int G = R / ns, per = pool_bwd_groups_per_chunk(G, ns), nch = (G + per - 1) / per;
     hipLaunchKernelGGL(pool_bwd_stats_kernel, dim3(nch), dim3(256), 0, s, dPooled, ldp, arg, G, ns, Z, ldz, mean, invstd, act_scale,
                        act_shift, C, static_cast<double*>(ws), per);
     hipLaunchKernelGGL(col_sums_finish_kernel, dim3(C), dim3(256), 0, s, static_cast<const double*>(ws), nch, C, sums, -1.0);
@@ -1583,17 +1646,37 @@ extern "C" int ptt_bn_update_running_f32(const float* mean, const float* var, co
     return check_launch("bn_running_update_kernel");
 }
 
-extern "C" int ptt_xcorr_z0_f32(const float* P, const float* cos_t, const float* w_sim, int B, int n2, int n1, int C, float* z0,
-                                ptt_stream_t stream) {
+static inline int xcorr_z0_grid(long long rows, int C, bool stats) {
+    const int Cq = C >> 2, RG = 256 / (Cq < 256 ? Cq : 256);
+    long long grid = (rows + RG * 8 - 1) / (RG * 8);
+    const long long cap = stats ? 4096 : 16384;           // with statistics the grid is also the number of partial sums
+    return (int)(grid > cap ? cap : grid);
+}
+static int xcorr_z0_launch(const float* P, const float* cos_t, const float* w_sim, int B, int n2, int n1, int C, float* z0, double* stats,
+                           ptt_stream_t stream) {
     if (B <= 0 || n2 <= 0 || n1 <= 0 || C <= 0 || (C & 3)) return fail(PTT_EINVAL, "ptt_xcorr_z0_f32: B=%d n2=%d n1=%d C=%d", B, n2, n1, C);
     if (!P || !cos_t || !w_sim || !z0 || !vec4_ok(P, C, C) || !vec4_ok(z0, C, C) || !vec4_ok(w_sim, 4, 4))
         return fail(PTT_EINVAL, "ptt_xcorr_z0_f32: null or misaligned pointer");
     const long long rows = (long long)B * n2 * n1;
-    const int Cq = C >> 2, RG = 256 / (Cq < 256 ? Cq : 256);
-    long long grid = (rows + RG * 8 - 1) / (RG * 8);
-    if (grid > 16384) grid = 16384;
-    hipLaunchKernelGGL(xcorr_z0_kernel, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), P, cos_t, w_sim, n2, n1, C, rows, z0);
+    hipLaunchKernelGGL(xcorr_z0_kernel, dim3((unsigned)xcorr_z0_grid(rows, C, stats != nullptr)), dim3(256), 0, as_stream(stream), P, cos_t,
+                       w_sim, n2, n1, C, rows, z0, stats);
     return check_launch("xcorr_z0_kernel");
+}
+extern "C" int ptt_xcorr_z0_f32(const float* P, const float* cos_t, const float* w_sim, int B, int n2, int n1, int C, float* z0,
+                                ptt_stream_t stream) {
+    return xcorr_z0_launch(P, cos_t, w_sim, B, n2, n1, C, z0, nullptr, stream);
+}
+extern "C" int ptt_xcorr_z0_stat_chunks(int B, int n2, int n1, int C) {
+    if (B <= 0 || n2 <= 0 || n1 <= 0 || C <= 0 || (C & 3) || C > 1024) return 0;
+    return xcorr_z0_grid((long long)B * n2 * n1, C, true);
+}
+extern "C" int ptt_xcorr_z0_stats_f32(const float* P, const float* cos_t, const float* w_sim, int B, int n2, int n1, int C, float* z0,
+                                      double* stats_partial, size_t partial_elems, ptt_stream_t stream) {
+    const int chunks = ptt_xcorr_z0_stat_chunks(B, n2, n1, C);
+    if (!chunks) return fail(PTT_EUNSUPPORTED, "ptt_xcorr_z0_stats_f32: B=%d n2=%d n1=%d C=%d (C %% 4 == 0, at most 1024 channels)", B, n2, n1, C);
+    if (!stats_partial || partial_elems < (size_t)chunks * 2 * (size_t)C)
+        return fail(PTT_EWORKSPACE, "ptt_xcorr_z0_stats_f32: the partial sums need %d x 2 x %d doubles", chunks, C);
+    return xcorr_z0_launch(P, cos_t, w_sim, B, n2, n1, C, z0, stats_partial, stream);
 }
 
 extern "C" size_t ptt_xcorr_z0_bwd_workspace(int B, int n1, int C) {

@@ -818,14 +818,21 @@ def bn_update_running(bn, mean, var, count):
             torch.autograd.graph.increment_version(t)
 
 
-def xcorr_z0(P, cos_t, w_sim):
-    """z0[b,j,i,:] = P[b,i,:] + cos_t[b,j,i] * w_sim — (B*n2*n1, C0) rows ordered (b, j, i) — ptt_xcorr_z0_f32."""
+def xcorr_z0(P, cos_t, w_sim, want_stats=False):
+    """z0[b,j,i,:] = P[b,i,:] + cos_t[b,j,i] * w_sim — (B*n2*n1, C0) rows ordered (b, j, i) — ptt_xcorr_z0_f32. want_stats:
+    -> (z0, the float64 partial sums (chunks, 2, C0) of z0's BatchNorm statistics summed by the same launch, or None)."""
     B, n1, C = P.shape
     n2 = cos_t.shape[1]
     z0 = torch.empty((B * n2 * n1, C), dtype=torch.float32, device=P.device)
+    chunks = _lib.lib().ptt_xcorr_z0_stat_chunks(B, n2, n1, C) if want_stats else 0
     with torch.cuda.device(P.device):
+        if chunks:
+            part = torch.empty((chunks, 2, C), dtype=torch.float64, device=P.device)
+            _lib.check(_lib.lib().ptt_xcorr_z0_stats_f32(_ptr(P), _ptr(cos_t), _ptr(w_sim), B, n2, n1, C, _ptr(z0), _ptr(part), part.numel(),
+                                                         _stream()), "ptt_xcorr_z0_stats_f32")
+            return z0, part
         _lib.check(_lib.lib().ptt_xcorr_z0_f32(_ptr(P), _ptr(cos_t), _ptr(w_sim), B, n2, n1, C, _ptr(z0), _stream()), "ptt_xcorr_z0_f32")
-    return z0
+    return (z0, None) if want_stats else z0
 
 
 def xcorr_z0_bwd(dz0, cos_t, w_sim, B, n2, n1):

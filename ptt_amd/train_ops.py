@@ -493,8 +493,8 @@ def xcorr_hoisted(search_feats, template_feats, template_xyz, mlp, eps):
     rows_i = torch.cat((template_xyz, template_feats.transpose(1, 2)), dim=2)           # (B,n1,3+C)
     wsim, wrest = _SplitCols.apply(w0, 1)
     P = _RowsLinear.apply(rows_i, wrest, None, None)                                    # (B,n1,C0)
-    z0 = _XcorrZ0.apply(P.contiguous(), cos.contiguous(), wsim.reshape(-1).contiguous())   # (B*n2*n1, C0) rows ordered (b, j, i)
-    return rows_mlp_pool(z0, mlp, n1, B, n2, preact=True)
+    z0, z0_part = _XcorrZ0.apply(P.contiguous(), cos.contiguous(), wsim.reshape(-1).contiguous())   # (B*n2*n1, C0) rows ordered (b, j, i)
+    return rows_mlp_pool(z0, mlp, n1, B, n2, preact=True, z0_part=z0_part if z0_part.numel() else None)
 
 
 class _CosMap(torch.autograd.Function):
@@ -528,12 +528,18 @@ class _XcorrZ0(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, P, cos, w):
+        """-> (z0, the float64 partial sums of z0's BatchNorm statistics (or an empty tensor), summed by the same launch)."""
+        ctx.set_materialize_grads(False)
         ctx.save_for_backward(cos, w)
         ctx.dims = (P.shape[0], cos.shape[1], P.shape[1])
-        return ops.xcorr_z0(P, cos, w)
+        z0, part = ops.xcorr_z0(P, cos, w, want_stats=True)
+        if part is None:
+            part = z0.new_empty(0, dtype=torch.float64)
+        ctx.mark_non_differentiable(part)
+        return z0, part
 
     @staticmethod
-    def backward(ctx, dz0):
+    def backward(ctx, dz0, _unused=None):
         cos, w = ctx.saved_tensors
         B, n2, n1 = ctx.dims
         dP, dcos, dw = ops.xcorr_z0_bwd(dz0.contiguous(), cos, w, B, n2, n1)
