@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PTT_ABI_VERSION 16
+#define PTT_ABI_VERSION 17
 
 enum {
     PTT_OK = 0,
@@ -386,6 +386,10 @@ int ptt_pt_attn_pair_f32(const ptt_attn_desc* d, ptt_stream_t stream);
  *   float64 dot product); keep points with lo2 < p < hi2 (the second crop_pc, in the box frame). Survivors are
  *   written to `out` as (count, 3) float32 rows IN THEIR ORIGINAL ORDER; *count receives their number (rows beyond
  *   `capacity` are counted, not written). The job array lives in DEVICE memory (the caller uploads it).
+ *   label_out != NULL (the training crop, crop_center_pc with gt_box, :308-312,322): label_out[r] = 1 where survivor r lies inside
+ *   the ground-truth box — get_label_by_box (:238-272) evaluated on the first crop's points in the CLOUD's frame, i.e.
+ *   p' = float32(lrot . float32(p + ltrans)), llo < p' < lhi with the ground-truth box's own translation / rotation / bounds —
+ *   carried through the second crop exactly as crop_pc carries `label` (:295-296).
  * ------------------------------------------------------------------------------- */
 typedef struct ptt_crop_job {
     const float* points;        /* (3, n_points) float32: row 0 = x, row 1 = y, row 2 = z (PointCloud.points) */
@@ -398,6 +402,10 @@ typedef struct ptt_crop_job {
     int32_t* count;
     int32_t n_points;
     int32_t capacity;
+    uint8_t* label_out;         /* (capacity) or NULL: the survivors' labels against the ground-truth box ... */
+    double ltrans[3];           /* ... whose frame is p' = lrot . (p + ltrans), bounds llo < p' < lhi */
+    double lrot[9];
+    double llo[3], lhi[3];
 } ptt_crop_job;
 
 int ptt_crop_compact_f32(const ptt_crop_job* jobs_device, int n_jobs, ptt_stream_t stream);

@@ -4,7 +4,7 @@ import this module; the product never does.
 
 Restated, function by function, from /root/reference:
   crop_pc            ptt/datasets/kitti/kitti_tracking_utils.py:281-298
-  crop_center_pc     :300-339 (points only; the per-point labels the tracking loop never reads are not restated)
+  crop_center_pc     :300-339 (points; with a ground-truth box also the per-point labels of get_label_by_box :238-272)
   get_model          :219-236
   regularize_pc      :342-367 with istrain=False (set_manual_seed(1) then np.random.randint)
   get_box_by_offset  :186-216
@@ -127,6 +127,51 @@ def crop_pc(points, box, offset=0, scale=1.0):
     close &= (points[1, :] > mini[1]) & (points[1, :] < maxi[1])
     close &= (points[2, :] > mini[2]) & (points[2, :] < maxi[2])
     return points[:, close]
+
+
+def _inside(points, box, offset, scale):
+    tmp = copy.deepcopy(box)
+    tmp.wlh = tmp.wlh * scale
+    c = tmp.corners()
+    maxi = np.max(c, 1) + offset
+    mini = np.min(c, 1) - offset
+    close = (points[0, :] > mini[0]) & (points[0, :] < maxi[0])
+    close &= (points[1, :] > mini[1]) & (points[1, :] < maxi[1])
+    close &= (points[2, :] > mini[2]) & (points[2, :] < maxi[2])
+    return close
+
+
+def get_label_by_box(points, box, offset=0.0, scale=1.0):
+    """:238-272: which columns of the (3,n) float32 cloud lie strictly inside `box` (scaled, grown by offset), tested in the
+    box's own frame: a float32 copy of the cloud translated by -centre and rotated by the transposed rotation."""
+    tmp = copy.deepcopy(box)
+    pts = np.asarray(points, np.float32).copy()
+    rot_mat = np.transpose(tmp.rotation_matrix)
+    trans = -tmp.center
+    for i in range(3):
+        pts[i, :] = pts[i, :] + trans[i]
+    tmp.translate(trans)
+    pts[:3, :] = np.dot(rot_mat, pts[:3, :])
+    tmp.rotate(_Quat.from_matrix(rot_mat))
+    return _inside(pts, tmp, offset, scale)
+
+
+def crop_center_pc_labels(points, sample_box, gt_box, offset=0.0, scale=1.0, refine_box=True):
+    """crop_center_pc with a ground-truth box (:300-339): -> ((3,m) float32 cloud, (m,) bool labels)."""
+    points = np.asarray(points, np.float32)
+    first = _inside(points, sample_box, 2 * offset, 4 * scale)
+    pts = points[:, first].copy()
+    label = get_label_by_box(pts, gt_box, offset if refine_box else 0.0, scale if refine_box else 1.0)
+    new_box = copy.deepcopy(sample_box)
+    rot_mat = np.transpose(new_box.rotation_matrix)
+    trans = -new_box.center
+    for i in range(3):
+        pts[i, :] = pts[i, :] + trans[i]
+    new_box.translate(trans)
+    pts[:3, :] = np.dot(rot_mat, pts[:3, :])
+    new_box.rotate(_Quat.from_matrix(rot_mat))
+    close = _inside(pts, new_box, offset + gt_box.wlh[1] * 0.6, 1 * scale)
+    return pts[:, close], label[close]
 
 
 def crop_center_pc(points, sample_box, gt_wlh1=None, offset=0.0, scale=1.0):

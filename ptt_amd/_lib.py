@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libptt_hip.so")
 
 PTT_SA_MAX_LAYERS = 4
-ABI_VERSION = 16            # PTT_ABI_VERSION of include/ptt_hip.h these structures mirror
+ABI_VERSION = 17            # PTT_ABI_VERSION of include/ptt_hip.h these structures mirror
 
 # every symbol include/ptt_hip.h declares (tests check the library exports all of them)
 EXPORTS = [
@@ -50,7 +50,8 @@ class CropJob(Structure):
     _fields_ = [("points", c_void_p), ("ld", c_int64),
                 ("lo1", c_double * 3), ("hi1", c_double * 3), ("trans", c_double * 3), ("rot", c_double * 9),
                 ("lo2", c_double * 3), ("hi2", c_double * 3),
-                ("out", c_void_p), ("count", c_void_p), ("n_points", c_int32), ("capacity", c_int32)]
+                ("out", c_void_p), ("count", c_void_p), ("n_points", c_int32), ("capacity", c_int32),
+                ("label_out", c_void_p), ("ltrans", c_double * 3), ("lrot", c_double * 9), ("llo", c_double * 3), ("lhi", c_double * 3)]
 
 
 class RegularizeJob(Structure):

@@ -72,13 +72,24 @@ __device__ __forceinline__ void crop_compact_body(const ptt_crop_job& j) {
     int written = 0;
     for (int base = 0; base < j.n_points; base += T) {
         const int i = base + (int)threadIdx.x;
-        bool keep = false;
+        bool keep = false, label = false;
         float ox = 0.f, oy = 0.f, oz = 0.f;
         if (i < j.n_points) {
             const float x = px[i], y = py[i], z = pz[i];
             // crop_pc in the cloud's frame: float32 point against float64 bounds, strict on both sides
             keep = (double)x > j.lo1[0] && (double)x < j.hi1[0] && (double)y > j.lo1[1] && (double)y < j.hi1[1] &&
                    (double)z > j.lo1[2] && (double)z < j.hi1[2];
+            if (keep && j.label_out) {
+                // get_label_by_box on the first crop: the same translate / rotate / strict test in the ground-truth box's frame
+                const double tx = (double)(float)((double)x + j.ltrans[0]);
+                const double ty = (double)(float)((double)y + j.ltrans[1]);
+                const double tz = (double)(float)((double)z + j.ltrans[2]);
+                const float lx = (float)fma(j.lrot[2], tz, fma(j.lrot[1], ty, j.lrot[0] * tx));
+                const float ly = (float)fma(j.lrot[5], tz, fma(j.lrot[4], ty, j.lrot[3] * tx));
+                const float lz = (float)fma(j.lrot[8], tz, fma(j.lrot[7], ty, j.lrot[6] * tx));
+                label = (double)lx > j.llo[0] && (double)lx < j.lhi[0] && (double)ly > j.llo[1] && (double)ly < j.lhi[1] &&
+                        (double)lz > j.llo[2] && (double)lz < j.lhi[2];
+            }
             if (keep) {
                 // PointCloud.translate: points[i,:] = points[i,:] + x[i] (float64 sum stored to the float32 array)
                 const double tx = (double)(float)((double)x + j.trans[0]);
@@ -98,6 +109,7 @@ __device__ __forceinline__ void crop_compact_body(const ptt_crop_job& j) {
             j.out[(size_t)r * 3 + 0] = ox;
             j.out[(size_t)r * 3 + 1] = oy;
             j.out[(size_t)r * 3 + 2] = oz;
+            if (j.label_out) j.label_out[r] = label ? 1 : 0;
         }
         written += total;
     }

@@ -173,8 +173,10 @@ def _crop_jobs(pcs, params, outs, counts):
     return jobs
 
 
-def _crop_on_device(pcs, boxes, offset, scale, extra2):
-    """crop_center_pc of every (pc, box) pair in ONE launch -> (list of (cap,3) device buffers, counts int32 (n,))."""
+def _crop_on_device(pcs, boxes, offset, scale, extra2, label_boxes=None, label_offset=0.0, label_scale=1.0):
+    """crop_center_pc of every (pc, box) pair in ONE launch -> (list of (cap,3) device buffers, counts int32 (n,)); with
+    label_boxes (one ground-truth box per pair) also the survivors' labels against those boxes (get_label_by_box :238-272
+    carried through the second crop), as a list of (cap,) uint8 device buffers."""
     dev = pcs[0].points.device
     center = np.stack([b.center for b in boxes])
     wlh = np.stack([b.wlh for b in boxes])
@@ -182,19 +184,35 @@ def _crop_on_device(pcs, boxes, offset, scale, extra2):
     params = bm.crop_bounds(center, wlh, quat, offset, scale, extra2)
     outs = [torch.empty((max(1, pc.nbr_points()), 3), dtype=torch.float32, device=dev) for pc in pcs]
     counts = torch.zeros(len(pcs), dtype=torch.int32, device=dev)
-    jobs = ops.upload_jobs(_crop_jobs(pcs, params, outs, counts))
-    ops.crop_compact(jobs, len(pcs))
-    return outs, counts
+    jobs = _crop_jobs(pcs, params, outs, counts)
+    labels = None
+    if label_boxes is not None:
+        lp = bm.crop_bounds(np.stack([b.center for b in label_boxes]), np.stack([b.wlh for b in label_boxes]),
+                            np.stack([b.orientation.q for b in label_boxes]), label_offset, label_scale, 0.0)
+        labels = [torch.zeros((o.shape[0],), dtype=torch.uint8, device=dev) for o in outs]
+        jobs['ltrans'], jobs['llo'], jobs['lhi'] = lp['trans'], lp['lo2'], lp['hi2']
+        jobs['lrot'] = lp['rot'].reshape(len(pcs), 9)
+        for i, lab in enumerate(labels):
+            jobs['label_out'][i] = lab.data_ptr()
+    ops.crop_compact(ops.upload_jobs(jobs), len(pcs))
+    return (outs, counts) if labels is None else (outs, counts, labels)
 
 
 def crop_center_pc(pc, sample_box, gt_box=None, sample_offsets=None, offset=0.0, scale=1.0, normalize=False,
                    visual_handle=None, refine_box=True):
-    """:300-339. Returns the cropped cloud in the sample box's frame (device-resident). With `gt_box` the reference
-    also returns per-point labels and a regression target; the tracking loop stores but never reads the labels
-    (eval_tracking_utils.py:128-138,175-182), so they are returned as None here; label_reg follows :325-329."""
+    """:300-339. Returns the cropped cloud in the sample box's frame (device-resident). With `gt_box` also the per-point
+    labels (:308-312 get_label_by_box on the first crop, carried through the second crop :322; a device bool tensor — the
+    same launch forms them) and the regression target label_reg (:325-329)."""
     extra2 = gt_box.wlh[1] * 0.6 if gt_box is not None else 0.0
-    outs, counts = _crop_on_device([pc], [sample_box], offset, scale, extra2)
+    new_label = None
+    if gt_box is not None:
+        outs, counts, labels = _crop_on_device([pc], [sample_box], offset, scale, extra2, [gt_box],
+                                               offset if refine_box else 0.0, scale if refine_box else 1.0)
+    else:
+        outs, counts = _crop_on_device([pc], [sample_box], offset, scale, extra2)
     n = int(counts.cpu()[0])
+    if gt_box is not None:
+        new_label = labels[0][:n].bool()
     new_pc = PointCloud.__new__(PointCloud)
     new_pc.points = outs[0][:n].t().contiguous()
     if normalize:
@@ -208,7 +226,7 @@ def crop_center_pc(pc, sample_box, gt_box=None, sample_offsets=None, offset=0.0,
         rot = np.transpose(sample_box.rotation_matrix)
         g = np.dot(rot, gt_box.center - sample_box.center)
         label_reg = np.array([g[0], g[1], g[2], -sample_offsets[-1]])
-    return new_pc, None, label_reg
+    return new_pc, new_label, label_reg
 
 
 def get_model(PCs, boxes, offset=0., scale=1.0, normalize=False, visual_handle=None):
@@ -229,20 +247,24 @@ def regularize_pc(pc, input_size, ratio=1, label=None, reg=None, istrain=True):
     istrain=False (the tracking loop): the index stream np.random.randint yields right after set_manual_seed(1), reproduced on
     the device (ptt_regularize_f32), numpy's global generator left as the reference leaves it. istrain=True (the data
     loader's form, :349-353 without the reseed): the indices are drawn here from numpy's running global generator, exactly as
-    the reference draws them, and gathered on the device. Per-point labels (`label`, produced by crop_center_pc with a
-    ground-truth box) are not mirrored."""
-    if label is not None:
-        raise NotImplementedError("regularize_pc: per-point labels are not mirrored (crop_center_pc returns None for them)")
+    the reference draws them, and gathered on the device. With `label` (crop_center_pc's per-point labels, a device tensor)
+    -> (points, label resampled with the same indices (:354-355; zeros for an (almost) empty crop :361-362), reg)."""
+    if label is not None and not (istrain and input_size > 0):
+        if input_size <= 0:
+            return pc.points.t().contiguous(), label, reg
+        raise NotImplementedError("regularize_pc: per-point labels are resampled in the data loader's form (istrain=True) only")
     if istrain and input_size > 0:
         size = int(input_size) // int(ratio)
         rows = pc.points.t().contiguous()
         n = rows.shape[0]
+        with_label = lambda pts, lab: pts if label is None else (pts, lab, reg)
         if n <= 2:
-            return torch.zeros((size, 3), dtype=torch.float32, device=rows.device)
+            return with_label(torch.zeros((size, 3), dtype=torch.float32, device=rows.device),
+                              torch.zeros((size,), dtype=torch.float64, device=rows.device))
         if n == size:
-            return rows
-        idx = np.random.randint(low=0, high=n, size=size, dtype=np.int64)
-        return rows.index_select(0, torch.from_numpy(idx).to(rows.device))
+            return with_label(rows, label)
+        idx = torch.from_numpy(np.random.randint(low=0, high=n, size=size, dtype=np.int64)).to(rows.device)
+        return with_label(rows.index_select(0, idx), label.index_select(0, idx) if label is not None else None)
     if input_size <= 0:
         return pc.points.t().contiguous()
     size = int(input_size) // int(ratio)

@@ -552,7 +552,8 @@ import numpy as np      # noqa: E402  (host-side job tables only)
 
 CROP_JOB = np.dtype([('points', '<u8'), ('ld', '<i8'), ('lo1', '<f8', 3), ('hi1', '<f8', 3), ('trans', '<f8', 3),
                      ('rot', '<f8', 9), ('lo2', '<f8', 3), ('hi2', '<f8', 3), ('out', '<u8'), ('count', '<u8'),
-                     ('n_points', '<i4'), ('capacity', '<i4')])                    # = ptt_crop_job, 232 bytes
+                     ('n_points', '<i4'), ('capacity', '<i4'), ('label_out', '<u8'), ('ltrans', '<f8', 3), ('lrot', '<f8', 9),
+                     ('llo', '<f8', 3), ('lhi', '<f8', 3)])                          # = ptt_crop_job, 384 bytes
 REGULARIZE_JOB = np.dtype([('seg', '<u8', 4), ('seg_count', '<u8', 4), ('seg_capacity', '<i4', 4), ('out', '<u8'),
                            ('info', '<u8'), ('n_seg', '<i4'), ('input_size', '<i4')])   # = ptt_regularize_job, 104 bytes
 assert CROP_JOB.itemsize == ctypes.sizeof(_lib.CropJob) and REGULARIZE_JOB.itemsize == ctypes.sizeof(_lib.RegularizeJob)

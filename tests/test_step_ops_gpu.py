@@ -63,7 +63,7 @@ def test_one_launch_losses_equal_the_heads_stock_losses(dev, B, N, Ns, M, near):
         assert float((a.grad - b.grad).abs().max()) <= 2e-6 * scale + 1e-10
     # labels given per seed (no index list)
     t2, v2 = train_ops.track_losses(seed_cls, votes, box, centres, cls_points.gather(1, inds).contiguous(), None, reg, pw_s, pw_b, w)
-    assert float(t2) == float(total)
+    assert float(t2.detach()) == float(total.detach())
 
 
 def test_loss_values_are_fetched_once_and_only_when_read(dev):

@@ -143,3 +143,18 @@ def test_c_host_box_math_equals_the_numpy_restatement():
         np.testing.assert_allclose(got['quat'][b], qq[0], rtol=0, atol=1e-14)
         np.testing.assert_array_equal(e2[b, :4], used[0].astype(np.float32))
     assert pos[3] == pos[5] == 1502 and pos[7] == 1504 and pos[0] == 1500
+
+
+def test_G16_oracle_training_crop_labels_equal_the_reference():
+    """crop_center_pc with a ground-truth box: cropped points and per-point labels (get_label_by_box carried through the second
+    crop) of the oracle's restatement against the reference's outputs, three settings x five frames."""
+    g, g16 = _g(), np.load(os.path.join(GOLD, "G16_crop_labels.npz"))
+    pos = 0
+    for i in range(1, int(g16["n_frames"])):
+        for k, (offset, scale, refine) in enumerate(g16["settings"]):
+            pts, label = TR.crop_center_pc_labels(g["cloud_%d" % i], _box(g, "ref", i), _box(g, "gt", i), float(offset), float(scale), bool(refine))
+            np.testing.assert_array_equal(pts, g16["points_%d_%d" % (i, k)])
+            np.testing.assert_array_equal(label, g16["label_%d_%d" % (i, k)])
+            pos += int(label.sum())
+            assert 0 < label.sum() < label.shape[0]                                # both classes present in every crop
+    assert pos > 5000

@@ -167,3 +167,34 @@ def test_overlapped_runners_give_the_same_boxes(dev):
         for x, y in zip(a, b):
             np.testing.assert_array_equal(x[0], y[0])
             np.testing.assert_array_equal(x[2], y[2])
+
+
+def test_G16_training_crop_labels_and_label_resampling_equal_the_reference(dev):
+    """The data loader's crop (reference kitti_dataset_tracking.py:129-148): crop_center_pc with a ground-truth box returns the
+    cropped cloud, the per-point labels (formed by the same launch) and the regression target; regularize_pc resamples points
+    and labels with the same indices from numpy's running generator — all bit-identical to fixture G16 (the reference's outputs),
+    for the shipped setting, a grown box, refine_box = False and an empty crop."""
+    import ptt.datasets.kitti.kitti_tracking_utils as ku
+    g, g16 = _g(), np.load(os.path.join(GOLD, "G16_crop_labels.npz"))
+    pcs = [ku.PointCloud(g["cloud_%d" % i]) for i in range(int(g["n_frames"]))]
+    for i in range(1, int(g16["n_frames"])):
+        for k, (offset, scale, refine) in enumerate(g16["settings"]):
+            pc, label, reg = ku.crop_center_pc(pcs[i], _kbox(g, "ref", i), _kbox(g, "gt", i), sample_offsets=g16["offsets_%d_%d" % (i, k)],
+                                               offset=float(offset), scale=float(scale), refine_box=bool(refine))
+            np.testing.assert_array_equal(pc.points.cpu().numpy(), g16["points_%d_%d" % (i, k)])
+            assert label.dtype == torch.bool and label.is_cuda
+            np.testing.assert_array_equal(label.cpu().numpy(), g16["label_%d_%d" % (i, k)])
+            np.testing.assert_allclose(reg, g16["reg_%d_%d" % (i, k)], rtol=0, atol=1e-12)
+            if k == 0:
+                np.random.seed(4000 + i)
+                pts, cls, reg2 = ku.regularize_pc(pc, 1024, label=label, reg=reg)
+                np.testing.assert_array_equal(pts.cpu().numpy(), g16["reg_points_%d" % i])
+                np.testing.assert_array_equal(cls.cpu().numpy().astype(g16["reg_label_%d" % i].dtype), g16["reg_label_%d" % i])
+                assert reg2 is reg
+    from ptt.datasets.kitti.kitti_tracking_utils import Box, Quaternion
+    far = Box(g["far_center"], g["wlh"], Quaternion(array=g["far_quat"]))
+    pc, label, reg = ku.crop_center_pc(pcs[1], far, _kbox(g, "gt", 1), sample_offsets=np.zeros(4, np.float32), offset=0.0, scale=1.25)
+    assert pc.nbr_points() == 0 and label.numel() == 0
+    pts, cls, _ = ku.regularize_pc(pc, 1024, label=label, reg=reg)
+    np.testing.assert_array_equal(pts.cpu().numpy(), g16["empty_reg_points"])
+    np.testing.assert_array_equal(cls.cpu().numpy(), g16["empty_reg_label"])
