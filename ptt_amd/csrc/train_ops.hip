@@ -603,7 +603,7 @@ __global__ __launch_bounds__(256) void pool_rows_bwd_kernel(const float* __restr
 constexpr int WG_KC = 32;            // rows per staged sub-chunk
 constexpr int WG_LD = 132;           // LDS row stride (floats)
 constexpr int WG_ROWS = 4096;        // rows per workgroup at most (fewer when that leaves CUs idle)
-constexpr int WG_MIN_ROWS = 256;
+constexpr int WG_MIN_ROWS = 64;         // (256 until round 4: a 6144-row layer was 96 workgroups of 8 stages, 28 us on a third of the CUs)
 
 template <bool VEC>   // VEC: ld % 4 == 0 and P 16-byte aligned -> whole float4s (channels past cmax are zeroed afterwards)
 __device__ __forceinline__ void wg_fetch(const float* __restrict__ P, int ld, int r0, int rmax, int c0, int cmax, int t,
