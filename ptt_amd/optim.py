@@ -14,6 +14,15 @@ import torch
 from . import ops
 
 
+def _bump_versions(params):
+    """The launch updated the parameters through raw pointers: tell autograd (saved-tensor checks) and every cache keyed on
+    `_version` (train_ops.packed: the MFMA weight packs) that they changed, as an in-place torch op would have."""
+    try:
+        torch._C._autograd._unsafe_set_version_counter(params, [p._version + 1 for p in params])
+    except (AttributeError, TypeError):
+        torch._foreach_add_(params, 0.0)             # older torch: a real (multi-tensor) in-place op
+
+
 class ClipAdam(torch.optim.Adam):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False):
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad, foreach=True)
@@ -71,6 +80,7 @@ class ClipAdam(torch.optim.Adam):
                                   group['weight_decay'], max_norm if max_norm is not None else 0.0)
             if max_norm is not None:
                 self.last_norm = norm
+            _bump_versions(params)
         return loss
 
     def _stock_group(self, group):

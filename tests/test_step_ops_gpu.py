@@ -94,7 +94,7 @@ def test_full_model_training_loss_takes_the_one_launch_path_and_matches_the_stoc
     ret2, tb2, _ = model(dict(batch))
     assert isinstance(tb2['centroids_cls_loss'], float)
     ret2['loss'].mean().backward()
-    assert abs(float(ret['loss']) - float(ret2['loss'])) <= 2e-6 * abs(float(ret2['loss']))
+    assert abs(float(ret['loss'].detach()) - float(ret2['loss'].detach())) <= 2e-6 * abs(float(ret2['loss'].detach()))
     for k in tb2:
         assert abs(float(tb[k]) - tb2[k]) <= 2e-6 * max(1.0, abs(tb2[k])), k
     named = dict(model.named_parameters())
@@ -213,3 +213,48 @@ def test_scatter_csr_is_the_stable_sort_by_bin(dev, B, N, E, hot):
     for b in range(B):
         assert np.array_equal(order[b], np.argsort(idx[b], kind="stable"))
         assert np.array_equal(start[b], np.searchsorted(np.sort(idx[b]), np.arange(N + 1), side="left"))
+
+
+def test_clip_adam_update_is_seen_by_the_weight_pack_cache_and_by_autograd(dev):
+    """The fused update writes the parameters through raw pointers: their version counters must advance as for an in-place torch
+    op, or train_ops.packed (keyed on the version) would keep multiplying by the previous step's weights."""
+    W = torch.nn.Parameter(torch.randn(128, 256, device=dev))
+    o = ClipAdam([W], lr=0.1)
+    for _ in range(2):
+        before = train_ops.packed(W).clone()
+        v0 = W._version
+        W.grad = torch.randn_like(W)
+        o.step(max_norm=10.0)
+        assert W._version > v0
+        after = train_ops.packed(W)
+        assert torch.equal(after, ops.pack_weight(W.detach())) and not torch.equal(after, before)
+
+
+def test_three_training_steps_with_clip_adam_track_the_stock_optimiser(dev):
+    """The full tracker for three steps: ClipAdam against clip_grad_norm_ + torch.optim.Adam on the same batches. The losses of
+    steps 2 and 3 depend on the updated weights (packed for the MFMA kernels once per step)."""
+    from ptt_amd.config import StubDataset, ptt_model_cfg
+    from ptt_amd.models import build_network
+    from ptt_amd.train_step import synthetic_train_batch
+    losses = []
+    for fused in (True, False):
+        torch.manual_seed(11)
+        model = build_network(ptt_model_cfg(), 1, StubDataset(training=True)).to(dev).train()
+        kw = dict(lr=1e-3, betas=(0.5, 0.999), eps=1e-6)
+        opt = ClipAdam(model.parameters(), **kw) if fused else torch.optim.Adam(model.parameters(), **kw)
+        run = []
+        for step in range(3):
+            ret, _, _ = model(dict(synthetic_train_batch(20 + step, 4, dev)))
+            opt.zero_grad(set_to_none=True)
+            ret['loss'].backward()
+            if fused:
+                opt.step(max_norm=10.0)
+            else:
+                torch.nn.utils.clip_grad_norm_(model.parameters(), 10.0)
+                opt.step()
+            run.append(float(ret['loss'].detach()))
+        losses.append(run)
+    a, b = losses
+    assert a[0] == b[0]
+    assert abs(a[1] - b[1]) <= 2e-3 * abs(b[1]) and abs(a[2] - b[2]) <= 5e-3 * abs(b[2]), (a, b)
+    assert abs(a[1] - a[0]) > 1e-3 * abs(a[0])                      # the second step did see new weights
