@@ -69,7 +69,7 @@ class ClipAdam(torch.optim.Adam):
             t = float(steps[0])
             if float(steps[-1]) != t:
                 raise RuntimeError("ClipAdam: parameters of one group at different step counts")
-            key = tuple(id(p) for p in params)
+            key = tuple((id(p), p.data_ptr()) for p in params)      # a moved parameter (model.to(...), p.data = ...) rebuilds the table
             cached = self._tables.get(gi)
             if cached is None or cached[0] != key:
                 cached = (key, ops.AdamTable(params, [self.state[p]['exp_avg'] for p in params], [self.state[p]['exp_avg_sq'] for p in params]))

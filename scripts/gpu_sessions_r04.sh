@@ -77,6 +77,7 @@ z)  # closing evidence of the round: parity tests, the default bench line (all c
     cp $O/serial_kernel_stats.stdout $O/serial_bench_line.json 2>/dev/null
     ktrace train_kernel_stats python $REPO/bench.py --workload train --steps 5 --warmup 2 --sustain 0
     cp $O/train_kernel_stats.stdout $O/train_profiled_bench_line.json 2>/dev/null
+    bash scripts/train_step_timeline.sh $REPO/$O/train_timeline > $O/train_timeline.log 2>&1; head -1 $O/train_timeline.log     # every launch of ONE step, in order and by shape
     ktrace b1_kernel_stats python $REPO/scripts/tracklet_b1_profile.py
     bash scripts/pmc_passes.sh $O/pmc "pair,sa0_s,sa1_s,sa2_s,sa_box,xcorr,lin_,rj" > $O/pmc.log 2>&1; tail -12 $O/pmc.log | cut -c1-300
     bash scripts/pmc_passes.sh $O/pmc_stress "pair" "" "--batch 32 --pair-n 2048,64" > $O/pmc_stress.log 2>&1; tail -4 $O/pmc_stress.log | cut -c1-300
