@@ -75,7 +75,7 @@ z)  # closing evidence of the round: parity tests, the default bench line (all c
     timeout 600 python bench.py --workload train --steps 20 --warmup 5 > $O/bench_train.json 2> $O/bench_train.err
     ktrace serial_kernel_stats python $REPO/bench.py --serial --steps 10 --warmup 3 --no-cpu-baseline --sustain 0 --no-workloads
     cp $O/serial_kernel_stats.stdout $O/serial_bench_line.json 2>/dev/null
-    ktrace train_kernel_stats python $REPO/bench.py --workload train --steps 5 --warmup 2 --sustain 0
+    ktrace train_kernel_stats python $REPO/bench.py --workload train --steps 20 --warmup 2 --sustain 0     # 22 steps: the first one's one-off launches (first-sight weight packs) weigh 1/22
     cp $O/train_kernel_stats.stdout $O/train_profiled_bench_line.json 2>/dev/null
     bash scripts/train_step_timeline.sh $REPO/$O/train_timeline > $O/train_timeline.log 2>&1; head -1 $O/train_timeline.log     # every launch of ONE step, in order and by shape
     ktrace b1_kernel_stats python $REPO/scripts/tracklet_b1_profile.py
@@ -101,12 +101,13 @@ t)  # the training step after a change: gradient parity (G10 / G14 / G15, reprod
     python -c "import json;d=json.load(open('$O/bench_train.json'));print('train', d['ms_per_step'], d['value'], d['sustained'])"
     ;;
 u)  # kernel trace of the training step
-    ktrace train_kernel_stats python $REPO/bench.py --workload train --steps 5 --warmup 2 --sustain 0
+    ktrace train_kernel_stats python $REPO/bench.py --workload train --steps 20 --warmup 2 --sustain 0
+    cp $O/train_kernel_stats.stdout $O/train_profiled_bench_line.json 2>/dev/null
     python - <<PY
 import csv
 rows = list(csv.DictReader(open("$O/train_kernel_stats.csv")))
 tot = sum(float(r['TotalDurationNs']) for r in rows)
-steps = 7
+steps = 22
 ptt = sum(float(r['TotalDurationNs']) for r in rows if 'ptt::' in r['Name'])
 print("device ms/step %.2f launches/step %.0f ptt share %.3f" % (tot / steps / 1e6, sum(int(r['Calls']) for r in rows) / steps, ptt / tot))
 for r in rows[:45]:
