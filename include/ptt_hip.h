@@ -676,6 +676,13 @@ int ptt_xcorr_z0_stat_chunks(int B, int n2, int n1, int C);
 int ptt_xcorr_z0_stats_f32(const float* P, const float* cos_t, const float* w_sim, int B, int n2, int n1, int C, float* z0,
                            double* stats_partial, size_t partial_elems, ptt_stream_t stream);
 size_t ptt_xcorr_z0_bwd_workspace(int B, int n1, int C);
+/* ptt_xcorr_z0_bwd_f32 when dz0 does not exist yet: G = the gradient w.r.t. relu(BatchNorm(z0)) as ptt_rows_gemm_bnbwd_f32 left it,
+ * with that launch's partial sums; layer 0's BatchNorm + ReLU backward is applied while G is read and z0 is recomputed from
+ * P / cos / w (neither z0 nor dz0 is read or written). Also returns dgamma / dbeta of that BatchNorm. Same workspace. */
+int ptt_xcorr_z0_bnbwd_f32(const double* partial, int chunks, const float* G, const float* P, const float* cos_t, const float* w_sim,
+                           const float* mean, const float* invstd, const float* gamma, const float* act_scale, const float* act_shift,
+                           int B, int n2, int n1, int C, float* dP, float* dcos, float* dw, float* dgamma, float* dbeta, void* workspace,
+                           size_t workspace_bytes, ptt_stream_t stream);
 int ptt_xcorr_z0_bwd_f32(const float* dz0, const float* cos_t, const float* w_sim, int B, int n2, int n1, int C, float* dP, float* dcos,
                          float* dw, void* workspace, size_t workspace_bytes, ptt_stream_t stream);
 /* Round 3, launch consolidation of the training step (the step is bound by device time, and ~250 of its launches were

@@ -35,7 +35,7 @@ EXPORTS = [
     "ptt_bn_bwd_pooled_f32", "ptt_bn_bwd_pooled_sums_f64", "ptt_bn_bwd_pooled_apply_f32",
     "ptt_pt_pair_input_ld_f32", "ptt_pt_attn_fwd_ld_f32",
     "ptt_rows_gemm_bnbwd_f32", "ptt_bn_bwd_from_partials_f32", "ptt_bn_bwd_sums_partials_f64",
-    "ptt_bn_update_running_f32", "ptt_xcorr_z0_f32", "ptt_xcorr_z0_stat_chunks", "ptt_xcorr_z0_stats_f32", "ptt_xcorr_z0_bwd_workspace", "ptt_xcorr_z0_bwd_f32",
+    "ptt_bn_update_running_f32", "ptt_xcorr_z0_f32", "ptt_xcorr_z0_stat_chunks", "ptt_xcorr_z0_stats_f32", "ptt_xcorr_z0_bnbwd_f32", "ptt_xcorr_z0_bwd_workspace", "ptt_xcorr_z0_bwd_f32",
     "ptt_bn_stats_train_f32", "ptt_bn_finish_partials_train_f32", "ptt_pack_weights_f32",
     "ptt_sa_z0_rows_f32",
     "ptt_row_jobs_f32", "ptt_point_jobs_f32", "ptt_fps_ball_knn_f32", "ptt_crop_compact_host_f32", "ptt_crop_regularize_f32", "ptt_colsum_workspace", "ptt_colsum_f32", "ptt_rows_gemm_pool_supported", "ptt_rows_gemm_pool_f32", "ptt_pool_select_f32", "ptt_sa_z0_rows_stat_chunks", "ptt_sa_z0_rows_stats_f32",
@@ -234,6 +234,7 @@ def _declare(lib):
         "ptt_sa_z0_rows_f32": [vp, vp, vp, vp, vp, i, i, i, i, i, i, f, i, vp, vp, vp],
         "ptt_xcorr_z0_f32": [vp, vp, vp, i, i, i, i, vp, vp],
         "ptt_xcorr_z0_stat_chunks": [i, i, i, i],
+        "ptt_xcorr_z0_bnbwd_f32": [vp, i, vp, vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, i, vp, vp, vp, vp, vp, vp, c_size_t, vp],
         "ptt_xcorr_z0_stats_f32": [vp, vp, vp, i, i, i, i, vp, vp, c_size_t, vp],
         "ptt_xcorr_z0_bwd_f32": [vp, vp, vp, i, i, i, i, vp, vp, vp, vp, c_size_t, vp],
         "ptt_bn_bwd_pooled_f32": [vp, i, vp, i, vp, i, vp, vp, vp, i, i, vp, i, vp, vp, vp, c_size_t, vp, vp, vp],

@@ -505,6 +505,94 @@ __global__ __launch_bounds__(256) void xcorr_z0_bwd_kernel(const float* __restri
     for (int c = threadIdx.x; c < C; c += 256) dw_partial[(size_t)blockIdx.x * C + c] = ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
 }
 
+// The same pass when dz0 does not exist yet: layer 0's BatchNorm + ReLU backward APPLIED ON THE FLY (round 4). G = the gradient
+// w.r.t. relu(BatchNorm(z0)); z0 is recomputed from P / cos / w exactly as the forward pass formed it (one fma), so neither z0 nor
+// dz0 is read or written: dz0 = gamma * invstd * (dy - s0 / R - xhat * s1 / R), dy = G where z0 * a + b > 0 (bn_bwd_apply4_kernel's
+// arithmetic, bit for bit). Replaces the apply pass (read G, read z0, write dz0) + the pass above (read dz0): 4 tensor passes -> 1.
+__global__ __launch_bounds__(256) void xcorr_z0_bnbwd_kernel(const float* __restrict__ G, const float* __restrict__ P,
+                                                             const float* __restrict__ cosm, const float* __restrict__ w,
+                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                             const float* __restrict__ gamma, const float* __restrict__ s0,
+                                                             const float* __restrict__ s1, const float* __restrict__ act_a,
+                                                             const float* __restrict__ act_b, float rinv, int B, int n2, int n1, int C,
+                                                             float* __restrict__ dP, float* __restrict__ dcos,
+                                                             float* __restrict__ dw_partial) {
+    __shared__ float red[4][256];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int bi = blockIdx.x * 4 + wv;                        // flat (b, i)
+    const int Cq = C >> 2;
+    const bool on = lane < Cq && bi < B * n1;
+    f32x4t accP = {0.f, 0.f, 0.f, 0.f}, accW = {0.f, 0.f, 0.f, 0.f};
+    if (bi < B * n1) {
+        const int b = bi / n1, i = bi - b * n1;
+        f32x4t w4 = {0.f, 0.f, 0.f, 0.f}, pv = w4, mu = w4, is = w4, k0 = w4, a0 = w4, a1 = w4, ca = w4, cb = w4;
+        if (on) {
+            w4 = *reinterpret_cast<const f32x4t*>(w + 4 * lane);
+            pv = *reinterpret_cast<const f32x4t*>(P + (size_t)bi * C + 4 * lane);
+            mu = *reinterpret_cast<const f32x4t*>(mean + 4 * lane);
+            is = *reinterpret_cast<const f32x4t*>(invstd + 4 * lane);
+            k0 = *reinterpret_cast<const f32x4t*>(gamma + 4 * lane);
+            a0 = *reinterpret_cast<const f32x4t*>(s0 + 4 * lane);
+            a1 = *reinterpret_cast<const f32x4t*>(s1 + 4 * lane);
+            ca = *reinterpret_cast<const f32x4t*>(act_a + 4 * lane);
+            cb = *reinterpret_cast<const f32x4t*>(act_b + 4 * lane);
+        }
+        auto dz_of = [&](const f32x4t& g, float cv) {
+            f32x4t d;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float z = __builtin_fmaf(cv, w4[k], pv[k]);                      // xcorr_z0_kernel's z0
+                const float dy = __builtin_fmaf(z, ca[k], cb[k]) > 0.f ? g[k] : 0.f;   // bn_bwd_apply4_kernel from here on
+                const float xh = (z - mu[k]) * is[k];
+                d[k] = k0[k] * is[k] * (dy - a0[k] * rinv - xh * (a1[k] * rinv));
+            }
+            return d;
+        };
+        int j = 0;
+        for (; j + 3 < n2; j += 4) {
+            f32x4t g[4];
+            float cv[4], dot[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long long r = ((long long)b * n2 + j + u) * n1 + i;
+                g[u] = f32x4t{0.f, 0.f, 0.f, 0.f};
+                if (on) g[u] = *reinterpret_cast<const f32x4t*>(G + r * C + 4 * lane);
+                cv[u] = cosm[r];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                f32x4t v = {0.f, 0.f, 0.f, 0.f};
+                if (on) v = dz_of(g[u], cv[u]);
+                dot[u] = 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { accP[k] += v[k]; accW[k] = __builtin_fmaf(v[k], cv[u], accW[k]); dot[u] = __builtin_fmaf(v[k], w4[k], dot[u]); }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) dot[u] += __shfl_xor(dot[u], off, 64);
+            if (lane < 4) dcos[((long long)b * n2 + j + lane) * n1 + i] = lane == 0 ? dot[0] : lane == 1 ? dot[1] : lane == 2 ? dot[2] : dot[3];
+        }
+        for (; j < n2; ++j) {
+            const long long r = ((long long)b * n2 + j) * n1 + i;
+            const float cv = cosm[r];
+            f32x4t v = {0.f, 0.f, 0.f, 0.f};
+            if (on) v = dz_of(*reinterpret_cast<const f32x4t*>(G + r * C + 4 * lane), cv);
+            float dot = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { accP[k] += v[k]; accW[k] = __builtin_fmaf(v[k], cv, accW[k]); dot = __builtin_fmaf(v[k], w4[k], dot); }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) dot += __shfl_xor(dot, off, 64);
+            if (lane == 0) dcos[r] = dot;
+        }
+        if (on) *reinterpret_cast<f32x4t*>(dP + (size_t)bi * C + 4 * lane) = accP;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) red[wv][4 * lane + k] = on ? accW[k] : 0.f;
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) dw_partial[(size_t)blockIdx.x * C + c] = ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
+}
+
 static inline bool vec4_ok(const void* p, int ld, int C) {
     return (C & 3) == 0 && (ld & 3) == 0 && (reinterpret_cast<uintptr_t>(p) & 15) == 0;
 }
@@ -1696,6 +1784,30 @@ extern "C" int ptt_xcorr_z0_bwd_f32(const float* dz0, const float* cos_t, const 
     hipLaunchKernelGGL(xcorr_z0_bwd_kernel, dim3(nwg), dim3(256), 0, s, dz0, cos_t, w_sim, B, n2, n1, C, dP, dcos, static_cast<float*>(ws));
     launch_wgrad_finish(static_cast<const float*>(ws), nwg, (size_t)C, 0, dw, s);
     return check_launch("xcorr_z0_bwd_kernel");
+}
+
+// CosineSimAug's layer 0 backward in ONE pass over the gradient of its activated output (training): the BatchNorm backward sums come
+// from the partials of the GEMM that produced G (ptt_rows_gemm_bnbwd_f32) -> dgamma, dbeta; then xcorr_z0_bnbwd_kernel.
+extern "C" int ptt_xcorr_z0_bnbwd_f32(const double* partial, int chunks, const float* G, const float* P, const float* cos_t,
+                                      const float* w_sim, const float* mean, const float* invstd, const float* gamma,
+                                      const float* act_scale, const float* act_shift, int B, int n2, int n1, int C, float* dP, float* dcos,
+                                      float* dw, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, ptt_stream_t stream) {
+    if (B <= 0 || n2 <= 0 || n1 <= 0 || C <= 0 || (C & 3) || C > 256 || chunks <= 0)
+        return fail(PTT_EINVAL, "ptt_xcorr_z0_bnbwd_f32: B=%d n2=%d n1=%d C=%d chunks=%d (C %% 4 == 0, C <= 256)", B, n2, n1, C, chunks);
+    if (!partial || !G || !P || !cos_t || !w_sim || !mean || !invstd || !gamma || !act_scale || !act_shift || !dP || !dcos || !dw || !dgamma ||
+        !dbeta || !vec4_ok(G, C, C) || !vec4_ok(P, C, C) || !vec4_ok(dP, C, C) || !vec4_ok(w_sim, 4, 4) || !vec4_ok(mean, 4, 4) ||
+        !vec4_ok(invstd, 4, 4) || !vec4_ok(gamma, 4, 4) || !vec4_ok(dgamma, 4, 4) || !vec4_ok(dbeta, 4, 4) || !vec4_ok(act_scale, 4, 4) ||
+        !vec4_ok(act_shift, 4, 4))
+        return fail(PTT_EINVAL, "ptt_xcorr_z0_bnbwd_f32: null or misaligned pointer");
+    if (!ws || ws_bytes < ptt_xcorr_z0_bwd_workspace(B, n1, C)) return fail(PTT_EWORKSPACE, "ptt_xcorr_z0_bnbwd_f32: workspace too small");
+    hipStream_t s = as_stream(stream);
+    const long long R = (long long)B * n2 * n1;
+    hipLaunchKernelGGL((col_stats_finish2_kernel<1>), dim3(C), dim3(256), 0, s, partial, chunks, C, (int)R, 0.f, dbeta, dgamma, nullptr, BnTail{});
+    const int nwg = (B * n1 + 3) / 4;
+    hipLaunchKernelGGL(xcorr_z0_bnbwd_kernel, dim3(nwg), dim3(256), 0, s, G, P, cos_t, w_sim, mean, invstd, gamma, dbeta, dgamma, act_scale,
+                       act_shift, 1.0f / (float)R, B, n2, n1, C, dP, dcos, static_cast<float*>(ws));
+    launch_wgrad_finish(static_cast<const float*>(ws), nwg, (size_t)C, 0, dw, s);
+    return check_launch("xcorr_z0_bnbwd_kernel");
 }
 
 // BatchNorm(train) + ReLU backward when the two sums were already taken by the GEMM that produced the gradient

@@ -849,6 +849,24 @@ def xcorr_z0_bwd(dz0, cos_t, w_sim, B, n2, n1):
     return dP, dcos, dw
 
 
+def xcorr_z0_bnbwd(part, g, P, cos_t, w_sim, mean, invstd, gamma, act_scale, act_shift):
+    """CosineSimAug's layer 0 backward from the gradient g (B*n2*n1, C) of its ACTIVATED output and the BatchNorm-backward partial
+    sums rows_gemm_bnbwd took with it: -> (dP (B,n1,C), dcos (B,n2,n1), dw (C,), dgamma, dbeta) in one pass over g — the apply pass
+    and the pass over dz0 of xcorr_z0_bwd folded together, z0 recomputed — ptt_xcorr_z0_bnbwd_f32."""
+    B, n1, C = P.shape
+    n2 = cos_t.shape[1]
+    dev = g.device
+    dP = torch.empty((B, n1, C), dtype=torch.float32, device=dev)
+    dcos = torch.empty((B, n2, n1), dtype=torch.float32, device=dev)
+    dw, dgamma, dbeta = (torch.empty((C,), dtype=torch.float32, device=dev) for _ in range(3))
+    ws = _ws(_lib.lib().ptt_xcorr_z0_bwd_workspace(B, n1, C), dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().ptt_xcorr_z0_bnbwd_f32(_ptr(part), part.shape[0], _ptr(g), _ptr(P), _ptr(cos_t), _ptr(w_sim), _ptr(mean), _ptr(invstd),
+                                                     _ptr(gamma), _ptr(act_scale), _ptr(act_shift), B, n2, n1, C, _ptr(dP), _ptr(dcos), _ptr(dw),
+                                                     _ptr(dgamma), _ptr(dbeta), _ptr(ws), ws.numel() * 8, _stream()), "ptt_xcorr_z0_bnbwd_f32")
+    return dP, dcos, dw, dgamma, dbeta
+
+
 def bn_bwd_pooled(dpooled, arg, ns, z, mean, invstd, gamma, act_scale, act_shift, out=None):
     """bn_bwd for the last layer of a SharedMLP + max-pool stage with the gradient still pooled (dpooled (G,C), arg (G,C)
     int32 from pool_rows): -> (dz (G*ns,C), dgamma, dbeta) — ptt_bn_bwd_pooled_f32."""

@@ -299,16 +299,23 @@ class _SharedMlpPool(torch.autograd.Function):
     xcorr_hoisted), so layer 0 is BatchNorm + ReLU only and its W entry is a placeholder that gets no gradient."""
 
     @staticmethod
-    def forward(ctx, x, ns, eps, preact, sync, bns, z0_part, *params):
+    def forward(ctx, x, ns, eps, preact, sync, bns, z0_part, fP, fcos, fw, *params):
         """Deferred activation: a layer's output relu(BatchNorm(z)) = relu(z * a + b) is never written — the next
         convolution, its weight gradient, the max-pool and the BatchNorm backward apply it while they load z.
         sync: per layer a torch.distributed process group (nn.SyncBatchNorm: the statistics are those of the rows of ALL
         ranks — one all-reduce of 2C + 1 float64 per layer and direction) or None. bns: per layer the BatchNorm module whose
         bookkeeping (running statistics, batch counter) the launch that forms the statistics does, with the activation
-        constants a, b (ops.bn_stats / bn_finish_partials with `bn`), or None: the caller does it (SyncBatchNorm layers)."""
+        constants a, b (ops.bn_stats / bn_finish_partials with `bn`), or None: the caller does it (SyncBatchNorm layers).
+        fP / fcos / fw (with preact, x = None): the rows are CosineSimAug's layer 0, z0 = fP[b,i] + fcos[b,j,i] * fw, built HERE
+        (ops.xcorr_z0, statistics summed by the same launch) so that the backward pass can end with ONE pass over the gradient of
+        the activated z0 (ops.xcorr_z0_bnbwd: BatchNorm backward applied on the fly, z0 recomputed) instead of an apply pass that
+        writes dz0 and a second pass that reads it."""
         ctx.set_materialize_grads(False)          # the statistics outputs carry no gradient: no zero tensors made for them
         L = len(params) // 3
         saved, stats, counts = [], [], []
+        ctx.front = fP is not None
+        if ctx.front:
+            x, z0_part = ops.xcorr_z0(fP, fcos, fw, want_stats=True)
         cur, cur_a, cur_b = x.contiguous(), None, None
         for l in range(L):
             W, gamma, beta = params[3 * l], params[3 * l + 1], params[3 * l + 2]
@@ -341,7 +348,7 @@ class _SharedMlpPool(torch.autograd.Function):
             stats += [mean, var, count]
             cur, cur_a, cur_b = z, a, b
         pooled, arg = ops.pool_select(extrema, cur_a, cur_b) if extrema is not None else ops.pool_rows(cur, ns, cur_a, cur_b)
-        ctx.save_for_backward(arg, *saved, *[p.detach() for p in params])
+        ctx.save_for_backward(arg, *saved, *[p.detach() for p in params], *((fP, fcos, fw) if ctx.front else ()))
         ctx.weights = tuple(params[3 * l] for l in range(L))     # the parameter objects themselves: keys of the pack cache
         ctx.L, ctx.ns, ctx.preact, ctx.sync = L, int(ns), bool(preact), tuple(sync)
         ctx.mark_non_differentiable(*stats)
@@ -351,10 +358,11 @@ class _SharedMlpPool(torch.autograd.Function):
     def backward(ctx, dpooled, *unused):
         L, ns = ctx.L, ctx.ns
         t = ctx.saved_tensors
-        arg, saved, params = t[0], t[1:1 + 9 * L], t[1 + 9 * L:]
+        arg, saved, params, front = t[0], t[1:1 + 9 * L], t[1 + 9 * L:1 + 12 * L], t[1 + 12 * L:]
         dpooled = dpooled.contiguous()
         g, part = None, None        # part: BatchNorm backward sums of THIS layer, taken by the GEMM that produced g
         grads = [None] * (3 * L)
+        front_grads = (None, None, None)
         for l in range(L - 1, -1, -1):
             x_in, in_a, in_b, z, mean, invstd, a, b, count = saved[9 * l:9 * l + 9]
             W, gamma = params[3 * l], params[3 * l + 1]
@@ -382,6 +390,12 @@ class _SharedMlpPool(torch.autograd.Function):
                                           act_scale=a, act_shift=b)
             elif last:
                 dz, dgamma, dbeta = ops.bn_bwd_pooled(dpooled, arg, ns, z, mean, invstd, gamma, a, b)
+            elif part is not None and l == 0 and ctx.preact and ctx.front and mean.shape[0] <= 256 and g.is_contiguous():
+                # CosineSimAug's layer 0: BatchNorm backward applied while its ONE consumer reads the gradient (no dz0 tensor)
+                *front_grads, dgamma, dbeta = ops.xcorr_z0_bnbwd(part, g, front[0], front[1], front[2], mean, invstd, gamma, a, b)
+                grads[1], grads[2] = dgamma, dbeta
+                g = None
+                break
             elif part is not None:
                 dz, dgamma, dbeta = ops.bn_bwd_from_partials(part, g, z, mean, invstd, gamma, a, b, out=g)   # in place over g
             else:
@@ -389,6 +403,10 @@ class _SharedMlpPool(torch.autograd.Function):
             grads[3 * l + 1], grads[3 * l + 2] = dgamma, dbeta
             if ctx.preact and l == 0:
                 g = dz                                                                  # d(loss)/d(layer-0 pre-activation)
+                if ctx.front:
+                    B, n1 = front[0].shape[0], front[0].shape[1]
+                    front_grads = ops.xcorr_z0_bwd(dz.contiguous(), front[1], front[2], B, front[1].shape[1], n1)
+                    g = None
                 break
             Wp = ctx.weights[l]
             w2 = Wp.reshape(Wp.shape[0], -1)
@@ -407,7 +425,7 @@ class _SharedMlpPool(torch.autograd.Function):
                 g, _ = conv_rows(dz, w2, transpose=True)                                # w.r.t. the (not normalised) input rows
             else:
                 g = None
-        return (g, None, None, None, None, None, None) + tuple(grads)
+        return (g, None, None, None, None, None, None) + tuple(front_grads) + tuple(grads)
 
 
 def shared_mlp_pool(grouped, mlp, pool_dim):
@@ -432,7 +450,7 @@ def _sync_group(bn):
     return group if dist.get_world_size(group) > 1 else None
 
 
-def rows_mlp_pool(rows, mlp, ns, B, keep, preact, z0_part=None):
+def rows_mlp_pool(rows, mlp, ns, B, keep, preact, z0_part=None, front=None):
     """The row form: rows (B * keep * ns, C) ordered (frame, kept position, pooled position) -> (B, C_L, keep).
     preact: rows are layer 0's convolution output already (hoisted by the caller); z0_part: its BatchNorm statistics as float64
     partial sums (chunks, 2, C), when the launch that built the rows summed them (ops.sa_z0_rows)."""
@@ -443,7 +461,8 @@ def rows_mlp_pool(rows, mlp, ns, B, keep, preact, z0_part=None):
         eps.append(float(bn.eps))
         sync.append(_sync_group(bn))
     bns = tuple(unit.normlayer.bn if g is None else None for unit, g in zip(mlp, sync))
-    out = _SharedMlpPool.apply(rows, ns, tuple(eps), bool(preact), tuple(sync), bns, z0_part, *params)
+    fP, fcos, fw = front if front is not None else (None, None, None)      # front: CosineSimAug's layer 0 built inside (rows = None)
+    out = _SharedMlpPool.apply(rows, ns, tuple(eps), bool(preact), tuple(sync), bns, z0_part, fP, fcos, fw, *params)
     pooled, stats = out[0], out[1:]
     with torch.no_grad():                                   # nn.BatchNorm's bookkeeping in training mode: done by the statistics'
         for l, unit in enumerate(mlp):                      # own launch, except for SyncBatchNorm layers (all-reduced count)
@@ -493,8 +512,9 @@ def xcorr_hoisted(search_feats, template_feats, template_xyz, mlp, eps):
     rows_i = torch.cat((template_xyz, template_feats.transpose(1, 2)), dim=2)           # (B,n1,3+C)
     wsim, wrest = _SplitCols.apply(w0, 1)
     P = _RowsLinear.apply(rows_i, wrest, None, None)                                    # (B,n1,C0)
-    z0, z0_part = _XcorrZ0.apply(P.contiguous(), cos.contiguous(), wsim.reshape(-1).contiguous())   # (B*n2*n1, C0) rows ordered (b, j, i)
-    return rows_mlp_pool(z0, mlp, n1, B, n2, preact=True, z0_part=z0_part if z0_part.numel() else None)
+    # z0 (B*n2*n1, C0), rows ordered (b, j, i), is built inside the stage's function: its backward ends with one pass over the
+    # gradient of the activated z0 (ops.xcorr_z0_bnbwd); _XcorrZ0 is the stand-alone form of the same layer
+    return rows_mlp_pool(None, mlp, n1, B, n2, preact=True, front=(P.contiguous(), cos.contiguous(), wsim.reshape(-1).contiguous()))
 
 
 class _CosMap(torch.autograd.Function):
