@@ -40,7 +40,7 @@ EXPORTS = [
     "ptt_sa_z0_rows_f32",
     "ptt_row_jobs_f32", "ptt_point_jobs_f32", "ptt_fps_ball_knn_f32", "ptt_crop_compact_host_f32", "ptt_crop_regularize_f32", "ptt_colsum_workspace", "ptt_colsum_f32", "ptt_rows_gemm_pool_supported", "ptt_rows_gemm_pool_f32", "ptt_pool_select_f32", "ptt_sa_z0_rows_stat_chunks", "ptt_sa_z0_rows_stats_f32",
     "ptt_track_losses_f32", "ptt_track_losses_bwd_f32", "ptt_adam_chunk_elems", "ptt_adam_clip_step_f32",
-    "ptt_unit_rows_f32", "ptt_cos_bwd_rows_f32",
+    "ptt_unit_rows_f32", "ptt_cos_bwd_rows_f32", "ptt_sa_z0_bnbwd_workspace", "ptt_sa_z0_bnbwd_f32",
 ]
 PTT_MAX_SEGMENTS = 4
 
@@ -234,6 +234,7 @@ def _declare(lib):
         "ptt_sa_z0_rows_f32": [vp, vp, vp, vp, vp, i, i, i, i, i, i, f, i, vp, vp, vp],
         "ptt_xcorr_z0_f32": [vp, vp, vp, i, i, i, i, vp, vp],
         "ptt_xcorr_z0_stat_chunks": [i, i, i, i],
+        "ptt_sa_z0_bnbwd_f32": [vp, i, vp, vp, vp, vp, vp, vp, vp, vp, c_longlong, i, vp, vp, vp, vp, vp, c_size_t, vp],
         "ptt_xcorr_z0_bnbwd_f32": [vp, i, vp, vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, i, vp, vp, vp, vp, vp, vp, c_size_t, vp],
         "ptt_xcorr_z0_stats_f32": [vp, vp, vp, i, i, i, i, vp, vp, c_size_t, vp],
         "ptt_xcorr_z0_bwd_f32": [vp, vp, vp, i, i, i, i, vp, vp, vp, vp, c_size_t, vp],
@@ -258,6 +259,8 @@ def _declare(lib):
     lib.ptt_linear_wgrad_workspace.argtypes = [i, i, i]
     lib.ptt_xcorr_z0_bwd_workspace.restype = c_size_t
     lib.ptt_xcorr_z0_bwd_workspace.argtypes = [i, i, i]
+    lib.ptt_sa_z0_bnbwd_workspace.restype = c_size_t
+    lib.ptt_sa_z0_bnbwd_workspace.argtypes = [c_longlong, i]
     lib.ptt_adam_chunk_elems.restype = c_int
     lib.ptt_adam_chunk_elems.argtypes = []
     lib.ptt_colsum_workspace.restype = c_size_t

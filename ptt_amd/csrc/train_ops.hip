@@ -1083,6 +1083,96 @@ __global__ __launch_bounds__(256) void scatter_rows_det_kernel(const float* __re
     }
 }
 
+// Layer 0 of a hoisted SA level, backward, from the gradient G w.r.t. relu(BatchNorm(z0)) as the input-gradient GEMM of layer 1 left
+// it (round 4): ONE pass in row order forms dz0 row by row (bn_bwd_apply4_kernel's arithmetic on G and the stored z0), accumulates
+// the K = 3 weight gradient d_wx[c, :] = sum over rows of dz0[row, c] * rel[row, :] (per-workgroup partials, summed in workgroup
+// order) and writes dz0 only when somebody else needs it (dz_out: a level with point features, whose row scatter reads it; may
+// alias G). Replaces the apply pass + wgrad_smallk_kernel's pass over dz0; a level without point features moves 2 tensors instead
+// of 4. (A form that also did the row scatter in CSR order was 1.7x SLOWER inside the step than in isolation: ball-query padding
+// makes a few points the neighbour of hundreds of centres, and the thread that owns such a bin walks it alone.)
+__global__ __launch_bounds__(256) void sa_z0_bnbwd_kernel(const float* __restrict__ G, const float* __restrict__ Z0,
+                                                          const float* __restrict__ rel, const float* __restrict__ mean,
+                                                          const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                          const float* __restrict__ s0, const float* __restrict__ s1,
+                                                          const float* __restrict__ act_a, const float* __restrict__ act_b, float rinv,
+                                                          long long R, int C, int rows_per_wg, float* dz_out,
+                                                          float* __restrict__ dwx_partial) {
+    __shared__ float red[256][12];
+    const int Cq = C >> 2, span = Cq < 256 ? Cq : 256, RG = 256 / span;          // C <= 1024: one channel quad per thread
+    const int q = threadIdx.x % span, rg = threadIdx.x / span;
+    float wacc[4][3];
+#pragma unroll
+    for (int x = 0; x < 4; ++x) wacc[x][0] = wacc[x][1] = wacc[x][2] = 0.f;
+    if (rg < RG) {
+        const f32x4t mu = *reinterpret_cast<const f32x4t*>(mean + 4 * q), is = *reinterpret_cast<const f32x4t*>(invstd + 4 * q);
+        const f32x4t ga = *reinterpret_cast<const f32x4t*>(gamma + 4 * q);
+        const f32x4t a0 = *reinterpret_cast<const f32x4t*>(s0 + 4 * q), a1 = *reinterpret_cast<const f32x4t*>(s1 + 4 * q);
+        const f32x4t ca = *reinterpret_cast<const f32x4t*>(act_a + 4 * q), cb = *reinterpret_cast<const f32x4t*>(act_b + 4 * q);
+        auto dz_of = [&](const f32x4t& g, const f32x4t& z) {
+            f32x4t d;
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                const float dy = __builtin_fmaf(z[x], ca[x], cb[x]) > 0.f ? g[x] : 0.f;
+                const float xh = (z[x] - mu[x]) * is[x];
+                d[x] = ga[x] * is[x] * (dy - a0[x] * rinv - xh * (a1[x] * rinv));
+            }
+            return d;
+        };
+        // the workgroup's rows r0 .. r1: row group rg takes rows r0 + rg, r0 + rg + RG, ... (a wave reads whole consecutive rows)
+        const long long r0 = (long long)blockIdx.x * rows_per_wg, r1 = r0 + rows_per_wg < R ? r0 + rows_per_wg : R;
+        long long r = r0 + rg;
+        for (; r + 3LL * RG < r1; r += 4LL * RG) {       // four rows in flight, consumed in row order
+            f32x4t g[4], z[4];
+            float rl[4][3];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long long e = r + (long long)u * RG;
+                g[u] = *reinterpret_cast<const f32x4t*>(G + e * C + 4 * q);
+                z[u] = *reinterpret_cast<const f32x4t*>(Z0 + e * C + 4 * q);
+                rl[u][0] = rel[e * 3 + 0]; rl[u][1] = rel[e * 3 + 1]; rl[u][2] = rel[e * 3 + 2];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const f32x4t d = dz_of(g[u], z[u]);
+                if (dz_out) *reinterpret_cast<f32x4t*>(dz_out + (r + (long long)u * RG) * C + 4 * q) = d;
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    wacc[x][0] = __builtin_fmaf(d[x], rl[u][0], wacc[x][0]);
+                    wacc[x][1] = __builtin_fmaf(d[x], rl[u][1], wacc[x][1]);
+                    wacc[x][2] = __builtin_fmaf(d[x], rl[u][2], wacc[x][2]);
+                }
+            }
+        }
+        for (; r < r1; r += RG) {
+            const f32x4t d = dz_of(*reinterpret_cast<const f32x4t*>(G + r * C + 4 * q), *reinterpret_cast<const f32x4t*>(Z0 + r * C + 4 * q));
+            if (dz_out) *reinterpret_cast<f32x4t*>(dz_out + r * C + 4 * q) = d;
+            const float l0 = rel[r * 3 + 0], l1 = rel[r * 3 + 1], l2 = rel[r * 3 + 2];
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                wacc[x][0] = __builtin_fmaf(d[x], l0, wacc[x][0]);
+                wacc[x][1] = __builtin_fmaf(d[x], l1, wacc[x][1]);
+                wacc[x][2] = __builtin_fmaf(d[x], l2, wacc[x][2]);
+            }
+        }
+    }
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) red[threadIdx.x][x * 3 + j] = wacc[x][j];
+    __syncthreads();
+    if (rg == 0) {                                       // the row groups' sums in group order
+        float* P = dwx_partial + (size_t)blockIdx.x * C * 3;
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                float t = 0.f;
+                for (int g = 0; g < RG; ++g) t += red[g * span + q][x * 3 + j];
+                P[(4 * q + x) * 3 + j] = t;
+            }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // Point-Transformer block in TRAINING mode: the element-wise chains around its GEMMs over the per-(point, neighbour)
 // tensors (B,N,k,D) (transformer_block/variants.py:156-163), each as ONE pass. Thread = (point, channel quad); the k
@@ -1808,6 +1898,35 @@ extern "C" int ptt_xcorr_z0_bnbwd_f32(const double* partial, int chunks, const f
                        act_shift, 1.0f / (float)R, B, n2, n1, C, dP, dcos, static_cast<float*>(ws));
     launch_wgrad_finish(static_cast<const float*>(ws), nwg, (size_t)C, 0, dw, s);
     return check_launch("xcorr_z0_bnbwd_kernel");
+}
+
+// rows per workgroup of sa_z0_bnbwd_kernel: ~2048 workgroups (and partial sums of d_wx) in all, a multiple of 64 rows
+static inline int sa_z0_bnbwd_rows(long long R) { return (int)(((R + 2047) / 2048 + 63) / 64 * 64); }
+extern "C" size_t ptt_sa_z0_bnbwd_workspace(long long R, int C) {
+    if (R <= 0 || C <= 0) return 0;
+    const int rows = sa_z0_bnbwd_rows(R);
+    return (size_t)((R + rows - 1) / rows) * C * 3 * sizeof(float);
+}
+// Layer 0 of a hoisted SA level, backward, from the gradient G (R, C) of its ACTIVATED output and the BatchNorm-backward partial
+// sums the GEMM that produced G took (ptt_rows_gemm_bnbwd_f32): dgamma / dbeta, then sa_z0_bnbwd_kernel.
+extern "C" int ptt_sa_z0_bnbwd_f32(const double* partial, int chunks, const float* G, const float* Z0, const float* rel_rows,
+                                   const float* mean, const float* invstd, const float* gamma, const float* act_scale,
+                                   const float* act_shift, long long R, int C, float* dz_out, float* dwx, float* dgamma, float* dbeta,
+                                   void* ws, size_t ws_bytes, ptt_stream_t stream) {
+    if (R <= 0 || R > 0x7fffffffLL || C <= 0 || (C & 3) || C > 1024 || chunks <= 0)
+        return fail(PTT_EINVAL, "ptt_sa_z0_bnbwd_f32: R=%lld C=%d chunks=%d (C %% 4 == 0, C <= 1024)", R, C, chunks);
+    if (!partial || !G || !Z0 || !rel_rows || !mean || !invstd || !gamma || !act_scale || !act_shift || !dwx || !dgamma || !dbeta ||
+        !vec4_ok(G, C, C) || !vec4_ok(Z0, C, C) || (dz_out && !vec4_ok(dz_out, C, C)) || !vec4_ok(mean, 4, 4) || !vec4_ok(invstd, 4, 4) ||
+        !vec4_ok(gamma, 4, 4) || !vec4_ok(dgamma, 4, 4) || !vec4_ok(dbeta, 4, 4) || !vec4_ok(act_scale, 4, 4) || !vec4_ok(act_shift, 4, 4))
+        return fail(PTT_EINVAL, "ptt_sa_z0_bnbwd_f32: null or misaligned pointer");
+    if (!ws || ws_bytes < ptt_sa_z0_bnbwd_workspace(R, C)) return fail(PTT_EWORKSPACE, "ptt_sa_z0_bnbwd_f32: workspace too small");
+    hipStream_t s = as_stream(stream);
+    hipLaunchKernelGGL((col_stats_finish2_kernel<1>), dim3(C), dim3(256), 0, s, partial, chunks, C, (int)R, 0.f, dbeta, dgamma, nullptr, BnTail{});
+    const int rows = sa_z0_bnbwd_rows(R), nwg = (int)((R + rows - 1) / rows);
+    hipLaunchKernelGGL(sa_z0_bnbwd_kernel, dim3(nwg), dim3(256), 0, s, G, Z0, rel_rows, mean, invstd, gamma, dbeta, dgamma, act_scale, act_shift,
+                       1.0f / (float)R, R, C, rows, dz_out, static_cast<float*>(ws));
+    launch_wgrad_finish(static_cast<const float*>(ws), nwg, (size_t)C * 3, 0, dwx, s);
+    return check_launch("sa_z0_bnbwd_kernel");
 }
 
 // BatchNorm(train) + ReLU backward when the two sums were already taken by the GEMM that produced the gradient

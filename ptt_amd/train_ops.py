@@ -299,23 +299,32 @@ class _SharedMlpPool(torch.autograd.Function):
     xcorr_hoisted), so layer 0 is BatchNorm + ReLU only and its W entry is a placeholder that gets no gradient."""
 
     @staticmethod
-    def forward(ctx, x, ns, eps, preact, sync, bns, z0_part, fP, fcos, fw, *params):
+    def forward(ctx, x, ns, eps, preact, sync, bns, z0_part, front, f0, f1, f2, f3, f4, *params):
         """Deferred activation: a layer's output relu(BatchNorm(z)) = relu(z * a + b) is never written — the next
         convolution, its weight gradient, the max-pool and the BatchNorm backward apply it while they load z.
         sync: per layer a torch.distributed process group (nn.SyncBatchNorm: the statistics are those of the rows of ALL
         ranks — one all-reduce of 2C + 1 float64 per layer and direction) or None. bns: per layer the BatchNorm module whose
         bookkeeping (running statistics, batch counter) the launch that forms the statistics does, with the activation
         constants a, b (ops.bn_stats / bn_finish_partials with `bn`), or None: the caller does it (SyncBatchNorm layers).
-        fP / fcos / fw (with preact, x = None): the rows are CosineSimAug's layer 0, z0 = fP[b,i] + fcos[b,j,i] * fw, built HERE
-        (ops.xcorr_z0, statistics summed by the same launch) so that the backward pass can end with ONE pass over the gradient of
-        the activated z0 (ops.xcorr_z0_bnbwd: BatchNorm backward applied on the fly, z0 recomputed) instead of an apply pass that
-        writes dz0 and a second pass that reads it."""
+        front (with preact, x = None): the rows z0 are built HERE from f0..f4, so that the backward pass can END with one pass over the
+        gradient of the activated z0 that applies layer 0's BatchNorm backward on the fly and feeds z0's consumers directly, instead
+        of an apply pass that writes dz0 and further passes that read it:
+          ('xcorr',): CosineSimAug's layer 0, z0 = f0[b,i] + f1[b,j,i] * f2 (P, cos, w_sim) — ops.xcorr_z0 / ops.xcorr_z0_bnbwd;
+          ('sa', radius, normalize_xyz): a hoisted SA level's layer 0, z0 = f3[idx] + f4 ((f0[idx] - f1) / radius) (xyz, new_xyz, idx,
+          per-point term | None, Wx) — ops.sa_z0_rows / ops.sa_z0_bnbwd."""
         ctx.set_materialize_grads(False)          # the statistics outputs carry no gradient: no zero tensors made for them
         L = len(params) // 3
         saved, stats, counts = [], [], []
-        ctx.front = fP is not None
-        if ctx.front:
-            x, z0_part = ops.xcorr_z0(fP, fcos, fw, want_stats=True)
+        ctx.front = front
+        front_saved = ()
+        if front is not None and front[0] == 'xcorr':
+            x, z0_part = ops.xcorr_z0(f0, f1, f2, want_stats=True)
+            front_saved = (f0, f1, f2)
+        elif front is not None:
+            x, rel, z0_part = ops.sa_z0_rows(f0.contiguous(), f1.contiguous(), f2, f3.contiguous() if f3 is not None else None, f4.detach(),
+                                             front[1], front[2], want_stats=True)
+            ctx.sa_points, ctx.has_term = f0.shape[1], f3 is not None
+            front_saved = (f2, rel)
         cur, cur_a, cur_b = x.contiguous(), None, None
         for l in range(L):
             W, gamma, beta = params[3 * l], params[3 * l + 1], params[3 * l + 2]
@@ -348,7 +357,7 @@ class _SharedMlpPool(torch.autograd.Function):
             stats += [mean, var, count]
             cur, cur_a, cur_b = z, a, b
         pooled, arg = ops.pool_select(extrema, cur_a, cur_b) if extrema is not None else ops.pool_rows(cur, ns, cur_a, cur_b)
-        ctx.save_for_backward(arg, *saved, *[p.detach() for p in params], *((fP, fcos, fw) if ctx.front else ()))
+        ctx.save_for_backward(arg, *saved, *[p.detach() for p in params], *front_saved)
         ctx.weights = tuple(params[3 * l] for l in range(L))     # the parameter objects themselves: keys of the pack cache
         ctx.L, ctx.ns, ctx.preact, ctx.sync = L, int(ns), bool(preact), tuple(sync)
         ctx.mark_non_differentiable(*stats)
@@ -362,7 +371,8 @@ class _SharedMlpPool(torch.autograd.Function):
         dpooled = dpooled.contiguous()
         g, part = None, None        # part: BatchNorm backward sums of THIS layer, taken by the GEMM that produced g
         grads = [None] * (3 * L)
-        front_grads = (None, None, None)
+        front_grads = [None] * 5
+        kind = ctx.front[0] if ctx.front is not None else None
         for l in range(L - 1, -1, -1):
             x_in, in_a, in_b, z, mean, invstd, a, b, count = saved[9 * l:9 * l + 9]
             W, gamma = params[3 * l], params[3 * l + 1]
@@ -390,9 +400,23 @@ class _SharedMlpPool(torch.autograd.Function):
                                           act_scale=a, act_shift=b)
             elif last:
                 dz, dgamma, dbeta = ops.bn_bwd_pooled(dpooled, arg, ns, z, mean, invstd, gamma, a, b)
-            elif part is not None and l == 0 and ctx.preact and ctx.front and mean.shape[0] <= 256 and g.is_contiguous():
+            elif part is not None and l == 0 and ctx.preact and kind == 'xcorr' and mean.shape[0] <= 256 and g.is_contiguous():
                 # CosineSimAug's layer 0: BatchNorm backward applied while its ONE consumer reads the gradient (no dz0 tensor)
-                *front_grads, dgamma, dbeta = ops.xcorr_z0_bnbwd(part, g, front[0], front[1], front[2], mean, invstd, gamma, a, b)
+                front_grads[0], front_grads[1], front_grads[2], dgamma, dbeta = ops.xcorr_z0_bnbwd(part, g, front[0], front[1], front[2], mean,
+                                                                                                   invstd, gamma, a, b)
+                grads[1], grads[2] = dgamma, dbeta
+                g = None
+                break
+            elif (part is not None and l == 0 and ctx.preact and kind == 'sa' and mean.shape[0] <= 1024 and g.is_contiguous()
+                  and z.is_contiguous()):
+                # a hoisted SA level's layer 0: the same for the K = 3 weight gradient (d_wx); dz0 is written (over g) only for the
+                # row scatter of a level with point features
+                idx, rel = front
+                want_term = ctx.has_term and ctx.needs_input_grad[11]
+                dz, front_grads[4], dgamma, dbeta = ops.sa_z0_bnbwd(part, g, z, rel, mean, invstd, gamma, a, b, want_term)
+                if want_term:
+                    B, M, ns_ = idx.shape
+                    front_grads[3] = ops.scatter_rows_det(dz.view(B, M * ns_, -1), idx.view(B, M * ns_), ctx.sa_points)
                 grads[1], grads[2] = dgamma, dbeta
                 g = None
                 break
@@ -403,9 +427,17 @@ class _SharedMlpPool(torch.autograd.Function):
             grads[3 * l + 1], grads[3 * l + 2] = dgamma, dbeta
             if ctx.preact and l == 0:
                 g = dz                                                                  # d(loss)/d(layer-0 pre-activation)
-                if ctx.front:
+                if kind == 'xcorr':
                     B, n1 = front[0].shape[0], front[0].shape[1]
-                    front_grads = ops.xcorr_z0_bwd(dz.contiguous(), front[1], front[2], B, front[1].shape[1], n1)
+                    front_grads[0], front_grads[1], front_grads[2] = ops.xcorr_z0_bwd(dz.contiguous(), front[1], front[2], B, front[1].shape[1], n1)
+                    g = None
+                elif kind == 'sa':
+                    idx, rel = front
+                    B, M, ns_ = idx.shape
+                    dzc = dz.contiguous()
+                    if ctx.has_term and ctx.needs_input_grad[11]:
+                        front_grads[3] = ops.scatter_rows_det(dzc.view(B, M * ns_, -1), idx.view(B, M * ns_), ctx.sa_points)
+                    front_grads[4] = ops.linear_wgrad(dzc, rel)
                     g = None
                 break
             Wp = ctx.weights[l]
@@ -425,7 +457,7 @@ class _SharedMlpPool(torch.autograd.Function):
                 g, _ = conv_rows(dz, w2, transpose=True)                                # w.r.t. the (not normalised) input rows
             else:
                 g = None
-        return (g, None, None, None, None, None, None) + tuple(front_grads) + tuple(grads)
+        return (g, None, None, None, None, None, None, None) + tuple(front_grads) + tuple(grads)
 
 
 def shared_mlp_pool(grouped, mlp, pool_dim):
@@ -453,7 +485,8 @@ def _sync_group(bn):
 def rows_mlp_pool(rows, mlp, ns, B, keep, preact, z0_part=None, front=None):
     """The row form: rows (B * keep * ns, C) ordered (frame, kept position, pooled position) -> (B, C_L, keep).
     preact: rows are layer 0's convolution output already (hoisted by the caller); z0_part: its BatchNorm statistics as float64
-    partial sums (chunks, 2, C), when the launch that built the rows summed them (ops.sa_z0_rows)."""
+    partial sums (chunks, 2, C), when the launch that built the rows summed them (ops.sa_z0_rows). front = (meta, tensors) with
+    rows = None: layer 0's rows are built inside the stage's autograd function (_SharedMlpPool.forward, `front`)."""
     params, eps, sync = [], [], []
     for unit in mlp:
         bn = unit.normlayer.bn
@@ -461,8 +494,8 @@ def rows_mlp_pool(rows, mlp, ns, B, keep, preact, z0_part=None, front=None):
         eps.append(float(bn.eps))
         sync.append(_sync_group(bn))
     bns = tuple(unit.normlayer.bn if g is None else None for unit, g in zip(mlp, sync))
-    fP, fcos, fw = front if front is not None else (None, None, None)      # front: CosineSimAug's layer 0 built inside (rows = None)
-    out = _SharedMlpPool.apply(rows, ns, tuple(eps), bool(preact), tuple(sync), bns, z0_part, fP, fcos, fw, *params)
+    meta, ft = (front[0], tuple(front[1]) + (None,) * (5 - len(front[1]))) if front is not None else (None, (None,) * 5)
+    out = _SharedMlpPool.apply(rows, ns, tuple(eps), bool(preact), tuple(sync), bns, z0_part, meta, *ft, *params)
     pooled, stats = out[0], out[1:]
     with torch.no_grad():                                   # nn.BatchNorm's bookkeeping in training mode: done by the statistics'
         for l, unit in enumerate(mlp):                      # own launch, except for SyncBatchNorm layers (all-reduced count)
@@ -487,8 +520,8 @@ def sa_level_hoisted(xyz, new_xyz, features, idx, mlp, radius, normalize_xyz):
         # fixed coordinates (the backbone's levels): the whole front — relative coordinates, gather of the per-point terms,
         # the three coordinate channels — is one launch; features None: a level without point features (layer 0 = Wx . rel)
         term = _RowsLinear.apply(features.transpose(1, 2), wf, None, None) if features is not None else None
-        z0, z0_part = _SaZ0.apply(xyz, new_xyz, idx, term, wx, float(radius), bool(normalize_xyz))
-        return rows_mlp_pool(z0, mlp, ns, B, M, preact=True, z0_part=z0_part if z0_part.numel() else None)
+        # z0 is built inside the stage's function (its backward ends with ops.sa_z0_bnbwd); _SaZ0 is the stand-alone form
+        return rows_mlp_pool(None, mlp, ns, B, M, preact=True, front=(('sa', float(radius), bool(normalize_xyz)), (xyz, new_xyz, idx, term, wx)))
     rel = pu.grouping_operation(xyz.transpose(1, 2).contiguous(), idx) - new_xyz.transpose(1, 2).unsqueeze(-1)   # (B,3,M,ns)
     if normalize_xyz:
         rel = rel / radius
@@ -514,7 +547,7 @@ def xcorr_hoisted(search_feats, template_feats, template_xyz, mlp, eps):
     P = _RowsLinear.apply(rows_i, wrest, None, None)                                    # (B,n1,C0)
     # z0 (B*n2*n1, C0), rows ordered (b, j, i), is built inside the stage's function: its backward ends with one pass over the
     # gradient of the activated z0 (ops.xcorr_z0_bnbwd); _XcorrZ0 is the stand-alone form of the same layer
-    return rows_mlp_pool(None, mlp, n1, B, n2, preact=True, front=(P.contiguous(), cos.contiguous(), wsim.reshape(-1).contiguous()))
+    return rows_mlp_pool(None, mlp, n1, B, n2, preact=True, front=(('xcorr',), (P.contiguous(), cos.contiguous(), wsim.reshape(-1).contiguous())))
 
 
 class _CosMap(torch.autograd.Function):
