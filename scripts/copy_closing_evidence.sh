@@ -5,7 +5,7 @@ set -e
 S=${1:-z}
 O=gpurun_out/r04$S
 for f in pytest_gpu.log bench_default.json bench_train.json serial_kernel_stats.csv serial_bench_line.json train_kernel_stats.csv \
-         train_profiled_bench_line.json b1_kernel_stats.csv; do
+         train_profiled_bench_line.json b1_kernel_stats.csv sa_z0_bnbwd_probe.log; do
     [ -f $O/$f ] && cp $O/$f profiles/r04${S}_$f
 done
 for f in last_step_by_shape.txt last_step_launches.txt; do

@@ -79,6 +79,7 @@ z)  # closing evidence of the round: parity tests, the default bench line (all c
     cp $O/train_kernel_stats.stdout $O/train_profiled_bench_line.json 2>/dev/null
     bash scripts/train_step_timeline.sh $REPO/$O/train_timeline > $O/train_timeline.log 2>&1; head -1 $O/train_timeline.log     # every launch of ONE step, in order and by shape
     ktrace b1_kernel_stats python $REPO/scripts/tracklet_b1_profile.py
+    timeout 300 python scripts/probes/sa_z0_bnbwd_probe.py 2>&1 | grep -v amdgpu.ids > $O/sa_z0_bnbwd_probe.log
     bash scripts/pmc_passes.sh $O/pmc "pair,sa0_s,sa1_s,sa2_s,sa_box,xcorr,lin_,rj" > $O/pmc.log 2>&1; tail -12 $O/pmc.log | cut -c1-300
     bash scripts/pmc_passes.sh $O/pmc_stress "pair" "" "--batch 32 --pair-n 2048,64" > $O/pmc_stress.log 2>&1; tail -4 $O/pmc_stress.log | cut -c1-300
     bash scripts/pmc_passes.sh $O/pmc_train_gemm - "python scripts/rows_gemm_bench.py --no-check --pmc" > $O/pmc_train_gemm.log 2>&1; tail -4 $O/pmc_train_gemm.log | cut -c1-300
