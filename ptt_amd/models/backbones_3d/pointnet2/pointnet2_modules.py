@@ -54,7 +54,12 @@ class PointnetSAModuleVotes(nn.Module):
         if self.sample_method == 'fps':
             return pointnet2_utils.furthest_point_sample(xyz, npoint)
         if self.sample_method in ('rs', 'sequence'):
-            return torch.arange(npoint, dtype=torch.int32, device=xyz.device).repeat(xyz.size(0), 1)
+            # the same (B, npoint) index table every call: built once per shape (callers only read it)
+            cache = self.__dict__.setdefault('_sequence_cache', {})
+            key = (xyz.size(0), int(npoint), xyz.device)
+            if key not in cache:
+                cache[key] = torch.arange(npoint, dtype=torch.int32, device=xyz.device).repeat(xyz.size(0), 1)
+            return cache[key]
         if self.sample_method == 'ffps':
             raise NotImplementedError("sample_method 'ffps' needs furthest_point_sampling_with_dist, which the "
                                       "reference's extension never provided (tools/cfgs/kitti_models/ptt.yaml:42)")

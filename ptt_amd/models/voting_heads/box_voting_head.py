@@ -121,7 +121,8 @@ class BoxVotingHead(VotingHeadTemplate):
             else:
                 offsets = layer_utils.rows_forward(self.refine_layer, rows)                      # (B,M,5)
             batch_dict['pred_box_center'] = centres
-            batch_dict['pred_box_data'] = torch.cat((offsets[..., 0:3] + centres, offsets[..., 3:]), dim=2)
+            off_xyz, off_rest = offsets.split([3, offsets.shape[-1] - 3], dim=2)                 # one split: its backward is one concatenation
+            batch_dict['pred_box_data'] = torch.cat((off_xyz + centres, off_rest), dim=2)
             if self.training:
                 self._train_labels(batch_dict, centres)
             return batch_dict

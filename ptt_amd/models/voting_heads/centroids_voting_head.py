@@ -80,9 +80,10 @@ class CentroidVotingHead(VotingHeadTemplate):
         cls_in = with_xyz if getattr(self.model_cfg, 'CLS_USE_SEARCH_XYZ', False) else rows
         cls_out = self._stack(self.cla_layer, cls_in).squeeze(-1)                 # (B,N)
         voted = self._stack(self.vote_layer, with_xyz, residual=with_xyz)
+        voted_xyz, voted_feats = voted.split([3, voted.shape[-1] - 3], dim=2)     # one split: its backward is one concatenation
         batch_dict['pred_centroids_cls'] = cls_out.squeeze(0)
-        batch_dict['pred_centroids_votes'] = voted[..., 0:3].contiguous()         # (B,N,3)
-        batch_dict['votes_feats'] = torch.cat((cls_out.sigmoid().unsqueeze(-1), voted[..., 3:]),
+        batch_dict['pred_centroids_votes'] = voted_xyz.contiguous()               # (B,N,3)
+        batch_dict['votes_feats'] = torch.cat((cls_out.sigmoid().unsqueeze(-1), voted_feats),
                                               dim=2).transpose(1, 2)              # (B,1+C,N) view
         if self.training:
             self.forward_ret_dict = {

@@ -482,7 +482,7 @@ def _sync_group(bn):
     return group if dist.get_world_size(group) > 1 else None
 
 
-def rows_mlp_pool(rows, mlp, ns, B, keep, preact, z0_part=None, front=None):
+def rows_mlp_pool(rows, mlp, ns, B, keep, preact, z0_part=None, front=None, as_rows=False):
     """The row form: rows (B * keep * ns, C) ordered (frame, kept position, pooled position) -> (B, C_L, keep).
     preact: rows are layer 0's convolution output already (hoisted by the caller); z0_part: its BatchNorm statistics as float64
     partial sums (chunks, 2, C), when the launch that built the rows summed them (ops.sa_z0_rows). front = (meta, tensors) with
@@ -501,6 +501,8 @@ def rows_mlp_pool(rows, mlp, ns, B, keep, preact, z0_part=None, front=None):
         for l, unit in enumerate(mlp):                      # own launch, except for SyncBatchNorm layers (all-reduced count)
             if bns[l] is None:
                 ops.bn_update_running(unit.normlayer.bn, stats[3 * l], stats[3 * l + 1], stats[3 * l + 2])
+    if as_rows:
+        return pooled                                       # (B * keep, C_L) rows as the kernels hold them: no views for autograd to undo
     return pooled.view(B, keep, -1).transpose(1, 2)         # (B, C_L, keep)
 
 
@@ -784,7 +786,9 @@ def conv1d_stack_rows(seq, rows, residual=None):
     bn_units = [u for u in units if hasattr(u, 'normlayer')]
     x = rows.reshape(B * N, -1)
     if bn_units:
-        x = rows_mlp_pool(x, bn_units, 1, 1, B * N, preact=False)[0].t()          # (B*N, C): a view of row-major storage
+        # (B*N, C) rows straight from the function: the (1, C, B*N) view + [0].t() of the general form cost a zero fill and two copies
+        # per stack in the backward pass (select_backward, then a .contiguous() of the transposed gradient)
+        x = rows_mlp_pool(x, bn_units, 1, 1, B * N, preact=False, as_rows=True)
     if len(bn_units) < len(units):
         last = units[-1].conv
         res2 = residual.reshape(B * N, -1) if residual is not None else None
