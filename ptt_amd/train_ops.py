@@ -805,6 +805,8 @@ class LossValues(object):
     one copy serves all of them, at the time a logger formats or adds them — never, if nobody looks."""
 
     class Value(object):
+        """One of the values: behaves as the float it will be (arithmetic, comparisons, formatting, numpy / tensorboard conversion,
+        pickling as a plain float); registered as numbers.Real."""
         __slots__ = ("owner", "k")
 
         def __init__(self, owner, k):
@@ -824,20 +826,21 @@ class LossValues(object):
         def __format__(self, spec):
             return format(float(self), spec)
 
-        def __add__(self, o): return float(self) + o
-        def __radd__(self, o): return o + float(self)
-        def __sub__(self, o): return float(self) - o
-        def __rsub__(self, o): return o - float(self)
-        def __mul__(self, o): return float(self) * o
-        def __rmul__(self, o): return o * float(self)
-        def __truediv__(self, o): return float(self) / o
-        def __rtruediv__(self, o): return o / float(self)
-        def __lt__(self, o): return float(self) < o
-        def __le__(self, o): return float(self) <= o
-        def __gt__(self, o): return float(self) > o
-        def __ge__(self, o): return float(self) >= o
-        def __eq__(self, o): return float(self) == o
-        def __hash__(self): return hash((id(self.owner), self.k))
+        def __array__(self, dtype=None, copy=None):
+            import numpy as np
+            return np.array(float(self), dtype=dtype or np.float64)
+
+        def __reduce__(self):
+            return (float, (float(self),))
+
+        def __hash__(self):
+            return hash(float(self))
+
+        def __bool__(self):
+            return bool(float(self))
+
+        def __int__(self):
+            return int(float(self))
 
     def __init__(self, device_values):
         self.device_values, self.host = device_values, None
@@ -870,6 +873,24 @@ class _TrackLosses(torch.autograd.Function):
         g = g_total.contiguous().float() if g_total is not None else None
         g_cls, g_votes, g_box = ops.track_losses_bwd(out, g, *t, ctx.weights)
         return g_cls, g_votes, g_box, None, None, None, None, None, None, None
+
+
+def _numeric_protocol(cls):
+    import numbers
+    import operator
+    for name in ("add", "sub", "mul", "truediv", "floordiv", "mod", "pow"):
+        op = getattr(operator, name)
+        setattr(cls, "__%s__" % name, lambda self, o, op=op: op(float(self), float(o) if isinstance(o, cls) else o))
+        setattr(cls, "__r%s__" % name, lambda self, o, op=op: op(float(o) if isinstance(o, cls) else o, float(self)))
+    for name in ("lt", "le", "gt", "ge", "eq", "ne"):
+        op = getattr(operator, name)
+        setattr(cls, "__%s__" % name, lambda self, o, op=op: op(float(self), float(o) if isinstance(o, cls) else o))
+    for name, fn in (("neg", operator.neg), ("pos", operator.pos), ("abs", abs), ("round", round)):
+        setattr(cls, "__%s__" % name, lambda self, *a, fn=fn: fn(float(self), *a))
+    numbers.Real.register(cls)
+
+
+_numeric_protocol(LossValues.Value)
 
 
 def track_losses_usable(*tensors):
