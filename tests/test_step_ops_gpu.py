@@ -258,3 +258,46 @@ def test_three_training_steps_with_clip_adam_track_the_stock_optimiser(dev):
     assert a[0] == b[0]
     assert abs(a[1] - b[1]) <= 2e-3 * abs(b[1]) and abs(a[2] - b[2]) <= 5e-3 * abs(b[2]), (a, b)
     assert abs(a[1] - a[0]) > 1e-3 * abs(a[0])                      # the second step did see new weights
+
+
+@pytest.mark.parametrize("R,C,want_dz", [(3 * 37 * 5, 64, True), (48 * 64 * 16, 256, False), (70001, 132, True), (64, 4, True)])
+def test_sa_layer0_bn_backward_folded_into_the_weight_gradient_pass(dev, R, C, want_dz):
+    """ptt_sa_z0_bnbwd_f32 against the two launches it replaces (ptt_bn_bwd_from_partials_f32, then ptt_linear_wgrad_f32 over dz0 and
+    the relative coordinates): dz0, dgamma, dbeta bit-identical (the same arithmetic), d_wx to float32 summation-order accuracy; row
+    counts that are no multiple of the row block, the chunk or 4 x the row groups."""
+    g = torch.Generator().manual_seed(R + C)
+    r = lambda *s: torch.randn(*s, generator=g).to(dev)
+    G, z, rel = r(R, C), r(R, C), r(R, 3)
+    mean, invstd, gamma, a, b = r(C), r(C).abs() + 0.5, r(C), r(C), r(C)
+    part = torch.randn(17, 2, C, generator=g, dtype=torch.float64).to(dev)
+    dz_ref, dgamma_ref, dbeta_ref = ops.bn_bwd_from_partials(part, G, z, mean, invstd, gamma, a, b)
+    dwx_ref = dz_ref.double().t() @ rel.double()
+    G2 = G.clone()
+    dz, dwx, dgamma, dbeta = ops.sa_z0_bnbwd(part, G2, z, rel, mean, invstd, gamma, a, b, want_dz)
+    assert torch.equal(dgamma, dgamma_ref) and torch.equal(dbeta, dbeta_ref)
+    if want_dz:
+        assert dz.data_ptr() == G2.data_ptr() and torch.equal(dz, dz_ref)            # written over the gradient
+    else:
+        assert dz is None and torch.equal(G2, G)                                      # nothing written
+    assert float((dwx.double() - dwx_ref).abs().max()) <= 1e-5 * float(dwx_ref.abs().max()) + 1e-6 * np.sqrt(R)
+    again = ops.sa_z0_bnbwd(part, G.clone(), z, rel, mean, invstd, gamma, a, b, want_dz)
+    assert torch.equal(again[1], dwx)                                                 # fixed summation order
+
+
+@pytest.mark.parametrize("B,n2,n1,C", [(2, 7, 5, 12), (3, 128, 64, 256), (1, 4, 1, 4), (2, 33, 10, 64)])
+def test_xcorr_layer0_bn_backward_folded_into_its_consumer_is_bit_identical(dev, B, n2, n1, C):
+    """ptt_xcorr_z0_bnbwd_f32 (z0 recomputed, BatchNorm backward applied on the fly) against ptt_bn_bwd_from_partials_f32 followed by
+    ptt_xcorr_z0_bwd_f32 on the stored z0: every output bit-identical, for search counts that are no multiple of the four rows in
+    flight."""
+    g = torch.Generator().manual_seed(B * 1000 + n2)
+    r = lambda *s: torch.randn(*s, generator=g).to(dev)
+    P, cos, w = r(B, n1, C), r(B, n2, n1).clamp(-1, 1), r(C)
+    z0 = ops.xcorr_z0(P, cos, w)
+    G = r(B * n2 * n1, C)
+    mean, invstd, gamma, a, b = r(C), r(C).abs() + 0.5, r(C), r(C), r(C)
+    part = torch.randn(9, 2, C, generator=g, dtype=torch.float64).to(dev)
+    dz_ref, dgamma_ref, dbeta_ref = ops.bn_bwd_from_partials(part, G, z0, mean, invstd, gamma, a, b)
+    ref = ops.xcorr_z0_bwd(dz_ref, cos, w, B, n2, n1)
+    got = ops.xcorr_z0_bnbwd(part, G, P, cos, w, mean, invstd, gamma, a, b)
+    for x, y, name in zip(got, tuple(ref) + (dgamma_ref, dbeta_ref), ("dP", "dcos", "dw", "dgamma", "dbeta")):
+        assert torch.equal(x, y), name
