@@ -802,7 +802,9 @@ __global__ __launch_bounds__(256, 2) void linear_wgrad_kernel(const float* __res
 #undef As
 #undef Bs
     if constexpr (NS > 1) {
-        // the shares of a quadrant, added in wave order (the loop's last barrier has released the staging buffers)
+        // the shares of a quadrant, added in wave order (the loop's last barrier has released the staging buffers). The
+        // accumulators are only STORED here and the sum is formed from the LDS copies: accumulators that are also written after the
+        // loop get copied to vector registers wholesale (256 VGPRs + 20 - 24 B of scratch per lane until round 4)
         float* slot = wg_smem + w * 4096;
 #pragma unroll
         for (int a = 0; a < 2; ++a)
@@ -813,15 +815,20 @@ __global__ __launch_bounds__(256, 2) void linear_wgrad_kernel(const float* __res
         __syncthreads();
         if (sidx != 0) return;
         const int step = (NS == 4) ? 1 : (narrow_i ? 1 : 2);           // the waves that share this wave's quadrant
-        for (int k = 1; k < NS; ++k) {
-            const float* other = wg_smem + (w + k * step) * 4096;
+        float* P = partial + (size_t)blockIdx.y * Cout * Cin;
+        for (int a = 0; a < 2; ++a)
+            for (int b = 0; b < 2; ++b) {
+                const int ci = i0 + wi + b * 32 + col;
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int b = 0; b < 2; ++b)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[a][b][r] += other[((a * 2 + b) * 16 + r) * 64 + lane];
-        }
+                for (int r = 0; r < 16; ++r) {
+                    const int e = ((a * 2 + b) * 16 + r) * 64 + lane;
+                    float v = slot[e];
+                    for (int k = 1; k < NS; ++k) v += wg_smem[(w + k * step) * 4096 + e];
+                    const int co = o0 + wo + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (co < Cout && ci < Cin) P[(size_t)co * Cin + ci] = v;
+                }
+            }
+        return;
     }
     // C/D layout: column (input channel) = lane & 31, row (output channel) = (reg & 3) + 8 * (reg >> 2) + 4 * half
     float* P = partial + (size_t)blockIdx.y * Cout * Cin;
