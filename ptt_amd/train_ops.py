@@ -264,35 +264,6 @@ class _SplitCols(torch.autograd.Function):
         return torch.cat((ga, gb), dim=1), None
 
 
-class _SaZ0(torch.autograd.Function):
-    """Layer 0 of a hoisted SA level, one row per (centre, neighbour), in one launch (ops.sa_z0_rows):
-    z0 = term[idx] + Wx ((xyz[idx] - centre) / radius). Coordinates carry no gradient here (asserted by the caller)."""
-
-    @staticmethod
-    def forward(ctx, xyz, new_xyz, idx, term, wx, radius, normalize_xyz):
-        """-> (z0, the float64 partial sums of z0's BatchNorm statistics (or an empty tensor), summed by the same launch)."""
-        ctx.set_materialize_grads(False)
-        z0, rel, part = ops.sa_z0_rows(xyz.contiguous(), new_xyz.contiguous(), idx, term.contiguous() if term is not None else None,
-                                       wx.detach(), radius, normalize_xyz, want_stats=True)
-        ctx.save_for_backward(idx, rel)
-        ctx.N, ctx.has_term = xyz.shape[1], term is not None
-        if part is None:
-            part = z0.new_empty(0, dtype=torch.float64)
-        ctx.mark_non_differentiable(part)
-        return z0, part
-
-    @staticmethod
-    def backward(ctx, g, _unused=None):
-        idx, rel = ctx.saved_tensors
-        B, M, ns = idx.shape
-        g = g.contiguous()
-        d_term = None
-        if ctx.has_term and ctx.needs_input_grad[3]:
-            d_term = ops.scatter_rows_det(g.view(B, M * ns, -1), idx.view(B, M * ns), ctx.N)
-        d_wx = ops.linear_wgrad(g, rel) if ctx.needs_input_grad[4] else None
-        return None, None, None, d_term, d_wx, None, None
-
-
 class _SharedMlpPool(torch.autograd.Function):
     """(rows (R,C0), ns, eps per layer, preact, [W, gamma, beta] per layer) -> (pooled (R/ns, C_L), [mean, var] per layer).
     preact: `rows` already IS layer 0's convolution output (the caller hoisted that layer: train_ops.sa_level_hoisted /
@@ -522,7 +493,7 @@ def sa_level_hoisted(xyz, new_xyz, features, idx, mlp, radius, normalize_xyz):
         # fixed coordinates (the backbone's levels): the whole front — relative coordinates, gather of the per-point terms,
         # the three coordinate channels — is one launch; features None: a level without point features (layer 0 = Wx . rel)
         term = _RowsLinear.apply(features.transpose(1, 2), wf, None, None) if features is not None else None
-        # z0 is built inside the stage's function (its backward ends with ops.sa_z0_bnbwd); _SaZ0 is the stand-alone form
+        # z0 = term[idx] + Wx . rel is built inside the stage's function (ops.sa_z0_rows): its backward ends with ops.sa_z0_bnbwd
         return rows_mlp_pool(None, mlp, ns, B, M, preact=True, front=(('sa', float(radius), bool(normalize_xyz)), (xyz, new_xyz, idx, term, wx)))
     rel = pu.grouping_operation(xyz.transpose(1, 2).contiguous(), idx) - new_xyz.transpose(1, 2).unsqueeze(-1)   # (B,3,M,ns)
     if normalize_xyz:
@@ -548,7 +519,7 @@ def xcorr_hoisted(search_feats, template_feats, template_xyz, mlp, eps):
     wsim, wrest = _SplitCols.apply(w0, 1)
     P = _RowsLinear.apply(rows_i, wrest, None, None)                                    # (B,n1,C0)
     # z0 (B*n2*n1, C0), rows ordered (b, j, i), is built inside the stage's function: its backward ends with one pass over the
-    # gradient of the activated z0 (ops.xcorr_z0_bnbwd); _XcorrZ0 is the stand-alone form of the same layer
+    # gradient of the activated z0 (ops.xcorr_z0_bnbwd)
     return rows_mlp_pool(None, mlp, n1, B, n2, preact=True, front=(('xcorr',), (P.contiguous(), cos.contiguous(), wsim.reshape(-1).contiguous())))
 
 
@@ -576,29 +547,6 @@ class _CosMap(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dt = ops.cos_bwd_rows(torch.bmm(g.transpose(1, 2), us), ut, nt, g, cos, False, ctx.like[1])
         return ds, dt, None
-
-
-class _XcorrZ0(torch.autograd.Function):
-    """z0[b,j,i,:] = P[b,i,:] + cos[b,j,i] * w[:] in one pass; backward in one pass over dz0 (ptt_xcorr_z0(_bwd)_f32)."""
-
-    @staticmethod
-    def forward(ctx, P, cos, w):
-        """-> (z0, the float64 partial sums of z0's BatchNorm statistics (or an empty tensor), summed by the same launch)."""
-        ctx.set_materialize_grads(False)
-        ctx.save_for_backward(cos, w)
-        ctx.dims = (P.shape[0], cos.shape[1], P.shape[1])
-        z0, part = ops.xcorr_z0(P, cos, w, want_stats=True)
-        if part is None:
-            part = z0.new_empty(0, dtype=torch.float64)
-        ctx.mark_non_differentiable(part)
-        return z0, part
-
-    @staticmethod
-    def backward(ctx, dz0, _unused=None):
-        cos, w = ctx.saved_tensors
-        B, n2, n1 = ctx.dims
-        dP, dcos, dw = ops.xcorr_z0_bwd(dz0.contiguous(), cos, w, B, n2, n1)
-        return dP, dcos, dw
 
 
 class _KnnRel(torch.autograd.Function):
