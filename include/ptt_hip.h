@@ -471,6 +471,12 @@ int ptt_track_crop_bounds(const ptt_track_box* boxes, int n, double offset, doub
                           ptt_crop_job* jobs_host, int job_stride);
 int ptt_track_box_by_offset(ptt_track_box* boxes, int n, float* offsets, int offset_stride, int use_z,
                             const int32_t* active, int64_t* rng_pos);
+/* The host side of post_process for one step in one call: per tracklet the first arg-max of the scores out of the (n,P,5) read-back
+ * (P == 1: rows already selected) -> est_out (n,5); rng_pos[i] <- the draw count of this frame's resampling (info (n,2,2) int32 =
+ * (points, draws used) of search / template: the template's if it resampled, else the search's; a negative count = the draw table
+ * ran out: PTT_EINVAL); then ptt_track_box_by_offset(boxes, est_out, ...). */
+int ptt_track_select_update(const float* proposals_host, int P, const int32_t* info_host, ptt_track_box* boxes, int n, int use_z,
+                            const int32_t* active, int64_t* rng_pos, float* est_out);
 
 /* ptt_select_box_f32 — post_process (eval_tracking_utils.py:266-274): for every frame b the row of
  * pred_box_data (B,P,5) with the largest score (column 4; first one among equals, as np.argmax) -> out (B,5);

@@ -40,7 +40,7 @@ EXPORTS = [
     "ptt_sa_z0_rows_f32",
     "ptt_row_jobs_f32", "ptt_point_jobs_f32", "ptt_fps_ball_knn_f32", "ptt_crop_compact_host_f32", "ptt_crop_regularize_f32", "ptt_colsum_workspace", "ptt_colsum_f32", "ptt_rows_gemm_pool_supported", "ptt_rows_gemm_pool_f32", "ptt_pool_select_f32", "ptt_sa_z0_rows_stat_chunks", "ptt_sa_z0_rows_stats_f32",
     "ptt_track_losses_f32", "ptt_track_losses_bwd_f32", "ptt_adam_chunk_elems", "ptt_adam_clip_step_f32",
-    "ptt_unit_rows_f32", "ptt_cos_bwd_rows_f32", "ptt_sa_z0_bnbwd_workspace", "ptt_sa_z0_bnbwd_f32",
+    "ptt_unit_rows_f32", "ptt_cos_bwd_rows_f32", "ptt_track_select_update", "ptt_sa_z0_bnbwd_workspace", "ptt_sa_z0_bnbwd_f32",
 ]
 PTT_MAX_SEGMENTS = 4
 
@@ -190,6 +190,7 @@ def _declare(lib):
         "ptt_adam_clip_step_f32": [vp, vp, vp, i, vp, vp, c_size_t, vp, vp],
         "ptt_unit_rows_f32": [vp, c_longlong, c_longlong, c_longlong, i, i, i, f, vp, vp, vp],
         "ptt_cos_bwd_rows_f32": [vp, vp, vp, vp, vp, c_longlong, c_longlong, c_longlong, i, i, i, i, vp, c_longlong, c_longlong, c_longlong, vp],
+        "ptt_track_select_update": [vp, i, vp, vp, i, i, vp, vp, vp],
         "ptt_regularize_f32": [vp, i, vp, i, vp],
         "ptt_mt19937_fill": [c_uint32, vp, i],
         "ptt_select_box_f32": [vp, i, i, vp, vp, vp],

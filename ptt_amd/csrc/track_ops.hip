@@ -437,3 +437,36 @@ extern "C" int ptt_select_box_f32(const float* pred_box_data, int B, int P, floa
     hipLaunchKernelGGL(select_box_kernel, dim3((B + 3) / 4), dim3(256), 0, as_stream(stream), pred_box_data, B, P, out, idx_out);
     return check_launch("select_box_kernel");
 }
+
+// The host side of post_process for one step of B tracklets in ONE call (eval_tracking_utils.py:266-274 + the generator bookkeeping
+// of the loop around it): for every tracklet the FIRST arg-max of the proposal scores (np.argmax, :267-269) out of the (B,P,5)
+// read-back (P == 1: the rows are already selected), the position of numpy's global generator after this frame's resampling
+// (the template's draw count if it resampled, else the search's: regularize_pc reseeds on every call, :349-350), then
+// ptt_track_box_by_offset. info (B,2,2) int32 = (n, draws used) of the search / template resampling; a negative draw count (the
+// draw table ran out) is reported as PTT_EINVAL. est_out (B,5) receives the selected rows with the offsets actually used.
+extern "C" int ptt_track_select_update(const float* proposals, int P, const int32_t* info, ptt_track_box* boxes, int n, int use_z,
+                                       const int32_t* active, int64_t* rng_pos, float* est_out) {
+    if (n < 0 || P < 1) return fail(PTT_EINVAL, "ptt_track_select_update: n=%d P=%d", n, P);
+    if (n == 0) return PTT_OK;
+    if (!proposals || !info || !boxes || !rng_pos || !est_out) return fail(PTT_EINVAL, "ptt_track_select_update: null pointer");
+    for (int b = 0; b < n; ++b) {
+        const float* rows = proposals + (size_t)b * P * 5;
+        int best = 0;
+        for (int k = 1; k < P; ++k)
+            if (rows[k * 5 + 4] > rows[best * 5 + 4]) best = k;             // strict: the first among equals; a NaN never wins
+        if (P > 1 && rows[4] != rows[4]) {                                   // np.argmax returns the first NaN
+            best = 0;
+        } else if (P > 1) {
+            for (int k = 0; k < P; ++k)
+                if (rows[k * 5 + 4] != rows[k * 5 + 4]) { best = k; break; }
+        }
+        for (int c = 0; c < 5; ++c) est_out[b * 5 + c] = rows[best * 5 + c];
+        const int32_t* f = info + b * 4;
+        if (f[1] < 0 || f[3] < 0)
+            return fail(PTT_EINVAL, "ptt_track_select_update: ptt_regularize_f32 ran out of pre-drawn MT19937 outputs (tracklet %d)", b);
+        const int32_t used = f[3] > 0 ? f[3] : f[1];
+        if (used > 0) rng_pos[b] = used;
+    }
+    return ptt_track_box_by_offset(boxes, n, est_out, 5, use_z, active, rng_pos);
+}
+

@@ -580,6 +580,18 @@ def track_box_by_offset(boxes, offsets, use_z, active=None, rng_pos=None):
                "ptt_track_box_by_offset")
 
 
+def track_select_update(proposals, info, boxes, use_z, active, rng_pos, est_out):
+    """ptt_track_select_update: the host side of one step's post-processing in one call — proposals: float32 host array (B,P,5) or
+    (B,5); info: int32 host array (B,2,2); boxes TRACK_BOX (B,) in place; rng_pos int64 (B,) in place; est_out float32 (B,5)."""
+    B = len(boxes)
+    P = proposals.shape[1] if proposals.ndim == 3 else 1
+    assert proposals.dtype == np.float32 and proposals.flags['C_CONTIGUOUS'] and info.dtype == np.int32 and info.flags['C_CONTIGUOUS']
+    assert est_out.dtype == np.float32 and est_out.shape == (B, 5) and est_out.flags['C_CONTIGUOUS'] and rng_pos.dtype == np.int64
+    rc = _lib.lib().ptt_track_select_update(proposals.ctypes.data, P, info.ctypes.data, boxes.ctypes.data, B, int(bool(use_z)),
+                                            active.ctypes.data if active is not None else None, rng_pos.ctypes.data, est_out.ctypes.data)
+    _lib.check(rc, "ptt_track_select_update")
+
+
 _mt_tables = {}
 
 

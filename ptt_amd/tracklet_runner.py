@@ -125,6 +125,12 @@ class TrackletRunner(object):
         self.out_ptr = (self.crop_out.data_ptr() + (np.arange(B)[:, None] * 3 + np.arange(3)[None]) * (cap * 3 * esz)).astype(np.uint64)
         self.cnt_ptr = (self.counts.data_ptr() + (np.arange(B)[:, None] * 3 + np.arange(3)[None]) * 4).astype(np.uint64)
         self.ptr[self.npts == 0] = self.crop_out.data_ptr()        # empty jobs still carry a valid address
+        # per tracked frame i the cloud fields of the interleaved 2B-job table: even jobs = frame i, odd jobs = frame i - 1
+        ff = [np.zeros((T, 2 * B), dt) for dt in (np.uint64, np.int64, np.int32)]
+        for dst, src in zip(ff, (self.ptr, self.ld, self.npts)):
+            dst[:, 0::2] = src
+            dst[1:, 1::2] = src[:-1]
+        self.frame_fields = ff
         # the resampling jobs never change within a group: fixed segment / output pointers
         rj = np.zeros(2 * B, ops.REGULARIZE_JOB)
         s, t = rj[0::2], rj[1::2]
@@ -161,6 +167,25 @@ class TrackletRunner(object):
             self.crop_jobs_dev.copy_(self.crop_jobs_host, non_blocking=True)
             ops.crop_compact(self.crop_jobs_dev, 2 * self.B)
 
+    def _frame_jobs(self, i, extra2):
+        """The crop table of tracked frame i >= 1 written into the pinned staging buffer with three array assignments and two
+        calls: job 2b = cloud i of tracklet b around its current box into slot 0 (the search crop, `extra2` = gt_wlh1 * 0.6),
+        job 2b + 1 = cloud i - 1 into slot 2 (get_model's previous-frame segment). The per-frame cloud fields were laid out for
+        all frames by _load (self.frame_fields); `out` / `count` were set for these slots once (_steps)."""
+        jobs = self.crop_jobs_host_np
+        pts, ld, npts = self.frame_fields
+        jobs['points'], jobs['ld'], jobs['n_points'] = pts[i], ld[i], npts[i]
+        ops.track_crop_bounds(self.boxes, self.search_offset, self.search_scale, extra2, jobs[0::2], job_stride=2)
+        ops.track_crop_bounds(self.boxes, self.model_offset, self.model_scale, None, jobs[1::2], job_stride=2)
+
+    def _launch_jobs(self):
+        jobs = self.crop_jobs_host_np
+        if self.few:
+            ops.crop_compact_host(jobs, 2 * self.B, self.device)
+        else:
+            self.crop_jobs_dev.copy_(self.crop_jobs_host, non_blocking=True)
+            ops.crop_compact(self.crop_jobs_dev, 2 * self.B)
+
     # ------------------------------------------------------------------ one group in lockstep
     def _steps(self, tracklets):
         """Generator form of one lockstep group: every `yield` sits between "frame i's device work is enqueued" and
@@ -190,6 +215,14 @@ class TrackletRunner(object):
         # table is written into it (every later frame waits for its boxes anyway)
         self._done.record(torch.cuda.current_stream(self.device))
         self._done.synchronize()
+        # every tracked frame crops into the same slots: search -> 0, previous-frame template segment -> 2
+        jobs = self.crop_jobs_host_np
+        jobs['out'][0::2], jobs['count'][0::2] = self.out_ptr[:, 0], self.cnt_ptr[:, 0]
+        jobs['out'][1::2], jobs['count'][1::2] = self.out_ptr[:, 2], self.cnt_ptr[:, 2]
+        extra_search = np.ascontiguousarray(gt_wlh1 * 0.6)        # (T, B): gt_box.wlh[1] * 0.6 enters the search crop (:321)
+        est_buf = np.zeros((B, 5), np.float32)
+        active_all = (np.arange(T)[:, None] < lengths[None, :]).astype(np.int32)
+        views = None                                             # numpy views of the pinned read-back buffers, made once
 
         prof = self.profile
         if prof is not None:
@@ -201,18 +234,19 @@ class TrackletRunner(object):
             if prof is not None:
                 t_a = time.perf_counter()
                 ev0.record(torch.cuda.current_stream(self.device))
-            active = (i < lengths).astype(np.int32)
+            active = active_all[i]
             # both crops of frame i are taken around the previous RESULT box (prepare_search :156-157, prepare_template
             # :189-194 with results_BBs[frame_id - 1]); a finished tracklet's later frames have n_points 0
             if self.few and self.use_graph:
                 # a handful of tracklets: the WHOLE frame is one hipGraph replay — crops (their table read from pinned host
                 # memory, rewritten here), resampling, read-back of the draw counts, tracker, read-back of the proposals
-                self._crop_jobs(i, 0, (self.search_offset, self.search_scale, gt_wlh1[i] * 0.6), i - 1, 2, model_cfg, launch=False)
+                self._frame_jobs(i, extra_search[i])
                 if self._frame is None:
                     self._capture_frame()
                 self._frame.replay()
             else:
-                self._crop_jobs(i, 0, (self.search_offset, self.search_scale, gt_wlh1[i] * 0.6), i - 1, 2, model_cfg)
+                self._frame_jobs(i, extra_search[i])
+                self._launch_jobs()
                 ops.regularize(self.reg_jobs_dev, 2 * B, self.draws)
                 self.info_host.copy_(self.info, non_blocking=True)   # behind the resampling, ahead of the model: off the frame's tail
                 rows = self._forward()
@@ -228,23 +262,19 @@ class TrackletRunner(object):
             if prof is not None:
                 t_c = time.perf_counter()
             if self.few and self.use_graph:                      # one buffer: (B,P,5) proposals, then the resampling counts
-                host = self.readback_host.numpy()
-                est, info = host[:self.n_box].reshape(B, self.P, 5), host[self.n_box:].view(np.int32).reshape(B, 2, 2)
-            else:
-                est = self.result_host.numpy()                    # (B,5) float32: x, y, z, theta (degrees), score
-                info = self.info_host.numpy()
-            if est.ndim == 3:                                     # (B,P,5): the first arg-max of the scores, as post_process takes it (:267-269)
-                est = est[np.arange(B), np.argmax(est[:, :, 4], axis=1)]
-            # post_process (:266-274): box_i = get_box_by_offset(box_{i-1}, best proposal, USE_Z_AXIS). An implausibly
-            # large x / y offset is redrawn from numpy's GLOBAL generator (:205-208), whose state then is "seeded with 1
-            # and advanced by the template's (else the search's) resampling draws" — the draw counts come back with the boxes
-            if (info[:, :, 1] < 0).any():
-                raise RuntimeError("ptt_regularize_f32 ran out of pre-drawn MT19937 outputs (a cloud was filled with NaN): "
-                                   "give mt19937_draws a longer table")
-            used = np.where(info[:, 1, 1] > 0, info[:, 1, 1], info[:, 0, 1])
-            rng_pos = np.where(used > 0, used, rng_pos).astype(np.int64)
-            ops.track_box_by_offset(boxes, est, self.use_z, active, rng_pos)
-            history.append((active, boxes['center'].copy(), boxes['quat'].copy(), est[:, 4].copy()))
+                if views is None:
+                    host = self.readback_host.numpy()
+                    views = (host[:self.n_box].reshape(B, self.P, 5), host[self.n_box:].view(np.int32).reshape(B, 2, 2))
+            elif views is None or views[2] is not self.result_host:
+                # (B,5) float32: x, y, z, theta (degrees), score
+                views = (self.result_host.numpy(), self.info_host.numpy(), self.result_host)
+            est, info = views[0], views[1]
+            # post_process (:266-274) in one call (ptt_track_select_update): the first arg-max of the scores where the read-back is
+            # (B,P,5) (:267-269), box_i = get_box_by_offset(box_{i-1}, best proposal, USE_Z_AXIS). An implausibly large x / y offset
+            # is redrawn from numpy's GLOBAL generator (:205-208), whose state then is "seeded with 1 and advanced by the template's
+            # (else the search's) resampling draws" — the draw counts come back with the boxes; a draw table that ran out raises
+            ops.track_select_update(est, info, boxes, self.use_z, active, rng_pos, est_buf)
+            history.append((active, boxes['center'].copy(), boxes['quat'].copy(), est_buf[:, 4].copy()))
             if prof is not None:
                 t_d = time.perf_counter()
                 ev1.synchronize()

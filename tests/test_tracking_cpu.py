@@ -158,3 +158,46 @@ def test_G16_oracle_training_crop_labels_equal_the_reference():
             pos += int(label.sum())
             assert 0 < label.sum() < label.shape[0]                                # both classes present in every crop
     assert pos > 5000
+
+
+def test_track_select_update_is_argmax_plus_generator_bookkeeping_plus_box_update():
+    """ptt_track_select_update (a HOST function: runs here) against its three numpy / library steps: np.argmax of the scores (first
+    among equals, first NaN), the generator position rule (template's draw count if it resampled, else the search's, else unchanged),
+    ptt_track_box_by_offset; a negative draw count raises."""
+    import pytest
+    from ptt_amd import ops
+    rs = np.random.RandomState(5)
+    B, P = 6, 64
+    prop = rs.standard_normal((B, P, 5)).astype(np.float32)
+    prop[1, 10, 4] = prop[1, 40, 4] = 9.0                       # a tie: the first wins
+    prop[2, 30, 4] = np.nan                                     # np.argmax returns the first NaN
+    info = np.zeros((B, 2, 2), np.int32)
+    info[:, 0, 1] = [100, 0, 7, 0, 50, 3]
+    info[:, 1, 1] = [0, 0, 9, 20, 60, 0]
+    def boxes():
+        bx = np.zeros(B, ops.TRACK_BOX)
+        bx['center'] = np.linspace(0, 1, B * 3).reshape(B, 3)
+        bx['wlh'], bx['quat'][:, 0] = (1.7, 4.2, 1.5), 1.0
+        return bx
+    active = np.array([1, 1, 1, 0, 1, 1], np.int32)
+    pos0 = np.arange(B).astype(np.int64) + 1000
+    a, pa, est = boxes(), pos0.copy(), np.zeros((B, 5), np.float32)
+    ops.track_select_update(prop, info, a, True, active, pa, est)
+    best = np.argmax(prop[:, :, 4], axis=1)
+    assert list(best[:3]) == [int(np.argmax(prop[0, :, 4])), 10, 30]
+    ref_est = prop[np.arange(B), best].copy()
+    used = np.where(info[:, 1, 1] > 0, info[:, 1, 1], info[:, 0, 1])
+    pb = np.where(used > 0, used, pos0).astype(np.int64)
+    b = boxes()
+    ops.track_box_by_offset(b, ref_est, True, active, pb)
+    np.testing.assert_array_equal(est, ref_est)
+    np.testing.assert_array_equal(pa, pb)
+    for k in ('center', 'quat', 'wlh'):
+        np.testing.assert_array_equal(a[k], b[k])
+    # rows already selected (the (B,5) read-back of a large batch)
+    a2, pa2, est2 = boxes(), pos0.copy(), np.zeros((B, 5), np.float32)
+    ops.track_select_update(np.ascontiguousarray(prop[np.arange(B), best]), info, a2, True, active, pa2, est2)
+    np.testing.assert_array_equal(a2['center'], a['center'])
+    info[4, 1, 1] = -1
+    with pytest.raises(RuntimeError, match="ran out of pre-drawn MT19937 outputs"):
+        ops.track_select_update(prop, info, boxes(), True, active, pos0.copy(), est)
