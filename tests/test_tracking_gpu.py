@@ -115,7 +115,7 @@ def test_select_box_is_first_argmax(dev):
         np.testing.assert_array_equal(out[b], x[b, x[b, :, 4].argmax()])
 
 
-@pytest.mark.parametrize("batch,lengths", [(1, [6]), (3, [5, 3, 6]), (2, [4, 4, 3])])
+@pytest.mark.parametrize("batch,lengths", [(1, [6]), (3, [5, 3, 6]), (2, [4, 4, 3]), (6, [4, 3, 5, 2, 4])])
 def test_tracklet_runner_equals_the_reference_loop(dev, batch, lengths):
     """TrackletRunner (clouds resident on the device, crop + resample + model graph + box selection per step, lockstep
     over `batch` tracklets, groups of tracklets when there are more than `batch`) against the oracle's restatement of
@@ -139,13 +139,18 @@ def test_tracklet_runner_equals_the_reference_loop(dev, batch, lengths):
                            'template_points': torch.from_numpy(np.ascontiguousarray(template)).to(dev), 'batch_size': 1})
         return out['pred_box_data'][0].cpu().numpy()
 
+    # batch 6: more than the "handful of tracklets" (ptt_amd.ops.CROP_JOBS_BY_VALUE_MAX / 2) — the job table is uploaded, the best
+    # proposal is selected on the device and (B,5) rows come back; the model then runs its many-frame kernels, whose sums are
+    # ordered differently from the one-frame chain the per-frame oracle loop takes (1e-5-level outputs): the boxes agree to 1e-4,
+    # not bit for bit (a wrong slot, tracklet order or generator position would be off by decimetres)
+    tol = 1e-9 if 2 * batch <= ops.CROP_JOBS_BY_VALUE_MAX else 1e-4
     n_moved = 0
     for (clouds, boxes), res in zip(tracklets, got):
         ref = TR.track(clouds, [TR.RefBox(*b) for b in boxes], infer, use_z=True)
         assert len(res) == len(ref) == len(clouds)
         for i, (r, o) in enumerate(zip(res, ref)):
-            np.testing.assert_allclose(r[0], o.center, rtol=0, atol=1e-9, err_msg="frame %d centre" % i)
-            np.testing.assert_allclose(bm.q_rotation_matrix(r[2]), o.rotation_matrix, rtol=0, atol=1e-9)
+            np.testing.assert_allclose(r[0], o.center, rtol=0, atol=tol, err_msg="frame %d centre" % i)
+            np.testing.assert_allclose(bm.q_rotation_matrix(r[2]), o.rotation_matrix, rtol=0, atol=tol)
             n_moved += int(i > 0 and float(np.abs(r[0] - res[0][0]).max()) > 1e-6)
     assert n_moved > 0
 
