@@ -451,14 +451,12 @@ extern "C" int ptt_track_select_update(const float* proposals, int P, const int3
     if (!proposals || !info || !boxes || !rng_pos || !est_out) return fail(PTT_EINVAL, "ptt_track_select_update: null pointer");
     for (int b = 0; b < n; ++b) {
         const float* rows = proposals + (size_t)b * P * 5;
-        int best = 0;
-        for (int k = 1; k < P; ++k)
-            if (rows[k * 5 + 4] > rows[best * 5 + 4]) best = k;             // strict: the first among equals; a NaN never wins
-        if (P > 1 && rows[4] != rows[4]) {                                   // np.argmax returns the first NaN
-            best = 0;
-        } else if (P > 1) {
-            for (int k = 0; k < P; ++k)
-                if (rows[k * 5 + 4] != rows[k * 5 + 4]) { best = k; break; }
+        int best = 0;                                                        // np.argmax: the first maximum; the first NaN if there is one
+        bool nan_seen = rows[4] != rows[4];
+        for (int k = 1; k < P && !nan_seen; ++k) {
+            const float v = rows[k * 5 + 4];
+            if (v != v) { best = k; nan_seen = true; }
+            else if (v > rows[best * 5 + 4]) best = k;
         }
         for (int c = 0; c < 5; ++c) est_out[b * 5 + c] = rows[best * 5 + c];
         const int32_t* f = info + b * 4;
