@@ -1060,8 +1060,9 @@ extern "C" int ptt_scatter_csr_i32(const int32_t* idx, int B, int N, int E, int3
     if (B < 0 || N <= 0 || E <= 0) return fail(PTT_EINVAL, "ptt_scatter_csr_i32: B=%d N=%d E=%d", B, N, E);
     if (B == 0) return PTT_OK;
     if (!idx || !order || !start) return fail(PTT_EINVAL, "ptt_scatter_csr_i32: null pointer");
-    if (E > 16384 || (unsigned long long)N * 16384ull > 0xffffffffull)
-        return fail(PTT_EUNSUPPORTED, "ptt_scatter_csr_i32: E=%d N=%d (at most 16384 entries per cloud)", E, N);
+    // the counting sort (N <= 2048 bins) has no limit on the entries; the bitonic network sorts 64 KB of keys in LDS
+    if (N > 2048 && (E > 16384 || (unsigned long long)N * 16384ull > 0xffffffffull))
+        return fail(PTT_EUNSUPPORTED, "ptt_scatter_csr_i32: E=%d N=%d (more than 2048 bins: at most 16384 entries per cloud)", E, N);
     return launch_scatter_csr(idx, B, N, E, order, start, as_stream(stream));
 }
 

@@ -199,7 +199,8 @@ def test_cos_map_function_equals_the_elementwise_formulation(dev):
 
 
 @pytest.mark.parametrize("B,N,E,hot", [(48, 1024, 16384, False), (3, 512, 8192, True), (2, 100, 37, False), (1, 16, 16384, True),
-                                       (2, 2048, 4096, False), (2, 3000, 5000, False), (4, 128, 2048, True), (1, 1, 700, False)])
+                                       (2, 2048, 4096, False), (2, 3000, 5000, False), (4, 128, 2048, True), (1, 1, 700, False),
+                                       (2, 1024, 65536, True)])          # more entries than the bitonic network holds: counting sort only
 def test_scatter_csr_is_the_stable_sort_by_bin(dev, B, N, E, hot):
     """ptt_scatter_csr_i32 (counting sort up to 2048 bins, bitonic above): order = the entries sorted by (bin, entry) — exactly
     numpy's stable argsort — and start = the bins' first slots; hot: most entries in a few bins (ball-query padding repeats a
