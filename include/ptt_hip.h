@@ -559,7 +559,8 @@ int ptt_pt_attn_fwd_ld_f32(const float* a, const float* vf, int ldv, const int32
 /* Grouping of point-major rows and its deterministic backward (the training-mode layer-0 hoist: the first MLP layer's
  * feature half is evaluated once per point, then gathered per (centre, neighbour) row):
  *   ptt_gather_rows_f32       out[b,e,:] = src[b, idx[b,e], :]        src (B,N,C), idx (B,E) -> out (B,E,C); C % 4 == 0
- *   ptt_scatter_csr_i32       order (B,E) / start (B,N+1): the entries of every cloud sorted by (idx, e)
+ *   ptt_scatter_csr_i32       order (B,E) / start (B,N+1): the entries of every cloud sorted by (idx, e) — a stable counting sort
+ *                             up to 2048 bins (any E), a bitonic network in LDS above (E <= 16384)
  *   ptt_scatter_rows_csr_f32  out[b,n,:] = sum of g[b,e,:] over idx[b,e] == n in ascending e (fixed order) */
 int ptt_gather_rows_f32(const float* src, const int32_t* idx, int B, int N, int E, int C, float* out, ptt_stream_t stream);
 int ptt_scatter_csr_i32(const int32_t* idx, int B, int N, int E, int32_t* order, int32_t* start, ptt_stream_t stream);
