@@ -5,12 +5,12 @@ set -e
 S=${1:-z}
 O=gpurun_out/r04$S
 for f in pytest_gpu.log bench_default.json bench_train.json serial_kernel_stats.csv serial_bench_line.json train_kernel_stats.csv \
-         train_profiled_bench_line.json b1_kernel_stats.csv sa_z0_bnbwd_probe.log; do
+         train_profiled_bench_line.json b1_kernel_stats.csv sa_z0_bnbwd_probe.log train_stream_kernels_bench.log; do
     [ -f $O/$f ] && cp $O/$f profiles/r04${S}_$f
 done
 for f in last_step_by_shape.txt last_step_launches.txt; do
     [ -f $O/train_timeline/$f ] && cp $O/train_timeline/$f profiles/r04${S}_train_$f
 done
-for d in pmc pmc_stress pmc_train_gemm; do
+for d in pmc pmc_stress pmc_train_gemm pmc_train_stream; do
     if [ -f $O/$d/pmc_summary.json ]; then mkdir -p profiles/r04${S}_$d; cp $O/$d/*.csv $O/$d/pmc_summary.json profiles/r04${S}_$d/; fi
 done

@@ -83,6 +83,8 @@ z)  # closing evidence of the round: parity tests, the default bench line (all c
     bash scripts/pmc_passes.sh $O/pmc "pair,sa0_s,sa1_s,sa2_s,sa_box,xcorr,lin_,rj" > $O/pmc.log 2>&1; tail -12 $O/pmc.log | cut -c1-300
     bash scripts/pmc_passes.sh $O/pmc_stress "pair" "" "--batch 32 --pair-n 2048,64" > $O/pmc_stress.log 2>&1; tail -4 $O/pmc_stress.log | cut -c1-300
     bash scripts/pmc_passes.sh $O/pmc_train_gemm - "python scripts/rows_gemm_bench.py --no-check --pmc" > $O/pmc_train_gemm.log 2>&1; tail -4 $O/pmc_train_gemm.log | cut -c1-300
+    timeout 300 python scripts/train_stream_kernels_bench.py 2>&1 | grep -v amdgpu.ids > $O/train_stream_kernels_bench.log
+    bash scripts/pmc_passes.sh $O/pmc_train_stream - "python scripts/train_stream_kernels_bench.py" > $O/pmc_train_stream.log 2>&1; tail -5 $O/pmc_train_stream.log | cut -c1-300
     python - <<PY
 import json
 d = json.load(open("$O/bench_default.json"))

@@ -25,7 +25,7 @@ pass() {
     fi
     f=$(find /tmp/pmc_$name -name "*counter_collection.csv" | head -1)
     if [ -n "$f" ]; then
-        grep -E "Counter_Name|pt_attn_pair|sa_fused_kernel|sa_wave_kernel|sa_stream_kernel|sa_lds_kernel|linear_kernel|linear_small_kernel|xcorr_fused|rows_gemm_kernel|wgrad2_kernel|linear_wgrad_kernel|rowjobs_kernel" "$f" > "$REPO/$OUT/pmc_$name.csv"
+        grep -E "Counter_Name|pt_attn_pair|sa_fused_kernel|sa_wave_kernel|sa_stream_kernel|sa_lds_kernel|linear_kernel|linear_small_kernel|xcorr_fused|rows_gemm_kernel|wgrad2_kernel|linear_wgrad_kernel|rowjobs_kernel|wgrad_stream_kernel|sa_z0_bnbwd_kernel|xcorr_z0_bnbwd_kernel|scatter_csr_count_kernel" "$f" > "$REPO/$OUT/pmc_$name.csv"
     else
         tail -5 /tmp/pmc_$name.log > "$REPO/$OUT/pmc_$name.err"
     fi
