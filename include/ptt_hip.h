@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PTT_ABI_VERSION 17
+#define PTT_ABI_VERSION 18
 
 enum {
     PTT_OK = 0,
@@ -55,6 +55,10 @@ const char* ptt_last_error_string(void);
  * ------------------------------------------------------------------------------- */
 int ptt_fps_f32(const float* xyz, int B, int N, int npoint, int32_t* idx_out,
                 ptt_stream_t stream);
+/* The same call for clouds of any size (the reference's op has no limit; ptt_fps_f32 answers PTT_EUNSUPPORTED for
+ * N > 16384 or npoint > 15360): the running min-distance in `workspace` (>= B*N floats), identical picks, slower. */
+int ptt_fps_ws_f32(const float* xyz, int B, int N, int npoint, int32_t* idx_out, float* workspace,
+                   size_t workspace_elems, ptt_stream_t stream);
 
 /* ---------------------------------------------------------------------------------
  * F2  gather centres

@@ -808,6 +808,55 @@ __global__ __launch_bounds__(256) void fps_ball_knn_kernel(FbkParams p) {
     }
 }
 
+// FPS of clouds beyond the register-resident kernel's reach (N > 16384 or npoint > 15360): the running min-distance lives
+// in a caller-provided workspace (4 N bytes per cloud, each thread touching only its own strided entries: no fence), the
+// coordinates are re-read from L2 every iteration and the picks go straight to global memory. One 1024-thread workgroup per
+// cloud; the arg-max travels as a (distance, index) pair — larger distance, then lower index — through the wave
+// (shuffles) and through one parity-double-buffered LDS slot per wave (one barrier per iteration). Same arithmetic
+// contract and the same picks as fps_kernel; ~N / 1024 L2 round trips per iteration instead of none — the slow, unlimited form.
+__device__ __forceinline__ void fps_better(float& v, int& i, float ov, int oi) {
+    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+}
+__global__ __launch_bounds__(1024) void fps_ws_kernel(const float* __restrict__ xyz, int N, int npoint, float* __restrict__ ws,
+                                                      int32_t* __restrict__ idx_out) {
+    __shared__ float slot_v[2][16];
+    __shared__ int slot_i[2][16];
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const float* __restrict__ pts = xyz + (size_t)b * N * 3;
+    float* __restrict__ md = ws + (size_t)b * N;
+    int32_t* __restrict__ out = idx_out + (size_t)b * npoint;
+    for (int k = t; k < N; k += 1024) {
+        const float x = pts[3 * k], y = pts[3 * k + 1], z = pts[3 * k + 2];
+        md[k] = ((x * x + y * y) + z * z > 1e-3f) ? 1e10f : -1.f;          // -1: skipped, never updated, never chosen
+    }
+    if (t == 0) out[0] = 0;
+    int last = 0;
+    for (int j = 1; j < npoint; ++j) {
+        const float lx = pts[3 * last], ly = pts[3 * last + 1], lz = pts[3 * last + 2];
+        float best = -1.f;
+        int besti = 0;
+        for (int k = t; k < N; k += 1024) {
+            const float m0 = md[k];
+            if (m0 < 0.f) continue;
+            const float d = sqdist3(pts[3 * k], pts[3 * k + 1], pts[3 * k + 2], lx, ly, lz);
+            const float m = d < m0 ? d : m0;
+            md[k] = m;
+            if (m > best) { best = m; besti = k; }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+            fps_better(best, besti, __shfl_xor(best, off, 64), __shfl_xor(besti, off, 64));
+        const int par = j & 1;
+        if (lane == 0) { slot_v[par][wv] = best; slot_i[par][wv] = besti; }
+        __syncthreads();
+        best = slot_v[par][0]; besti = slot_i[par][0];
+#pragma unroll
+        for (int w = 1; w < 16; ++w) fps_better(best, besti, slot_v[par][w], slot_i[par][w]);
+        last = besti;
+        if (t == 0) out[j] = besti;
+    }
+}
+
 }  // namespace ptt
 
 using namespace ptt;
@@ -849,8 +898,20 @@ extern "C" int ptt_fps_f32(const float* xyz, int B, int N, int npoint, int32_t* 
     if (N <= 8192) return launch_fps<1024, 8>(xyz, B, N, npoint, idx_out, s);
     if (N <= 16384) return launch_fps<1024, 16>(xyz, B, N, npoint, idx_out, s);
     // 32 points per thread (clouds up to 32768 points) is the whole 128-register budget of a 1024-thread workgroup and spilled
-    // 164-180 bytes per lane: no BASELINE config reaches it (the largest is 16384), so it is refused rather than shipped slow
-    return fail(PTT_EUNSUPPORTED, "ptt_fps_f32: N=%d exceeds the register-resident limit 16384", N);
+    // 164-180 bytes per lane: no BASELINE config reaches it (the largest is 16384); such clouds take ptt_fps_ws_f32
+    return fail(PTT_EUNSUPPORTED, "ptt_fps_f32: N=%d exceeds the register-resident limit 16384 (use ptt_fps_ws_f32)", N);
+}
+
+extern "C" int ptt_fps_ws_f32(const float* xyz, int B, int N, int npoint, int32_t* idx_out, float* workspace, size_t workspace_elems,
+                              ptt_stream_t stream) {
+    if (B < 0 || N <= 0 || npoint < 0) return fail(PTT_EINVAL, "ptt_fps_ws_f32: B=%d N=%d npoint=%d", B, N, npoint);
+    if (B == 0 || npoint == 0) return PTT_OK;
+    if (!xyz || !idx_out) return fail(PTT_EINVAL, "ptt_fps_ws_f32: null pointer");
+    if ((long long)N * 3 > INT_MAX) return fail(PTT_EUNSUPPORTED, "ptt_fps_ws_f32: N=%d", N);
+    if (!workspace || workspace_elems < (size_t)B * N)
+        return fail(PTT_EWORKSPACE, "ptt_fps_ws_f32: %zu floats of workspace needed", (size_t)B * N);
+    hipLaunchKernelGGL(fps_ws_kernel, dim3(B), dim3(1024), 0, as_stream(stream), xyz, N, npoint, workspace, idx_out);
+    return check_launch("fps_ws_kernel");
 }
 
 // centres per wave of the ball-query kernels: 4 when the launch still has at least two waves per SIMD of the device and

@@ -27,7 +27,9 @@ __device__ __forceinline__ float smooth_l1_grad(float d) { return fabsf(d) < 1.f
 __device__ __forceinline__ float seed_label(const ptt_track_loss_desc& d, int i) {
     if (!d.search_inds) return d.cls_label[i];
     const int b = i / d.N;
-    return d.cls_label[(size_t)b * d.Ns + d.search_inds[i]];
+    // the torch.gather this replaces raises on an index outside the cloud; here it must at least never leave the buffer
+    const long long k = d.search_inds[i];
+    return d.cls_label[(size_t)b * d.Ns + (size_t)(k < 0 ? 0 : (k >= d.Ns ? d.Ns - 1 : k))];
 }
 // box_voting_head.py:96-101: label = dist < 0.3, mask = dist < 0.3 or dist > 0.6, dist = sqrt(|centre - gt centre|^2 + 1e-6)
 __device__ __forceinline__ void proposal_label(const ptt_track_loss_desc& d, int j, float& label, float& mask) {
@@ -279,6 +281,7 @@ extern "C" int ptt_adam_clip_step_f32(const ptt_adam_tensor* tensors_device, con
     if (hyper->max_norm > 0.f) {
         if (!partial || partial_elems < (size_t)n_chunks) return fail(PTT_EWORKSPACE, "ptt_adam_clip_step_f32: %d partial sums needed", n_chunks);
         hipLaunchKernelGGL(grad_sqsum_kernel, dim3(n_chunks), dim3(256), 0, s, tensors_device, chunk_tensor_device, chunk_first_device, partial);
+        if (int rc = check_launch("grad_sqsum_kernel")) return rc;
     }
     hipLaunchKernelGGL(adam_update_kernel, dim3(n_chunks), dim3(256), 0, s, tensors_device, chunk_tensor_device, chunk_first_device, partial,
                        n_chunks, *hyper, norm_out);

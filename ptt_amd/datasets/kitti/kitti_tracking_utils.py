@@ -201,8 +201,8 @@ def _crop_on_device(pcs, boxes, offset, scale, extra2, label_boxes=None, label_o
 def crop_center_pc(pc, sample_box, gt_box=None, sample_offsets=None, offset=0.0, scale=1.0, normalize=False,
                    visual_handle=None, refine_box=True):
     """:300-339. Returns the cropped cloud in the sample box's frame (device-resident). With `gt_box` also the per-point
-    labels (:308-312 get_label_by_box on the first crop, carried through the second crop :322; a device bool tensor — the
-    same launch forms them) and the regression target label_reg (:325-329)."""
+    labels (:308-312 get_label_by_box on the first crop, carried through the second crop :322; a device float64 0/1 tensor,
+    the dtype get_label_by_box :269-271 returns — the same launch forms them) and the regression target label_reg (:325-329)."""
     extra2 = gt_box.wlh[1] * 0.6 if gt_box is not None else 0.0
     new_label = None
     if gt_box is not None:
@@ -212,7 +212,7 @@ def crop_center_pc(pc, sample_box, gt_box=None, sample_offsets=None, offset=0.0,
         outs, counts = _crop_on_device([pc], [sample_box], offset, scale, extra2)
     n = int(counts.cpu()[0])
     if gt_box is not None:
-        new_label = labels[0][:n].bool()
+        new_label = labels[0][:n].to(torch.float64)
     new_pc = PointCloud.__new__(PointCloud)
     new_pc.points = outs[0][:n].t().contiguous()
     if normalize:
@@ -248,12 +248,11 @@ def regularize_pc(pc, input_size, ratio=1, label=None, reg=None, istrain=True):
     the device (ptt_regularize_f32), numpy's global generator left as the reference leaves it. istrain=True (the data
     loader's form, :349-353 without the reseed): the indices are drawn here from numpy's running global generator, exactly as
     the reference draws them, and gathered on the device. With `label` (crop_center_pc's per-point labels, a device tensor)
-    -> (points, label resampled with the same indices (:354-355; zeros for an (almost) empty crop :361-362), reg)."""
-    if label is not None and not (istrain and input_size > 0):
-        if input_size <= 0:
-            return pc.points.t().contiguous(), label, reg
-        raise NotImplementedError("regularize_pc: per-point labels are resampled in the data loader's form (istrain=True) only")
-    if istrain and input_size > 0:
+    -> (points, label resampled with the same indices (:354-355; zeros for an (almost) empty crop :361-362), reg), float64
+    labels in every branch and for both values of istrain."""
+    if label is not None and input_size <= 0:
+        return pc.points.t().contiguous(), label, reg
+    if input_size > 0 and (istrain or label is not None):
         size = int(input_size) // int(ratio)
         rows = pc.points.t().contiguous()
         n = rows.shape[0]
@@ -261,8 +260,15 @@ def regularize_pc(pc, input_size, ratio=1, label=None, reg=None, istrain=True):
         if n <= 2:
             return with_label(torch.zeros((size, 3), dtype=torch.float32, device=rows.device),
                               torch.zeros((size,), dtype=torch.float64, device=rows.device))
+        if label is not None:
+            label = label.to(torch.float64)                    # one dtype in every branch (the reference's: float64 0/1)
         if n == size:
             return with_label(rows, label)
+        if not istrain:
+            # the evaluation form with labels (:348-355): the same draws the tracking loop's form below reproduces on the
+            # device, taken on the host here because the labels ride on the indices; numpy's global generator is left
+            # seeded with 1 and advanced by exactly these draws, as the reference leaves it
+            np.random.seed(1)
         idx = torch.from_numpy(np.random.randint(low=0, high=n, size=size, dtype=np.int64)).to(rows.device)
         return with_label(rows.index_select(0, idx), label.index_select(0, idx) if label is not None else None)
     if input_size <= 0:

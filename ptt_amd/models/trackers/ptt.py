@@ -34,7 +34,8 @@ class PTT(Tracker3DTemplate):
                 return None
         t = (dc['pred_centroids_cls'], dc['pred_centroids_votes'], db['pred_box_data'], db['centres'], dc['cls_label_points'], dc['reg_label'],
              c.cls_loss_func.pos_weight, b.cls_loss_func.pos_weight)
-        if not train_ops.track_losses_usable(*t) or dc['pred_centroids_cls'].dim() != 2 or db['pred_box_data'].shape[-1] != 5:
+        if dc['pred_centroids_cls'].dim() != 2 or db['pred_box_data'].shape[-1] != 5 or not train_ops.track_losses_usable(
+                *t, search_inds=dc['search_inds'], seeds_shape=dc['pred_centroids_cls'].shape):
             return None
         wc, wb = c.model_cfg.LOSS_CONFIG.LOSS_WEIGHTS, b.model_cfg.LOSS_CONFIG.LOSS_WEIGHTS
         total, vals = train_ops.track_losses(t[0], t[1], t[2], t[3], t[4], dc['search_inds'], t[5], t[6], t[7],

@@ -241,7 +241,8 @@ class TransformerBlockSTD(nn.Module):
         self._cache = (key, P)
         return P
 
-    def forward(self, xyz, features):
+    def forward(self, xyz, features, knn=None):
+        # `knn`: the callers hand every block the neighbour table formed beside their sampling; full attention has no use for it
         if self._fusable(xyz, features):
             P, D = self._params(), self.d_model
             B, N, _ = xyz.shape

@@ -115,13 +115,21 @@ def _ptr(t):
 
 
 # --------------------------------------------------------------------------- _ext-compatible ops
+FPS_RESIDENT_MAX_N, FPS_RESIDENT_MAX_NPOINT = 16384, 15360         # ptt_fps_f32's register / LDS-resident reach
+
+
 def furthest_point_sampling(xyz, npoint):
     """(B,N,3) f32 -> (B,npoint) i32.  Replaces _ext.furthest_point_sampling (pointnet2_utils.py:78)."""
     _chk(xyz, "xyz", torch.float32, 3)
     B, N, _ = xyz.shape
     out = torch.empty((B, int(npoint)), dtype=torch.int32, device=xyz.device)
     with torch.cuda.device(xyz.device), _timed('ptt_fps_f32'):
-        _lib.check(_lib.lib().ptt_fps_f32(_ptr(xyz), B, N, int(npoint), _ptr(out), _stream()), "ptt_fps_f32")
+        if N <= FPS_RESIDENT_MAX_N and int(npoint) <= FPS_RESIDENT_MAX_NPOINT:
+            _lib.check(_lib.lib().ptt_fps_f32(_ptr(xyz), B, N, int(npoint), _ptr(out), _stream()), "ptt_fps_f32")
+        else:           # the reference's op has no size limit: min-distances in a workspace, identical picks, slower
+            ws = torch.empty((B * N,), dtype=torch.float32, device=xyz.device)
+            _lib.check(_lib.lib().ptt_fps_ws_f32(_ptr(xyz), B, N, int(npoint), _ptr(out), _ptr(ws), ws.numel(), _stream()),
+                       "ptt_fps_ws_f32")
     return out
 
 

@@ -841,8 +841,15 @@ def _numeric_protocol(cls):
 _numeric_protocol(LossValues.Value)
 
 
-def track_losses_usable(*tensors):
-    return all(t is not None and t.is_cuda and t.dtype == torch.float32 for t in tensors)
+def track_losses_usable(*tensors, search_inds=None, seeds_shape=None):
+    """The one-launch losses take float32 device tensors and, with `search_inds`, a (B, N) int64 index table on the device
+    (what ops._track_loss_desc would otherwise refuse with a ValueError: the caller falls back to the heads' own losses)."""
+    if not all(t is not None and t.is_cuda and t.dtype == torch.float32 for t in tensors):
+        return False
+    if search_inds is not None:
+        return bool(search_inds.is_cuda and search_inds.dtype == torch.int64
+                    and (seeds_shape is None or tuple(search_inds.shape) == tuple(seeds_shape)))
+    return True
 
 
 def track_losses(seed_cls, votes, box_data, centres, cls_label, search_inds, reg_label, pw_seed, pw_box, weights):

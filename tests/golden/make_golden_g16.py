@@ -55,6 +55,12 @@ def main():
                 np.random.seed(4000 + i)
                 pts, cls, _ = ref_ku.regularize_pc(pc, 1024, label=label, reg=reg)
                 out["reg_points_%d" % i], out["reg_label_%d" % i] = np.asarray(pts, np.float32), np.asarray(cls)
+                # the evaluation form with labels (:348-355, istrain=False: set_manual_seed(1) in front of the draws), and
+                # the first draw of numpy's global generator after it (the state the call leaves behind)
+                np.random.seed(77)
+                pts, cls, _ = ref_ku.regularize_pc(pc, 1024, label=label, reg=reg, istrain=False)
+                out["eval_reg_points_%d" % i], out["eval_reg_label_%d" % i] = np.asarray(pts, np.float32), np.asarray(cls)
+                out["eval_next_draw_%d" % i] = np.asarray(np.random.randint(0, 1 << 30, size=4, dtype=np.int64))
     far = ref_ku.Box(g12["far_center"], wlh, PQ(array=g12["far_quat"]))
     pc, label, reg = ref_ku.crop_center_pc(ref_ku.PointCloud(g12["cloud_1"].copy()), far, box("gt", 1), sample_offsets=np.zeros(4, np.float32),
                                            offset=0.0, scale=1.25)

@@ -37,7 +37,8 @@ def test_gpus_2_spawns_two_ranks_itself():
     assert p.returncode != 0
     spawns = [l for l in p.stderr.splitlines() if "spawn: 2 ranks" in l]
     assert len(spawns) == 2 and "--workload train" in spawns[1] and "--workload train" not in spawns[0], p.stderr[-2000:]
-    assert p.stderr.count("bench.py needs a HIP device") >= 4, p.stderr[-2000:]
+    # one rank's exit makes torchrun SIGTERM its sibling, which may not have printed yet: at least one per launch
+    assert p.stderr.count("bench.py needs a HIP device") >= 2, p.stderr[-2000:]
 
 
 def test_gpus_2_with_another_workload_is_one_launch():

@@ -1,0 +1,109 @@
+"""Round-5 GPU tests: the callers of the transformer block with the variant `build_transformer` also serves
+(TransformerBlockSTD, variants.py:12-40), and the gaps the round-4 review named."""
+import numpy as np
+import pytest
+import torch
+
+from ptt_amd import synth
+from tests.util import fill_state_dict_
+
+pytestmark = pytest.mark.gpu
+
+
+def _std_cfg():
+    from ptt_amd.config import ptt_model_cfg
+    cfg = ptt_model_cfg()
+    cfg.CENTROID_HEAD.TRANSFORMER_BLOCK.NAME = 'TransformerBlockSTD'
+    cfg.BOX_HEAD.TRANSFORMER_BLOCK.NAME = 'TransformerBlockSTD'
+    return cfg
+
+
+def test_both_heads_and_the_hot_path_run_the_std_variant(dev):
+    """Both voting heads and FrameHotPath hand every block the kNN table formed beside their sampling
+    (centroids_voting_head.py:71-76, box_voting_head.py:81-86 call `transformer_block(xyz, features)`): the dense variant
+    has no use for it and must accept it. Eval on the MFMA path == eval on the stock layers; a training step runs."""
+    from ptt_amd.config import StubDataset
+    from ptt_amd.hot_path import FrameHotPath, kitti_model_cfg, randomize_
+    from ptt_amd.models import build_network
+    from ptt_amd.models.transformer_block.variants import TransformerBlockSTD
+    s, t = synth.frames(31, 2, 1024, 512)
+    s, t = torch.from_numpy(s).to(dev), torch.from_numpy(t).to(dev)
+    model = fill_state_dict_(build_network(_std_cfg(), 1, StubDataset()), 7).to(dev).eval()
+    blocks = [model.centroid_voting_head.transformer_block, model.box_voting_head.transformer_block]
+    assert all(isinstance(b, TransformerBlockSTD) for b in blocks)
+    with torch.no_grad():
+        a = model({'search_points': s, 'template_points': t, 'batch_size': 2})
+        a = {k: a[k].clone() for k in ('pred_centroids_votes', 'votes_feats', 'pred_box_data')}
+        for b in blocks:
+            b._fusable = lambda *x: False                                   # the stock layers of the same module
+        b_ = model({'search_points': s, 'template_points': t, 'batch_size': 2})
+    for k in ('pred_centroids_votes', 'votes_feats'):
+        np.testing.assert_allclose(a[k].cpu().numpy(), b_[k].cpu().numpy(), atol=2e-4, rtol=2e-4, err_msg=k)
+    assert a['pred_box_data'].shape == b_['pred_box_data'].shape and torch.isfinite(a['pred_box_data']).all()
+
+    cfg = kitti_model_cfg()
+    cfg.CENTROID_HEAD.TRANSFORMER_BLOCK.NAME = 'TransformerBlockSTD'
+    cfg.BOX_HEAD.TRANSFORMER_BLOCK.NAME = 'TransformerBlockSTD'
+    hp = randomize_(FrameHotPath(cfg), seed=2).to(dev).eval()
+    with torch.no_grad():
+        d = hp(s, t)
+    assert tuple(d['box_feats'].shape) == (2, 64, 256) and torch.isfinite(d['box_feats']).all()
+
+    train = fill_state_dict_(build_network(_std_cfg(), 1, StubDataset(training=True)), 7).to(dev).train()
+    rs = np.random.RandomState(0)
+    ret, _, _ = train({'search_points': s, 'template_points': t, 'batch_size': 2,
+                       'cls_label': torch.from_numpy((rs.rand(2, 1024) < 0.3).astype(np.float32)).to(dev),
+                       'reg_label': torch.from_numpy(rs.standard_normal((2, 4)).astype(np.float32)).to(dev)})
+    ret['loss'].mean().backward()
+    g = train.centroid_voting_head.transformer_block.w_qs.weight.grad
+    assert g is not None and torch.isfinite(g).all() and float(g.abs().sum()) > 0
+
+
+def test_one_launch_losses_fall_back_on_an_index_table_they_cannot_take(dev):
+    """ptt.py::_one_launch_losses: an int32 (or mis-shaped) search_inds makes the gate answer None — the heads' own get_loss
+    runs (centroids_voting_head.py:29-62) — instead of a ValueError from the descriptor; an out-of-range index never reads
+    outside cls_label (the kernel clamps; the torch.gather it replaces would have raised)."""
+    from ptt_amd import ops, train_ops
+    f = lambda *s: torch.randn(*s, device=dev)
+    B, N, M, Ns = 2, 128, 64, 1024
+    t = (f(B, N), f(B, N, 3), f(B, M, 5), f(B, M, 3), (f(B, Ns) > 0).float(), f(B, 4), torch.tensor([1.0], device=dev), torch.tensor([2.0], device=dev))
+    inds = torch.randint(0, Ns, (B, N), device=dev)
+    assert train_ops.track_losses_usable(*t, search_inds=inds, seeds_shape=(B, N))
+    assert not train_ops.track_losses_usable(*t, search_inds=inds.int(), seeds_shape=(B, N))
+    assert not train_ops.track_losses_usable(*t, search_inds=inds[:, :64], seeds_shape=(B, N))
+    assert train_ops.track_losses_usable(*t, search_inds=inds.t().contiguous().t(), seeds_shape=(B, N))       # made contiguous inside
+    w = (0.2, 1.0, 1.5, 0.2)
+    total, vals = train_ops.track_losses(t[0], t[1], t[2], t[3], t[4], inds, t[5], t[6], t[7], w)
+    bad = inds.clone()
+    bad[0, 0], bad[1, 5] = Ns + 12345678, -7                                 # clamped to the last / first point of the frame
+    ref = inds.clone()
+    ref[0, 0], ref[1, 5] = Ns - 1, 0
+    a, _ = train_ops.track_losses(t[0], t[1], t[2], t[3], t[4], bad, t[5], t[6], t[7], w)
+    b, _ = train_ops.track_losses(t[0], t[1], t[2], t[3], t[4], ref, t[5], t[6], t[7], w)
+    assert torch.equal(a, b) and torch.isfinite(total)
+
+
+@pytest.mark.parametrize("N,npoint", [(20000, 96), (32768, 64), (40000, 50), (1000, 200)])
+def test_fps_beyond_the_register_resident_limit_matches_oracle(dev, N, npoint):
+    """The reference's furthest_point_sampling (pointnet2_utils.py:78) has no size limit: clouds past ptt_fps_f32's 16384
+    points take ptt_fps_ws_f32 (min-distances in a workspace) with the same picks — duplicates, an all-zero cloud, points
+    inside the origin ball and a coarse grid (exact distance ties) included. (1000, 200): the workspace form called directly
+    on a size both kernels serve."""
+    from oracle import index_ops as O
+    from ptt_amd import _lib, ops
+    rs = np.random.RandomState(N)
+    xyz, _ = synth.frames(N, 4, N, 64, K_s=max(8, int(N * 0.6)), K_t=32)
+    xyz[1] = 0.0
+    xyz[2, :300] = rs.uniform(-0.015, 0.015, (300, 3))
+    xyz[3] = rs.uniform(-1, 1, (N, 3)).round(1)
+    x = torch.from_numpy(xyz).to(dev)
+    ref = O.fps(xyz, npoint)
+    if N > ops.FPS_RESIDENT_MAX_N:
+        np.testing.assert_array_equal(ops.furthest_point_sampling(x, npoint).cpu().numpy(), ref)
+    out = torch.empty((4, npoint), dtype=torch.int32, device=dev)
+    ws = torch.empty((4 * N,), dtype=torch.float32, device=dev)
+    rc = _lib.lib().ptt_fps_ws_f32(x.data_ptr(), 4, N, npoint, out.data_ptr(), ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    np.testing.assert_array_equal(out.cpu().numpy(), ref)
+    assert _lib.lib().ptt_fps_ws_f32(x.data_ptr(), 4, N, npoint, out.data_ptr(), ws.data_ptr(), ws.numel() - 1,
+                                     torch.cuda.current_stream().cuda_stream) == -4           # PTT_EWORKSPACE

@@ -187,7 +187,7 @@ def test_G16_training_crop_labels_and_label_resampling_equal_the_reference(dev):
             pc, label, reg = ku.crop_center_pc(pcs[i], _kbox(g, "ref", i), _kbox(g, "gt", i), sample_offsets=g16["offsets_%d_%d" % (i, k)],
                                                offset=float(offset), scale=float(scale), refine_box=bool(refine))
             np.testing.assert_array_equal(pc.points.cpu().numpy(), g16["points_%d_%d" % (i, k)])
-            assert label.dtype == torch.bool and label.is_cuda
+            assert label.dtype == torch.float64 and label.is_cuda             # get_label_by_box :269-271 returns float64 0/1
             np.testing.assert_array_equal(label.cpu().numpy(), g16["label_%d_%d" % (i, k)])
             np.testing.assert_allclose(reg, g16["reg_%d_%d" % (i, k)], rtol=0, atol=1e-12)
             if k == 0:
@@ -195,7 +195,12 @@ def test_G16_training_crop_labels_and_label_resampling_equal_the_reference(dev):
                 pts, cls, reg2 = ku.regularize_pc(pc, 1024, label=label, reg=reg)
                 np.testing.assert_array_equal(pts.cpu().numpy(), g16["reg_points_%d" % i])
                 np.testing.assert_array_equal(cls.cpu().numpy().astype(g16["reg_label_%d" % i].dtype), g16["reg_label_%d" % i])
-                assert reg2 is reg
+                assert reg2 is reg and cls.dtype == torch.float64
+                np.random.seed(77)                                            # the evaluation form reseeds with 1 itself (:349-350)
+                pts, cls, _ = ku.regularize_pc(pc, 1024, label=label, reg=reg, istrain=False)
+                np.testing.assert_array_equal(pts.cpu().numpy(), g16["eval_reg_points_%d" % i])
+                np.testing.assert_array_equal(cls.cpu().numpy(), g16["eval_reg_label_%d" % i])
+                np.testing.assert_array_equal(np.random.randint(0, 1 << 30, size=4, dtype=np.int64), g16["eval_next_draw_%d" % i])
     from ptt.datasets.kitti.kitti_tracking_utils import Box, Quaternion
     far = Box(g["far_center"], g["wlh"], Quaternion(array=g["far_quat"]))
     pc, label, reg = ku.crop_center_pc(pcs[1], far, _kbox(g, "gt", 1), sample_offsets=np.zeros(4, np.float32), offset=0.0, scale=1.25)
@@ -203,3 +208,4 @@ def test_G16_training_crop_labels_and_label_resampling_equal_the_reference(dev):
     pts, cls, _ = ku.regularize_pc(pc, 1024, label=label, reg=reg)
     np.testing.assert_array_equal(pts.cpu().numpy(), g16["empty_reg_points"])
     np.testing.assert_array_equal(cls.cpu().numpy(), g16["empty_reg_label"])
+    assert cls.dtype == torch.float64                                         # the same dtype as the non-empty crops' labels
