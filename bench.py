@@ -90,6 +90,9 @@ def parse_args():
     ap.add_argument("--no-workloads", action="store_true",
                     help="default car run at N = 1: do not append the short ped / stress / train runs (`workloads` object)")
     ap.add_argument("--workloads", default="ped,stress,train", help="which short side runs the default car line carries")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="take the multi-rank branches (RCCL process group, ranks-seen all-reduce, DistributedDataParallel, the "
+                         "no_sync() exposure measurement) at ANY world size, 1 included: how a one-GPU box runs the code an 8-GPU launch runs")
     return ap.parse_args()
 
 
@@ -135,16 +138,12 @@ def spawn_ranks(n):
     rc2, train = launch(["--gpus", str(n), "--workload", "train", "--steps", "5", "--warmup", "2", "--sustain", "0",
                          "--no-cpu-baseline", "--no-workloads"], True)
     if line is not None:
-        keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "dtype", "scaling", "roofline", "loss",
-                "rccl_ranks_seen", "grad_bytes_allreduced_per_step", "allreduce")
         if train is not None and rc2 == 0:
-            rec = {k: train[k] for k in keep if train.get(k) is not None}
-            rec["config"] = {"workload": train["config"]["workload"], "name": "train", "ref": WORKLOADS["train"]["ref"],
-                             "sharding": train["config"].get("sharding")}
+            rec = side_record(train, "train")
         else:
             rec = {"error": "the train launch on %d ranks exited with code %d" % (n, rc2)}
         line.setdefault("workloads", {})["train"] = rec
-        print(json.dumps(line), flush=True)
+        print(json.dumps(compact_line(line)), flush=True)
     return rc
 
 
@@ -273,7 +272,8 @@ def cpu_baseline(model, cfg, s_np, t_np, frames, ns, nt):
     note("cpu baseline: %d iterations of %d frames, %.2f s each" % (n_iter, nf, t_iter))
     dt = float(np.median(times))
     out = {"value": round(nf / dt, 3), "unit": "frames/s", "cores": ncpu, "kind": "port",
-           "sample": "%d frames (%d+%d pts) per iteration, median of %d iterations after 3 warm-ups, through oracle/frame_ref.py "
+           "sample": "%d frames (%d+%d pts) per iteration, median of %d iterations, oracle/frame_ref.py on %d threads" % (nf, ns, nt, len(times), ncpu),
+           "sample_detail": "%d frames (%d+%d pts) per iteration, median of %d iterations after 3 warm-ups, through oracle/frame_ref.py "
                      "(C index ops with OpenMP + torch-CPU dense path) with torch / OpenMP threads = all %d usable cores (%d "
                      "visible, %s) (BASELINE.md section 3 protocol; 20 iterations unless they exceed a 12 s budget)"
                      % (nf, ns, nt, len(times), ncpu, visible, quota_note)}
@@ -314,9 +314,10 @@ def main():
     dev = torch.device("cuda", local_rank)
     dist = None
     ranks_seen = 1
-    if world > 1:
+    if world > 1 or args.force_collective:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))             # only unset outside torch.distributed.run (one rank)
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
         one = torch.ones(1, device=dev)
         dist.all_reduce(one)                                # every rank adds 1 over RCCL
@@ -343,9 +344,41 @@ def main():
             out["workloads"][name] = side_workload(name, steps, warm)
     note("done")
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        print("[bench detail] " + json.dumps(out), file=sys.stderr, flush=True)     # every key, with its prose
+        print(json.dumps(compact_line(out)), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+# keys that hold prose (how a number was taken): DESIGN.md section 6 says it once; the stdout line carries numbers and names
+PROSE_KEYS = ("how", "split", "note", "traffic_note", "per_frame", "launch", "timing", "process", "per_launch_shape", "sample_detail",
+              "sharding_detail")
+LINE_ORDER = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline", "speedup_vs_cpu_baseline", "rccl_ranks_seen", "latency_b1", "workloads",
+              "sustained", "full_model", "whole_step", "index_ops", "loss", "grad_bytes_allreduced_per_step", "allreduce",
+              "kernel_ms_per_step")
+LINE_LIMIT = 6144            # the driver keeps a tail of its child's stdout: the ONE line must fit it whole
+
+
+def strip_prose(v):
+    if isinstance(v, dict):
+        return {k: strip_prose(x) for k, x in v.items() if k not in PROSE_KEYS and x is not None or k in ("traffic", "vs_baseline", "cpu_baseline")}
+    if isinstance(v, float):
+        return float("%.6g" % v)
+    return v
+
+
+def compact_line(out):
+    """The stdout line: `out` without its prose, contract keys first, then the objects a reader looks for (roofline, cpu_baseline,
+    latency_b1, workloads) and the per-kernel tables last; at most LINE_LIMIT characters (the tables go first if it is not)."""
+    d = strip_prose(out)
+    d = {k: d[k] for k in LINE_ORDER if k in d}
+    d.update({k: v for k, v in strip_prose(out).items() if k not in d})
+    for drop in ("kernel_ms_per_step", "index_ops", "whole_step", "full_model", "sustained"):
+        if len(json.dumps(d)) <= LINE_LIMIT:
+            break
+        d.pop(drop, None)
+    return d
 
 
 def side_workload(name, steps, warmup):
@@ -364,12 +397,25 @@ def side_workload(name, steps, warmup):
         sub = json.loads(line[-1])
     except (subprocess.TimeoutExpired, ValueError, OSError) as e:
         return {"error": "%s: %s" % (type(e).__name__, e)}
-    keep = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "roofline", "whole_step", "index_ops",
-            "kernel_ms_per_step", "loss")
+    return side_record(sub, name, "own process: " + " ".join(cmd[1:]), round(time.perf_counter() - t0, 2))
+
+
+def side_record(sub, name, process=None, wall_s=None):
+    """A side workload's line reduced to what the headline line carries of it: the contract numbers and the roofline's numbers."""
+    keep = ("value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "dtype", "scaling", "loss", "rccl_ranks_seen",
+            "grad_bytes_allreduced_per_step", "allreduce")
     rec = {k: sub[k] for k in keep if sub.get(k) is not None}
+    r = sub.get("roofline") or {}
+    rec["roofline"] = {k: r.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms") if k in r}
+    if (sub.get("whole_step") or {}).get("frac_of_mfma_peak") is not None:
+        rec["whole_step_frac_of_mfma_peak"] = sub["whole_step"]["frac_of_mfma_peak"]
     rec["config"] = {"workload": sub["config"]["workload"], "name": name, "ref": WORKLOADS[name]["ref"]}
-    rec["process"] = "own process: " + " ".join(cmd[1:])
-    rec["wall_s"] = round(time.perf_counter() - t0, 2)
+    if sub["config"].get("sharding") and name == "train":
+        rec["config"]["sharding"] = sub["config"]["sharding"]
+    if process:
+        rec["process"] = process
+    if wall_s is not None:
+        rec["wall_s"] = wall_s
     return rec
 
 
@@ -553,12 +599,12 @@ def run_infer(args, torch, ops, dev, dist, world, rank, ranks_seen, sync_all, B,
         "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%s: %s (%s): batch %d per GPU, %d search + %d template points, 3 SA levels x 2 "
-                               "branches (%s / %s centres) + vote-aggregation SA + 2 TransformerBlocks (d_model 512, "
-                               "k 16), random-init weights, eval mode"
-                               % (args.workload, W["text"], W["ref"], B, NS, NT, W["npoints_s"], W["npoints_t"]),
+        "config": {"workload": "%s (%s): batch %d per GPU, %d search + %d template points, SA centres %s / %s, eval"
+                               % (args.workload, W["ref"], B, NS, NT, W["npoints_s"], W["npoints_t"]),
+                   "sample_detail": "%s; 3 SA levels x 2 branches + vote-aggregation SA + 2 TransformerBlocks (d_model 512, k 16), "
+                                    "random-init weights" % W["text"],
                    "name": args.workload, "frames_per_gpu_per_step": B, "search_points": NS, "template_points": NT,
-                   "sharding": "frames across ranks, no data-path collective",
+                   "sharding": "frames across ranks, no collective",
                    "launch": ("eager, one stream" if args.serial else "eager" if graphed is None else
                               "hipGraph replay, template branch on a second stream" +
                               ("; software-pipelined across batches: FPS of batch n+1 runs on a side stream during the "
@@ -689,7 +735,8 @@ def run_train(args, torch, dev, dist, world, rank, ranks_seen, sync_all, B, NS, 
     from ptt_amd.train_step import GRAD_ELEMS, DataParallelTrainer, synthetic_train_batch
     torch.manual_seed(1)                                    # tools/train_tracking.py:73-79
     model = build_network(ptt_model_cfg(), 1, StubDataset(training=True)).to(dev).train()
-    trainer = DataParallelTrainer(model, dev)
+    collective = dist is not None                          # world > 1, or --force-collective at world 1
+    trainer = DataParallelTrainer(model, dev, force_ddp=collective)
     batch = synthetic_train_batch(100 + rank, B, dev, NS, NT, K_s=W["K_s"], K_t=W["K_t"])
     last = {}
 
@@ -707,7 +754,7 @@ def run_train(args, torch, dev, dist, world, rank, ranks_seen, sync_all, B, NS, 
                      "ms_per_step": round(dt / n_sus * 1e3, 4)}
     value = B * world * args.steps / elapsed
     allreduce = None
-    if world > 1:
+    if collective:
         # what the gradient all-reduce costs the step: the same steps with DDP's synchronisation switched off
         # (model.no_sync(): gradients stay local; the replicas drift apart, which is why this runs last)
         def step_local():
@@ -729,12 +776,11 @@ def run_train(args, torch, dev, dist, world, rank, ranks_seen, sync_all, B, NS, 
         "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "train: %s (%s): batch %d per GPU, %d search + %d template points, full PTT tracker in "
-                               "train mode (batch-statistics BatchNorm), Adam lr 1e-3 betas .5/.999 eps 1e-6, clip 10"
-                               % (W["text"], W["ref"], B, NS, NT),
+        "config": {"workload": "train (%s): batch %d per GPU, %d search + %d template points, full tracker, fwd + bwd + clip + Adam"
+                               % (W["ref"], B, NS, NT),
+                   "sample_detail": "%s; train mode (batch-statistics BatchNorm), Adam lr 1e-3 betas .5/.999 eps 1e-6, clip 10" % W["text"],
                    "name": "train", "frames_per_gpu_per_step": B, "search_points": NS, "template_points": NT,
-                   "sharding": "batch across ranks; DistributedDataParallel, one %.1f MB gradient bucket all-reduced "
-                               "over RCCL per step" % (GRAD_ELEMS * 4 / 1e6) if world > 1 else "single rank, no collective",
+                   "sharding": "batch across ranks, DDP gradient all-reduce over RCCL" if collective else "single rank, no collective",
                    "launch": "eager"},
         "rccl_ranks_seen": ranks_seen,
         "roofline": {"kernel": "whole training step (no single dominant kernel)", "bound": "mfma",
@@ -745,7 +791,7 @@ def run_train(args, torch, dev, dist, world, rank, ranks_seen, sync_all, B, NS, 
         "cpu_baseline": None,
         "sustained": sustained,
         "loss": float(last["loss"].detach()),
-        "grad_bytes_allreduced_per_step": GRAD_ELEMS * 4 if world > 1 else 0,
+        "grad_bytes_allreduced_per_step": trainer.grad_bytes_allreduced() if collective else 0,
         "allreduce": allreduce,
     }
 

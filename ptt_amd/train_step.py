@@ -41,15 +41,18 @@ class DataParallelTrainer(object):
         loss = trainer.step(batch)          # forward, backward (all-reduce inside), clip, Adam
     """
 
-    def __init__(self, model, device, lr=1e-3, betas=(0.5, 0.999), eps=1e-6, clip=10.0, bucket_cap_mb=25, sync_bn=False):
+    def __init__(self, model, device, lr=1e-3, betas=(0.5, 0.999), eps=1e-6, clip=10.0, bucket_cap_mb=25, sync_bn=False, force_ddp=False):
+        """force_ddp: wrap in DistributedDataParallel whenever a process group is initialised, a ONE-rank group included (the
+        bucket all-reduce then runs on the device with one participant: how a one-GPU box exercises the multi-GPU code)."""
         self.device = torch.device(device)
         self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        self.ddp = self.world > 1 or (force_ddp and dist.is_available() and dist.is_initialized())
         if sync_bn and self.world > 1:
             # tools/train_tracking.py:133-134 (--sync_bn). The SharedMLP stages keep running on the hand-written row
             # kernels: their statistics are exchanged as 2C + 1 float64 sums per layer (ptt_amd/train_ops.py)
             model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
         self.tracker = model
-        if self.world > 1:
+        if self.ddp:
             ids = [self.device.index] if self.device.type == 'cuda' else None
             # bucket_cap_mb 25 > 19.6 MB: the whole gradient is one bucket, one all-reduce per step; for a message
             # this small RCCL's direct algorithms over the 7 xGMI links beat a ring (SURVEY.md §5)
@@ -74,9 +77,15 @@ class DataParallelTrainer(object):
         self.tracker.update_global_step()
         return loss
 
+    def grad_bytes_allreduced(self):
+        """Bytes of gradient one step hands to the bucket all-reduce (0 without DDP): every parameter that requires a gradient."""
+        if not self.ddp:
+            return 0
+        return sum(p.numel() * p.element_size() for p in self.model.parameters() if p.requires_grad)
+
     def ranks_seen(self):
         """All-reduce of ones: how many ranks actually take part in the collective."""
-        if self.world == 1:
+        if not self.ddp:
             return 1
         one = torch.ones(1, device=self.device)
         dist.all_reduce(one)

@@ -1,0 +1,61 @@
+#!/usr/bin/env python
+"""The multi-GPU training code on a ONE-GPU box: an `nccl` (= RCCL) process group with one rank, the full tracker inside
+DistributedDataParallel on the hand-written row kernels, against the same model without the wrap.
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port P scripts/rccl_one_rank_check.py
+
+With one participant the bucket all-reduce is an identity that still runs on the device through RCCL, and DDP divides the
+gradient by world size 1: every gradient, and every parameter after clip + Adam, must equal the unwrapped run's BIT FOR BIT
+(what tools/train_tracking.py:158-159 + ptt/utils/common_utils.py:275-289 set up in the reference). Prints one JSON line."""
+import json
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ptt_amd.config import StubDataset, ptt_model_cfg                     # noqa: E402
+from ptt_amd.models import build_network                                 # noqa: E402
+from ptt_amd.train_step import GRAD_ELEMS, DataParallelTrainer, synthetic_train_batch   # noqa: E402
+
+
+def main():
+    world, rank, local = int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    env_seen = {k: os.environ.get(k) for k in ("HSA_ENABLE_IPC_MODE_LEGACY", "NCCL_DEBUG", "HSA_FORCE_FINE_GRAIN_PCIE", "NCCL_P2P_DISABLE")}
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    one = torch.ones(1, device=dev)
+    dist.all_reduce(one)                                               # RCCL communicator creation + one collective
+
+    def run(force_ddp, steps):
+        torch.manual_seed(1)
+        model = build_network(ptt_model_cfg(), 1, StubDataset(training=True)).to(dev).train()
+        trainer = DataParallelTrainer(model, dev, force_ddp=force_ddp)
+        batch = synthetic_train_batch(100, 8, dev)
+        trainer.forward_backward(batch)
+        grads = {k: p.grad.detach().clone() for k, p in trainer.tracker.named_parameters() if p.grad is not None}
+        for _ in range(steps):
+            loss = trainer.step(batch)
+        params = {k: p.detach().clone() for k, p in trainer.tracker.named_parameters()}
+        return trainer, grads, params, float(loss)
+
+    t0, g0, p0, l0 = run(False, 2)
+    t1, g1, p1, l1 = run(True, 2)
+    with t1.model.no_sync():                                           # the exposure measurement's branch of bench.py
+        t1.step(synthetic_train_batch(100, 8, dev))
+    out = {"world": world, "ranks_seen": int(one.item()), "ddp": bool(t1.ddp) and type(t1.model).__name__ == "DistributedDataParallel",
+           "unwrapped_is_plain": not t0.ddp, "grad_keys_equal": sorted(g0) == sorted(g1),
+           "grads_bit_equal": all(torch.equal(g0[k], g1[k]) for k in g0), "params_bit_equal": all(torch.equal(p0[k], p1[k]) for k in p0),
+           "n_grads": len(g1), "grad_bytes_allreduced_per_step": t1.grad_bytes_allreduced(), "expected_grad_bytes": GRAD_ELEMS * 4,
+           "loss_equal": l0 == l1, "loss": l1, "env": env_seen, "backend": dist.get_backend()}
+    torch.cuda.synchronize()
+    dist.destroy_process_group()
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

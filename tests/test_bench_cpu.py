@@ -85,3 +85,25 @@ def test_side_workload_reports_a_failing_process_instead_of_raising(monkeypatch)
     monkeypatch.setattr(bench.subprocess, "run", lambda *a, **k: Q())
     rec = bench.side_workload("ped", 10, 3)
     assert rec["value"] == 1.0 and rec["config"]["ref"] == "BASELINE.json configs[2]" and "cpu_baseline" not in rec
+
+
+def test_the_stdout_line_is_compact_ordered_and_bounded():
+    """compact_line: prose keys dropped, contract keys first, latency_b1 / workloads in front of the per-kernel tables, and at most
+    LINE_LIMIT characters (the tables are dropped first when a line would not fit)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    out = {"kernel_ms_per_step": {"k%d" % i: 0.123456789 for i in range(8)}, "latency_b1": {"tracklet_loop": {"b1": {"ms_per_step": 0.61, "split": "x" * 900}}},
+           "workloads": {"ped": {"value": 1.0, "process": "own process", "roofline": {"frac": 0.9, "traffic": None, "traffic_note": "y" * 500}}},
+           "roofline": {"frac": 0.5, "traffic": None, "timing": "z" * 300, "traffic_source": {"file": "profiles/x", "per_launch_shape": {"a": 1}}},
+           "cpu_baseline": None, "vs_baseline": None, "value": 12345.678912, "metric": "m", "config": {"workload": "w", "launch": "v" * 400},
+           "index_ops": {"fps": {"note": "n" * 300, "alg_GBps": 5.8}}}
+    line = bench.compact_line(out)
+    keys = list(line)
+    assert keys[:2] == ["metric", "value"] and keys.index("latency_b1") < keys.index("workloads") < keys.index("kernel_ms_per_step")
+    text = json.dumps(line)
+    assert len(text) < 900 and "xxxx" not in text and "yyyy" not in text and "zzzz" not in text and "vvvv" not in text and "nnnn" not in text
+    assert line["roofline"]["traffic"] is None and line["cpu_baseline"] is None and line["vs_baseline"] is None      # contract keys stay
+    assert line["roofline"]["traffic_source"] == {"file": "profiles/x"} and line["value"] == 12345.7
+    out["kernel_ms_per_step"] = {"k%d" % i: 1.0 for i in range(2000)}
+    small = bench.compact_line(out)
+    assert len(json.dumps(small)) <= bench.LINE_LIMIT and "kernel_ms_per_step" not in small and "latency_b1" in small

@@ -52,3 +52,58 @@ def test_training_line():
     d = _run("--workload", "train", "--steps", "2", "--warmup", "1", "--sustain", "0", "--no-cpu-baseline")
     _contract(d, 2, 1)
     assert "forward + backward" in d["metric"] and d["ms_per_step"] < 100.0
+
+
+def _torchrun_one_rank(script, *flags):
+    """`python -m torch.distributed.run --nproc-per-node 1 ...`: the launcher a multi-GPU driver uses, with one rank."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, script)] + list(flags), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=900, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_the_rccl_branches_of_the_training_line_run_at_world_size_one():
+    """What an 8-GPU launch runs, on this one-GPU box: init_process_group("nccl", device_id=...), the ranks-seen all-reduce,
+    DistributedDataParallel around the tracker on the row kernels (one 19.6 MB bucket all-reduced per step on the device), and the
+    no_sync() exposure measurement (tools/train_tracking.py:158-159, ptt/utils/common_utils.py:275-289)."""
+    d = _torchrun_one_rank("bench.py", "--gpus", "1", "--workload", "train", "--steps", "2", "--warmup", "1", "--sustain", "0",
+                           "--no-cpu-baseline", "--force-collective")
+    _contract(d, 2, 1)
+    assert d["rccl_ranks_seen"] == 1 and d["grad_bytes_allreduced_per_step"] == 4903113 * 4
+    a = d["allreduce"]
+    assert a["ms_per_step_without_allreduce"] > 0 and abs(a["exposed_ms_per_step"]) < d["ms_per_step"]
+    assert "RCCL" in d["config"]["sharding"]
+
+
+def test_ddp_on_one_rccl_rank_is_bit_identical_to_the_unwrapped_trainer():
+    d = _torchrun_one_rank("scripts/rccl_one_rank_check.py")
+    assert d["backend"] == "nccl" and d["world"] == 1 and d["ranks_seen"] == 1 and d["ddp"] and d["unwrapped_is_plain"]
+    assert d["grad_keys_equal"] and d["grads_bit_equal"] and d["params_bit_equal"] and d["loss_equal"], d
+    assert d["grad_bytes_allreduced_per_step"] == d["expected_grad_bytes"] == 4903113 * 4
+
+
+def test_the_default_line_fits_the_drivers_tail_and_carries_every_workload():
+    """`python bench.py` exactly as the driver runs it (N = 1): ONE stdout line of at most 6144 characters — the driver keeps a tail
+    of the output — that still holds the B = 1 tracklet latency and the ped / stress / train workloads."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                       timeout=1500, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and len(lines[0]) < 6144, (len(lines), len(lines[0]))
+    d = json.loads(lines[0])
+    _contract(d, 20, 5)
+    assert d["latency_b1"]["tracklet_loop"]["b1"]["ms_per_step"] > 0 and d["latency_b1"]["tracklet_loop"]["b48"]["frames_per_s"] > 0
+    for name in ("ped", "stress", "train"):
+        w = d["workloads"][name]
+        assert "error" not in w and w["value"] > 0 and 0 < w["roofline"]["frac"] < 1, (name, w)
+    assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1
+    assert any(l.startswith("[bench detail] {") for l in p.stderr.splitlines())          # the prose went to stderr
