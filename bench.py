@@ -702,6 +702,8 @@ def tracklet_loop(torch, dev, tracker, frames_b1=120, frames_b48=30):
 def launches_per_frame(torch, dev, tracker, runner):
     """Kernel launches of ONE tracklet frame = the kernels of one eager tracker forward at the runner's sizes (counted by
     torch.profiler; the same launches the runner's hipGraph replays) + crop, resample and box selection."""
+    if os.environ.get("PTT_BENCH_NO_PROFILER"):             # scripts/probes/graph_sequence_probe.py: bisecting a crash
+        return {"skipped": "PTT_BENCH_NO_PROFILER"}
     try:
         from torch.profiler import ProfilerActivity, profile
         s = torch.zeros((1, runner.S, 3), device=dev)

@@ -655,6 +655,32 @@ int ptt_bn_bwd_from_partials_f32(const double* partial, int chunks, const float*
                                  const float* invstd, const float* gamma, int R, int C, float* dZ, int ldd, float* dgamma, float* dbeta,
                                  const float* act_scale, const float* act_shift, ptt_stream_t stream);
 int ptt_bn_bwd_sums_partials_f64(const double* partial, int chunks, int C, double* sums, ptt_stream_t stream);
+/* Round 5: the BatchNorm + ReLU backward of a layer APPLIED BY ITS CONSUMER. With dbeta = sum dy, dgamma = sum dy * xhat
+ *   dz = gamma * invstd * (dy - dbeta / R - xhat * dgamma / R) = c0 + c1 * (z - mean) + (mask ? k1 * g : 0)
+ * (k1 = gamma * invstd, c1 = -k1 * invstd * dgamma / R, c0 = -k1 * dbeta / R): three per-channel
+ * constants instead of a pass that reads g and z and writes dz (ptt_bn_bwd_from_partials_f32 / ptt_bn_bwd_pooled_f32's last
+ * launch, 1.5 ms of a 21-ms training step). ptt_bn_bwd_consts_f32 combines the partials of ptt_rows_gemm_bnbwd_f32 (dense
+ * gradient), ptt_bn_bwd_pooled_consts_f32 sums over a POOLED gradient first (as ptt_bn_bwd_pooled_f32); both write dgamma,
+ * dbeta and the constants. ptt_rows_gemm_bnbwd_fused_f32 = ptt_rows_gemm_bnbwd_f32 whose A operand is that dz, formed while
+ * its rows are staged, and (dz_out) written out once for the layer's weight gradient. */
+typedef struct ptt_bn_bwd_input {
+    const float* g; int ldg;            /* dense: the gradient w.r.t. the layer's activated output (R,K); pooled: (R / ns, K) */
+    const int32_t* arg; int ns;         /* pooled: arg-max row inside every group of ns rows, (R / ns, K) contiguous; NULL, 0: dense */
+    const float* z; int ldz;            /* the layer's convolution output (R,K) */
+    const float* k1; const float* c0; const float* c1; const float* mean;
+    const float* act_a; const float* act_b;     /* the ReLU mask: z * act_a + act_b > 0 */
+    float* dz_out; int ldd;             /* optional (R,K): dz written by the launch */
+} ptt_bn_bwd_input;
+int ptt_bn_bwd_consts_f32(const double* partial, int chunks, const float* mean, const float* invstd, const float* gamma, int R, int C,
+                          float* dgamma, float* dbeta, float* k1, float* c0, float* c1, ptt_stream_t stream);
+int ptt_bn_bwd_pooled_consts_f32(const float* dPooled, int ldp, const int32_t* arg, int ns, const float* Z, int ldz, const float* mean,
+                                 const float* invstd, const float* gamma, int R, int C, float* dgamma, float* dbeta, float* k1,
+                                 float* c0, float* c1, void* workspace, size_t workspace_bytes, const float* act_scale,
+                                 const float* act_shift, ptt_stream_t stream);
+int ptt_rows_gemm_bnbwd_fused_supported(int rows, int K, int N, int ns);
+int ptt_rows_gemm_bnbwd_fused_f32(const ptt_bn_bwd_input* in, int rows, int K, const float* Wpacked, int N, const float* Z, int ldz,
+                                  const float* mean, const float* invstd, const float* act_scale, const float* act_shift, float* out,
+                                  int ldo, double* sums_partial, size_t partial_elems, ptt_stream_t stream);
 int ptt_bn_finish_partials_f32(const double* partial, int chunks, int C, int R, float eps, float* mean, float* var, float* invstd,
                                ptt_stream_t stream);
 int ptt_bn_sums_partials_f64(const double* partial, int chunks, int C, int R, double* sums, ptt_stream_t stream);

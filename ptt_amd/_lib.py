@@ -35,6 +35,7 @@ EXPORTS = [
     "ptt_bn_bwd_pooled_f32", "ptt_bn_bwd_pooled_sums_f64", "ptt_bn_bwd_pooled_apply_f32",
     "ptt_pt_pair_input_ld_f32", "ptt_pt_attn_fwd_ld_f32",
     "ptt_rows_gemm_bnbwd_f32", "ptt_bn_bwd_from_partials_f32", "ptt_bn_bwd_sums_partials_f64",
+    "ptt_bn_bwd_consts_f32", "ptt_bn_bwd_pooled_consts_f32", "ptt_rows_gemm_bnbwd_fused_supported", "ptt_rows_gemm_bnbwd_fused_f32",
     "ptt_bn_update_running_f32", "ptt_xcorr_z0_f32", "ptt_xcorr_z0_stat_chunks", "ptt_xcorr_z0_stats_f32", "ptt_xcorr_z0_bnbwd_f32", "ptt_xcorr_z0_bwd_workspace", "ptt_xcorr_z0_bwd_f32",
     "ptt_bn_stats_train_f32", "ptt_bn_finish_partials_train_f32", "ptt_pack_weights_f32",
     "ptt_sa_z0_rows_f32",
@@ -66,6 +67,13 @@ class BnTrainTail(Structure):
     """ptt_bn_train_tail: a training-mode BatchNorm's bookkeeping, done by the launch that forms the statistics."""
     _fields_ = [("gamma", c_void_p), ("beta", c_void_p), ("act_a", c_void_p), ("act_b", c_void_p),
                 ("running_mean", c_void_p), ("running_var", c_void_p), ("num_batches_tracked", c_void_p), ("momentum", c_float)]
+
+
+class BnBwdInput(Structure):
+    """ptt_bn_bwd_input: a layer's BatchNorm + ReLU backward as the A operand of ptt_rows_gemm_bnbwd_fused_f32."""
+    _fields_ = [("g", c_void_p), ("ldg", c_int), ("arg", c_void_p), ("ns", c_int), ("z", c_void_p), ("ldz", c_int),
+                ("k1", c_void_p), ("c0", c_void_p), ("c1", c_void_p), ("mean", c_void_p), ("act_a", c_void_p), ("act_b", c_void_p),
+                ("dz_out", c_void_p), ("ldd", c_int)]
 
 
 class PackJob(Structure):
@@ -226,6 +234,10 @@ def _declare(lib):
         "ptt_linear_wgrad2_f32": [vp, i, vp, i, i, i, i, vp, i, vp, c_size_t, vp, vp, vp],
         "ptt_rows_gemm_bnbwd_f32": [vp, i, i, i, vp, i, vp, i, vp, vp, vp, vp, vp, i, vp, c_size_t, vp],
         "ptt_bn_bwd_from_partials_f32": [vp, i, vp, i, vp, i, vp, vp, vp, i, i, vp, i, vp, vp, vp, vp, vp],
+        "ptt_bn_bwd_consts_f32": [vp, i, vp, vp, vp, i, i, vp, vp, vp, vp, vp, vp],
+        "ptt_bn_bwd_pooled_consts_f32": [vp, i, vp, i, vp, i, vp, vp, vp, i, i, vp, vp, vp, vp, vp, vp, c_size_t, vp, vp, vp],
+        "ptt_rows_gemm_bnbwd_fused_supported": [i, i, i, i],
+        "ptt_rows_gemm_bnbwd_fused_f32": [POINTER(BnBwdInput), i, i, vp, i, vp, i, vp, vp, vp, vp, vp, i, vp, c_size_t, vp],
         "ptt_bn_bwd_sums_partials_f64": [vp, i, i, vp, vp],
         "ptt_pt_pair_input_ld_f32": [vp, i, vp, i, vp, vp, i, i, i, i, vp, vp],
         "ptt_pt_attn_fwd_ld_f32": [vp, vp, i, vp, vp, i, i, i, i, f, vp, vp, vp],

@@ -20,6 +20,8 @@ namespace ptt {
 
 typedef float g32x16 __attribute__((ext_vector_type(16)));
 typedef float g32x4 __attribute__((ext_vector_type(4)));
+typedef int gi32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int gu32x4 __attribute__((__vector_size__(4 * sizeof(unsigned int))));
 
 namespace {
 
@@ -81,6 +83,14 @@ struct RowsGemmParams {
     // the group) that holds it — what the max-pool of relu(BatchNorm(y)) needs once the batch statistics (which this same launch
     // sums) are known: the sign of gamma * invstd picks max or min (ptt_pool_select_f32)
     float* pmax; float* pmin; int* amax; int* amin;
+    // AIN instantiations: the A operand is NOT read from memory as it stands, it is the BatchNorm + ReLU backward of the layer this
+    // launch is the input gradient of, formed while the rows are staged (the pass that used to write it is gone):
+    //   dz = c0 + c1 * (z - mean) + (z * in_a + in_b > 0 [and the row is its group's arg-max] ? k1 * g : 0)
+    // AIN 2: X = the dense gradient g (rows, K); AIN 16 / 32 / 64: X = z itself and the gradient is POOLED over groups of AIN rows,
+    // tg (rows / AIN, K) with the arg-max row of every (group, channel) in targ. tz / ldtz = z for AIN 2. a_out (optional): dz
+    // written out once (by the workgroups of column group 0) for the weight gradient of the same layer.
+    const float* tz; int ldtz; const float* tk1; const float* tc0; const float* tc1; const float* tmu;
+    const float* tg; int ldtg; const int* targ; float* a_out; int lda_out;
 };
 
 // WR x WC waves (WR * WC = 4): wave (wr, wc) owns row tiles wr*RT .. wr*RT+RT-1 of the workgroup's 32*RT*WR rows and the
@@ -91,9 +101,11 @@ struct RowsGemmParams {
 #define PTT_RG_PD 3          // weight fragments requested this many K-blocks ahead
 #endif
 // BNB: the statistics are the BatchNorm backward sums of the producing layer (p.bz ...), not those of the output
-template <int WR, int RT, int CT, int KC, bool STATS, bool ACT, int EXP = 0, bool BNB = false, int POOL = 0>
+template <int WR, int RT, int CT, int KC, bool STATS, bool ACT, int EXP = 0, bool BNB = false, int POOL = 0, int AIN = 0>
 __global__ __launch_bounds__(256, 2) void rows_gemm_kernel(RowsGemmParams p) {
     static_assert(!BNB || (STATS && !ACT), "the backward-sums epilogue is a statistics epilogue of a plain input gradient");
+    static_assert(AIN == 0 || AIN == 2 || AIN == 16 || AIN == 32 || AIN == 64, "A-operand form");
+    static_assert(AIN == 0 || (!ACT && POOL == 0), "the BatchNorm-backward A operand excludes the deferred-activation one");
     static_assert(POOL == 0 || (STATS && !BNB && (POOL == 16 || POOL == 32 || (POOL == 64 && RT % 2 == 0))), "pooled statistics epilogue");
     constexpr int WC = 4 / WR, TR = 32 * RT * WR, NKB = KC / 8, LDK = KC + 4, BUF = TR * LDK, QPR = KC / 4;
     constexpr int SLOTS = TR * QPR / 256, PD = PTT_RG_PD;
@@ -139,14 +151,55 @@ __global__ __launch_bounds__(256, 2) void rows_gemm_kernel(RowsGemmParams p) {
 
     g32x4 st[SLOTS];
     g32x4 ta = {1.f, 1.f, 1.f, 1.f}, tb = {0.f, 0.f, 0.f, 0.f};
+    // AIN: z beside the gradient (AIN 2) / the pooled gradient and the arg-max of the row's group beside z (AIN 3), the five
+    // per-channel constants of the chunk, and where the staged dz goes when this workgroup writes it out
+    constexpr bool PIN = AIN >= 16;                             // pooled gradient
+    constexpr int TS = AIN == 2 ? SLOTS : 1, NG = PIN ? TR / AIN : 1, SPG = SLOTS / NG;      // slots of a thread per group
+    static_assert(!PIN || (TR % AIN == 0 && AIN % (256 / QPR) == 0 && SLOTS % NG == 0), "a thread's slots fall into whole groups");
+    g32x4 sz[TS], sg[NG];
+    gi32x4 sarg[NG];
+    g32x4 tk1 = {0.f, 0.f, 0.f, 0.f}, tc0 = tk1, tc1 = tk1, tmu = tk1;
+    int aout_off = 0, aout_c = 0;
+    const bool write_a = AIN != 0 && p.a_out != nullptr && cg == 0;
+    const __amdgpu_buffer_rsrc_t rtz = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(AIN == 2 ? p.tz : p.X), 0,
+                                                                          AIN == 2 ? ((p.rows - 1) * p.ldtz + p.K) * 4 : 0, 0x00020000);
+    const int groups = PIN ? p.rows / (PIN ? AIN : 1) : 1;
+    const __amdgpu_buffer_rsrc_t rtg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(PIN ? p.tg : p.X), 0,
+                                                                          PIN ? ((groups - 1) * p.ldtg + p.K) * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rta = __builtin_amdgcn_make_buffer_rsrc(const_cast<int*>(PIN ? p.targ : nullptr), 0,
+                                                                          PIN ? groups * p.K * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rao = __builtin_amdgcn_make_buffer_rsrc(AIN ? p.a_out : nullptr, 0,
+                                                                          (AIN && p.a_out) ? ((p.rows - 1) * p.lda_out + p.K) * 4 : 0, 0x00020000);
     auto fetch = [&](int tile, int c) {
         // tiles past the last one (the prefetch of the final unit): any offset beyond the descriptor reads zeros
-        const int tb_off = (tile < p.ntiles ? tile : p.ntiles) * tile_bytes + slot_off;
+        const int tcl = tile < p.ntiles ? tile : p.ntiles;
+        const int tb_off = tcl * tile_bytes + slot_off;
 #pragma unroll
         for (int i = 0; i < SLOTS; ++i) st[i] = g_load4(rx, tb_off + i * (RSTEP * ldx4), c * (KC * 4));
-        if (ACT) {
+        if (ACT || AIN) {
             ta = *reinterpret_cast<const g32x4*>(p.in_a + c * KC + 4 * q);
             tb = *reinterpret_cast<const g32x4*>(p.in_b + c * KC + 4 * q);
+        }
+        if constexpr (AIN != 0) {
+            tk1 = *reinterpret_cast<const g32x4*>(p.tk1 + c * KC + 4 * q);
+            tc0 = *reinterpret_cast<const g32x4*>(p.tc0 + c * KC + 4 * q);
+            tc1 = *reinterpret_cast<const g32x4*>(p.tc1 + c * KC + 4 * q);
+            tmu = *reinterpret_cast<const g32x4*>(p.tmu + c * KC + 4 * q);
+            aout_off = (tcl * TR + r0) * (p.lda_out * 4) + q * 16;
+            aout_c = c * (KC * 4);
+        }
+        if constexpr (AIN == 2) {
+            const int z_off = (tcl * TR + r0) * (p.ldtz * 4) + q * 16;
+#pragma unroll
+            for (int i = 0; i < SLOTS; ++i) sz[i] = g_load4(rtz, z_off + i * (RSTEP * p.ldtz * 4), c * (KC * 4));
+        }
+        if constexpr (PIN) {        // slot i lies in group i / SPG of the tile (RSTEP divides the group size, r0 < RSTEP)
+#pragma unroll
+            for (int gq = 0; gq < NG; ++gq) {
+                const int grp = tcl * NG + gq;
+                sg[gq] = g_load4(rtg, grp * (p.ldtg * 4) + q * 16, c * (KC * 4));
+                sarg[gq] = __builtin_bit_cast(gi32x4, g_load4(rta, grp * (p.K * 4) + q * 16, c * (KC * 4)));
+            }
         }
     };
     auto stage = [&](float* buf, int i) {                       // deferred BatchNorm + ReLU of the producing layer, LDS write
@@ -155,7 +208,29 @@ __global__ __launch_bounds__(256, 2) void rows_gemm_kernel(RowsGemmParams p) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) v[k] = fmaxf(__builtin_fmaf(v[k], ta[k], tb[k]), 0.f);
         }
+        if constexpr (AIN == 2) {
+            const g32x4 z = sz[i];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float t = __builtin_fmaf(tc1[k], z[k] - tmu[k], tc0[k]);
+                v[k] = __builtin_fmaf(z[k], ta[k], tb[k]) > 0.f ? __builtin_fmaf(tk1[k], v[k], t) : t;
+            }
+        }
+        if constexpr (PIN) {
+            const g32x4 z = v, gp = sg[i / SPG];
+            const gi32x4 ar = sarg[i / SPG];
+            const int srow = r0 + (i % SPG) * RSTEP;            // this slot's row inside its group
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float t = __builtin_fmaf(tc1[k], z[k] - tmu[k], tc0[k]);
+                v[k] = (ar[k] == srow && __builtin_fmaf(z[k], ta[k], tb[k]) > 0.f) ? __builtin_fmaf(tk1[k], gp[k], t) : t;
+            }
+        }
         *reinterpret_cast<g32x4*>(buf + lds_slot + i * (RSTEP * LDK)) = v;
+        if constexpr (AIN != 0) {
+            if (write_a)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(gu32x4, v), rao, aout_off + i * (RSTEP * p.lda_out * 4), aout_c, 0);
+        }
     };
 
     // bias / ReLU branch-free: a missing bias reads any valid address and is replaced by 0, no ReLU = floor -inf
@@ -375,9 +450,15 @@ __global__ __launch_bounds__(512, 1) void wgrad2_kernel(const float* __restrict_
     float* const Bs = smem + 2 * RS * LDA;          // [2][RS][LDB]
     const int t = threadIdx.x, lane = t & 63, half = lane >> 5, col = lane & 31;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6), wn = w >> 2, wk = w & 3;
-    const int bo = blockIdx.x / nbk, bi = blockIdx.x - bo * nbk;
+    // the output tiles of ONE row chunk read the same rows of dZ / X (a 512 x 512 gradient in 256 x 256 tiles: every operand
+    // quad twice): consecutive LOGICAL blocks share an XCD, so the tiles of a chunk meet in that XCD's L2 instead of each
+    // fetching its operands from the fabric (profiles/r04z_pmc_train_gemm: 805 MB read per launch against 402 MB compulsory)
+    const int ntile = (Cout / BN) * nbk;
+    const int lb = g_logical_block();
+    const int tile_id = lb % ntile, chunk = lb / ntile;
+    const int bo = tile_id / nbk, bi = tile_id - bo * nbk;
     const int o0 = bo * BN, i0 = bi * BK;
-    const int r_begin = blockIdx.y * chunk_rows, r_end = min(R, r_begin + chunk_rows);
+    const int r_begin = chunk * chunk_rows, r_end = min(R, r_begin + chunk_rows);
     const __amdgpu_buffer_rsrc_t rz = g_rsrc(dZ), rxx = g_rsrc(X);
     const int qa = t % QA, ra = t / QA, qb = t % QB, rb = t / QB;
     constexpr int RSA = 512 / QA, RSB = 512 / QB;
@@ -457,7 +538,7 @@ __global__ __launch_bounds__(512, 1) void wgrad2_kernel(const float* __restrict_
         buf ^= 1;
     }
     // C/D layout: column (input channel) = lane & 31, row (output channel) = (reg & 3) + 8 (reg >> 2) + 4 half
-    float* P = partial + (size_t)blockIdx.y * Cout * Cin;
+    float* P = partial + (size_t)chunk * Cout * Cin;
 #pragma unroll
     for (int a = 0; a < TN; ++a)
 #pragma unroll
@@ -530,7 +611,41 @@ struct PoolArgs { float* pmax; float* pmin; int32_t* amax; int32_t* amin; int ns
 static int rows_gemm_launch(const float* X, int rows, int K, int ldx, const float* in_scale, const float* in_shift,
                             const float* Wpacked, int N, const float* bias, int relu, const float* residual, int ldr,
                             const float* mask, int ldm, float* out, int ldo, double* stats, size_t stats_elems, ptt_stream_t stream,
-                            const BnBwdArgs* bn = nullptr, const PoolArgs* pool = nullptr);
+                            const BnBwdArgs* bn = nullptr, const PoolArgs* pool = nullptr, const ptt_bn_bwd_input* ain = nullptr);
+
+extern "C" int ptt_rows_gemm_bnbwd_fused_supported(int rows, int K, int N, int ns) {
+    if (!ptt_rows_gemm_supported(rows, K, N, K, N) || (ns != 0 && ns != 16 && ns != 32 && ns != 64) || (ns > 0 && rows % ns)) return 0;
+    const RowsGemmGeom g = rows_gemm_geom(rows, K, N);
+    if (g.WR == 1 && g.RT == 4) return 0;            // the 128-row x 64-channel tile has no registers left for a second operand stream
+    return (long long)rows * K < (1LL << 29) ? 1 : 0;
+}
+
+// The input gradient of a layer whose OWN BatchNorm + ReLU backward is formed while its rows are staged (in), with the backward
+// sums of the layer below out of the epilogue (as ptt_rows_gemm_bnbwd_f32): g_below = dz @ W^T, dz never read from memory.
+extern "C" int ptt_rows_gemm_bnbwd_fused_f32(const ptt_bn_bwd_input* in, int rows, int K, const float* Wpacked, int N, const float* Z,
+                                             int ldz, const float* mean, const float* invstd, const float* act_scale,
+                                             const float* act_shift, float* out, int ldo, double* sums_partial, size_t partial_elems,
+                                             ptt_stream_t stream) {
+    if (!in || !in->z || !in->g || !in->k1 || !in->c0 || !in->c1 || !in->mean || !in->act_a || !in->act_b || in->ldz < K || in->ldg < K ||
+        (in->arg != nullptr) != (in->ns > 0) || (in->dz_out && in->ldd < K))
+        return fail(PTT_EINVAL, "ptt_rows_gemm_bnbwd_fused_f32: bad input descriptor");
+    if (!Z || !mean || !invstd || !act_scale || !act_shift || !sums_partial || ldz < N)
+        return fail(PTT_EINVAL, "ptt_rows_gemm_bnbwd_fused_f32: null pointer or ldz=%d < N=%d", ldz, N);
+    if (!ptt_rows_gemm_bnbwd_fused_supported(rows, K, N, in->ns) || (in->ldz & 3) || (in->ldg & 3) || (in->ldd & 3) ||
+        (long long)rows * in->ldz >= (1LL << 29) || (long long)rows * in->ldg >= (1LL << 29) || (long long)rows * in->ldd >= (1LL << 29) ||
+        (long long)rows * ldz >= (1LL << 29))
+        return fail(PTT_EUNSUPPORTED, "ptt_rows_gemm_bnbwd_fused_f32: rows=%d K=%d N=%d ns=%d", rows, K, N, in->ns);
+    const uintptr_t al = reinterpret_cast<uintptr_t>(in->z) | reinterpret_cast<uintptr_t>(in->g) | reinterpret_cast<uintptr_t>(in->k1) |
+                         reinterpret_cast<uintptr_t>(in->c0) | reinterpret_cast<uintptr_t>(in->c1) | reinterpret_cast<uintptr_t>(in->mean) | reinterpret_cast<uintptr_t>(in->act_a) |
+                         reinterpret_cast<uintptr_t>(in->act_b) | reinterpret_cast<uintptr_t>(in->arg) | reinterpret_cast<uintptr_t>(in->dz_out);
+    if (al & 15) return fail(PTT_EINVAL, "ptt_rows_gemm_bnbwd_fused_f32: 16-byte aligned rows and constants expected");
+    const BnBwdArgs bn{Z, ldz, mean, invstd, act_scale, act_shift};
+    // the kernel's X operand: the dense gradient, or (pooled) z itself
+    const float* X = in->ns > 0 ? in->z : in->g;
+    const int ldx = in->ns > 0 ? in->ldz : in->ldg;
+    return rows_gemm_launch(X, rows, K, ldx, nullptr, nullptr, Wpacked, N, nullptr, 0, nullptr, 0, nullptr, 0, out, ldo, sums_partial,
+                            partial_elems, stream, &bn, nullptr, in);
+}
 
 extern "C" int ptt_rows_gemm_bnbwd_f32(const float* X, int rows, int K, int ldx, const float* Wpacked, int N, const float* Z, int ldz,
                                        const float* mean, const float* invstd, const float* act_scale, const float* act_shift,
@@ -575,7 +690,7 @@ extern "C" int ptt_rows_gemm_masked_f32(const float* X, int rows, int K, int ldx
 static int rows_gemm_launch(const float* X, int rows, int K, int ldx, const float* in_scale, const float* in_shift,
                             const float* Wpacked, int N, const float* bias, int relu, const float* residual, int ldr,
                             const float* mask, int ldm, float* out, int ldo, double* stats, size_t stats_elems, ptt_stream_t stream,
-                            const BnBwdArgs* bn, const PoolArgs* pool) {
+                            const BnBwdArgs* bn, const PoolArgs* pool, const ptt_bn_bwd_input* ain) {
     if (rows < 0 || K <= 0 || N <= 0 || ldx < K || ldo < N || (residual && ldr < N))
         return fail(PTT_EINVAL, "ptt_rows_gemm_f32: rows=%d K=%d N=%d ldx=%d ldo=%d ldr=%d", rows, K, N, ldx, ldo, ldr);
     if (rows == 0) return PTT_OK;
@@ -606,6 +721,12 @@ static int rows_gemm_launch(const float* X, int rows, int K, int ldx, const floa
     p.stats = stats; p.rows = rows; p.K = K; p.ldx = ldx; p.N = N; p.NT = N / 32; p.relu = relu; p.ldr = ldr; p.ldo = ldo;
     p.ntiles = g.ntiles; p.G = g.G; p.ncg = g.ncg; p.nchunks = K / g.KC;
     p.pmax = pool ? pool->pmax : nullptr; p.pmin = pool ? pool->pmin : nullptr; p.amax = pool ? pool->amax : nullptr; p.amin = pool ? pool->amin : nullptr;
+    p.tz = nullptr; p.ldtz = 0; p.tk1 = p.tc0 = p.tc1 = p.tmu = nullptr; p.tg = nullptr; p.ldtg = 0; p.targ = nullptr; p.a_out = nullptr; p.lda_out = 0;
+    if (ain) {
+        if (!bn) return fail(PTT_EINVAL, "ptt_rows_gemm_f32: the fused BatchNorm-backward operand comes with the backward-sums epilogue");
+        p.tz = ain->z; p.ldtz = ain->ldz; p.tk1 = ain->k1; p.tc0 = ain->c0; p.tc1 = ain->c1; p.tmu = ain->mean; p.in_a = ain->act_a; p.in_b = ain->act_b;
+        p.tg = ain->g; p.ldtg = ain->ldg; p.targ = ain->arg; p.a_out = ain->dz_out; p.lda_out = ain->ldd;
+    }
     const int lds = 2 * g.TR * (g.KC + 4) * (int)sizeof(float);
     const dim3 grid(g.G * g.ncg);
     hipStream_t s = as_stream(stream);
@@ -640,9 +761,22 @@ static int rows_gemm_launch(const float* X, int rows, int K, int ldx, const floa
         if ((rc = set_lds_limit(reinterpret_cast<const void*>(rows_gemm_kernel<WR_, RT_, CT_, KC_, ST_, AC_>), lds))) return rc; \
         hipLaunchKernelGGL((rows_gemm_kernel<WR_, RT_, CT_, KC_, ST_, AC_>), grid, dim3(256), lds, s, p);               \
     }
-#define PTT_RG_CASE(WR_, RT_, CT_, KC_)                                                                                 \
+#define PTT_RG_AIN(WR_, RT_, CT_, KC_, AIN_)                                                                            \
+    {                                                                                                                   \
+        if ((rc = set_lds_limit(reinterpret_cast<const void*>(rows_gemm_kernel<WR_, RT_, CT_, KC_, true, false, 0, true, 0, AIN_>), lds))) return rc; \
+        hipLaunchKernelGGL((rows_gemm_kernel<WR_, RT_, CT_, KC_, true, false, 0, true, 0, AIN_>), grid, dim3(256), lds, s, p); \
+    }
+#define PTT_RG_AINS(WR_, RT_, CT_, KC_)                                                                                 \
+        if (bn && ain && ain->ns == 16) PTT_RG_AIN(WR_, RT_, CT_, KC_, 16)                                              \
+        else if (bn && ain && ain->ns == 32) PTT_RG_AIN(WR_, RT_, CT_, KC_, 32)                                         \
+        else if (bn && ain && ain->ns == 64) PTT_RG_AIN(WR_, RT_, CT_, KC_, 64)                                         \
+        else if (bn && ain) PTT_RG_AIN(WR_, RT_, CT_, KC_, 2)                                                           \
+        else
+#define PTT_RG_NO_AINS(WR_, RT_, CT_, KC_)
+#define PTT_RG_CASE(WR_, RT_, CT_, KC_, AINS_)                                                                          \
     if (g.WR == WR_ && g.RT == RT_ && g.CT == CT_ && g.KC == KC_) {                                                     \
-        if (bn) {                                                                                                       \
+        AINS_(WR_, RT_, CT_, KC_)                                                                                       \
+        if (bn) {                                                                                                  \
             if ((rc = set_lds_limit(reinterpret_cast<const void*>(rows_gemm_kernel<WR_, RT_, CT_, KC_, true, false, 0, true>), lds))) return rc; \
             hipLaunchKernelGGL((rows_gemm_kernel<WR_, RT_, CT_, KC_, true, false, 0, true>), grid, dim3(256), lds, s, p); \
         } else if (stats && in_scale) PTT_RG_LAUNCH(WR_, RT_, CT_, KC_, true, true)                                     \
@@ -650,8 +784,12 @@ static int rows_gemm_launch(const float* X, int rows, int K, int ldx, const floa
         else if (in_scale) PTT_RG_LAUNCH(WR_, RT_, CT_, KC_, false, true)                                               \
         else PTT_RG_LAUNCH(WR_, RT_, CT_, KC_, false, false)                                                            \
     }
-    PTT_RG_CASE(1, 2, 2, 128) PTT_RG_CASE(1, 2, 1, 128) PTT_RG_CASE(1, 4, 1, 64) PTT_RG_CASE(2, 2, 1, 64)
+    PTT_RG_CASE(1, 2, 2, 128, PTT_RG_AINS) PTT_RG_CASE(1, 2, 1, 128, PTT_RG_AINS) PTT_RG_CASE(1, 4, 1, 64, PTT_RG_NO_AINS)
+    PTT_RG_CASE(2, 2, 1, 64, PTT_RG_AINS)
 #undef PTT_RG_CASE
+#undef PTT_RG_AINS
+#undef PTT_RG_NO_AINS
+#undef PTT_RG_AIN
 #undef PTT_RG_LAUNCH
     return check_launch("rows_gemm_kernel");
 }
@@ -705,7 +843,7 @@ extern "C" int ptt_linear_wgrad2_f32(const float* dZ, int ldz, const float* X, i
     if (!ws || ws_bytes < ptt_linear_wgrad2_workspace(R, Cout, Cin)) return fail(PTT_EWORKSPACE, "ptt_linear_wgrad2_f32: workspace too small");
     hipStream_t s = as_stream(stream);
     const int lds = 2 * 32 * (g.BN + 4 + g.BK + 4) * (int)sizeof(float);
-    const dim3 grid(g.nbo * g.nbk, g.nchunks);
+    const dim3 grid(g.nbo * g.nbk * g.nchunks);
     int rc = PTT_OK;
 #define PTT_WG2_CASE(TN_, TK_)                                                                                          \
     if (g.TN == TN_ && g.TK == TK_) {                                                                                   \

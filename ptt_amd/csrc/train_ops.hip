@@ -216,6 +216,35 @@ __global__ __launch_bounds__(256) void col_stats_finish2_kernel(const double* __
     }
 }
 
+// The same combine (MODE 1's order) for a BatchNorm backward whose dz is formed by its CONSUMER: dbeta = sum dy, dgamma = sum dy * xhat and
+// the three per-channel constants of  dz = c0 + c1 * (z - mean) + (mask ? k1 * g : 0)  (include/ptt_hip.h: ptt_bn_bwd_consts_f32)
+__global__ __launch_bounds__(256) void bn_bwd_consts_kernel(const double* __restrict__ partial, int nchunks, int C, int R,
+                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                            float* __restrict__ dbeta, float* __restrict__ dgamma,
+                                                            float* __restrict__ k1, float* __restrict__ c0, float* __restrict__ c1) {
+    __shared__ double t0[256], t1[256];
+    const int c = blockIdx.x, t = threadIdx.x;
+    double s0 = 0.0, s1 = 0.0;
+    for (int k = t; k < nchunks; k += 256) {
+        s0 += partial[((size_t)k * 2 + 0) * C + c];
+        s1 += partial[((size_t)k * 2 + 1) * C + c];
+    }
+    t0[t] = s0; t1[t] = s1;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (t < w) { t0[t] += t0[t + w]; t1[t] += t1[t + w]; }
+        __syncthreads();
+    }
+    if (t == 0) {
+        const float db = (float)t0[0], dg = (float)t1[0];
+        dbeta[c] = db; dgamma[c] = dg;
+        const double is = (double)invstd[c], kk = (double)gamma[c] * is, rinv = 1.0 / (double)R;
+        k1[c] = (float)kk;
+        c1[c] = (float)(-kk * ((double)dg * rinv * is));            // coefficient of (z - mean)
+        c0[c] = (float)(-kk * ((double)db * rinv));
+    }
+}
+
 // SyncBatchNorm pieces: the two column sums themselves in float64 (sums[c], sums[C + c]), combined in the same fixed order
 // as col_stats_finish2_kernel, so that ranks can add their sums before the statistics are formed ...
 __global__ __launch_bounds__(256) void col_sums_finish_kernel(const double* __restrict__ partial, int nchunks, int C,
@@ -1962,4 +1991,28 @@ extern "C" int ptt_bn_bwd_sums_partials_f64(const double* partial, int chunks, i
     if (chunks <= 0 || C <= 0 || !partial || !sums) return fail(PTT_EINVAL, "ptt_bn_bwd_sums_partials_f64: chunks=%d C=%d", chunks, C);
     hipLaunchKernelGGL(col_sums_finish_kernel, dim3(C), dim3(256), 0, as_stream(stream), partial, chunks, C, sums, -1.0);
     return check_launch("col_sums_finish_kernel");
+}
+
+extern "C" int ptt_bn_bwd_consts_f32(const double* partial, int chunks, const float* mean, const float* invstd, const float* gamma, int R,
+                                     int C, float* dgamma, float* dbeta, float* k1, float* c0, float* c1, ptt_stream_t stream) {
+    if (R <= 0 || C <= 0 || chunks <= 0) return fail(PTT_EINVAL, "ptt_bn_bwd_consts_f32: R=%d C=%d chunks=%d", R, C, chunks);
+    if (!partial || !mean || !invstd || !gamma || !dgamma || !dbeta || !k1 || !c0 || !c1) return fail(PTT_EINVAL, "ptt_bn_bwd_consts_f32: null pointer");
+    hipLaunchKernelGGL(bn_bwd_consts_kernel, dim3(C), dim3(256), 0, as_stream(stream), partial, chunks, C, R, invstd, gamma, dbeta, dgamma, k1, c0, c1);
+    return check_launch("bn_bwd_consts_kernel");
+}
+
+extern "C" int ptt_bn_bwd_pooled_consts_f32(const float* dPooled, int ldp, const int32_t* arg, int ns, const float* Z, int ldz,
+                                            const float* mean, const float* invstd, const float* gamma, int R, int C, float* dgamma,
+                                            float* dbeta, float* k1, float* c0, float* c1, void* ws, size_t ws_bytes,
+                                            const float* act_scale, const float* act_shift, ptt_stream_t stream) {
+    if (int rc = pooled_args_ok("ptt_bn_bwd_pooled_consts_f32", dPooled, ldp, arg, ns, Z, ldz, mean, invstd, R, C, act_scale, act_shift)) return rc;
+    if (!gamma || !dgamma || !dbeta || !k1 || !c0 || !c1) return fail(PTT_EINVAL, "ptt_bn_bwd_pooled_consts_f32: null pointer");
+    if (!ws || ws_bytes < ptt_bn_stats_workspace(R, C)) return fail(PTT_EWORKSPACE, "ptt_bn_bwd_pooled_consts_f32: workspace too small");
+    hipStream_t s = as_stream(stream);
+    const int G = R / ns, per = pool_bwd_groups_per_chunk(G, ns), nch = (G + per - 1) / per;
+    hipLaunchKernelGGL(pool_bwd_stats_kernel, dim3(nch), dim3(256), 0, s, dPooled, ldp, arg, G, ns, Z, ldz, mean, invstd, act_scale,
+                       act_shift, C, static_cast<double*>(ws), per);
+    hipLaunchKernelGGL(bn_bwd_consts_kernel, dim3(C), dim3(256), 0, s, static_cast<const double*>(ws), nch, C, R, invstd, gamma, dbeta, dgamma,
+                       k1, c0, c1);
+    return check_launch("ptt_bn_bwd_pooled_consts_f32");
 }

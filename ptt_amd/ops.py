@@ -1094,6 +1094,63 @@ def bn_bwd_from_partials(part, g, z, mean, invstd, gamma, act_scale, act_shift, 
     return out, dgamma, dbeta
 
 
+def bn_bwd_consts(part, mean, invstd, gamma, rows):
+    """(dgamma, dbeta, (k1, c0, c1)) from rows_gemm_bnbwd's partials: the layer's BatchNorm + ReLU backward as three per-channel
+    constants, dz = c0 + c1 (z - mean) + (mask ? k1 g : 0), for the consumer that applies it (rows_gemm_bnbwd_fused) —
+    ptt_bn_bwd_consts_f32."""
+    chunks, _, C = part.shape
+    out = torch.empty((5, C), dtype=torch.float32, device=part.device)
+    with torch.cuda.device(part.device):
+        _lib.check(_lib.lib().ptt_bn_bwd_consts_f32(_ptr(part), chunks, _ptr(mean), _ptr(invstd), _ptr(gamma), int(rows), C, _ptr(out[0]),
+                                                    _ptr(out[1]), _ptr(out[2]), _ptr(out[3]), _ptr(out[4]), _stream()), "ptt_bn_bwd_consts_f32")
+    return out[0], out[1], (out[2], out[3], out[4])
+
+
+def bn_bwd_pooled_consts(dpooled, arg, ns, z, mean, invstd, gamma, act_scale, act_shift):
+    """The same for the last layer of a SharedMLP + max-pool stage, the gradient still pooled — ptt_bn_bwd_pooled_consts_f32."""
+    _rows(dpooled, "dpooled"); _rows(z, "z")
+    R, C = z.shape
+    out = torch.empty((5, C), dtype=torch.float32, device=z.device)
+    ws = _ws(_lib.lib().ptt_bn_stats_workspace(R, C), z.device)
+    with torch.cuda.device(z.device):
+        _lib.check(_lib.lib().ptt_bn_bwd_pooled_consts_f32(_ptr(dpooled), dpooled.stride(0), _ptr(arg), int(ns), _ptr(z), z.stride(0), _ptr(mean),
+                                                           _ptr(invstd), _ptr(gamma), R, C, _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), _ptr(out[3]),
+                                                           _ptr(out[4]), _ptr(ws), ws.numel() * 8, _ptr(act_scale), _ptr(act_shift), _stream()),
+                   "ptt_bn_bwd_pooled_consts_f32")
+    return out[0], out[1], (out[2], out[3], out[4])
+
+
+def rows_gemm_bnbwd_fused_supported(rows, K, cout, ns, *tensors):
+    """ptt_rows_gemm_bnbwd_fused_f32 takes the shape and the layouts: contiguous 16-byte aligned rows (row stride == K)."""
+    if not _lib.lib().ptt_rows_gemm_bnbwd_fused_supported(int(rows), int(K), int(cout), int(ns)):
+        return False
+    return all(t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1 and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0
+               for t in tensors if t is not None)
+
+
+def rows_gemm_bnbwd_fused(g, arg, ns, z, consts, mean, act_a, act_b, wpacked, cout, zp, mp, ip, ap, bp, want_dz=True):
+    """The input gradient of a layer whose own BatchNorm + ReLU backward is formed while the rows are staged: g_below = dz @ W^T with
+    dz = c0 + c1 (z - mean) + (mask ? k1 g : 0), g dense (rows, K) (arg None, ns 0) or pooled (rows / ns, K) with the arg-max rows;
+    the backward sums of the layer BELOW (zp, mp, ip, ap, bp as rows_gemm_bnbwd) out of the epilogue; want_dz: dz written out once
+    for the layer's weight gradient. -> (g_below, partials, dz | None) — ptt_rows_gemm_bnbwd_fused_f32."""
+    rows, K = z.shape
+    cout = int(cout)
+    dev = z.device
+    out = torch.empty((rows, cout), dtype=torch.float32, device=dev)
+    dz = torch.empty((rows, K), dtype=torch.float32, device=dev) if want_dz else None
+    chunks = _lib.lib().ptt_rows_gemm_stat_chunks(rows, K, cout)
+    part = torch.empty((max(1, chunks), 2, cout), dtype=torch.float64, device=dev)
+    d = _lib.BnBwdInput(g=g.data_ptr(), ldg=g.stride(0), arg=arg.data_ptr() if arg is not None else None, ns=int(ns), z=z.data_ptr(),
+                        ldz=z.stride(0), k1=consts[0].data_ptr(), c0=consts[1].data_ptr(), c1=consts[2].data_ptr(), mean=mean.data_ptr(),
+                        act_a=act_a.data_ptr(), act_b=act_b.data_ptr(), dz_out=dz.data_ptr() if dz is not None else None,
+                        ldd=dz.stride(0) if dz is not None else 0)
+    with torch.cuda.device(dev), _timed('ptt_rows_gemm_f32'):
+        _lib.check(_lib.lib().ptt_rows_gemm_bnbwd_fused_f32(ctypes.byref(d), rows, K, _ptr(wpacked), cout, _ptr(zp), zp.stride(0), _ptr(mp),
+                                                            _ptr(ip), _ptr(ap), _ptr(bp), _ptr(out), cout, _ptr(part), part.numel(), _stream()),
+                   "ptt_rows_gemm_bnbwd_fused_f32")
+    return out, part, dz
+
+
 def bn_bwd_sums_from_partials(part):
     """The (2, C) float64 sums of bn_bwd_sums from rows_gemm_bnbwd's partials (SyncBatchNorm: all-reduce them, then bn_bwd_apply)."""
     chunks, _, C = part.shape
@@ -1132,14 +1189,15 @@ def bn_sums_partials(partials, rows):
     return sums
 
 
-def colsum(x):
+def colsum(x, out=None):
     """(rows, C) -> (C,) column sums in a fixed order (ptt_colsum_f32): the bias gradient of a row-wise layer (float4 loads where
     the rows allow them, scalar loads otherwise)."""
     _rows(x, "x")
     R, C = x.shape
     if R == 0:
-        return x.sum(0)
-    out = torch.empty((C,), dtype=torch.float32, device=x.device)
+        return x.sum(0) if out is None else out.zero_()
+    if out is None:
+        out = torch.empty((C,), dtype=torch.float32, device=x.device)
     ws = _ws(_lib.lib().ptt_colsum_workspace(R, C), x.device)
     with torch.cuda.device(x.device):
         _lib.check(_lib.lib().ptt_colsum_f32(_ptr(x), R, C, x.stride(0), _ptr(out), _ptr(ws), ws.numel() * 8, _stream()), "ptt_colsum_f32")

@@ -19,6 +19,7 @@ replaces `mlp(grouped).max(dim=pool_dim)[0]` (= F.max_pool2d over that axis) whe
 a HIP device and has the plain [conv1x1 (no bias) -> BatchNorm2d -> ReLU] units every shipped config builds (`usable`).
 Every reduction runs in a fixed order: a step is bit-reproducible run to run (tests/test_train_config3_gpu.py).
 """
+import os
 import weakref
 
 import torch
@@ -141,6 +142,8 @@ class _PackPlan:
         return True
 
 
+FUSED_BN_BWD = os.environ.get("PTT_FUSED_BN_BWD", "1") != "0"     # a layer's BatchNorm + ReLU backward applied by its input-gradient GEMM
+#                                                                  (dev A/B: 0 = the apply pass of round 4)
 POOL_EPILOGUE = True   # the last layer's max-pool from the extrema its GEMM's epilogue takes (False: a pooling pass over z)
 _pack_plans = {}       # device -> _PackPlan
 PACK_PLAN = True       # False: every weight packed by its own launch (development comparisons)
@@ -350,6 +353,28 @@ class _SharedMlpPool(torch.autograd.Function):
             last = l == L - 1
             # the last layer's gradient arrives POOLED: max-pool backward, BatchNorm sums and dz are formed from (dpooled,
             # arg) — the (R, C) gradient of the pooled layer is never written (ptt_bn_bwd_pooled_f32)
+            fused = None
+            if FUSED_BN_BWD and ctx.sync[l] is None and l > 0 and (last or part is not None):
+                # the layer's BatchNorm + ReLU backward is applied by its input-gradient GEMM while that stages its rows (three
+                # per-channel constants instead of a pass that reads g and z and writes dz); the GEMM writes dz out once for the
+                # weight gradient, which therefore runs after it
+                src = dpooled if last else g
+                pooled = last and ns > 1
+                w2 = ctx.weights[l].reshape(ctx.weights[l].shape[0], -1)
+                if ops.rows_gemm_bnbwd_fused_supported(z.shape[0], w2.shape[0], w2.shape[1], ns if pooled else 0, src, z):
+                    if last:
+                        dgamma, dbeta, consts = ops.bn_bwd_pooled_consts(dpooled, arg, ns, z, mean, invstd, gamma, a, b)
+                    else:
+                        dgamma, dbeta, consts = ops.bn_bwd_consts(part, mean, invstd, gamma, z.shape[0])
+                    zp, mp, ip, ap, bp = saved[9 * (l - 1) + 3], saved[9 * (l - 1) + 4], saved[9 * (l - 1) + 5], saved[9 * (l - 1) + 6], saved[9 * (l - 1) + 7]
+                    fused = ops.rows_gemm_bnbwd_fused(src, arg if pooled else None, ns if pooled else 0, z, consts, mean, a, b,
+                                                      packed(w2, True), w2.shape[1], zp, mp, ip, ap, bp)
+            if fused is not None:
+                g, part, dz = fused
+                grads[3 * l + 1], grads[3 * l + 2] = dgamma, dbeta
+                has_t = in_a.numel() > 0
+                grads[3 * l] = ops.linear_wgrad(dz, x_in, x_scale=in_a if has_t else None, x_shift=in_b if has_t else None).view_as(W)
+                continue
             if ctx.sync[l] is not None:
                 # torch's SyncBatchNorm: dgamma / dbeta are the rank's LOCAL sums (DDP averages parameter gradients); dz
                 # uses the sums of all ranks

@@ -107,3 +107,46 @@ def test_fps_beyond_the_register_resident_limit_matches_oracle(dev, N, npoint):
     np.testing.assert_array_equal(out.cpu().numpy(), ref)
     assert _lib.lib().ptt_fps_ws_f32(x.data_ptr(), 4, N, npoint, out.data_ptr(), ws.data_ptr(), ws.numel() - 1,
                                      torch.cuda.current_stream().cuda_stream) == -4           # PTT_EWORKSPACE
+
+
+@pytest.mark.parametrize("B,M,ns,spec", [(2, 70, 32, [64, 128, 128, 256]), (1, 48, 64, [128, 256, 256, 256]), (2, 100, 16, [256, 512, 512, 512]),
+                                         (3, 33, 32, [64, 64, 128, 128]), (1, 1031, 1, [128, 128, 256])])
+def test_bn_backward_applied_by_the_input_gradient_gemm_equals_the_apply_pass(dev, B, M, ns, spec):
+    """A layer's BatchNorm + ReLU backward formed while its input-gradient GEMM stages the rows (ptt_rows_gemm_bnbwd_fused_f32,
+    dense and pooled gradients, whole and ragged row tiles, dz written out for the weight gradient) against the round-4 form
+    (a pass that writes dz) and against the reference op sequence in stock torch (SharedMLP in train mode + max,
+    pytorch_utils.py:12-36, pointnet2_modules.py:84-88): every gradient within 3e-6 of the gradient's largest element."""
+    from ptt_amd import train_ops
+    from ptt_amd.models.backbones_3d.pointnet2 import pytorch_utils as pt_utils
+    torch.manual_seed(11)
+    mods = [pt_utils.SharedMLP(list(spec), bn=True).to(dev).train() for _ in range(3)]
+    with torch.no_grad():
+        for u in mods[0]:
+            u.normlayer.bn.weight.uniform_(0.5, 1.5)
+            u.normlayer.bn.bias.normal_(0, 0.2)
+    for m in mods[1:]:
+        m.load_state_dict(mods[0].state_dict())
+    x0 = torch.randn(B, spec[0], M, ns, device=dev)
+    up = torch.randn(B, spec[-1], M, device=dev)
+    grads = []
+    for k, m in enumerate(mods):
+        x = x0.clone().requires_grad_(True)
+        if k < 2:
+            train_ops.FUSED_BN_BWD = k == 0
+            try:
+                assert train_ops.usable(m, x)
+                y = train_ops.shared_mlp_pool(x, m, 3)
+                y.backward(up)
+            finally:
+                train_ops.FUSED_BN_BWD = True
+        else:
+            m(x).max(dim=3)[0].backward(up)
+        grads.append([x.grad] + [p.grad for p in m.parameters()])
+    names = ["input"] + [n for n, _ in mods[0].named_parameters()]
+    worst = 0.0
+    for name, a, b, c in zip(names, *grads):
+        scale = float(c.abs().max()) + 1e-12
+        e_apply, e_torch = float((a - b).abs().max()) / scale, float((a - c).abs().max()) / scale
+        worst = max(worst, e_apply, e_torch)
+        assert e_apply < 3e-6 and e_torch < 3e-6, (name, e_apply, e_torch)
+    print("fused BatchNorm backward %s ns %d: worst relative gradient difference %.2e" % (spec, ns, worst))
