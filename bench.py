@@ -384,8 +384,9 @@ def compact_line(out):
 def side_workload(name, steps, warmup):
     """One short run of another workload in its OWN process (`python bench.py --workload name ...`), reduced to the keys a
     reader needs. A fresh process per workload: the graphs, streams and memory pools of the headline run stay out of its
-    way (an in-process sequence car -> ped -> stress was seen to crash inside hipGraphLaunch on ROCm 7.2), and a failing side
-    workload cannot take the headline line down with it."""
+    way, and a failing side workload cannot take the headline line down with it. (An in-process sequence car -> ped -> stress
+    crashes inside hipGraphLaunch on ROCm 7.2 when two parallel branches of a graph are given the same hardware queue — DESIGN.md
+    section 6, scripts/probes/graph_queue_repro.py; GPU_MAX_HW_QUEUES=8 avoids it at the price of slower graph replays.)"""
     cmd = [sys.executable, os.path.abspath(__file__), "--workload", name, "--steps", str(steps), "--warmup", str(warmup),
            "--sustain", "0", "--no-cpu-baseline", "--no-full-model", "--no-latency", "--no-workloads"]
     t0 = time.perf_counter()

@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256, 2) void rows_gemm_kernel(RowsGemmParams p) {
     g32x4 sz[TS], sg[NG];
     gi32x4 sarg[NG];
     g32x4 tk1 = {0.f, 0.f, 0.f, 0.f}, tc0 = tk1, tc1 = tk1, tmu = tk1;
-    int aout_off = 0, aout_c = 0;
+    int aout_off = 0;
     const bool write_a = AIN != 0 && p.a_out != nullptr && cg == 0;
     const __amdgpu_buffer_rsrc_t rtz = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(AIN == 2 ? p.tz : p.X), 0,
                                                                           AIN == 2 ? ((p.rows - 1) * p.ldtz + p.K) * 4 : 0, 0x00020000);
@@ -185,8 +185,11 @@ __global__ __launch_bounds__(256, 2) void rows_gemm_kernel(RowsGemmParams p) {
             tc0 = *reinterpret_cast<const g32x4*>(p.tc0 + c * KC + 4 * q);
             tc1 = *reinterpret_cast<const g32x4*>(p.tc1 + c * KC + 4 * q);
             tmu = *reinterpret_cast<const g32x4*>(p.tmu + c * KC + 4 * q);
-            aout_off = (tcl * TR + r0) * (p.lda_out * 4) + q * 16;
-            aout_c = c * (KC * 4);
+            // row part AND chunk part in the vector offset, no scalar offset: a 128-bit buffer store WITH an SGPR offset showed the
+            // "store data overwritten by the next VALU instruction" hazard on gfx950 (element 1 of a quad, lanes 12-15 of every 16,
+            // one launch in a few) that hipcc only guards against for stores WITHOUT one (scripts/probes/fused_bnbwd_probe.py);
+            // the range check still drops rows past the end (lda_out >= K)
+            aout_off = (tcl * TR + r0) * (p.lda_out * 4) + q * 16 + c * (KC * 4);
         }
         if constexpr (AIN == 2) {
             const int z_off = (tcl * TR + r0) * (p.ldtz * 4) + q * 16;
@@ -229,7 +232,7 @@ __global__ __launch_bounds__(256, 2) void rows_gemm_kernel(RowsGemmParams p) {
         *reinterpret_cast<g32x4*>(buf + lds_slot + i * (RSTEP * LDK)) = v;
         if constexpr (AIN != 0) {
             if (write_a)
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(gu32x4, v), rao, aout_off + i * (RSTEP * p.lda_out * 4), aout_c, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(gu32x4, v), rao, aout_off + i * (RSTEP * p.lda_out * 4), 0, 0);
         }
     };
 
@@ -804,7 +807,11 @@ static Wgrad2Geom wgrad2_geom(int R, int Cout, int Cin) {
     // the largest block that still fills the chip with row chunks of >= 768 rows (one workgroup per CU, one round)
     const int ncu = cu_count();
     const int cand[4][2] = {{4, 2}, {4, 1}, {2, 2}, {2, 1}};
-    for (int k = 0; k < 4; ++k) {
+    int first = 0;
+#ifdef PTT_GEMM_DEV
+    if (const char* e = getenv("PTT_WG2_FIRST")) first = atoi(e);       // dev: skip the larger blocks (tile-shape experiments)
+#endif
+    for (int k = first; k < 4; ++k) {
         const int TN = cand[k][0], TK = cand[k][1];
         if (Cout % (64 * TN) || Cin % (128 * TK)) continue;
         const int blocks = (Cout / (64 * TN)) * (Cin / (128 * TK));

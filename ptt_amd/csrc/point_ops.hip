@@ -36,16 +36,13 @@ __device__ __forceinline__ float lane_bcast(float v, int src_lane) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src_lane));
 }
 
-// LX: a copy of the cloud lives in LDS (one float4 per point) and the per-point update tracks only (distance, index): every
-// lane requests ITS candidate's coordinates from LDS right after its scan — the read completes under the wave reduction — and
-// the winner's coordinates travel with its distance through the slot exchange (until round 5 the winner's index was exchanged
-// and its coordinates read back afterwards: a second dependent LDS round trip per iteration), instead of riding through three
-// more selects per point, and
+// LX: a copy of the cloud lives in LDS and the per-point update tracks only (distance, index): the winner's
+// coordinates are read back from LDS once per iteration instead of riding through three more selects per point, and
 // the squared distances are formed two points at a time with packed fp32 instructions (v_pk_add / v_pk_mul: the same
 // IEEE operations, no FMA) — 8 instead of 15 vector-ALU instructions per point. It is every instruction of this
 // kernel, not its 0.4 ms, that the pipelined step pays for: the FPS of the next batch runs beside the MFMA kernels
 // and costs them 0.14 ms per step (scripts/probes/fps_interference_probe.py, fps_vs_pair_probe.py; 0.07 with LX). LX needs
-// 16 N bytes of LDS beside the index buffer: clouds up to 4096 points; larger ones keep the coordinates in the selects.
+// 12 N bytes of LDS beside the index buffer: clouds up to ~4096 points; larger ones keep the coordinates in the selects.
 typedef float fps_f2 __attribute__((ext_vector_type(2)));
 
 template <int T, int P, bool LX>
@@ -62,8 +59,8 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
     // The chosen indices are collected in LDS and written out once at the end: a global store inside
     // the loop puts its write-acknowledge latency (vmcnt counts stores; the barrier waits vmcnt(0))
     // on the critical path of every iteration. LX: the cloud's coordinates follow the index buffer.
-    extern __shared__ __attribute__((aligned(16))) int sel_lds[];
-    float* xyz_lds = reinterpret_cast<float*>(sel_lds + ((npoint + 3) & ~3));      // LX: [N] float4 {x, y, z, -}
+    extern __shared__ int sel_lds[];
+    float* xyz_lds = reinterpret_cast<float*>(sel_lds + ((npoint + 3) & ~3));
 
     float px[P], py[P], pz[P], md[P];
 #pragma unroll
@@ -76,12 +73,12 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
             z = pts[3 * k + 2];
             const float mag = (x * x + y * y) + z * z;
             m = (mag > 1e-3f) ? 1e10f : -1.0f;
-            if (LX) *reinterpret_cast<float4*>(xyz_lds + 4 * k) = make_float4(x, y, z, 0.f);
+            if (LX) { xyz_lds[3 * k + 0] = x; xyz_lds[3 * k + 1] = y; xyz_lds[3 * k + 2] = z; }
         }
         px[i] = x; py[i] = y; pz[i] = z; md[i] = m;
     }
 
-    // slots[parity][wave] = {dist, x, y, z | idx(bits)}
+    // slots[parity][wave] = {dist, idx(bits), x, y | z}   (LX: only the first two are used)
     __shared__ __attribute__((aligned(16))) float slots[2][W > 1 ? W : 1][8];
 
     float lx = pts[0], ly = pts[1], lz = pts[2];
@@ -128,19 +125,15 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
                 }
             }
         }
-        if constexpr (LX) {
-            // this lane's candidate, requested now: the LDS read completes under the wave reduction below, and the winner's
-            // coordinates then travel with its distance (one exchange per iteration instead of exchange + coordinate read-back)
-            const float4 c = *reinterpret_cast<const float4*>(xyz_lds + 4 * besti);
-            bx = c.x; by = c.y; bz = c.z;
-        }
         const float wmax = wave_max_f32_fused(best);
         const unsigned long long winners = __ballot(best == wmax);
         const int src = __ffsll((long long)winners) - 1;          // lowest lane among the maxima
         if constexpr (W == 1) {
             int widx = __builtin_amdgcn_readlane(besti, src);
-            if (wmax < 0.f) {                    // no selectable point left: index 0 (upstream's besti init)
-                widx = 0;
+            if (wmax < 0.f) widx = 0;            // no selectable point left: index 0 (upstream's besti init)
+            if constexpr (LX) {
+                lx = xyz_lds[3 * widx + 0]; ly = xyz_lds[3 * widx + 1]; lz = xyz_lds[3 * widx + 2];
+            } else if (wmax < 0.f) {
                 lx = pts[0]; ly = pts[1]; lz = pts[2];
             } else {
                 lx = lane_bcast(bx, src); ly = lane_bcast(by, src); lz = lane_bcast(bz, src);
@@ -149,9 +142,13 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
         } else {
             const int par = j & 1;
             if (lane == src) {                   // the winning lane publishes its own candidate
-                float4* s4 = reinterpret_cast<float4*>(slots[par][wv]);
-                s4[0] = make_float4(best, bx, by, bz);
-                slots[par][wv][4] = __builtin_bit_cast(float, besti);
+                if constexpr (LX) {
+                    *reinterpret_cast<float2*>(slots[par][wv]) = make_float2(best, __builtin_bit_cast(float, besti));
+                } else {
+                    float4* s4 = reinterpret_cast<float4*>(slots[par][wv]);
+                    s4[0] = make_float4(best, __builtin_bit_cast(float, besti), bx, by);
+                    slots[par][wv][4] = bz;
+                }
             }
             __syncthreads();
             float gd, gx = 0.f, gy = 0.f, gz = 0.f;
@@ -160,26 +157,46 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
                 gd = -1.0f; gi = 0;
 #pragma unroll
                 for (int w = 0; w < W; ++w) {      // ascending waves hold ascending indices: strict > keeps the lowest
-                    const float4 s4 = *reinterpret_cast<const float4*>(slots[par][w]);
-                    const int si = __builtin_bit_cast(int, slots[par][w][4]);
-                    const bool take = s4.x > gd;
-                    gd = take ? s4.x : gd;
-                    gi = take ? si : gi;
-                    gx = take ? s4.y : gx;
-                    gy = take ? s4.z : gy;
-                    gz = take ? s4.w : gz;
+                    if constexpr (LX) {
+                        const float2 s2 = *reinterpret_cast<const float2*>(slots[par][w]);
+                        const bool take = s2.x > gd;
+                        gd = take ? s2.x : gd;
+                        gi = take ? __builtin_bit_cast(int, s2.y) : gi;
+                    } else {
+                        const float4 s4 = *reinterpret_cast<const float4*>(slots[par][w]);
+                        const float sz = slots[par][w][4];
+                        const bool take = s4.x > gd;
+                        gd = take ? s4.x : gd;
+                        gi = take ? __builtin_bit_cast(int, s4.y) : gi;
+                        gx = take ? s4.z : gx;
+                        gy = take ? s4.w : gy;
+                        gz = take ? sz : gz;
+                    }
                 }
             } else {                                // many waves: fold the slots with one more wave reduction
-                float4 s4 = make_float4(-1.0f, 0.f, 0.f, 0.f);
-                int si = 0;
-                if (lane < W) { s4 = *reinterpret_cast<const float4*>(slots[par][lane]); si = __builtin_bit_cast(int, slots[par][lane][4]); }
-                gd = wave_max_f32_fused(s4.x);
-                const int sl = __ffsll((long long)__ballot(s4.x == gd)) - 1;
-                gi = __builtin_amdgcn_readlane(si, sl);
-                gx = lane_bcast(s4.y, sl); gy = lane_bcast(s4.z, sl); gz = lane_bcast(s4.w, sl);
+                if constexpr (LX) {
+                    float2 s2 = make_float2(-1.0f, 0.f);
+                    if (lane < W) s2 = *reinterpret_cast<const float2*>(slots[par][lane]);
+                    gd = wave_max_f32_fused(s2.x);
+                    const int sl = __ffsll((long long)__ballot(s2.x == gd)) - 1;
+                    gi = __builtin_amdgcn_readlane(__builtin_bit_cast(int, s2.y), sl);
+                } else {
+                    float4 s4 = make_float4(-1.0f, 0.f, 0.f, 0.f);
+                    float sz = 0.f;
+                    if (lane < W) { s4 = *reinterpret_cast<const float4*>(slots[par][lane]); sz = slots[par][lane][4]; }
+                    gd = wave_max_f32_fused(s4.x);
+                    const int sl = __ffsll((long long)__ballot(s4.x == gd)) - 1;
+                    gi = __builtin_amdgcn_readlane(__builtin_bit_cast(int, s4.y), sl);
+                    gx = lane_bcast(s4.z, sl); gy = lane_bcast(s4.w, sl); gz = lane_bcast(sz, sl);
+                }
             }
-            if (gd < 0.f) { gi = 0; gx = pts[0]; gy = pts[1]; gz = pts[2]; }
-            lx = gx; ly = gy; lz = gz;
+            if (gd < 0.f) gi = 0;
+            if constexpr (LX) {
+                lx = xyz_lds[3 * gi + 0]; ly = xyz_lds[3 * gi + 1]; lz = xyz_lds[3 * gi + 2];
+            } else {
+                if (gd < 0.f) { gx = pts[0]; gy = pts[1]; gz = pts[2]; }
+                lx = gx; ly = gy; lz = gz;
+            }
             if (t == 0) sel_lds[j] = gi;
         }
     }
@@ -190,11 +207,8 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
 template <int T, int P>
 static int launch_fps(const float* xyz, int B, int N, int npoint, int32_t* idx, hipStream_t s) {
     const size_t sel_bytes = (size_t)((npoint + 3) & ~3) * sizeof(int);
-    const size_t lx_bytes = sel_bytes + (size_t)N * 16;
-    if (lx_bytes + 1024 <= 98304 && !dev_switches().fps_plain) {                      // 4096 points + their picks: 80 KB
-        if (lx_bytes + 1024 > 65536)
-            if (int rc = set_lds_limit(reinterpret_cast<const void*>(fps_kernel<T, P, true>), (int)lx_bytes)) return rc;
-        hipLaunchKernelGGL((fps_kernel<T, P, true>), dim3(B), dim3(T), lx_bytes, s, xyz, N, npoint, idx);
+    if (sel_bytes + (size_t)N * 12 + 1024 <= 65536 && !dev_switches().fps_plain) {   // fits the default 64 KB with the slots
+        hipLaunchKernelGGL((fps_kernel<T, P, true>), dim3(B), dim3(T), sel_bytes + (size_t)N * 12, s, xyz, N, npoint, idx);
         return check_launch("fps_kernel");
     }
     hipLaunchKernelGGL((fps_kernel<T, P, false>), dim3(B), dim3(T), sel_bytes, s, xyz, N, npoint, idx);

@@ -1099,25 +1099,28 @@ def bn_bwd_consts(part, mean, invstd, gamma, rows):
     constants, dz = c0 + c1 (z - mean) + (mask ? k1 g : 0), for the consumer that applies it (rows_gemm_bnbwd_fused) —
     ptt_bn_bwd_consts_f32."""
     chunks, _, C = part.shape
-    out = torch.empty((5, C), dtype=torch.float32, device=part.device)
+    # dgamma / dbeta become .grad of their parameters: tensors of their own, not rows of the constants' buffer
+    dgamma, dbeta = (torch.empty((C,), dtype=torch.float32, device=part.device) for _ in range(2))
+    out = torch.empty((3, C), dtype=torch.float32, device=part.device)
     with torch.cuda.device(part.device):
-        _lib.check(_lib.lib().ptt_bn_bwd_consts_f32(_ptr(part), chunks, _ptr(mean), _ptr(invstd), _ptr(gamma), int(rows), C, _ptr(out[0]),
-                                                    _ptr(out[1]), _ptr(out[2]), _ptr(out[3]), _ptr(out[4]), _stream()), "ptt_bn_bwd_consts_f32")
-    return out[0], out[1], (out[2], out[3], out[4])
+        _lib.check(_lib.lib().ptt_bn_bwd_consts_f32(_ptr(part), chunks, _ptr(mean), _ptr(invstd), _ptr(gamma), int(rows), C, _ptr(dgamma),
+                                                    _ptr(dbeta), _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), _stream()), "ptt_bn_bwd_consts_f32")
+    return dgamma, dbeta, (out[0], out[1], out[2])
 
 
 def bn_bwd_pooled_consts(dpooled, arg, ns, z, mean, invstd, gamma, act_scale, act_shift):
     """The same for the last layer of a SharedMLP + max-pool stage, the gradient still pooled — ptt_bn_bwd_pooled_consts_f32."""
     _rows(dpooled, "dpooled"); _rows(z, "z")
     R, C = z.shape
-    out = torch.empty((5, C), dtype=torch.float32, device=z.device)
+    dgamma, dbeta = (torch.empty((C,), dtype=torch.float32, device=z.device) for _ in range(2))
+    out = torch.empty((3, C), dtype=torch.float32, device=z.device)
     ws = _ws(_lib.lib().ptt_bn_stats_workspace(R, C), z.device)
     with torch.cuda.device(z.device):
         _lib.check(_lib.lib().ptt_bn_bwd_pooled_consts_f32(_ptr(dpooled), dpooled.stride(0), _ptr(arg), int(ns), _ptr(z), z.stride(0), _ptr(mean),
-                                                           _ptr(invstd), _ptr(gamma), R, C, _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), _ptr(out[3]),
-                                                           _ptr(out[4]), _ptr(ws), ws.numel() * 8, _ptr(act_scale), _ptr(act_shift), _stream()),
+                                                           _ptr(invstd), _ptr(gamma), R, C, _ptr(dgamma), _ptr(dbeta), _ptr(out[0]), _ptr(out[1]),
+                                                           _ptr(out[2]), _ptr(ws), ws.numel() * 8, _ptr(act_scale), _ptr(act_shift), _stream()),
                    "ptt_bn_bwd_pooled_consts_f32")
-    return out[0], out[1], (out[2], out[3], out[4])
+    return dgamma, dbeta, (out[0], out[1], out[2])
 
 
 def rows_gemm_bnbwd_fused_supported(rows, K, cout, ns, *tensors):

@@ -232,33 +232,44 @@ def test_clip_adam_update_is_seen_by_the_weight_pack_cache_and_by_autograd(dev):
 
 
 def test_three_training_steps_with_clip_adam_track_the_stock_optimiser(dev):
-    """The full tracker for three steps: ClipAdam against clip_grad_norm_ + torch.optim.Adam on the same batches. The losses of
-    steps 2 and 3 depend on the updated weights (packed for the MFMA kernels once per step)."""
+    """The full tracker for three steps: ClipAdam against clip_grad_norm_ + torch.optim.Adam. The twin that the stock optimiser drives
+    takes over the ClipAdam model's weights before every forward pass, so both see bit-identical losses and gradients (the row
+    kernels are deterministic) and only the two optimisers' arithmetic is compared: every parameter after every step within 1e-6
+    (a thousandth of the learning rate). Free-running twins are not comparable beyond two steps: a 1e-7 difference flips a near-tie
+    of the box head's furthest point sampling in one of them (scripts/probes/three_step_diag.py). The losses of steps 2 and 3
+    depend on the updated weights (packed for the MFMA kernels once per step)."""
     from ptt_amd.config import StubDataset, ptt_model_cfg
     from ptt_amd.models import build_network
     from ptt_amd.train_step import synthetic_train_batch
-    losses = []
+    kw = dict(lr=1e-3, betas=(0.5, 0.999), eps=1e-6)
+    models, opts = [], []
     for fused in (True, False):
         torch.manual_seed(11)
         model = build_network(ptt_model_cfg(), 1, StubDataset(training=True)).to(dev).train()
-        kw = dict(lr=1e-3, betas=(0.5, 0.999), eps=1e-6)
-        opt = ClipAdam(model.parameters(), **kw) if fused else torch.optim.Adam(model.parameters(), **kw)
+        models.append(model)
+        opts.append(ClipAdam(model.parameters(), **kw) if fused else torch.optim.Adam(model.parameters(), **kw))
+    losses, worst = [], 0.0
+    for step in range(3):
+        models[1].load_state_dict(models[0].state_dict())
         run = []
-        for step in range(3):
+        for model, opt in zip(models, opts):
             ret, _, _ = model(dict(synthetic_train_batch(20 + step, 4, dev)))
             opt.zero_grad(set_to_none=True)
             ret['loss'].backward()
-            if fused:
-                opt.step(max_norm=10.0)
-            else:
-                torch.nn.utils.clip_grad_norm_(model.parameters(), 10.0)
-                opt.step()
             run.append(float(ret['loss'].detach()))
-        losses.append(run)
-    a, b = losses
-    assert a[0] == b[0]
-    assert abs(a[1] - b[1]) <= 2e-3 * abs(b[1]) and abs(a[2] - b[2]) <= 5e-3 * abs(b[2]), (a, b)
-    assert abs(a[1] - a[0]) > 1e-3 * abs(a[0])                      # the second step did see new weights
+        assert run[0] == run[1], (step, run)
+        for (n, p), (_, q) in zip(models[0].named_parameters(), models[1].named_parameters()):
+            assert (p.grad is None) == (q.grad is None) and (p.grad is None or torch.equal(p.grad, q.grad)), n
+        opts[0].step(max_norm=10.0)
+        torch.nn.utils.clip_grad_norm_(models[1].parameters(), 10.0)
+        opts[1].step()
+        for (n, p), (_, q) in zip(models[0].named_parameters(), models[1].named_parameters()):
+            d = float((p.detach() - q.detach()).abs().max())
+            worst = max(worst, d)
+            assert d <= 1e-6, (step, n, d)
+        losses.append(run[0])
+    print("ClipAdam vs clip_grad_norm_ + Adam over three steps: losses %s, largest parameter difference %.2e" % (losses, worst))
+    assert abs(losses[1] - losses[0]) > 1e-3 * abs(losses[0]) and abs(losses[2] - losses[1]) > 1e-4 * abs(losses[1])   # new weights were seen
 
 
 @pytest.mark.parametrize("R,C,want_dz", [(3 * 37 * 5, 64, True), (48 * 64 * 16, 256, False), (70001, 132, True), (64, 4, True)])
