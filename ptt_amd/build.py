@@ -39,6 +39,13 @@ def _stale(target, deps):
 
 
 def build_hip(force=False, verbose=False):
+    if force and os.path.isdir(LIBDIR):
+        # a forced build starts from an empty directory: whatever an earlier toolchain invocation left there (--save-temps
+        # bundles, objects of sources that no longer exist) would otherwise keep travelling to every GPU box
+        for f in os.listdir(LIBDIR):
+            path = os.path.join(LIBDIR, f)
+            if os.path.isfile(path):
+                os.remove(path)
     os.makedirs(LIBDIR, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(ROOT, "include", "ptt_hip.h"))

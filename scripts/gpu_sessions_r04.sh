@@ -14,6 +14,23 @@ ktrace() {   # ktrace <out csv> <cmd...>: rocprofv3 kernel trace + stats of a co
 }
 
 case $S in
+a)  # (first session of the round) row-job unit tests, launch-floor probe, the one-tracklet baseline
+    timeout 600 python -m pytest tests/test_rowjobs_gpu.py -x -q 2>&1 | tail -15 > $O/rowjobs_test.log
+    timeout 600 python scripts/probes/launch_floor_probe.py > $O/launch_floor.log 2>&1
+    timeout 300 python scripts/tracklet_b1_profile.py > $O/b1_baseline.log 2>&1
+    cat $O/rowjobs_test.log $O/launch_floor.log $O/b1_baseline.log
+    ;;
+b)  # graph dot dump, parity, one tracklet
+    timeout 120 python scripts/probes/graph_dot_probe.py > $O/dot.log 2>&1
+    timeout 900 python -m pytest tests -x -q -m gpu 2>&1 | tail -25 > $O/pytest.log
+    timeout 300 python scripts/tracklet_b1_profile.py > $O/b1.log 2>&1
+    head -60 $O/dot.log; cat $O/pytest.log $O/b1.log
+    ;;
+c)  # parity, kernel trace of one tracklet
+    timeout 900 python -m pytest tests -x -q -m gpu 2>&1 | tail -25 > $O/pytest.log
+    ktrace b1_kernel_stats python $REPO/scripts/tracklet_b1_profile.py
+    cat $O/pytest.log
+    ;;
 d)  # the one-frame launch chain on row jobs: parity, then where a tracklet frame's time is
     timeout 900 python -m pytest tests -x -q -m gpu > $O/pytest.log 2>&1; tail -25 $O/pytest.log
     timeout 300 python scripts/tracklet_b1_profile.py > $O/b1.log 2>&1; grep -v amdgpu.ids $O/b1.log

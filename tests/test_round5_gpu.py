@@ -217,3 +217,35 @@ def test_fused_bn_backward_gemm_writes_dz_out_exactly_once_and_reproducibly(dev,
     sums = outs[0][1].sum(0)
     assert float((sums[0] - dy.sum(0)).abs().max()) <= 1e-6 * float(dy.abs().sum(0).max())
     assert float((sums[1] - (dy * zp.double()).sum(0)).abs().max()) <= 1e-6 * float((dy * zp.double()).abs().sum(0).max())
+
+
+def test_stress_config_full_batch_properties(dev):
+    """BASELINE.json configs[4] at its full per-GPU batch (32 frames of 16384 + 4096 points, SA centres [8192, 4096, 2048] /
+    [2048, 1024, 512]) — the oracle finishes one or two such frames (tests/test_hot_path_gpu.py), so at 32 the size-independent
+    properties: indices in range and the seeds ARE the gathered raw points (index composition, pointnet2_backbone.py:48), finite
+    features, the first two frames equal the two-frame batch the oracle is checked on (indices bit for bit, features to float32
+    rounding: frames are independent), and frame 0 of a batch of 32 = frame 0 of the same batch rolled by one."""
+    from ptt_amd.hot_path import FrameHotPath, kitti_model_cfg, randomize_
+    cfg = kitti_model_cfg()
+    cfg.BACKBONE_3D.SA_CONFIG.NPOINTS_SEARCH = [8192, 4096, 2048]
+    cfg.BACKBONE_3D.SA_CONFIG.NPOINTS_TEMPLATE = [2048, 1024, 512]
+    model = randomize_(FrameHotPath(cfg), seed=11).to(dev).eval()
+    s, t = synth.frames(31, 32, 16384, 4096, kind="dense")
+    sd, td = torch.from_numpy(s).to(dev), torch.from_numpy(t).to(dev)
+    with torch.no_grad():
+        out = model(sd, td)
+        two = model(sd[:2].contiguous(), td[:2].contiguous())
+        rolled = model(torch.roll(sd, 1, 0), torch.roll(td, 1, 0))
+    inds = out["search_inds"]
+    assert inds.dtype == torch.int64 and tuple(inds.shape) == (32, 2048) and int(inds.min()) >= 0 and int(inds.max()) < 16384
+    assert int(out["template_inds"].max()) < 4096 and tuple(out["template_inds"].shape) == (32, 512)
+    assert torch.equal(torch.gather(sd, 1, inds[..., None].expand(-1, -1, 3)), out["search_seeds"])
+    assert (torch.sort(inds, 1)[0][:, 1:] != torch.sort(inds, 1)[0][:, :-1]).all()          # dense clouds: 2048 distinct picks per frame
+    assert tuple(out["search_feats"].shape) == (32, 256, 2048) and tuple(out["box_feats"].shape) == (32, 64, 256)
+    for k in ("search_feats", "template_feats", "centroid_feats", "box_feats"):
+        assert torch.isfinite(out[k]).all(), k
+    for k in ("search_inds", "template_inds"):
+        assert torch.equal(out[k][:2], two[k]) and torch.equal(out[k], torch.roll(rolled[k], -1, 0)), k
+    for k in ("search_feats", "centroid_feats"):
+        torch.testing.assert_close(out[k][:2], two[k], rtol=2e-5, atol=2e-5, msg=k)
+        torch.testing.assert_close(out[k], torch.roll(rolled[k], -1, 0), rtol=2e-5, atol=2e-5, msg=k)
