@@ -806,6 +806,9 @@ static Wgrad2Geom wgrad2_geom(int R, int Cout, int Cin) {
     if (R < 2048 || Cout % 128 || Cin % 128) return g;
     // the largest block that still fills the chip with row chunks of >= 768 rows (one workgroup per CU, one round)
     const int ncu = cu_count();
+    // block shapes, largest first. (Round 5, scripts/wgrad_bench.py: in isolation the 128 x 256 block is 5-8 % faster than 256 x 256
+    // at >= 98304 rows — 107 against 99 TFLOP/s — but inside the training step, where the launch follows a GEMM that leaves its
+    // operands in the Infinity Cache, preferring it cost 0.24 ms per step: 20.42 against 20.18 ms.)
     const int cand[4][2] = {{4, 2}, {4, 1}, {2, 2}, {2, 1}};
     int first = 0;
 #ifdef PTT_GEMM_DEV

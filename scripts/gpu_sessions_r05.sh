@@ -55,6 +55,11 @@ h)  # ptt_rows_gemm_bnbwd_fused_f32: the dz it writes out (store hazard), the th
 g)  # weight-gradient tile shapes (needs a build with PTT_GEMM_FLAGS=-DPTT_GEMM_DEV)
     WG_FIRSTS=0,1,2,3 timeout 600 python scripts/wgrad_bench.py 2>&1 | grep -v amdgpu.ids | tee $O/wgrad_bench.log
     ;;
+t)  # the training step after a change: gradient parity (G10 / G14 / G15, reproducibility, weight-gradient kernels), then the step time
+    timeout 1500 python -m pytest tests/test_train_gpu.py tests/test_train_config3_gpu.py tests/test_gemm_gpu.py tests/test_step_ops_gpu.py tests/test_round5_gpu.py -q -m gpu > $O/pytest.log 2>&1
+    grep -E "^FAILED|passed|failed" $O/pytest.log | cut -c1-200
+    for i in 1 2; do timeout 600 python bench.py --workload train --steps 20 --warmup 5 --no-cpu-baseline 2> $O/bench_train.err | tee $O/bench_train.json | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('train', d['ms_per_step'], d['value'], d['sustained'])"; done
+    ;;
 u)  # kernel trace of the training step, per-dispatch timeline of its last step
     ktrace train_kernel_stats python $REPO/bench.py --workload train --steps 20 --warmup 2 --sustain 0 --no-cpu-baseline
     bash scripts/train_step_timeline.sh $REPO/$O/timeline > $O/timeline.log 2>&1; tail -3 $O/timeline.log
