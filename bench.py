@@ -189,7 +189,8 @@ def committed_traffic(kernel_prefix, tag=None):
     -> (bytes per launch averaged over the kernel's launch shapes, source dict) or (None, None)."""
     import glob
     files = sorted(p for p in glob.glob(os.path.join(ROOT, "profiles", "*pmc*", "pmc_summary.json"))
-                   if (os.path.basename(os.path.dirname(p)).endswith("_" + tag) if tag else not os.path.basename(os.path.dirname(p)).endswith("_stress")))
+                   if (os.path.basename(os.path.dirname(p)).endswith("_" + tag) if tag
+                       else not os.path.basename(os.path.dirname(p)).endswith(("_stress", "_stress_sampling_order", "_train_step"))))
     for path in reversed(files):
         try:
             d = json.load(open(path))
@@ -731,6 +732,20 @@ def launches_per_frame(torch, dev, tracker, runner):
         return {"error": "%s: %s" % (type(e).__name__, e)}
 
 
+def train_roofline(achieved, flops, B, NS, NT):
+    """The training step has no single dominant kernel: the roofline object is the whole step against the fp32-MFMA peak;
+    `traffic` = HBM-side bytes of one step (every launch) from the committed PMC passes of scripts/pmc_train_step.sh, taken at the
+    shipped shape (48 frames of 1024 + 512 points)."""
+    r = {"kernel": "whole training step (no single dominant kernel)", "bound": "mfma", "achieved": round(achieved, 2),
+         "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+         "alg_flops_per_step": flops, "timing": "wall clock of the timed steps (3 x 12.3 GFLOP per frame dense fp32)"}
+    if (B, NS, NT) == (48, 1024, 512):
+        tr, src = committed_traffic("whole training step", "train_step")
+        if tr is not None:
+            r["traffic"], r["traffic_source"] = tr, src
+    return r
+
+
 def run_train(args, torch, dev, dist, world, rank, ranks_seen, sync_all, B, NS, NT, W):
     """configs[3]: forward + backward + clip + Adam of the full tracker, DDP gradient all-reduce when world > 1."""
     from ptt_amd.config import StubDataset, ptt_model_cfg
@@ -786,11 +801,7 @@ def run_train(args, torch, dev, dist, world, rank, ranks_seen, sync_all, B, NS, 
                    "sharding": "batch across ranks, DDP gradient all-reduce over RCCL" if collective else "single rank, no collective",
                    "launch": "eager"},
         "rccl_ranks_seen": ranks_seen,
-        "roofline": {"kernel": "whole training step (no single dominant kernel)", "bound": "mfma",
-                     "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
-                     "alg_flops_per_step": flops,
-                     "timing": "wall clock of the timed steps (3 x 12.3 GFLOP per frame dense fp32)"},
+        "roofline": train_roofline(achieved, flops, B, NS, NT),
         "cpu_baseline": None,
         "sustained": sustained,
         "loss": float(last["loss"].detach()),

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PTT_ABI_VERSION 18
+#define PTT_ABI_VERSION 19
 
 enum {
     PTT_OK = 0,
@@ -374,9 +374,14 @@ typedef struct ptt_attn_desc {
     float* res;            /* (B,N,D) */
     float* attn;           /* (B,N,k,D) or NULL */
     int B, N, k, D;
+    const int32_t* order;  /* (B,N) from ptt_spatial_order_f32, or NULL: which flat point (b*N + n) launch slot s works on. A
+                              permutation inside every cloud; results do not depend on it (L2 locality of the k | v gathers) */
 } ptt_attn_desc;
 
 int ptt_pt_attn_pair_f32(const ptt_attn_desc* d, ptt_stream_t stream);
+/* order (B,N) i32: the points of every cloud along a Morton curve through the cloud's bounding box (flat indices b*N + n,
+ * ties by index: a permutation inside each cloud), N <= 8192. Neighbours in space become neighbours in launch order. */
+int ptt_spatial_order_f32(const float* xyz, int B, int N, int32_t* order, ptt_stream_t stream);
 
 /* ---------------------------------------------------------------------------------
  * N4  device-side pre/post-processing of the sequential tracking loop

@@ -10,12 +10,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libptt_hip.so")
 
 PTT_SA_MAX_LAYERS = 4
-ABI_VERSION = 18            # PTT_ABI_VERSION of include/ptt_hip.h these structures mirror
+ABI_VERSION = 19            # PTT_ABI_VERSION of include/ptt_hip.h these structures mirror
 
 # every symbol include/ptt_hip.h declares (tests check the library exports all of them)
 EXPORTS = [
     "ptt_version", "ptt_error_name", "ptt_last_error_string",
-    "ptt_fps_f32", "ptt_fps_ws_f32", "ptt_gather_f32", "ptt_gather_grad_f32", "ptt_select_centres_f32", "ptt_ball_query_f32",
+    "ptt_fps_f32", "ptt_fps_ws_f32", "ptt_spatial_order_f32", "ptt_gather_f32", "ptt_gather_grad_f32", "ptt_select_centres_f32", "ptt_ball_query_f32",
     "ptt_group_f32", "ptt_group_grad_f32", "ptt_scatter_add_det_workspace", "ptt_scatter_add_det_f32",
     "ptt_knn_f32", "ptt_knn_rel_f32",
     "ptt_packed_weight_elems", "ptt_pack_weight_f32", "ptt_pack_weight_rot_f32", "ptt_linear_f32",
@@ -152,7 +152,7 @@ class AttnDesc(Structure):
                 ("Wd1p", c_void_p), ("Wd2p", c_void_p), ("bd2", c_void_p),
                 ("Wg1p", c_void_p), ("bg1", c_void_p), ("Wg2p", c_void_p), ("bg2", c_void_p),
                 ("res", c_void_p), ("attn", c_void_p),
-                ("B", c_int), ("N", c_int), ("k", c_int), ("D", c_int)]
+                ("B", c_int), ("N", c_int), ("k", c_int), ("D", c_int), ("order", c_void_p)]
 
 
 _lib = None
@@ -167,6 +167,7 @@ def _declare(lib):
     sigs = {
         "ptt_fps_f32": [vp, i, i, i, vp, vp],
         "ptt_fps_ws_f32": [vp, i, i, i, vp, vp, c_size_t, vp],
+        "ptt_spatial_order_f32": [vp, i, i, vp, vp],
         "ptt_gather_f32": [vp, vp, i, i, i, i, vp, vp],
         "ptt_gather_grad_f32": [vp, vp, i, i, i, i, vp, vp],
         "ptt_select_centres_f32": [vp, vp, i, i, i, vp, vp, vp],

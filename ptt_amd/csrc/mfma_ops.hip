@@ -1686,6 +1686,7 @@ struct AttnParams {
     const float* xyz; const float* rel; const int32_t* knn; const float* qkv; const float* Wd1p;
     const float* Wd2p; const float* bd2; const float* Wg1p; const float* bg1; const float* Wg2p; const float* bg2;
     float* res; float* attn;
+    const int32_t* order;   // optional: the flat point tile slot s works on (a permutation inside every cloud), NULL = s
     int BN, N, first_wave, stagger;
     long long* dbg;   // dev only: per-phase s_memtime stamps (PTT_DEBUG_STAMPS), NULL in production
 };
@@ -1699,16 +1700,19 @@ __global__ __launch_bounds__(256, 2) void pt_attn_pair_kernel(AttnParams p) {
     constexpr int LDR = 12;                                 // [rel.x rel.y rel.z 1 | 0 0 0 0] + pad (stride = 4 mod 8)
     float* relt = smem + 32 * LDK + 32;                     // [32][LDR]: the A operand of fc_delta[0]
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, half = lane >> 5;
-    const int pt0 = logical_block() * 2;                     // flat point index of tile row 0
-    const int npts = min(2, p.BN - pt0);
+    const int slot0 = logical_block() * 2;                   // the tile's two point slots
+    const int npts = min(2, p.BN - slot0);
+    // the points behind the slots (ptt_spatial_order_f32: neighbours in space next to each other in launch order); both lie in
+    // the same cloud (N is even, the order permutes inside clouds)
+    const int s0 = slot0 < p.BN ? slot0 : p.BN - 1, s1 = slot0 + 1 < p.BN ? slot0 + 1 : p.BN - 1;
+    const int pt0 = p.order ? p.order[s0] : s0, pt1 = p.order ? p.order[s1] : s1;
     f32x4 pre[CT];
     prefetch_first_block_full<CT>(p.Wd1p, w, lane, pre);    // fc_delta[0]'s only weight block: requested first
     stagger_second_slot(p.first_wave, p.stagger);
     PTT_STAMP(0);
 
     if (t < 32) {
-        int pt = pt0 + (t >> 4);
-        if (pt >= p.BN) pt = p.BN - 1;
+        const int pt = (t >> 4) ? pt1 : pt0;
         const int b = pt / p.N;
         const int n = p.knn[(size_t)pt * KNN + (t & 15)];
         const int flat = b * p.N + n;
@@ -1761,7 +1765,7 @@ __global__ __launch_bounds__(256, 2) void pt_attn_pair_kernel(AttnParams p) {
     // Gathers of neighbour k / v rows: raw buffer loads on a descriptor based at the cloud's first q|k|v row. The
     // per-(row, lane) byte offset is ONE 32-bit VGPR per tile row; channel group and the k / v column block are
     // immediates or an SGPR — a flat 64-bit address per load costs 3-4 vector-ALU instructions, 64 loads per phase.
-    const int cloud = ((pt0 < p.BN ? pt0 : p.BN - 1) / p.N);
+    const int cloud = pt0 / p.N;
     const __amdgpu_buffer_rsrc_t rq = weight_rsrc(p.qkv + (size_t)cloud * p.N * 3 * D);
     int nrow[16];  // byte offset of (neighbour row, this lane's first column) for each of this lane's 16 tile rows
 #pragma unroll
@@ -1770,7 +1774,7 @@ __global__ __launch_bounds__(256, 2) void pt_attn_pair_kernel(AttnParams p) {
     lds_barrier();  // all waves done with h
     // t = (q_i - k_j) + delta  -> X
     {
-        const int pa = pt0, pb = (npts > 1) ? pt0 + 1 : pt0;
+        const int pa = pt0, pb = (npts > 1) ? pt1 : pt0;
 #pragma unroll
         for (int u = 0; u < CT; ++u) {
             const float qa = p.qkv[(size_t)pa * 3 * D + cols[u]];
@@ -1847,10 +1851,10 @@ __global__ __launch_bounds__(256, 2) void pt_attn_pair_kernel(AttnParams p) {
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
                     const int row = tile_row(pp * 8 + r, half);  // = pp*16 + j
-                    p.attn[((size_t)(pt0 + pp) * KNN + (row & 15)) * D + cols[u]] = s[r] * rsum;
+                    p.attn[((size_t)(pp ? pt1 : pt0) * KNN + (row & 15)) * D + cols[u]] = s[r] * rsum;
                 }
             }
-            if (half == 0 && pp < npts) p.res[(size_t)(pt0 + pp) * D + cols[u]] = o * rsum;
+            if (half == 0 && pp < npts) p.res[(size_t)(pp ? pt1 : pt0) * D + cols[u]] = o * rsum;
         }
     }
     PTT_STAMP(7);
@@ -2277,6 +2281,7 @@ extern "C" int ptt_pt_attn_pair_f32(const ptt_attn_desc* d, ptt_stream_t stream)
     AttnParams p;
     p.xyz = d->xyz; p.rel = d->rel; p.knn = d->knn; p.qkv = d->qkv; p.Wd1p = d->Wd1p; p.Wd2p = d->Wd2p; p.bd2 = d->bd2;
     p.Wg1p = d->Wg1p; p.bg1 = d->bg1; p.Wg2p = d->Wg2p; p.bg2 = d->bg2; p.res = d->res; p.attn = d->attn;
+    p.order = d->order;
     p.BN = d->B * d->N; p.N = d->N;
     p.first_wave = 512; p.stagger = dev_switches().pair_stagger;
     p.dbg = dev_switches().stamps;

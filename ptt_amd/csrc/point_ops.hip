@@ -857,6 +857,71 @@ __global__ __launch_bounds__(1024) void fps_ws_kernel(const float* __restrict__ 
     }
 }
 
+// A spatial processing order for the points of every cloud: Morton keys (10 bits per axis inside the cloud's bounding box) sorted
+// in LDS (bitonic, one workgroup per cloud). The Point-Transformer pair kernel gives a workgroup two points and gathers the k | v
+// rows of their 32 neighbours: in sampling order (furthest point sampling = as far apart as possible) consecutive workgroups
+// share no neighbour and every row is fetched from HBM ~10 times at 2048 points per cloud (profiles/r04z_pmc_stress); along the
+// Morton curve the workgroups that run together on an XCD gather from the same few hundred rows. Pure scheduling: results do not
+// depend on the order.
+__device__ __forceinline__ unsigned morton_spread10(unsigned v) {        // 10 bits -> every third bit
+    v &= 0x3ffu;
+    v = (v | (v << 16)) & 0x030000ffu;
+    v = (v | (v << 8)) & 0x0300f00fu;
+    v = (v | (v << 4)) & 0x030c30c3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+__global__ __launch_bounds__(1024) void spatial_order_kernel(const float* __restrict__ xyz, int N, int P, int32_t* __restrict__ order) {
+    extern __shared__ unsigned long long mkeys[];                         // [P]
+    __shared__ float red[6][16];
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const float* __restrict__ pts = xyz + (size_t)b * N * 3;
+    float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    for (int k = t; k < N; k += 1024)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { const float v = pts[3 * k + c]; lo[c] = fminf(lo[c], v); hi[c] = fmaxf(hi[c], v); }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float l = wave_min_f32(lo[c]), h = wave_max_f32(hi[c]);
+        if (lane == 0) { red[c][wv] = l; red[3 + c][wv] = h; }
+    }
+    __syncthreads();
+    float scale[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float l = red[c][0], h = red[3 + c][0];
+        for (int w = 1; w < 16; ++w) { l = fminf(l, red[c][w]); h = fmaxf(h, red[3 + c][w]); }
+        lo[c] = l;
+        scale[c] = h > l ? 1023.0f / (h - l) : 0.f;
+    }
+    for (int k = t; k < P; k += 1024) {
+        unsigned long long key = ~0ull;                                  // padding sorts to the end
+        if (k < N) {
+            unsigned m = 0;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float q = (pts[3 * k + c] - lo[c]) * scale[c];
+                q = q < 0.f ? 0.f : (q > 1023.f ? 1023.f : q);           // (NaN coordinates: cell 0)
+                m |= morton_spread10((unsigned)q) << c;
+            }
+            key = ((unsigned long long)m << 32) | (unsigned)k;           // the index breaks ties: the result is a permutation
+        }
+        mkeys[k] = key;
+    }
+    __syncthreads();
+    for (int size = 2; size <= P; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int i = t; i < (P >> 1); i += 1024) {
+                const int lo_i = 2 * i - (i & (stride - 1)), hi_i = lo_i + stride;
+                const bool up = (lo_i & size) == 0;
+                const unsigned long long a = mkeys[lo_i], c2 = mkeys[hi_i];
+                if ((a > c2) == up) { mkeys[lo_i] = c2; mkeys[hi_i] = a; }
+            }
+            __syncthreads();
+        }
+    for (int k = t; k < N; k += 1024) order[(size_t)b * N + k] = b * N + (int)(unsigned)mkeys[k];
+}
+
 }  // namespace ptt
 
 using namespace ptt;
@@ -900,6 +965,19 @@ extern "C" int ptt_fps_f32(const float* xyz, int B, int N, int npoint, int32_t* 
     // 32 points per thread (clouds up to 32768 points) is the whole 128-register budget of a 1024-thread workgroup and spilled
     // 164-180 bytes per lane: no BASELINE config reaches it (the largest is 16384); such clouds take ptt_fps_ws_f32
     return fail(PTT_EUNSUPPORTED, "ptt_fps_f32: N=%d exceeds the register-resident limit 16384 (use ptt_fps_ws_f32)", N);
+}
+
+extern "C" int ptt_spatial_order_f32(const float* xyz, int B, int N, int32_t* order, ptt_stream_t stream) {
+    if (B < 0 || N <= 0) return fail(PTT_EINVAL, "ptt_spatial_order_f32: B=%d N=%d", B, N);
+    if (B == 0) return PTT_OK;
+    if (!xyz || !order) return fail(PTT_EINVAL, "ptt_spatial_order_f32: null pointer");
+    if (N > 8192 || (long long)B * N > INT_MAX) return fail(PTT_EUNSUPPORTED, "ptt_spatial_order_f32: N=%d (at most 8192 points per cloud are sorted in LDS)", N);
+    int P = 2;
+    while (P < N) P <<= 1;
+    const int lds = P * (int)sizeof(unsigned long long);
+    if (int rc = set_lds_limit(reinterpret_cast<const void*>(spatial_order_kernel), lds)) return rc;
+    hipLaunchKernelGGL(spatial_order_kernel, dim3(B), dim3(1024), lds, as_stream(stream), xyz, N, P, order);
+    return check_launch("spatial_order_kernel");
 }
 
 extern "C" int ptt_fps_ws_f32(const float* xyz, int B, int N, int npoint, int32_t* idx_out, float* workspace, size_t workspace_elems,

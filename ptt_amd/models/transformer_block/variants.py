@@ -35,6 +35,9 @@ def _rows2d(layers, x):
     return layers(x.reshape(-1, x.shape[-1])).reshape(*x.shape[:-1], -1)
 
 
+SPATIAL_ORDER_MIN_POINTS = 512       # clouds from this size on are handed to the pair kernel in Morton order
+
+
 class TransformerBlock(nn.Module):
     def __init__(self, d_points, d_model, k, **kwargs) -> None:
         super().__init__()
@@ -144,8 +147,12 @@ class TransformerBlock(nn.Module):
                 a = ops.linear(g, P['wg2'], D, None, P['bg2']).view_as(t)
                 res, attn = ops.pt_attn_fwd_qkv(a, qkv, knn_idx, pos, D, 1.0 / np.sqrt(D), self.materialize_attn)
             else:
+                # many points per cloud: the workgroups take them along a space-filling curve, so that those running together
+                # gather k | v rows of the same neighbourhood out of L2 (FPS order = far apart: ~10x the compulsory HBM reads
+                # at 2048 points); the k | v rows of a 128-point cloud fit L2 whole
+                order = ops.spatial_order(xyz) if SPATIAL_ORDER_MIN_POINTS <= xyz.shape[1] <= 8192 else None
                 res, attn = ops.pt_attn_pair(xyz, knn_idx, qkv, P['wd1'], P['wd2'], P['bd2'], P['wg1'],
-                                             P['bg1'], P['wg2'], P['bg2'], D, self.materialize_attn, rel=rel)
+                                             P['bg1'], P['wg2'], P['bg2'], D, self.materialize_attn, rel=rel, order=order)
             res = ops.linear(res, P['fc2'], self.d_points, None, P['fc2_b'], False, features)
             return res, attn
 

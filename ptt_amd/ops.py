@@ -530,9 +530,21 @@ def pack_delta0(weight, bias):
                                   bias.detach().float().reshape(-1, 1)], dim=1).contiguous())
 
 
-def pt_attn_pair(xyz, knn_idx, qkv, wd1p, wd2p, bd2, wg1p, bg1, wg2p, bg2, d_model, want_attn=True, rel=None):
+def spatial_order(xyz):
+    """(B,N,3) -> (B,N) int32: every cloud's points along a Morton curve through its bounding box, as flat indices b*N + n
+    (ptt_spatial_order_f32, N <= 8192) — the launch order that keeps pt_attn_pair's neighbour gathers in L2."""
+    _chk(xyz, "xyz", torch.float32, 3)
+    B, N, _ = xyz.shape
+    order = torch.empty((B, N), dtype=torch.int32, device=xyz.device)
+    with torch.cuda.device(xyz.device):
+        _lib.check(_lib.lib().ptt_spatial_order_f32(_ptr(xyz), B, N, _ptr(order), _stream()), "ptt_spatial_order_f32")
+    return order
+
+
+def pt_attn_pair(xyz, knn_idx, qkv, wd1p, wd2p, bd2, wg1p, bg1, wg2p, bg2, d_model, want_attn=True, rel=None, order=None):
     """Fused per-(point,neighbour) part of TransformerBlock.forward (variants.py:158-163).
-    wd1p = pack_delta0(fc_delta[0].weight, fc_delta[0].bias); the other weights from pack_weight.
+    wd1p = pack_delta0(fc_delta[0].weight, fc_delta[0].bias); the other weights from pack_weight. order: spatial_order(xyz) or
+    None — which point every launch slot works on (the results do not depend on it).
     Returns (res (B,N,D), attn (B,N,k,D) | None)."""
     _chk(xyz, "xyz", torch.float32, 3)
     _chk(knn_idx, "knn_idx", torch.int32, 3)
@@ -550,6 +562,11 @@ def pt_attn_pair(xyz, knn_idx, qkv, wd1p, wd2p, bd2, wg1p, bg1, wg2p, bg2, d_mod
     d.res = res.data_ptr()
     d.attn = attn.data_ptr() if attn is not None else None
     d.B, d.N, d.k, d.D = B, N, k, D
+    if order is not None:
+        _chk(order, "order", torch.int32, 2)
+        if tuple(order.shape) != (B, N):
+            raise ValueError("order: (B,N) int32 expected")
+        d.order = order.data_ptr()
     with torch.cuda.device(xyz.device), _timed('ptt_pt_attn_pair_f32'):
         _lib.check(_lib.lib().ptt_pt_attn_pair_f32(ctypes.byref(d), _stream()), "ptt_pt_attn_pair_f32")
     return res, attn

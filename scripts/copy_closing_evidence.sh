@@ -12,6 +12,6 @@ done
 for f in last_step_by_shape.txt last_step_launches.txt; do
     [ -f $O/train_timeline/$f ] && cp $O/train_timeline/$f profiles/r$R${S}_train_$f
 done
-for d in pmc pmc_stress pmc_train_gemm pmc_train_stream; do
+for d in pmc pmc_stress pmc_stress_sampling_order pmc_train_gemm pmc_train_stream pmc_train_step; do
     if [ -f $O/$d/pmc_summary.json ]; then mkdir -p profiles/r$R${S}_$d; cp $O/$d/*.csv $O/$d/pmc_summary.json profiles/r$R${S}_$d/; fi
 done

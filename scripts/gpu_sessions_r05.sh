@@ -55,6 +55,13 @@ h)  # ptt_rows_gemm_bnbwd_fused_f32: the dz it writes out (store hazard), the th
 g)  # weight-gradient tile shapes (needs a build with PTT_GEMM_FLAGS=-DPTT_GEMM_DEV)
     WG_FIRSTS=0,1,2,3 timeout 600 python scripts/wgrad_bench.py 2>&1 | grep -v amdgpu.ids | tee $O/wgrad_bench.log
     ;;
+s)  # the pair kernel in Morton order at the stress size: parity, kernel time and HBM traffic with / without the order, the workload
+    timeout 900 python -m pytest tests/test_round5_gpu.py tests/test_hot_path_gpu.py tests/test_golden_gpu.py -q -m gpu > $O/pytest.log 2>&1; grep -E "^FAILED|passed|failed" $O/pytest.log | cut -c1-200
+    for o in none spatial none spatial; do PAIR_ORDER=$o timeout 300 python scripts/kernel_bench.py --only pair --batch 32 --pair-n 2048,64 --iters 10 2>&1 | grep pair_N2048 | sed "s/^/$o /"; done | tee $O/pair_order.log
+    PAIR_ORDER=none bash scripts/pmc_passes.sh $O/pmc_stress_sampling_order "pair" "" "--batch 32 --pair-n 2048,64" > $O/pmc_none.log 2>&1; tail -3 $O/pmc_none.log | cut -c1-400
+    bash scripts/pmc_passes.sh $O/pmc_stress "pair" "" "--batch 32 --pair-n 2048,64" > $O/pmc_spatial.log 2>&1; tail -3 $O/pmc_spatial.log | cut -c1-400
+    for i in 1 2; do timeout 600 python bench.py --workload stress --steps 8 --warmup 3 --no-cpu-baseline --sustain 0 2> $O/stress.err | tee $O/stress.json | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('stress', d['ms_per_step'], d['value'], d['roofline']['frac'], d['kernel_ms_per_step'])"; done
+    ;;
 t)  # the training step after a change: gradient parity (G10 / G14 / G15, reproducibility, weight-gradient kernels), then the step time
     timeout 1500 python -m pytest tests/test_train_gpu.py tests/test_train_config3_gpu.py tests/test_gemm_gpu.py tests/test_step_ops_gpu.py tests/test_round5_gpu.py -q -m gpu > $O/pytest.log 2>&1
     grep -E "^FAILED|passed|failed" $O/pytest.log | cut -c1-200
@@ -90,7 +97,9 @@ p)  # PMC passes (separate counter-only runs, scripts/pmc_passes.sh): car pair k
     cat ptt_amd/lib/BUILD_ID
     bash scripts/pmc_passes.sh $O/pmc "pair,sa0_s,sa1_s,sa2_s,sa_box,xcorr,lin_,rj" > $O/pmc.log 2>&1; tail -12 $O/pmc.log | cut -c1-300
     bash scripts/pmc_passes.sh $O/pmc_stress "pair" "" "--batch 32 --pair-n 2048,64" > $O/pmc_stress.log 2>&1; tail -4 $O/pmc_stress.log | cut -c1-300
+    PAIR_ORDER=none bash scripts/pmc_passes.sh $O/pmc_stress_sampling_order "pair" "" "--batch 32 --pair-n 2048,64" > $O/pmc_stress_sampling_order.log 2>&1
     bash scripts/pmc_passes.sh $O/pmc_train_gemm - "python scripts/rows_gemm_bench.py --no-check --pmc" > $O/pmc_train_gemm.log 2>&1; tail -4 $O/pmc_train_gemm.log | cut -c1-300
+    bash scripts/pmc_train_step.sh $O/pmc_train_step > $O/pmc_train_step.log 2>&1; tail -2 $O/pmc_train_step.log
     ;;
 *)  echo "unknown session $S"; exit 2 ;;
 esac

@@ -51,12 +51,14 @@ def main():
         qkv = torch.randn(B, N, 1536, device=dev)
         packs = [ops.pack_weight(P[k]) for k in ("fc_delta.2.weight", "fc_gamma.0.weight", "fc_gamma.2.weight")]
         wd1p = ops.pack_delta0(P["fc_delta.0.weight"], P["fc_delta.0.bias"])
+        # as TransformerBlock.forward launches it: clouds of >= 512 points in Morton order (PAIR_ORDER=none: sampling order)
+        order = ops.spatial_order(xyz) if (N >= 512 and os.environ.get("PAIR_ORDER", "spatial") != "none") else None
         fn = lambda: ops.pt_attn_pair(xyz, knn, qkv, wd1p, packs[0],
                                       P["fc_delta.2.bias"], packs[1], P["fc_gamma.0.bias"], packs[2],
-                                      P["fc_gamma.2.bias"], 512, False)
+                                      P["fc_gamma.2.bias"], 512, False, order=order)
         ms = timeit(fn, a.iters)
         fl = 2.0 * B * N * 16 * (3 * 512 + 3 * 512 * 512)
-        print("%-14s %8.4f ms  %7.2f TFLOP/s" % (name, ms, fl / ms / 1e9))
+        print("%-14s %8.4f ms  %7.2f TFLOP/s%s" % (name, ms, fl / ms / 1e9, "  (Morton order)" if order is not None else ""))
 
     # ---- SA levels ----
     sa_cases = [("sa0_s", 2048, 512, 0, [3, 64, 64, 128], 0.3, 32), ("sa1_s", 512, 256, 128, [131, 128, 128, 256], 0.5, 32),

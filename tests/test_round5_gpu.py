@@ -249,3 +249,35 @@ def test_stress_config_full_batch_properties(dev):
     for k in ("search_feats", "centroid_feats"):
         torch.testing.assert_close(out[k][:2], two[k], rtol=2e-5, atol=2e-5, msg=k)
         torch.testing.assert_close(out[k], torch.roll(rolled[k], -1, 0), rtol=2e-5, atol=2e-5, msg=k)
+
+
+@pytest.mark.parametrize("B,N", [(2, 2048), (3, 600), (1, 8192), (2, 128)])
+def test_spatial_order_is_a_permutation_and_the_pair_kernel_does_not_depend_on_it(dev, B, N):
+    """ptt_spatial_order_f32: every cloud's points along a Morton curve — a permutation inside each cloud (duplicates and an
+    all-zero cloud included), spatially close points close in the order; ptt_pt_attn_pair_f32 run in that order returns bit for
+    bit what it returns in sampling order (variants.py:158-163: rows are independent)."""
+    from ptt_amd import ops
+    from tests.util import transformer_params
+    s, _ = synth.frames(5, B, N, 64, K_s=max(8, N // 2))
+    if B > 1:
+        s[-1] = 0.0
+    xyz = torch.from_numpy(s).to(dev)
+    order = ops.spatial_order(xyz)
+    assert order.dtype == torch.int32 and tuple(order.shape) == (B, N)
+    local = order.long() - torch.arange(B, device=dev)[:, None] * N
+    assert torch.equal(torch.sort(local, 1)[0], torch.arange(N, device=dev).expand(B, N))
+    if N >= 600:                                            # neighbours along the curve are near in space
+        p = torch.gather(xyz[0], 0, local[0][:, None].expand(-1, 3))
+        step = (p[1:] - p[:-1]).norm(dim=1).mean()
+        rnd = (xyz[0][1:] - xyz[0][:-1]).norm(dim=1).mean()
+        assert float(step) < 0.5 * float(rnd), (float(step), float(rnd))
+    P = {k: v.to(dev).contiguous() for k, v in transformer_params(1).items()}
+    knn, rel = ops.knn(xyz, 16, want_rel=True)
+    qkv = torch.randn(B, N, 1536, device=dev)
+    packs = [ops.pack_weight(P[k]) for k in ("fc_delta.2.weight", "fc_gamma.0.weight", "fc_gamma.2.weight")]
+    wd1p = ops.pack_delta0(P["fc_delta.0.weight"], P["fc_delta.0.bias"])
+    args = (xyz, knn, qkv, wd1p, packs[0], P["fc_delta.2.bias"], packs[1], P["fc_gamma.0.bias"], packs[2], P["fc_gamma.2.bias"], 512)
+    want_attn = N <= 600
+    r0, a0 = ops.pt_attn_pair(*args, want_attn, rel=rel)
+    r1, a1 = ops.pt_attn_pair(*args, want_attn, rel=rel, order=order)
+    assert torch.equal(r0, r1) and (a0 is None or torch.equal(a0, a1))
