@@ -272,7 +272,11 @@ def test_spatial_order_is_a_permutation_and_the_pair_kernel_does_not_depend_on_i
         rnd = (xyz[0][1:] - xyz[0][:-1]).norm(dim=1).mean()
         assert float(step) < 0.5 * float(rnd), (float(step), float(rnd))
     P = {k: v.to(dev).contiguous() for k, v in transformer_params(1).items()}
-    knn, rel = ops.knn(xyz, 16, want_rel=True)
+    if N <= 4096:
+        knn, rel = ops.knn(xyz, 16, want_rel=True)
+    else:                                                   # past the kNN kernel's 4096 points: any neighbour table serves the comparison
+        knn = torch.randint(0, N, (B, N, 16), device=dev, dtype=torch.int32)
+        rel = torch.randn(B, N, 16, 3, device=dev) * 0.1
     qkv = torch.randn(B, N, 1536, device=dev)
     packs = [ops.pack_weight(P[k]) for k in ("fc_delta.2.weight", "fc_gamma.0.weight", "fc_gamma.2.weight")]
     wd1p = ops.pack_delta0(P["fc_delta.0.weight"], P["fc_delta.0.bias"])
