@@ -203,8 +203,7 @@ def committed_traffic(kernel_prefix, tag=None):
         src = {"file": os.path.relpath(path, ROOT), "build": d.get("build", "see the file's directory name (round / session)"),
                "per_launch_shape": {k: {"read_bytes": e["read_bytes"], "write_bytes": e["write_bytes"],
                                         "l2_hit_rate": round(e.get("l2_hit_rate", 0.0), 4)} for k, e in rows},
-               "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCC passes in separate counter-only runs on "
-                      "scripts/kernel_bench.py (same kernels, same launch shapes as this workload), committed; NOT collected by this process"}
+               "how": d.get("note", "rocprofv3 --pmc passes in separate counter-only runs") + " — committed; NOT collected by this process"}
         return sum(per.values()) / len(per), src
     return None, None
 
@@ -759,7 +758,9 @@ def run_train(args, torch, dev, dist, world, rank, ranks_seen, sync_all, B, NS, 
     last = {}
 
     def step():
-        last["loss"] = trainer.step(batch)
+        # the next batch is on the device before its step starts (synthetic data: the same tensors; a loader with prefetch: the
+        # next ones), so its level-0 sampling runs beside this step's backward pass — every step still executes every kernel
+        last["loss"] = trainer.step(batch, next_batch=batch)
 
     for _ in range(args.warmup):
         step()
@@ -777,7 +778,7 @@ def run_train(args, torch, dev, dist, world, rank, ranks_seen, sync_all, B, NS, 
         # (model.no_sync(): gradients stay local; the replicas drift apart, which is why this runs last)
         def step_local():
             with trainer.model.no_sync():
-                last["loss"] = trainer.step(batch)
+                last["loss"] = trainer.step(batch, next_batch=batch)
         for _ in range(2):
             step_local()
         local = reduce_max(torch, dist, dev, timed_loop(step_local, args.steps, sync_all))
