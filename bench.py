@@ -758,9 +758,7 @@ def run_train(args, torch, dev, dist, world, rank, ranks_seen, sync_all, B, NS, 
     last = {}
 
     def step():
-        # the next batch is on the device before its step starts (synthetic data: the same tensors; a loader with prefetch: the
-        # next ones), so its level-0 sampling runs beside this step's backward pass — every step still executes every kernel
-        last["loss"] = trainer.step(batch, next_batch=batch)
+        last["loss"] = trainer.step(batch)
 
     for _ in range(args.warmup):
         step()
@@ -778,7 +776,7 @@ def run_train(args, torch, dev, dist, world, rank, ranks_seen, sync_all, B, NS, 
         # (model.no_sync(): gradients stay local; the replicas drift apart, which is why this runs last)
         def step_local():
             with trainer.model.no_sync():
-                last["loss"] = trainer.step(batch, next_batch=batch)
+                last["loss"] = trainer.step(batch)
         for _ in range(2):
             step_local()
         local = reduce_max(torch, dist, dev, timed_loop(step_local, args.steps, sync_all))

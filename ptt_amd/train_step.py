@@ -62,53 +62,17 @@ class DataParallelTrainer(object):
         # torch.optim.Adam with clip_grad_norm_ folded into step(): two launches on a HIP device, the stock path elsewhere
         self.optimizer = ClipAdam(self.model.parameters(), lr=lr, betas=betas, eps=eps)
         self.clip = clip
-        self._ahead = None          # (key of the batch, (inds_search, inds_template), event): level-0 sampling done ahead of its step
-        self._side = None
 
-    @staticmethod
-    def _batch_key(batch):
-        s, t = batch['search_points'], batch['template_points']
-        return (s.data_ptr(), s._version, tuple(s.shape), t.data_ptr(), t._version, tuple(t.shape))
-
-    def _sample_ahead(self, next_batch):
-        """The level-0 furthest point sampling of the NEXT batch (a data loader with prefetch has it on the device) on a side
-        stream, queued behind this step's forward pass: the 511-iteration chain that occupies 96 of the 256 CUs' worth of
-        workgroups for 0.2 ms runs beside the backward pass instead of in front of the next forward pass (what PipelinedHotPath
-        does for inference). The picks are the same (FPS is exact); the next step finds them by the batch's tensors."""
-        s = next_batch['search_points']
-        if not s.is_cuda or not hasattr(self.tracker, 'backbone_3d') or not hasattr(self.tracker.backbone_3d, 'sample'):
-            return
-        main = torch.cuda.current_stream(s.device)
-        if self._side is None:
-            self._side = torch.cuda.Stream(device=s.device)
-        self._side.wait_stream(main)
-        with torch.cuda.stream(self._side), torch.no_grad():
-            inds = self.tracker.backbone_3d.sample(s, next_batch['template_points'])
-            done = torch.cuda.Event()
-            done.record(self._side)
-        for t in inds:
-            t.record_stream(main)                               # allocated on the side stream, consumed on this one
-        self._ahead = (self._batch_key(next_batch), inds, done)
-
-    def forward_backward(self, batch, next_batch=None):
-        """loss.mean() and its gradients (averaged over ranks by DDP); no optimiser step. next_batch: see _sample_ahead."""
-        b = dict(batch)
-        if self._ahead is not None:
-            key, inds, done = self._ahead
-            self._ahead = None
-            if key == self._batch_key(batch) and 'fps_inds' not in b:
-                torch.cuda.current_stream(inds[0].device).wait_event(done)
-                b['fps_inds'] = inds
-        ret, _, _ = self.model(b)
+    def forward_backward(self, batch):
+        """loss.mean() and its gradients (averaged over ranks by DDP); no optimiser step."""
+        ret, _, _ = self.model(dict(batch))
         loss = ret['loss'] if ret['loss'].dim() == 0 else ret['loss'].mean()
         self.optimizer.zero_grad(set_to_none=True)
-        if next_batch is not None:
-            self._sample_ahead(next_batch)
         loss.backward()
         return loss
 
-    def step(self, batch, next_batch=None):
-        loss = self.forward_backward(batch, next_batch)
+    def step(self, batch):
+        loss = self.forward_backward(batch)
         self.optimizer.step(max_norm=self.clip if self.clip else None)
         self.tracker.update_global_step()
         return loss

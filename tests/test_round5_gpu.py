@@ -286,28 +286,3 @@ def test_spatial_order_is_a_permutation_and_the_pair_kernel_does_not_depend_on_i
     r1, a1 = ops.pt_attn_pair(*args, want_attn, rel=rel, order=order)
     assert torch.equal(r0, r1) and (a0 is None or torch.equal(a0, a1))
 
-
-def test_sampling_the_next_batch_ahead_changes_nothing_but_the_schedule(dev):
-    """DataParallelTrainer.step(batch, next_batch=...): the next batch's level-0 furthest point sampling runs on a side stream
-    beside this step's backward pass (tools/train_utils/train_utils.py:47-51 with a prefetching loader). FPS is exact, so three
-    steps with and without it leave bit-identical losses and parameters; a next_batch that is NOT the batch of the following step
-    is simply not used."""
-    from ptt_amd.config import StubDataset, ptt_model_cfg
-    from ptt_amd.models import build_network
-    from ptt_amd.train_step import DataParallelTrainer, synthetic_train_batch
-    batches = [synthetic_train_batch(30 + k, 6, dev) for k in range(3)]
-    runs = []
-    for ahead in (False, True, "wrong"):
-        torch.manual_seed(3)
-        model = build_network(ptt_model_cfg(), 1, StubDataset(training=True)).to(dev).train()
-        trainer = DataParallelTrainer(model, dev)
-        losses = []
-        for k, b in enumerate(batches):
-            nxt = None if not ahead else (batches[(k + 1) % 3] if ahead is True else batches[k])
-            losses.append(float(trainer.step(b, next_batch=nxt).detach()))
-            if ahead is True and k < 2:
-                assert trainer._ahead is not None and trainer._ahead[0] == trainer._batch_key(batches[k + 1])
-        runs.append((losses, [p.detach().clone() for p in model.parameters()]))
-    for losses, params in runs[1:]:
-        assert losses == runs[0][0], (losses, runs[0][0])
-        assert all(torch.equal(p, q) for p, q in zip(params, runs[0][1]))
