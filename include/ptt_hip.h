@@ -196,6 +196,16 @@ int ptt_rows_mlp_f32(const float* X, int rows, int K, int ldx, const ptt_sa_laye
  *           k inside the level's points — the results of ptt_centres_ball_query_f32 on the level's own point tensor;
  *   kind 1  kNN of the Npts <= 128 points among themselves (M == Npts): idx_out (B,Npts,nsample), rel_out (B,Npts,nsample,3)
  *           or NULL — the results of ptt_knn_rel_f32 on the points' own tensor. */
+/* F3 for large clouds (round 5): the same results as ptt_ball_query_f32 / ptt_centres_ball_query_f32 through a uniform grid —
+ * the cloud's points binned into cells of edge >= 1.001 radius, a centre tests the points of its 27 neighbouring cells only, the
+ * first nsample hits IN INDEX ORDER restored by a bitmap (bit-identical to the sweep). workspace: ptt_ball_query_grid_workspace(B, N)
+ * bytes, 16-byte aligned (PTT_EWORKSPACE if smaller); N <= 131072. Worth it from a few thousand points per cloud on. */
+size_t ptt_ball_query_grid_workspace(int B, int N);
+int ptt_ball_query_grid_f32(const float* new_xyz, const float* xyz, int B, int M, int N, float radius, int nsample,
+                            int32_t* idx_out, void* workspace, size_t workspace_bytes, ptt_stream_t stream);
+int ptt_centres_ball_query_grid_f32(const float* xyz, const int32_t* sel, int B, int N, int M, float radius, int nsample,
+                                    float* new_xyz, int64_t* idx64_out, int32_t* idx_out, void* workspace, size_t workspace_bytes,
+                                    ptt_stream_t stream);
 /* One launch for a small FPS-sampled set-abstraction level whose centres then meet in a TransformerBlock (vote_aggregation +
  * the box head's transformer at one tracklet frame, box_voting_head.py:75-86): ptt_fps_f32 + ptt_centres_ball_query_f32 +
  * ptt_knn_rel_f32 (of the CENTRES among themselves) with identical results. xyz (B,N<=256,3) -> inds (B,M) i32, inds64 (B,M)

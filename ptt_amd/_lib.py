@@ -15,7 +15,8 @@ ABI_VERSION = 19            # PTT_ABI_VERSION of include/ptt_hip.h these structu
 # every symbol include/ptt_hip.h declares (tests check the library exports all of them)
 EXPORTS = [
     "ptt_version", "ptt_error_name", "ptt_last_error_string",
-    "ptt_fps_f32", "ptt_fps_ws_f32", "ptt_spatial_order_f32", "ptt_gather_f32", "ptt_gather_grad_f32", "ptt_select_centres_f32", "ptt_ball_query_f32",
+    "ptt_fps_f32", "ptt_fps_ws_f32", "ptt_spatial_order_f32", "ptt_ball_query_grid_workspace", "ptt_ball_query_grid_f32",
+    "ptt_centres_ball_query_grid_f32", "ptt_gather_f32", "ptt_gather_grad_f32", "ptt_select_centres_f32", "ptt_ball_query_f32",
     "ptt_group_f32", "ptt_group_grad_f32", "ptt_scatter_add_det_workspace", "ptt_scatter_add_det_f32",
     "ptt_knn_f32", "ptt_knn_rel_f32",
     "ptt_packed_weight_elems", "ptt_pack_weight_f32", "ptt_pack_weight_rot_f32", "ptt_linear_f32",
@@ -168,6 +169,8 @@ def _declare(lib):
         "ptt_fps_f32": [vp, i, i, i, vp, vp],
         "ptt_fps_ws_f32": [vp, i, i, i, vp, vp, c_size_t, vp],
         "ptt_spatial_order_f32": [vp, i, i, vp, vp],
+        "ptt_ball_query_grid_f32": [vp, vp, i, i, i, f, i, vp, vp, c_size_t, vp],
+        "ptt_centres_ball_query_grid_f32": [vp, vp, i, i, i, f, i, vp, vp, vp, vp, c_size_t, vp],
         "ptt_gather_f32": [vp, vp, i, i, i, i, vp, vp],
         "ptt_gather_grad_f32": [vp, vp, i, i, i, i, vp, vp],
         "ptt_select_centres_f32": [vp, vp, i, i, i, vp, vp, vp],
@@ -268,6 +271,8 @@ def _declare(lib):
     lib.ptt_packed_weight_elems.argtypes = [i, i]
     lib.ptt_scatter_add_det_workspace.restype = c_size_t
     lib.ptt_scatter_add_det_workspace.argtypes = [i, i, i]
+    lib.ptt_ball_query_grid_workspace.restype = c_size_t
+    lib.ptt_ball_query_grid_workspace.argtypes = [i, i]
     lib.ptt_bn_stats_workspace.restype = c_size_t
     lib.ptt_bn_stats_workspace.argtypes = [i, i]
     lib.ptt_linear_wgrad_workspace.restype = c_size_t

@@ -922,6 +922,191 @@ __global__ __launch_bounds__(1024) void spatial_order_kernel(const float* __rest
     for (int k = t; k < N; k += 1024) order[(size_t)b * N + k] = b * N + (int)(unsigned)mkeys[k];
 }
 
+// ------------------------------------------------------------------------------------------
+// Ball query through a uniform grid (round 5), for large clouds. The sweep above tests every (centre, point) pair until a ball
+// is full: at 16384 points and radius 0.3 most balls never fill (9 hits expected) and a centre walks the whole cloud — 4.3e9 pair
+// tests for level 0 of the stress frames. Here a cloud's points are binned into cells of edge >= 1.001 r (grid_build_kernel, one
+// workgroup per cloud: bounding box, cell histogram / prefix / scatter with LDS atomics — the order INSIDE a cell is arbitrary),
+// and a wave tests only the points of its centre's 27 neighbouring cells. The contract "the first nsample hits in index order"
+// is restored by a bitmap: every hit sets bit k of an N-bit LDS bitmap, which is then read in ascending order — the result
+// does not depend on the order the candidates were met in, so it is bit-identical to the sweep's (same sqdist3, same strict <).
+// ------------------------------------------------------------------------------------------
+constexpr int GRID_MAX_CELLS = 8192;
+struct GridHead { float ox, oy, oz, inv; int nx, ny, nz, pad; };          // per cloud, at the start of its workspace slice
+__host__ __device__ inline size_t grid_slice_ints(int N) { return 8 + (size_t)GRID_MAX_CELLS + 1 + (size_t)N; }
+
+__device__ __forceinline__ int grid_cell_coord(float v, float o, float inv, int n) {
+    const float q = (v - o) * inv;
+    int c = (int)q;                                      // NaN -> 0 by the comparisons below
+    c = (q >= 0.f) ? c : 0;
+    return c < n ? c : n - 1;
+}
+
+__global__ __launch_bounds__(1024) void grid_build_kernel(const float* __restrict__ xyz, int N, float radius, int32_t* __restrict__ ws) {
+    __shared__ int hist[GRID_MAX_CELLS];
+    __shared__ float red[6][16];
+    __shared__ int wsum[16];
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const float* __restrict__ pts = xyz + (size_t)b * N * 3;
+    int32_t* __restrict__ slice = ws + (size_t)b * grid_slice_ints(N);
+    float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    for (int k = t; k < N; k += 1024)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float v = pts[3 * k + c];
+            if (v == v && fabsf(v) < 1.0e30f) { lo[c] = fminf(lo[c], v); hi[c] = fmaxf(hi[c], v); }     // NaN / inf take no part
+        }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float l = wave_min_f32(lo[c]), h = wave_max_f32(hi[c]);
+        if (lane == 0) { red[c][wv] = l; red[3 + c][wv] = h; }
+    }
+    for (int k = t; k < GRID_MAX_CELLS; k += 1024) hist[k] = 0;
+    __syncthreads();
+    float ext[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float l = red[c][0], h = red[3 + c][0];
+        for (int w = 1; w < 16; ++w) { l = fminf(l, red[c][w]); h = fmaxf(h, red[3 + c][w]); }
+        if (!(h >= l)) { l = 0.f; h = 0.f; }             // no finite point
+        lo[c] = l; ext[c] = h - l;
+    }
+    float cell = radius * 1.001f;
+    if (!(cell > 0.f)) cell = 1.f;
+    int nx, ny, nz;
+    for (;;) {                                           // the same loop in every thread: grow the cells until the grid fits
+        const float fx = ext[0] / cell + 1.f, fy = ext[1] / cell + 1.f, fz = ext[2] / cell + 1.f;
+        if (fx * fy * fz <= (float)GRID_MAX_CELLS && fx < 4096.f && fy < 4096.f && fz < 4096.f) {
+            nx = (int)fx; ny = (int)fy; nz = (int)fz;
+            if ((long long)nx * ny * nz <= GRID_MAX_CELLS) break;
+        }
+        cell *= 1.25f;
+    }
+    const float inv = 1.f / cell;
+    const int cells = nx * ny * nz;
+    for (int k = t; k < N; k += 1024) {
+        const int ci = (grid_cell_coord(pts[3 * k + 2], lo[2], inv, nz) * ny + grid_cell_coord(pts[3 * k + 1], lo[1], inv, ny)) * nx +
+                       grid_cell_coord(pts[3 * k], lo[0], inv, nx);
+        atomicAdd(&hist[ci], 1);
+    }
+    __syncthreads();
+    // exclusive prefix over the cells: 8 consecutive cells per thread, wave scan, cross-wave offsets
+    constexpr int PER = GRID_MAX_CELLS / 1024;
+    int loc[PER], sum = 0;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) { loc[i] = hist[t * PER + i]; sum += loc[i]; }
+    int incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off, 64); if (lane >= off) incl += v; }
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wv; ++w) base += wsum[w];
+    int run = base + incl - sum;
+    int32_t* __restrict__ cstart = slice + 8;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) { hist[t * PER + i] = run; cstart[t * PER + i] = run; run += loc[i]; }     // hist = the scatter cursors
+    if (t == 1023) cstart[GRID_MAX_CELLS] = run;
+    if (t == 0) {
+        GridHead h{lo[0], lo[1], lo[2], inv, nx, ny, nz, cells};
+        *reinterpret_cast<GridHead*>(slice) = h;
+    }
+    __syncthreads();
+    int32_t* __restrict__ cpts = slice + 8 + GRID_MAX_CELLS + 1;
+    for (int k = t; k < N; k += 1024) {
+        const int ci = (grid_cell_coord(pts[3 * k + 2], lo[2], inv, nz) * ny + grid_cell_coord(pts[3 * k + 1], lo[1], inv, ny)) * nx +
+                       grid_cell_coord(pts[3 * k], lo[0], inv, nx);
+        cpts[atomicAdd(&hist[ci], 1)] = k;
+    }
+}
+
+// One wave per centre. centres: new_xyz (B,M,3) given (sel_mode 0), or taken from the cloud through sel / the first M points
+// (sel_mode 1: also written to new_xyz_out / idx64 as centres_ball_query_kernel does).
+__global__ __launch_bounds__(256) void ball_query_grid_kernel(const float* __restrict__ xyz, const float* __restrict__ centres,
+                                                              const int32_t* __restrict__ sel, int sel_mode, int BM, int M, int N,
+                                                              float r2, int ns, const int32_t* __restrict__ ws,
+                                                              float* __restrict__ new_xyz_out, long long* __restrict__ idx64,
+                                                              int32_t* __restrict__ idx_out) {
+    extern __shared__ unsigned bq_bits[];                                 // [4 waves][words]
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int centre = blockIdx.x * 4 + wv;
+    if (centre >= BM) return;
+    const int words = (N + 31) >> 5;
+    unsigned* __restrict__ bits = bq_bits + (size_t)wv * words;
+    const int b = centre / M;
+    const float* __restrict__ pts = xyz + (size_t)b * N * 3;
+    const int32_t* __restrict__ slice = ws + (size_t)b * grid_slice_ints(N);
+    const GridHead g = *reinterpret_cast<const GridHead*>(slice);
+    const int32_t* __restrict__ cstart = slice + 8;
+    const int32_t* __restrict__ cpts = slice + 8 + GRID_MAX_CELLS + 1;
+    float cx, cy, cz;
+    if (sel_mode) {
+        const int n = sel ? sel[centre] : centre - b * M;
+        cx = pts[3 * n]; cy = pts[3 * n + 1]; cz = pts[3 * n + 2];
+        if (lane == 0) {
+            new_xyz_out[(size_t)centre * 3] = cx; new_xyz_out[(size_t)centre * 3 + 1] = cy; new_xyz_out[(size_t)centre * 3 + 2] = cz;
+            if (idx64) idx64[centre] = n;
+        }
+    } else {
+        cx = centres[(size_t)centre * 3]; cy = centres[(size_t)centre * 3 + 1]; cz = centres[(size_t)centre * 3 + 2];
+    }
+    for (int w = lane; w < words; w += 64) bits[w] = 0u;
+    __builtin_amdgcn_wave_barrier();
+    // the centre's cell by the same arithmetic that binned the points, then its 27 neighbours (clipped). A centre outside the
+    // bounding box (a ball query with foreign centres) is clamped to the border cell: its ball can only reach border cells' points
+    // if it is within one cell of the box, which the clamped cell's neighbourhood covers... unless it is farther away than a cell —
+    // then no point can be within r of it anyway.
+    const int ix = grid_cell_coord(cx, g.ox, g.inv, g.nx), iy = grid_cell_coord(cy, g.oy, g.inv, g.ny), iz = grid_cell_coord(cz, g.oz, g.inv, g.nz);
+    for (int dz = -1; dz <= 1; ++dz) {
+        const int z = iz + dz;
+        if (z < 0 || z >= g.nz) continue;
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int y = iy + dy;
+            if (y < 0 || y >= g.ny) continue;
+            // the (up to) three cells along x are consecutive in the cell order: one contiguous candidate range
+            const int x0 = ix > 0 ? ix - 1 : 0, x1 = ix + 1 < g.nx ? ix + 1 : g.nx - 1;
+            const int c0 = (z * g.ny + y) * g.nx + x0;
+            const int s0 = cstart[c0], s1 = cstart[c0 + (x1 - x0) + 1];
+            for (int e = s0 + lane; e < s1; e += 64) {
+                const int k = cpts[e];
+                const float d = sqdist3(cx, cy, cz, pts[3 * k], pts[3 * k + 1], pts[3 * k + 2]);
+                if (d < r2) atomicOr(&bits[k >> 5], 1u << (k & 31));
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the LDS atomics of this wave have landed
+    // read the bitmap in index order: 64 words (2048 indices) per round, prefix of the popcounts across the wave
+    int32_t* __restrict__ out = idx_out + (size_t)centre * ns;
+    int cnt = 0, first = 0;
+    for (int w0 = 0; w0 < words && cnt < ns; w0 += 64) {
+        const int w = w0 + lane;
+        unsigned v = w < words ? bits[w] : 0u;
+        const int mine = __popc(v);
+        int incl = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const int u = __shfl_up(incl, off, 64); if (lane >= off) incl += u; }
+        const int total = __shfl(incl, 63, 64);
+        if (total == 0) continue;
+        if (cnt == 0) {
+            const unsigned long long any = __ballot(mine > 0);
+            const int fl = __ffsll((long long)any) - 1;
+            const unsigned fv = __shfl(v, fl, 64);
+            first = ((w0 + fl) << 5) + (__ffs(fv) - 1);
+        }
+        int pos = cnt + incl - mine;
+        while (v != 0u && pos < ns) {
+            const int bit = __ffs(v) - 1;
+            out[pos++] = (w << 5) + bit;
+            v &= v - 1u;
+        }
+        cnt += total;
+    }
+    const int have = cnt < ns ? cnt : ns;
+    const int fill = cnt > 0 ? first : 0;
+    for (int s2 = have + lane; s2 < ns; s2 += 64) out[s2] = fill;
+}
+
 }  // namespace ptt
 
 using namespace ptt;
@@ -1090,6 +1275,45 @@ extern "C" int ptt_centres_ball_query_f32(const float* xyz, const int32_t* sel, 
         hipLaunchKernelGGL((centres_ball_query_kernel<1>), dim3((BM + 3) / 4), dim3(256), 0, as_stream(stream), xyz, sel, BM, M,
                            N, radius * radius, nsample, new_xyz, reinterpret_cast<long long*>(idx64_out), idx_out);
     return check_launch("centres_ball_query_kernel");
+}
+
+
+extern "C" size_t ptt_ball_query_grid_workspace(int B, int N) {
+    if (B <= 0 || N <= 0) return 0;
+    return (size_t)B * grid_slice_ints(N) * sizeof(int32_t);
+}
+
+static int ball_query_grid_launch(const char* who, const float* xyz, const float* centres, const int32_t* sel, int sel_mode, int B, int N, int M,
+                                  float radius, int nsample, float* new_xyz, int64_t* idx64, int32_t* idx_out, void* ws, size_t ws_bytes,
+                                  ptt_stream_t stream) {
+    if (B < 0 || M < 0 || N <= 0 || nsample <= 0) return fail(PTT_EINVAL, "%s: B=%d M=%d N=%d nsample=%d", who, B, M, N, nsample);
+    if (B == 0 || M == 0) return PTT_OK;
+    if (N > 131072) return fail(PTT_EUNSUPPORTED, "%s: N=%d (the hit bitmap of a wave lives in LDS: at most 131072 points)", who, N);
+    if (!ws || ws_bytes < ptt_ball_query_grid_workspace(B, N) || (reinterpret_cast<uintptr_t>(ws) & 15))
+        return fail(PTT_EWORKSPACE, "%s: %zu bytes of 16-byte aligned workspace needed", who, ptt_ball_query_grid_workspace(B, N));
+    hipStream_t s = as_stream(stream);
+    hipLaunchKernelGGL(grid_build_kernel, dim3(B), dim3(1024), 0, s, xyz, N, radius, static_cast<int32_t*>(ws));
+    const int BM = B * M, lds = 4 * ((N + 31) / 32) * (int)sizeof(unsigned);
+    if (int rc = set_lds_limit(reinterpret_cast<const void*>(ball_query_grid_kernel), lds)) return rc;
+    hipLaunchKernelGGL(ball_query_grid_kernel, dim3((BM + 3) / 4), dim3(256), lds, s, xyz, centres, sel, sel_mode, BM, M, N, radius * radius,
+                       nsample, static_cast<const int32_t*>(ws), new_xyz, reinterpret_cast<long long*>(idx64), idx_out);
+    return check_launch(who);
+}
+
+extern "C" int ptt_ball_query_grid_f32(const float* new_xyz, const float* xyz, int B, int M, int N, float radius, int nsample,
+                                       int32_t* idx_out, void* workspace, size_t workspace_bytes, ptt_stream_t stream) {
+    if ((B > 0 && M > 0) && (!new_xyz || !xyz || !idx_out)) return fail(PTT_EINVAL, "ptt_ball_query_grid_f32: null pointer");
+    return ball_query_grid_launch("ptt_ball_query_grid_f32", xyz, new_xyz, nullptr, 0, B, N, M, radius, nsample, nullptr, nullptr, idx_out,
+                                  workspace, workspace_bytes, stream);
+}
+
+extern "C" int ptt_centres_ball_query_grid_f32(const float* xyz, const int32_t* sel, int B, int N, int M, float radius, int nsample,
+                                               float* new_xyz, int64_t* idx64_out, int32_t* idx_out, void* workspace,
+                                               size_t workspace_bytes, ptt_stream_t stream) {
+    if (!sel && M > N) return fail(PTT_EINVAL, "ptt_centres_ball_query_grid_f32: M=%d > N=%d without a selection", M, N);
+    if ((B > 0 && M > 0) && (!xyz || !new_xyz || !idx_out)) return fail(PTT_EINVAL, "ptt_centres_ball_query_grid_f32: null pointer");
+    return ball_query_grid_launch("ptt_centres_ball_query_grid_f32", xyz, nullptr, sel, 1, B, N, M, radius, nsample, new_xyz, idx64_out,
+                                  idx_out, workspace, workspace_bytes, stream);
 }
 
 extern "C" int ptt_fps_ball_knn_f32(const float* xyz, int B, int N, int M, float radius, int nsample, int k, int32_t* inds,

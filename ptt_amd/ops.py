@@ -209,6 +209,9 @@ def select_centres(xyz, idx, npoint, want_idx64=True):
     return new_xyz, idx64
 
 
+GRID_BALL_QUERY_MIN_POINTS = 4096      # clouds from this size on take the uniform-grid ball query (same results)
+
+
 def ball_query(new_xyz, xyz, radius, nsample):
     """centres first: (B,M,3), (B,N,3) -> (B,M,nsample) i32.  Replaces _ext.ball_query (pointnet2_utils.py:287)."""
     _chk(new_xyz, "new_xyz", torch.float32, 3)
@@ -217,8 +220,13 @@ def ball_query(new_xyz, xyz, radius, nsample):
     N = xyz.shape[1]
     out = torch.empty((B, M, int(nsample)), dtype=torch.int32, device=xyz.device)
     with torch.cuda.device(xyz.device), _timed('ptt_ball_query_f32'):
-        _lib.check(_lib.lib().ptt_ball_query_f32(_ptr(new_xyz), _ptr(xyz), B, M, N, float(radius), int(nsample),
-                                                 _ptr(out), _stream()), "ptt_ball_query_f32")
+        if GRID_BALL_QUERY_MIN_POINTS <= N <= 131072:          # large clouds: 27 cells of a uniform grid instead of the whole cloud
+            ws = _ws(_lib.lib().ptt_ball_query_grid_workspace(B, N), xyz.device)
+            _lib.check(_lib.lib().ptt_ball_query_grid_f32(_ptr(new_xyz), _ptr(xyz), B, M, N, float(radius), int(nsample), _ptr(out),
+                                                          _ptr(ws), ws.numel() * 8, _stream()), "ptt_ball_query_grid_f32")
+        else:
+            _lib.check(_lib.lib().ptt_ball_query_f32(_ptr(new_xyz), _ptr(xyz), B, M, N, float(radius), int(nsample),
+                                                     _ptr(out), _stream()), "ptt_ball_query_f32")
     return out
 
 
@@ -234,8 +242,14 @@ def centres_ball_query(xyz, sel, npoint, radius, nsample, want_idx64=True):
     idx64 = torch.empty((B, M), dtype=torch.int64, device=xyz.device) if (want_idx64 and sel is not None) else None
     idx = torch.empty((B, M, int(nsample)), dtype=torch.int32, device=xyz.device)
     with torch.cuda.device(xyz.device), _timed('ptt_ball_query_f32'):
-        _lib.check(_lib.lib().ptt_centres_ball_query_f32(_ptr(xyz), _ptr(sel), B, N, M, float(radius), int(nsample), _ptr(new_xyz),
-                                                         _ptr(idx64), _ptr(idx), _stream()), "ptt_centres_ball_query_f32")
+        if GRID_BALL_QUERY_MIN_POINTS <= N <= 131072:
+            ws = _ws(_lib.lib().ptt_ball_query_grid_workspace(B, N), xyz.device)
+            _lib.check(_lib.lib().ptt_centres_ball_query_grid_f32(_ptr(xyz), _ptr(sel), B, N, M, float(radius), int(nsample), _ptr(new_xyz),
+                                                                  _ptr(idx64), _ptr(idx), _ptr(ws), ws.numel() * 8, _stream()),
+                       "ptt_centres_ball_query_grid_f32")
+        else:
+            _lib.check(_lib.lib().ptt_centres_ball_query_f32(_ptr(xyz), _ptr(sel), B, N, M, float(radius), int(nsample), _ptr(new_xyz),
+                                                             _ptr(idx64), _ptr(idx), _stream()), "ptt_centres_ball_query_f32")
     return new_xyz, idx64, idx
 
 

@@ -62,8 +62,8 @@ s)  # the pair kernel in Morton order at the stress size: parity, kernel time an
     bash scripts/pmc_passes.sh $O/pmc_stress "pair" "" "--batch 32 --pair-n 2048,64" > $O/pmc_spatial.log 2>&1; tail -3 $O/pmc_spatial.log | cut -c1-400
     for i in 1 2; do timeout 600 python bench.py --workload stress --steps 8 --warmup 3 --no-cpu-baseline --sustain 0 2> $O/stress.err | tee $O/stress.json | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('stress', d['ms_per_step'], d['value'], d['roofline']['frac'], d['kernel_ms_per_step'])"; done
     ;;
-q)  # ball query with two centres per packed instruction: index parity, then the stress and car workloads
-    timeout 900 python -m pytest tests/test_point_ops_gpu.py tests/test_golden_gpu.py tests/test_hot_path_gpu.py tests/test_tracking_gpu.py -q -m gpu > $O/pytest.log 2>&1; grep -E "^FAILED|passed|failed" $O/pytest.log | cut -c1-200
+q)  # the uniform-grid ball query: index parity (sweep, oracle), then the stress and car workloads
+    timeout 900 python -m pytest tests/test_round5_gpu.py tests/test_point_ops_gpu.py tests/test_golden_gpu.py tests/test_hot_path_gpu.py tests/test_tracking_gpu.py -q -m gpu > $O/pytest.log 2>&1; grep -E "^FAILED|passed|failed" $O/pytest.log | cut -c1-200
     for w in stress stress car; do timeout 600 python bench.py --workload $w --steps 10 --warmup 3 --no-cpu-baseline --sustain 0 --no-workloads --no-full-model --no-latency 2> $O/$w.err | tee $O/$w.json | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$w', d['ms_per_step'], d['value'], d['kernel_ms_per_step'])"; done
     ;;
 t)  # the training step after a change: gradient parity (G10 / G14 / G15, reproducibility, weight-gradient kernels), then the step time

@@ -286,3 +286,53 @@ def test_spatial_order_is_a_permutation_and_the_pair_kernel_does_not_depend_on_i
     r1, a1 = ops.pt_attn_pair(*args, want_attn, rel=rel, order=order)
     assert torch.equal(r0, r1) and (a0 is None or torch.equal(a0, a1))
 
+
+
+@pytest.mark.parametrize("N,M,r,ns,kind", [(16384, 8192, 0.3, 32, "dense"), (8192, 4096, 0.5, 32, "dense"), (4096, 2048, 0.7, 32, "dense"),
+                                           (5000, 777, 0.3, 16, "car"), (4096, 512, 0.3, 64, "ped"), (300, 64, 5.0, 64, "car"),
+                                           (20000, 100, 0.05, 8, "dense")])
+def test_grid_ball_query_equals_the_sweep_and_the_oracle(dev, N, M, r, ns, kind):
+    """ptt_ball_query_grid_f32 / ptt_centres_ball_query_grid_f32 (what ops.ball_query takes from 4096 points per cloud on) against
+    the sweep kernels bit for bit — dense clouds, heavy duplication, an all-zero cloud, points inside each other's cells, a radius
+    that makes the grid one cell, centres that are NOT points of the cloud (outside its bounding box too) — and, at the sizes
+    the oracle finishes quickly, against the oracle (_ext.ball_query, pointnet2_utils.py:287: first nsample hits in index order)."""
+    from oracle import index_ops as O
+    from ptt_amd import _lib, ops
+    B = 3
+    K = N if kind == "dense" else max(8, N // 3)
+    s, _ = synth.frames(N + M, B, N, 64, K_s=K, K_t=32, kind=kind if kind != "dense" else "dense")
+    s[-1] = 0.0
+    xyz = torch.from_numpy(s).to(dev)
+    rs = np.random.RandomState(N)
+    sel = torch.from_numpy(np.stack([rs.permutation(N)[:M] for _ in range(B)]).astype(np.int32)).to(dev)
+    L, st = _lib.lib(), torch.cuda.current_stream().cuda_stream
+    ws = torch.empty((L.ptt_ball_query_grid_workspace(B, N) + 7) // 8, dtype=torch.float64, device=dev)
+
+    def centres(grid, sel_t):
+        new_xyz = torch.empty((B, M, 3), device=dev)
+        i64 = torch.empty((B, M), dtype=torch.int64, device=dev) if sel_t is not None else None
+        idx = torch.empty((B, M, ns), dtype=torch.int32, device=dev)
+        p = lambda t: t.data_ptr() if t is not None else None
+        if grid:
+            rc = L.ptt_centres_ball_query_grid_f32(xyz.data_ptr(), p(sel_t), B, N, M, r, ns, new_xyz.data_ptr(), p(i64), idx.data_ptr(), ws.data_ptr(), ws.numel() * 8, st)
+        else:
+            rc = L.ptt_centres_ball_query_f32(xyz.data_ptr(), p(sel_t), B, N, M, r, ns, new_xyz.data_ptr(), p(i64), idx.data_ptr(), st)
+        assert rc == 0
+        return new_xyz, i64, idx
+    for sel_t in (sel, None):
+        a, b = centres(True, sel_t), centres(False, sel_t)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2]) and (sel_t is None or torch.equal(a[1], b[1]))
+    # foreign centres: jittered points, some far outside the cloud's bounding box
+    c = (xyz[:, :M] + torch.randn(B, M, 3, device=dev) * 0.2).contiguous()
+    c[:, :5] += 50.0
+    c[:, 5:10] -= torch.tensor([0.31, 0.0, 0.0], device=dev)
+    out_g = torch.empty((B, M, ns), dtype=torch.int32, device=dev)
+    out_s = torch.empty_like(out_g)
+    assert L.ptt_ball_query_grid_f32(c.data_ptr(), xyz.data_ptr(), B, M, N, r, ns, out_g.data_ptr(), ws.data_ptr(), ws.numel() * 8, st) == 0
+    assert L.ptt_ball_query_f32(c.data_ptr(), xyz.data_ptr(), B, M, N, r, ns, out_s.data_ptr(), st) == 0
+    assert torch.equal(out_g, out_s)
+    assert L.ptt_ball_query_grid_f32(c.data_ptr(), xyz.data_ptr(), B, M, N, r, ns, out_g.data_ptr(), ws.data_ptr(), 64, st) == -4      # PTT_EWORKSPACE
+    if N * M <= 5000 * 800:
+        np.testing.assert_array_equal(out_g.cpu().numpy(), O.ball_query(c.cpu().numpy(), s, r, ns))
+    if N >= ops.GRID_BALL_QUERY_MIN_POINTS:                 # and the front end takes the grid path by itself
+        assert torch.equal(ops.ball_query(c, xyz, r, ns), out_s)
