@@ -105,5 +105,10 @@ p)  # PMC passes (separate counter-only runs, scripts/pmc_passes.sh): car pair k
     bash scripts/pmc_passes.sh $O/pmc_train_gemm - "python scripts/rows_gemm_bench.py --no-check --pmc" > $O/pmc_train_gemm.log 2>&1; tail -4 $O/pmc_train_gemm.log | cut -c1-300
     bash scripts/pmc_train_step.sh $O/pmc_train_step > $O/pmc_train_step.log 2>&1; tail -2 $O/pmc_train_step.log
     ;;
+y)  # stability of the closing build: the GPU suite three times in fresh processes, smoke(), the default bench line twice
+    for i in 1 2 3; do timeout 1500 python -m pytest tests -m gpu -q -x 2>&1 | tail -1; done | tee $O/suite_x3.log
+    timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee $O/smoke.log
+    for i in 1 2; do timeout 900 python bench.py --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['latency_b1']['tracklet_loop']['b1']['ms_per_step'], {k: v.get('ms_per_step') for k, v in d['workloads'].items()})"; done | tee $O/bench_x2.log
+    ;;
 *)  echo "unknown session $S"; exit 2 ;;
 esac
