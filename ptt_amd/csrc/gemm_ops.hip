@@ -576,7 +576,15 @@ static RowsGemmGeom rows_gemm_geom(int rows, int K, int N) {
     RowsGemmGeom g{};
     g.ok = false;
     if (rows <= 0 || K <= 0 || N <= 0) return g;
-    if (N % 128 == 0 && K % 128 == 0) { g.WR = 1; g.RT = 2; g.CT = (N % 256 == 0) ? 2 : 1; g.KC = 128; }
+    if (N % 128 == 0 && K % 128 == 0) {
+        // 256 columns per workgroup (two accumulator tiles per row tile: each staged row feeds twice the MFMAs) — unless the launch is
+        // too small to give every CU its two workgroups that way (the 6144-row layers of the transformer blocks and the heads are
+        // 96 row tiles: 96 or 192 workgroups on 256 CUs): then 128 columns per workgroup, twice the workgroups. Measured on the
+        // training step (round 5): always 256 columns 20.18 ms, 128 below one workgroup per CU 19.78, below two 19.70, below four 19.79
+        const int tiles64 = (rows + 63) / 64;
+        g.WR = 1; g.RT = 2; g.KC = 128;
+        g.CT = (N % 256 == 0 && (long long)tiles64 * (N / 256) >= 2 * cu_count()) ? 2 : 1;
+    }
     else if (N % 128 == 0 && K % 64 == 0) { g.WR = 1; g.RT = 4; g.CT = 1; g.KC = 64; }
     else if (N % 64 == 0 && K % 64 == 0) { g.WR = 2; g.RT = 2; g.CT = 1; g.KC = 64; }
     else return g;
@@ -664,7 +672,7 @@ extern "C" int ptt_rows_gemm_bnbwd_f32(const float* X, int rows, int K, int ldx,
 extern "C" int ptt_rows_gemm_pool_supported(int rows, int K, int N, int ldx, int ns) {
     if (!ptt_rows_gemm_supported(rows, K, N, ldx, N) || ns <= 0 || rows % ns) return 0;
     const RowsGemmGeom g = rows_gemm_geom(rows, K, N);
-    return ((g.WR == 1 && g.RT == 2 && g.CT == 2 && g.KC == 128 && (ns == 16 || ns == 32 || ns == 64)) ||
+    return ((g.WR == 1 && g.RT == 2 && g.KC == 128 && (ns == 16 || ns == 32 || ns == 64)) ||
             (g.WR == 1 && g.RT == 4 && g.CT == 1 && g.KC == 64 && ns == 32)) ? 1 : 0;
 }
 
@@ -709,7 +717,7 @@ static int rows_gemm_launch(const float* X, int rows, int K, int ldx, const floa
     if (pool && (!stats || bias || residual || mask || bn || !in_scale || relu || !pool->pmax || !pool->pmin || !pool->amax || !pool->amin ||
                  rows % pool->ns))
         return fail(PTT_EINVAL, "ptt_rows_gemm_pool_f32: a statistics launch with a deferred-activation input, whole groups of rows");
-    if (pool && !((g.WR == 1 && g.RT == 2 && g.CT == 2 && g.KC == 128 && (pool->ns == 16 || pool->ns == 32 || pool->ns == 64)) ||
+    if (pool && !((g.WR == 1 && g.RT == 2 && g.KC == 128 && (pool->ns == 16 || pool->ns == 32 || pool->ns == 64)) ||
                   (g.WR == 1 && g.RT == 4 && g.CT == 1 && g.KC == 64 && pool->ns == 32)))
         return fail(PTT_EUNSUPPORTED, "ptt_rows_gemm_pool_f32: K=%d N=%d ns=%d is not an instantiated shape (ptt_rows_gemm_pool_supported)", K, N, pool->ns);
     if (stats && (bias || stats_elems < (size_t)g.chunks * 2 * N))
@@ -756,6 +764,7 @@ static int rows_gemm_launch(const float* X, int rows, int K, int ldx, const floa
             hipLaunchKernelGGL((rows_gemm_kernel<WR_, RT_, CT_, KC_, true, true, 0, false, NS_>), grid, dim3(256), lds, s, p); \
         }
         PTT_RG_POOL(1, 2, 2, 128, 16) PTT_RG_POOL(1, 2, 2, 128, 32) PTT_RG_POOL(1, 2, 2, 128, 64) PTT_RG_POOL(1, 4, 1, 64, 32)
+        PTT_RG_POOL(1, 2, 1, 128, 16) PTT_RG_POOL(1, 2, 1, 128, 32) PTT_RG_POOL(1, 2, 1, 128, 64)      // launches too small for 256 columns per workgroup
 #undef PTT_RG_POOL
         return check_launch("rows_gemm_kernel(pool)");
     }
