@@ -808,6 +808,9 @@ static int rows_gemm_launch(const float* X, int rows, int K, int ldx, const floa
 
 // ---- weight gradient, large blocks ----
 namespace ptt {
+#ifndef PTT_WG2_MIN_ROWS
+#define PTT_WG2_MIN_ROWS 768      // rows per chunk at least
+#endif
 struct Wgrad2Geom { int TN, TK, BN, BK, nbo, nbk, chunk_rows, nchunks; bool ok; };
 static Wgrad2Geom wgrad2_geom(int R, int Cout, int Cin) {
     Wgrad2Geom g{};
@@ -830,7 +833,7 @@ static Wgrad2Geom wgrad2_geom(int R, int Cout, int Cin) {
         if (blocks > ncu) continue;
         int nch = ncu / blocks;                                 // floor: never a second round of workgroups
         int rows = (R + nch - 1) / nch;
-        if (rows < 768) rows = 768;
+        if (rows < PTT_WG2_MIN_ROWS) rows = PTT_WG2_MIN_ROWS;
         rows = (rows + 31) & ~31;
         const int nchunks = (R + rows - 1) / rows;
         if (nchunks * blocks * 4 < ncu * 3 && k < 3) continue;  // under 3/4 of the CUs busy: try a smaller block
