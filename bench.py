@@ -746,7 +746,7 @@ def train_roofline(achieved, flops, B, NS, NT):
 
 
 def run_train(args, torch, dev, dist, world, rank, ranks_seen, sync_all, B, NS, NT, W):
-    """configs[3]: forward + backward + clip + Adam of the full tracker, DDP gradient all-reduce when world > 1."""
+    """configs[3]: forward + backward + clip + Adam of the full tracker, one gradient all-reduce per step when world > 1."""
     from ptt_amd.config import StubDataset, ptt_model_cfg
     from ptt_amd.models import build_network
     from ptt_amd.train_step import GRAD_ELEMS, DataParallelTrainer, synthetic_train_batch
@@ -775,15 +775,15 @@ def run_train(args, torch, dev, dist, world, rank, ranks_seen, sync_all, B, NS, 
         # what the gradient all-reduce costs the step: the same steps with DDP's synchronisation switched off
         # (model.no_sync(): gradients stay local; the replicas drift apart, which is why this runs last)
         def step_local():
-            with trainer.model.no_sync():
+            with trainer.no_sync():
                 last["loss"] = trainer.step(batch)
         for _ in range(2):
             step_local()
         local = reduce_max(torch, dist, dev, timed_loop(step_local, args.steps, sync_all))
         allreduce = {"ms_per_step_without_allreduce": round(local / args.steps * 1e3, 4),
                      "exposed_ms_per_step": round((elapsed - local) / args.steps * 1e3, 4),
-                     "how": "step time minus the same steps under DistributedDataParallel.no_sync(); DDP overlaps the one "
-                            "%.1f MB bucket with the tail of the backward pass, so this is what is NOT hidden" % (GRAD_ELEMS * 4 / 1e6)}
+                     "how": "step time minus the same steps with the gradient all-reduce switched off (trainer.no_sync()): the "
+                            "one %.1f MB all-reduce over the flat gradient buffer runs between the backward pass and the optimiser" % (GRAD_ELEMS * 4 / 1e6)}
     # dense FLOPs of one training step: forward 12.3 GFLOP per frame at 1024+512 (SURVEY.md §8a totals) x 3 (the
     # backward of a linear layer is two GEMMs of the forward's size)
     flops = 3.0 * 12.3e9 * B
@@ -797,7 +797,7 @@ def run_train(args, torch, dev, dist, world, rank, ranks_seen, sync_all, B, NS, 
                                % (W["ref"], B, NS, NT),
                    "sample_detail": "%s; train mode (batch-statistics BatchNorm), Adam lr 1e-3 betas .5/.999 eps 1e-6, clip 10" % W["text"],
                    "name": "train", "frames_per_gpu_per_step": B, "search_points": NS, "template_points": NT,
-                   "sharding": "batch across ranks, DDP gradient all-reduce over RCCL" if collective else "single rank, no collective",
+                   "sharding": "batch across ranks, one gradient all-reduce per step over RCCL (%s)" % trainer.reducer if collective else "single rank, no collective",
                    "launch": "eager"},
         "rccl_ranks_seen": ranks_seen,
         "roofline": train_roofline(achieved, flops, B, NS, NT),

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PTT_ABI_VERSION 19
+#define PTT_ABI_VERSION 20
 
 enum {
     PTT_OK = 0,
@@ -854,6 +854,32 @@ size_t ptt_sa_z0_bnbwd_workspace(long long R, int C);
 int ptt_sa_z0_bnbwd_f32(const double* partial, int chunks, const float* G, const float* Z0, const float* rel_rows, const float* mean,
                         const float* invstd, const float* gamma, const float* act_scale, const float* act_shift, long long R, int C,
                         float* dz_out, float* dwx, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, ptt_stream_t stream);
+
+/* The parameter gradients of a training step finished by ONE launch (reference tools/train_utils/train_utils.py:47-49:
+ * loss.backward() has every .grad complete before clip_grad_norm_ reads it; tools/train_tracking.py:158-159: the gradient that
+ * DistributedDataParallel averages over ranks). The *_partials entries are ptt_linear_wgrad_f32 / ptt_linear_wgrad2_f32 /
+ * ptt_colsum_f32 without their finishing launch: the row-chunk partial sums [*nchunks][Cout * Cin] (resp. [*nchunks][C]) stay in
+ * `workspace` (same size queries). ptt_grad_finish_f32 then adds, for every SEGMENT (one destination inside the flat float32
+ * gradient buffer `flat`: n elements as rows of `cols`, row stride `ld`, first element `dst`; 16-byte aligned pieces when `vec`),
+ * the chunks of its jobs [job0, job0 + njobs) in a fixed order; `out` (a power of two, 4 ... 256) = outputs per workgroup, the
+ * other 256 / out thread groups split the chunks. blocks_device: pairs (segment, first output unit) per workgroup; a unit is
+ * 4 elements of a vec segment, else 1. Every job of a segment holds partials of that segment's n. Tables live on the device. */
+typedef struct ptt_grad_job {
+    const float* partial;
+    int32_t nchunks, reserved;
+} ptt_grad_job;
+typedef struct ptt_grad_segment {
+    int64_t dst;
+    int32_t n, cols, ld, job0, njobs, out, vec, reserved;
+} ptt_grad_segment;
+int ptt_linear_wgrad_partials_f32(const float* dZ, int ldz, const float* X, int ldx, int R, int Cout, int Cin, void* workspace,
+                                  size_t workspace_bytes, const float* x_scale, const float* x_shift, int* nchunks, ptt_stream_t stream);
+int ptt_linear_wgrad2_partials_f32(const float* dZ, int ldz, const float* X, int ldx, int R, int Cout, int Cin, void* workspace,
+                                   size_t workspace_bytes, const float* x_scale, const float* x_shift, int* nchunks, ptt_stream_t stream);
+int ptt_colsum_partials_f32(const float* X, int R, int C, int ldx, void* workspace, size_t workspace_bytes, int* nchunks,
+                            ptt_stream_t stream);
+int ptt_grad_finish_f32(const ptt_grad_segment* segments_device, const ptt_grad_job* jobs_device, const int32_t* blocks_device,
+                        int n_blocks, float* flat, ptt_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libptt_hip.so")
 
 PTT_SA_MAX_LAYERS = 4
-ABI_VERSION = 19            # PTT_ABI_VERSION of include/ptt_hip.h these structures mirror
+ABI_VERSION = 20            # PTT_ABI_VERSION of include/ptt_hip.h these structures mirror
 
 # every symbol include/ptt_hip.h declares (tests check the library exports all of them)
 EXPORTS = [
@@ -42,6 +42,7 @@ EXPORTS = [
     "ptt_sa_z0_rows_f32",
     "ptt_row_jobs_f32", "ptt_point_jobs_f32", "ptt_fps_ball_knn_f32", "ptt_crop_compact_host_f32", "ptt_crop_regularize_f32", "ptt_colsum_workspace", "ptt_colsum_f32", "ptt_rows_gemm_pool_supported", "ptt_rows_gemm_pool_f32", "ptt_pool_select_f32", "ptt_sa_z0_rows_stat_chunks", "ptt_sa_z0_rows_stats_f32",
     "ptt_track_losses_f32", "ptt_track_losses_bwd_f32", "ptt_adam_chunk_elems", "ptt_adam_clip_step_f32",
+    "ptt_linear_wgrad_partials_f32", "ptt_linear_wgrad2_partials_f32", "ptt_colsum_partials_f32", "ptt_grad_finish_f32",
     "ptt_unit_rows_f32", "ptt_cos_bwd_rows_f32", "ptt_track_select_update", "ptt_sa_z0_bnbwd_workspace", "ptt_sa_z0_bnbwd_f32",
 ]
 PTT_MAX_SEGMENTS = 4
@@ -115,6 +116,17 @@ class TrackLossDesc(Structure):
 class AdamTensor(Structure):
     """ptt_adam_tensor: one parameter with its gradient and moments; arrays of these are uploaded to the device."""
     _fields_ = [("param", c_void_p), ("grad", c_void_p), ("exp_avg", c_void_p), ("exp_avg_sq", c_void_p), ("n", c_int64)]
+
+
+class GradJob(Structure):
+    """ptt_grad_job: one contribution to a parameter gradient (row-chunk partial sums); arrays of these are uploaded to the device."""
+    _fields_ = [("partial", c_void_p), ("nchunks", c_int32), ("reserved", c_int32)]
+
+
+class GradSegment(Structure):
+    """ptt_grad_segment: one destination inside the flat gradient buffer with its jobs."""
+    _fields_ = [("dst", c_int64), ("n", c_int32), ("cols", c_int32), ("ld", c_int32), ("job0", c_int32), ("njobs", c_int32), ("out", c_int32),
+                ("vec", c_int32), ("reserved", c_int32)]
 
 
 class AdamHyper(Structure):
@@ -236,6 +248,10 @@ def _declare(lib):
         "ptt_bn_finish_partials_f32": [vp, i, i, i, f, vp, vp, vp, vp],
         "ptt_bn_sums_partials_f64": [vp, i, i, i, vp, vp],
         "ptt_linear_wgrad2_f32": [vp, i, vp, i, i, i, i, vp, i, vp, c_size_t, vp, vp, vp],
+        "ptt_linear_wgrad_partials_f32": [vp, i, vp, i, i, i, i, vp, c_size_t, vp, vp, vp, vp],
+        "ptt_linear_wgrad2_partials_f32": [vp, i, vp, i, i, i, i, vp, c_size_t, vp, vp, vp, vp],
+        "ptt_colsum_partials_f32": [vp, i, i, i, vp, c_size_t, vp, vp],
+        "ptt_grad_finish_f32": [vp, vp, vp, i, vp, vp],
         "ptt_rows_gemm_bnbwd_f32": [vp, i, i, i, vp, i, vp, i, vp, vp, vp, vp, vp, i, vp, c_size_t, vp],
         "ptt_bn_bwd_from_partials_f32": [vp, i, vp, i, vp, i, vp, vp, vp, i, i, vp, i, vp, vp, vp, vp, vp],
         "ptt_bn_bwd_consts_f32": [vp, i, vp, vp, vp, i, i, vp, vp, vp, vp, vp, vp],

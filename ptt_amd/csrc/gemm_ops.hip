@@ -851,15 +851,16 @@ extern "C" size_t ptt_linear_wgrad2_workspace(int R, int Cout, int Cin) {
     return g.ok ? (size_t)g.nchunks * Cout * Cin * sizeof(float) : 0;
 }
 
-extern "C" int ptt_linear_wgrad2_f32(const float* dZ, int ldz, const float* X, int ldx, int R, int Cout, int Cin, float* dW,
-                                     int accumulate, void* ws, size_t ws_bytes, const float* x_scale, const float* x_shift,
-                                     ptt_stream_t stream) {
+// dW == nullptr: the row-chunk partials [nchunks][Cout * Cin] stay in the workspace (ptt_linear_wgrad2_partials_f32)
+static int linear_wgrad2_run(const float* dZ, int ldz, const float* X, int ldx, int R, int Cout, int Cin, float* dW,
+                             int accumulate, void* ws, size_t ws_bytes, const float* x_scale, const float* x_shift,
+                             int* nchunks_out, ptt_stream_t stream) {
     const Wgrad2Geom g = wgrad2_geom(R, Cout, Cin);
     if (!g.ok || (ldz & 3) || (ldx & 3) || ((reinterpret_cast<uintptr_t>(dZ) | reinterpret_cast<uintptr_t>(X)) & 15) ||
         (long long)R * ldz >= (1LL << 29) || (long long)R * ldx >= (1LL << 29))
         return fail(PTT_EUNSUPPORTED, "ptt_linear_wgrad2_f32: R=%d Cout=%d Cin=%d ldz=%d ldx=%d (needs R >= 2048, Cout %% 128 == 0, "
                                       "Cin %% 128 == 0, 16-byte aligned rows)", R, Cout, Cin, ldz, ldx);
-    if (ldz < Cout || ldx < Cin || !dZ || !X || !dW) return fail(PTT_EINVAL, "ptt_linear_wgrad2_f32: bad argument");
+    if (ldz < Cout || ldx < Cin || !dZ || !X || (!dW && !nchunks_out)) return fail(PTT_EINVAL, "ptt_linear_wgrad2_f32: bad argument");
     if (x_scale && (!x_shift || ((reinterpret_cast<uintptr_t>(x_scale) | reinterpret_cast<uintptr_t>(x_shift)) & 15)))
         return fail(PTT_EINVAL, "ptt_linear_wgrad2_f32: the input transform needs 16-byte aligned scale / shift");
     if (!ws || ws_bytes < ptt_linear_wgrad2_workspace(R, Cout, Cin)) return fail(PTT_EWORKSPACE, "ptt_linear_wgrad2_f32: workspace too small");
@@ -875,6 +876,19 @@ extern "C" int ptt_linear_wgrad2_f32(const float* dZ, int ldz, const float* X, i
     }
     PTT_WG2_CASE(4, 2) PTT_WG2_CASE(4, 1) PTT_WG2_CASE(2, 2) PTT_WG2_CASE(2, 1)
 #undef PTT_WG2_CASE
-    launch_wgrad_finish(static_cast<const float*>(ws), g.nchunks, (size_t)Cout * Cin, accumulate, dW, s);
+    if (dW) launch_wgrad_finish(static_cast<const float*>(ws), g.nchunks, (size_t)Cout * Cin, accumulate, dW, s);
+    if (nchunks_out) *nchunks_out = g.nchunks;
     return check_launch("wgrad2_kernel");
+}
+extern "C" int ptt_linear_wgrad2_f32(const float* dZ, int ldz, const float* X, int ldx, int R, int Cout, int Cin, float* dW,
+                                     int accumulate, void* ws, size_t ws_bytes, const float* x_scale, const float* x_shift,
+                                     ptt_stream_t stream) {
+    if (!dW) return fail(PTT_EINVAL, "ptt_linear_wgrad2_f32: bad argument");
+    return linear_wgrad2_run(dZ, ldz, X, ldx, R, Cout, Cin, dW, accumulate, ws, ws_bytes, x_scale, x_shift, nullptr, stream);
+}
+extern "C" int ptt_linear_wgrad2_partials_f32(const float* dZ, int ldz, const float* X, int ldx, int R, int Cout, int Cin, void* ws,
+                                              size_t ws_bytes, const float* x_scale, const float* x_shift, int* nchunks,
+                                              ptt_stream_t stream) {
+    if (!nchunks) return fail(PTT_EINVAL, "ptt_linear_wgrad2_partials_f32: null pointer");
+    return linear_wgrad2_run(dZ, ldz, X, ldx, R, Cout, Cin, nullptr, 0, ws, ws_bytes, x_scale, x_shift, nchunks, stream);
 }

@@ -1005,6 +1005,60 @@ __global__ __launch_bounds__(256) void wgrad_finish_kernel(const float* __restri
     }
 }
 
+// Every parameter gradient of a training step in ONE launch (ptt_grad_finish_f32). The weight-gradient kernels above leave their
+// row-chunk partials where they are (ptt_linear_wgrad*_partials_f32, ptt_colsum_partials_f32) instead of each being followed by
+// its own wgrad_finish_kernel launch — 75 launches of 5 - 10 us per step, most of them a few KB of output — and by autograd's
+// add of the two branches' gradients of a shared weight. A SEGMENT is one destination (a parameter, or a column slice of one,
+// inside the flat gradient buffer) with the JOBS that contribute to it, in the order the backward pass issued them; chunk k of
+// the concatenated chunk list goes to thread group k % G, groups are folded in group order, the result is added to what the
+// destination holds: a fixed summation tree per (job list), bit-reproducible run to run. blocks[2 w] = segment of workgroup w,
+// blocks[2 w + 1] = its first output unit (a unit = 4 elements of a `vec` segment, else 1).
+__global__ __launch_bounds__(256) void grad_finish_kernel(const ptt_grad_segment* __restrict__ segs, const ptt_grad_job* __restrict__ jobs,
+                                                          const int32_t* __restrict__ blocks, float* __restrict__ flat) {
+    __shared__ f32x4t part[256];
+    const ptt_grad_segment sg = segs[blocks[2 * blockIdx.x]];
+    const int OUT = sg.out, G = 256 / OUT;
+    const int lane = threadIdx.x % OUT, g = threadIdx.x / OUT;
+    const int e = (blocks[2 * blockIdx.x + 1] + lane) * (sg.vec ? 4 : 1);
+    f32x4t s = {0.f, 0.f, 0.f, 0.f};
+    if (e < sg.n) {
+        int kbase = 0;
+        for (int j = 0; j < sg.njobs; ++j) {
+            const ptt_grad_job jb = jobs[sg.job0 + j];
+            int c = g - kbase % G;
+            if (c < 0) c += G;
+            if (sg.vec) {
+                for (; c < jb.nchunks; c += G) {
+                    const f32x4t v = *reinterpret_cast<const f32x4t*>(jb.partial + (size_t)c * sg.n + e);
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) s[x] += v[x];
+                }
+            } else {
+                for (; c < jb.nchunks; c += G) s[0] += jb.partial[(size_t)c * sg.n + e];
+            }
+            kbase += jb.nchunks;
+        }
+    }
+    part[g * OUT + lane] = s;
+    __syncthreads();
+    if (g == 0 && e < sg.n) {
+        f32x4t tot = part[lane];
+        for (int q = 1; q < G; ++q)
+#pragma unroll
+            for (int x = 0; x < 4; ++x) tot[x] += part[q * OUT + lane][x];
+        const int row = e / sg.cols, col = e - row * sg.cols;
+        float* d = flat + sg.dst + (long long)row * sg.ld + col;
+        if (sg.vec) {
+            f32x4t o = *reinterpret_cast<const f32x4t*>(d);
+#pragma unroll
+            for (int x = 0; x < 4; ++x) o[x] += tot[x];
+            *reinterpret_cast<f32x4t*>(d) = o;
+        } else {
+            *d += tot[0];
+        }
+    }
+}
+
 // out[b, e, :] = src[b, idx[b, e], :] over point-major rows (float4 quads; C % 4 == 0): the forward of grouping once the
 // first MLP layer has been evaluated per POINT (the training-mode layer-0 hoist, ptt_amd/train_ops.py).
 __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, const int32_t* __restrict__ idx, int N,
@@ -1750,18 +1804,28 @@ extern "C" size_t ptt_colsum_workspace(int R, int C) {
     const int rows = colsum_rows_per_chunk(R, C);
     return (size_t)((R + rows - 1) / rows) * (size_t)C * sizeof(float);
 }
-extern "C" int ptt_colsum_f32(const float* X, int R, int C, int ldx, float* out, void* ws, size_t ws_bytes, ptt_stream_t stream) {
+// out == nullptr: the chunk partials [nch][C] stay in the workspace (ptt_colsum_partials_f32), *nchunks_out = nch
+static int colsum_run(const float* X, int R, int C, int ldx, float* out, void* ws, size_t ws_bytes, int* nchunks_out, ptt_stream_t stream) {
     if (R <= 0 || C <= 0 || ldx < C) return fail(PTT_EINVAL, "ptt_colsum_f32: R=%d C=%d ldx=%d", R, C, ldx);
-    if (!X || !out) return fail(PTT_EINVAL, "ptt_colsum_f32: null pointer");
-    const bool vec = !(C & 3) && !(ldx & 3) && !((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(out)) & 15);
+    if (!X || (!out && !nchunks_out)) return fail(PTT_EINVAL, "ptt_colsum_f32: null pointer");
     const int rows = colsum_rows_per_chunk(R, C), nch = (R + rows - 1) / rows;
     hipStream_t s2 = as_stream(stream);
-    if (nch > 1 && (!ws || ws_bytes < ptt_colsum_workspace(R, C))) return fail(PTT_EWORKSPACE, "ptt_colsum_f32: workspace too small");
-    float* part = nch == 1 ? out : static_cast<float*>(ws);
+    if ((nch > 1 || !out) && (!ws || ws_bytes < ptt_colsum_workspace(R, C))) return fail(PTT_EWORKSPACE, "ptt_colsum_f32: workspace too small");
+    float* part = (nch == 1 && out) ? out : static_cast<float*>(ws);
+    const bool vec = !(C & 3) && !(ldx & 3) && !((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(part)) & 15);
     if (vec) hipLaunchKernelGGL(colsum_partial_kernel, dim3(nch, (C / 4 + 63) / 64), dim3(256), 0, s2, X, ldx, R, C, rows, part);
     else hipLaunchKernelGGL(colsum_partial_scalar_kernel, dim3(nch, (C + 63) / 64), dim3(256), 0, s2, X, ldx, R, C, rows, part);
-    if (nch > 1) launch_wgrad_finish(part, nch, (size_t)C, 0, out, s2);
+    if (nch > 1 && out) launch_wgrad_finish(part, nch, (size_t)C, 0, out, s2);
+    if (nchunks_out) *nchunks_out = nch;
     return check_launch("colsum_partial_kernel");
+}
+extern "C" int ptt_colsum_f32(const float* X, int R, int C, int ldx, float* out, void* ws, size_t ws_bytes, ptt_stream_t stream) {
+    if (!out) return fail(PTT_EINVAL, "ptt_colsum_f32: null pointer");
+    return colsum_run(X, R, C, ldx, out, ws, ws_bytes, nullptr, stream);
+}
+extern "C" int ptt_colsum_partials_f32(const float* X, int R, int C, int ldx, void* ws, size_t ws_bytes, int* nchunks, ptt_stream_t stream) {
+    if (!nchunks) return fail(PTT_EINVAL, "ptt_colsum_partials_f32: null pointer");
+    return colsum_run(X, R, C, ldx, nullptr, ws, ws_bytes, nchunks, stream);
 }
 
 extern "C" size_t ptt_linear_wgrad_workspace(int R, int Cout, int Cin) {
@@ -1771,14 +1835,15 @@ extern "C" size_t ptt_linear_wgrad_workspace(int R, int Cout, int Cin) {
     return (size_t)((R + rows - 1) / rows) * (size_t)Cout * Cin * sizeof(float);
 }
 
-extern "C" int ptt_linear_wgrad_f32(const float* dZ, int ldz, const float* X, int ldx, int R, int Cout, int Cin, float* dW,
-                                    int accumulate, void* ws, size_t ws_bytes, const float* x_scale, const float* x_shift,
-                                    ptt_stream_t stream) {
+// dW == nullptr: the chunk partials [nchunks][Cout * Cin] stay in the workspace (ptt_linear_wgrad_partials_f32)
+static int linear_wgrad_run(const float* dZ, int ldz, const float* X, int ldx, int R, int Cout, int Cin, float* dW,
+                            int accumulate, void* ws, size_t ws_bytes, const float* x_scale, const float* x_shift,
+                            int* nchunks_out, ptt_stream_t stream) {
     if (x_scale && (!x_shift || (Cin & 3) || ((reinterpret_cast<uintptr_t>(x_scale) | reinterpret_cast<uintptr_t>(x_shift)) & 15)))
         return fail(PTT_EINVAL, "ptt_linear_wgrad_f32: the input transform needs Cin %% 4 == 0 and 16-byte aligned scale / shift");
     if (R <= 0 || Cout <= 0 || Cin <= 0 || ldz < Cout || ldx < Cin)
         return fail(PTT_EINVAL, "ptt_linear_wgrad_f32: R=%d Cout=%d Cin=%d ldz=%d ldx=%d", R, Cout, Cin, ldz, ldx);
-    if (!dZ || !X || !dW) return fail(PTT_EINVAL, "ptt_linear_wgrad_f32: null pointer");
+    if (!dZ || !X || (!dW && !nchunks_out)) return fail(PTT_EINVAL, "ptt_linear_wgrad_f32: null pointer");
     if (!ws || ws_bytes < ptt_linear_wgrad_workspace(R, Cout, Cin))
         return fail(PTT_EWORKSPACE, "ptt_linear_wgrad_f32: workspace too small");
     if (wgrad_smallk_ok(Cout, Cin) && !x_scale && (ldz & 3) == 0 && (reinterpret_cast<uintptr_t>(dZ) & 15) == 0) {
@@ -1789,14 +1854,16 @@ extern "C" int ptt_linear_wgrad_f32(const float* dZ, int ldz, const float* X, in
         else if (Cin == 2) hipLaunchKernelGGL((wgrad_smallk_kernel<2>), dim3(nch), dim3(256), 0, s2, dZ, ldz, X, ldx, R, Cout, part);
         else if (Cin == 3) hipLaunchKernelGGL((wgrad_smallk_kernel<3>), dim3(nch), dim3(256), 0, s2, dZ, ldz, X, ldx, R, Cout, part);
         else hipLaunchKernelGGL((wgrad_smallk_kernel<4>), dim3(nch), dim3(256), 0, s2, dZ, ldz, X, ldx, R, Cout, part);
-        launch_wgrad_finish(part, nch, (size_t)Cout * Cin, accumulate, dW, s2);
+        if (dW) launch_wgrad_finish(part, nch, (size_t)Cout * Cin, accumulate, dW, s2);
+        if (nchunks_out) *nchunks_out = nch;
         return check_launch("wgrad_smallk_kernel");
     }
     if (wgrad_stream_ok(R, Cout, Cin, ldz, ldx)) {       // narrow layers over many rows: the streaming form (wgrad_stream.hip)
         const int rows = wgrad_stream_rows(R), nch = (R + rows - 1) / rows;
         hipStream_t s2 = as_stream(stream);
         if (int rc = launch_wgrad_stream(dZ, ldz, X, ldx, R, Cout, Cin, rows, static_cast<float*>(ws), x_scale, x_shift, s2)) return rc;
-        launch_wgrad_finish(static_cast<const float*>(ws), nch, (size_t)Cout * Cin, accumulate, dW, s2);
+        if (dW) launch_wgrad_finish(static_cast<const float*>(ws), nch, (size_t)Cout * Cin, accumulate, dW, s2);
+        if (nchunks_out) *nchunks_out = nch;
         return check_launch("wgrad_stream_kernel");
     }
     const int rows = wgrad_chunk_rows(R, Cout, Cin);
@@ -1826,8 +1893,31 @@ extern "C" int ptt_linear_wgrad_f32(const float* dZ, int ldz, const float* X, in
     }
     PTT_WGRAD_CASE(true, true) PTT_WGRAD_CASE(true, false) PTT_WGRAD_CASE(false, true) PTT_WGRAD_CASE(false, false)
 #undef PTT_WGRAD_CASE
-    launch_wgrad_finish(static_cast<const float*>(ws), nchunks, (size_t)Cout * Cin, accumulate, dW, s);
+    if (dW) launch_wgrad_finish(static_cast<const float*>(ws), nchunks, (size_t)Cout * Cin, accumulate, dW, s);
+    if (nchunks_out) *nchunks_out = nchunks;
     return check_launch("linear_wgrad_kernel");
+}
+extern "C" int ptt_linear_wgrad_f32(const float* dZ, int ldz, const float* X, int ldx, int R, int Cout, int Cin, float* dW,
+                                    int accumulate, void* ws, size_t ws_bytes, const float* x_scale, const float* x_shift,
+                                    ptt_stream_t stream) {
+    if (!dW) return fail(PTT_EINVAL, "ptt_linear_wgrad_f32: null pointer");
+    return linear_wgrad_run(dZ, ldz, X, ldx, R, Cout, Cin, dW, accumulate, ws, ws_bytes, x_scale, x_shift, nullptr, stream);
+}
+extern "C" int ptt_linear_wgrad_partials_f32(const float* dZ, int ldz, const float* X, int ldx, int R, int Cout, int Cin, void* ws,
+                                             size_t ws_bytes, const float* x_scale, const float* x_shift, int* nchunks,
+                                             ptt_stream_t stream) {
+    if (!nchunks) return fail(PTT_EINVAL, "ptt_linear_wgrad_partials_f32: null pointer");
+    return linear_wgrad_run(dZ, ldz, X, ldx, R, Cout, Cin, nullptr, 0, ws, ws_bytes, x_scale, x_shift, nchunks, stream);
+}
+
+extern "C" int ptt_grad_finish_f32(const ptt_grad_segment* segments_device, const ptt_grad_job* jobs_device, const int32_t* blocks_device,
+                                   int n_blocks, float* flat, ptt_stream_t stream) {
+    if (n_blocks < 0) return fail(PTT_EINVAL, "ptt_grad_finish_f32: n_blocks=%d", n_blocks);
+    if (n_blocks == 0) return PTT_OK;
+    if (!segments_device || !jobs_device || !blocks_device || !flat || (reinterpret_cast<uintptr_t>(flat) & 15))
+        return fail(PTT_EINVAL, "ptt_grad_finish_f32: null table or a gradient buffer that is not 16-byte aligned");
+    hipLaunchKernelGGL(grad_finish_kernel, dim3(n_blocks), dim3(256), 0, as_stream(stream), segments_device, jobs_device, blocks_device, flat);
+    return check_launch("grad_finish_kernel");
 }
 
 extern "C" int ptt_bn_finish_partials_train_f32(const double* partial, int chunks, int C, int R, float eps, float* mean, float* var,

@@ -1267,6 +1267,110 @@ def linear_wgrad(dz, x, out=None, accumulate=False, x_scale=None, x_shift=None):
     return out
 
 
+def linear_wgrad_partials(dz, x, x_scale=None, x_shift=None):
+    """linear_wgrad without its finishing launch: -> (workspace holding the row-chunk partials [nchunks][Cout * Cin] float32,
+    nchunks) — ptt_linear_wgrad2_partials_f32 / ptt_linear_wgrad_partials_f32; GradFinishPlan sums them later."""
+    _rows(dz, "dz"); _rows(x, "x")
+    R, Cout = dz.shape
+    Cin = x.shape[1]
+    ok2 = (dz.stride(0) % 4 == 0 and x.stride(0) % 4 == 0 and dz.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0
+           and R * max(dz.stride(0), x.stride(0)) < (1 << 29))
+    nb2 = _lib.lib().ptt_linear_wgrad2_workspace(R, Cout, Cin) if ok2 else 0
+    nch = ctypes.c_int(0)
+    two = bool(nb2 and WGRAD2)
+    ws = _ws(nb2 if two else _lib.lib().ptt_linear_wgrad_workspace(R, Cout, Cin), dz.device)
+    fn = _lib.lib().ptt_linear_wgrad2_partials_f32 if two else _lib.lib().ptt_linear_wgrad_partials_f32
+    with torch.cuda.device(dz.device), _timed('ptt_linear_wgrad_f32'):
+        _lib.check(fn(_ptr(dz), dz.stride(0), _ptr(x), x.stride(0), R, Cout, Cin, _ptr(ws), ws.numel() * 8, _ptr(x_scale), _ptr(x_shift),
+                      ctypes.byref(nch), _stream()), "ptt_linear_wgrad_partials_f32")
+    return ws, nch.value
+
+
+def colsum_partials(x):
+    """colsum without its finishing launch: -> (workspace holding [nchunks][C] float32 partial column sums, nchunks)."""
+    _rows(x, "x")
+    R, C = x.shape
+    ws = _ws(_lib.lib().ptt_colsum_workspace(R, C), x.device)
+    nch = ctypes.c_int(0)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().ptt_colsum_partials_f32(_ptr(x), R, C, x.stride(0), _ptr(ws), ws.numel() * 8, ctypes.byref(nch), _stream()),
+                   "ptt_colsum_partials_f32")
+    return ws, nch.value
+
+
+class GradFinishPlan(object):
+    """ptt_grad_finish_f32 over the contributions one backward pass left behind: `jobs` = [(dst, cols, ld, n, data_ptr, nchunks)] in the
+    order they were issued (dst = first element inside the flat buffer; the n elements form rows of `cols` with row stride `ld`).
+    The segment / workgroup tables depend only on the jobs' shapes and are rebuilt when those change (a training step repeats
+    them); the partials' addresses are uploaded every call through one pinned copy."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.signature = None
+        self.uploaded = torch.cuda.Event()
+
+    @staticmethod
+    def _outputs_per_group(total_chunks):
+        # a function of the chunk count only: the summation tree of a destination is fixed by its job list
+        return 4 if total_chunks > 1024 else 8 if total_chunks > 256 else 32 if total_chunks > 8 else 64 if total_chunks > 2 else 256
+
+    def _build(self, sig):
+        by_dst, order = {}, []
+        for k, (dst, cols, ld, n, nch) in enumerate(sig):
+            key = (dst, cols, ld, n)
+            if key not in by_dst:
+                by_dst[key] = []
+                order.append(key)
+            by_dst[key].append(k)
+        nseg = len(order)
+        segs = (_lib.GradSegment * nseg)()
+        blocks, self.job_order = [], []
+        for si, key in enumerate(order):
+            dst, cols, ld, n = key
+            ks = by_dst[key]
+            total = sum(sig[k][4] for k in ks)
+            vec = int(n % 4 == 0 and cols % 4 == 0 and ld % 4 == 0 and dst % 4 == 0)
+            out = self._outputs_per_group(total)
+            segs[si] = _lib.GradSegment(dst=dst, n=n, cols=cols, ld=ld, job0=len(self.job_order), njobs=len(ks), out=out, vec=vec, reserved=0)
+            self.job_order += ks
+            units = n // 4 if vec else n
+            for u in range(0, units, out):
+                blocks += [si, u]
+        self.vec_jobs = [bool(segs[si].vec) for si, key in enumerate(order) for _ in by_dst[key]]
+        self.n_blocks = len(blocks) // 2
+        self.segs = torch.frombuffer(bytearray(bytes(segs)), dtype=torch.uint8).to(self.device)
+        self.blocks = torch.tensor(blocks, dtype=torch.int32, device=self.device)
+        nj = len(self.job_order)
+        self.host = torch.zeros((nj, ctypes.sizeof(_lib.GradJob)), dtype=torch.uint8).pin_memory()
+        self.rows = (_lib.GradJob * nj).from_address(self.host.data_ptr())
+        self.table = torch.empty_like(self.host, device=self.device)
+        self.signature = sig
+
+    def run(self, jobs, flat):
+        if not jobs:
+            return
+        if flat.dtype != torch.float32 or not flat.is_contiguous() or flat.device != self.device or flat.data_ptr() % 16:
+            raise ValueError("GradFinishPlan: a contiguous, 16-byte aligned float32 gradient buffer on %s expected" % self.device)
+        total = flat.numel()
+        sig = tuple((int(d), int(c), int(l), int(n), int(nch)) for d, c, l, n, _, nch in jobs)
+        if sig != self.signature:
+            for d, c, l, n, nch in sig:
+                if n <= 0 or c <= 0 or n % c or l < c or nch <= 0 or d < 0 or d + (n // c - 1) * l + c > total:
+                    raise ValueError("GradFinishPlan: job (dst %d, cols %d, ld %d, n %d, chunks %d) outside the %d-element buffer" % (d, c, l, n, nch, total))
+            self._build(sig)
+        self.uploaded.synchronize()                            # the previous call's upload has left the pinned table
+        for r, k, vec in zip(self.rows, self.job_order, self.vec_jobs):
+            ptr = int(jobs[k][4])
+            if vec and ptr % 16:
+                raise ValueError("GradFinishPlan: partial sums of a float4 segment must be 16-byte aligned")
+            r.partial, r.nchunks = ptr, sig[k][4]
+        self.table.copy_(self.host, non_blocking=True)
+        self.uploaded.record()
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().ptt_grad_finish_f32(_ptr(self.segs), _ptr(self.table), _ptr(self.blocks), self.n_blocks, _ptr(flat), _stream()),
+                       "ptt_grad_finish_f32")
+
+
 # --------------------------------------------------------------------------- T-opt: dense attention as batched MFMA GEMMs
 def pack_weight_strided(src, cout, k, stride_out, stride_k, batch, stride_batch):
     """`batch` (cout x k) matrices addressed by element strides inside the float32 device tensor `src` -> packed

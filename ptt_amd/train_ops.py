@@ -215,6 +215,134 @@ def _row_count(rows, device):
     return _row_counts[key]
 
 
+class GradSink(object):
+    """Where the parameter gradients of ONE backward pass go when a trainer owns the whole step (train_step.DataParallelTrainer):
+    a flat float32 buffer holding every parameter's gradient (`.grad` of each parameter is a view of it, so the optimiser, a
+    logger or a gradient all-reduce see ordinary gradients — the all-reduce is ONE collective over the buffer), filled by ONE
+    launch after the backward pass (ops.GradFinishPlan) from what the functions of this module left behind: the row-chunk partial
+    sums of the weight-gradient and bias-gradient kernels, and the small gradients (BatchNorm scale / shift, coordinate columns)
+    other launches produced as a by-product. The functions then return None for those inputs: no finishing launch per weight
+    gradient, no autograd add for the weights the search and template branches share, no concatenation of column-slice
+    gradients (~120 launches of a 530-launch step). The sum per parameter runs in the order the contributions were issued — a
+    step stays bit-reproducible. Without an active sink every function returns finished gradient tensors as before.
+
+        sink = GradSink(model.parameters(), device)        # sets p.grad = views of sink.flat
+        with sink.collecting():                            # sink.flat was zeroed: gradients autograd forms itself add in place
+            loss.backward()
+        sink.flush()                                       # one launch; then clip / all-reduce / optimiser on the views
+    """
+    active = None
+
+    def __init__(self, params, device):
+        self.device = torch.device(device)
+        self.params = [p for p in params if p.requires_grad]
+        self.index, off = {}, 0
+        for p in self.params:
+            if not (p.is_cuda and p.device == self.device and p.dtype == torch.float32 and p.is_contiguous()):
+                raise ValueError("GradSink: contiguous float32 parameters on %s expected" % self.device)
+            self.index[p.data_ptr()] = (off, p.numel())
+            off += (p.numel() + 3) // 4 * 4                      # every parameter starts on a 16-byte boundary
+        self.flat = torch.zeros((max(off, 4),), dtype=torch.float32, device=self.device)
+        self.views = [self.flat[self.index[p.data_ptr()][0]:self.index[p.data_ptr()][0] + p.numel()].view_as(p) for p in self.params]
+        self.plan = ops.GradFinishPlan(self.device)
+        self.jobs, self.keep = [], []
+        self.attach()
+
+    def attach(self):
+        """p.grad = this sink's views (again, after something replaced them)."""
+        for p, v in zip(self.params, self.views):
+            p.grad = v
+
+    def collecting(self):
+        sink = self
+
+        class _Scope(object):
+            def __enter__(self):
+                if GradSink.active is not None:
+                    raise RuntimeError("GradSink: another backward pass is being collected")
+                if any(p.grad is not v for p, v in zip(sink.params, sink.views)):
+                    sink.attach()
+                sink.flat.zero_()
+                sink.jobs, sink.keep = [], []
+                GradSink.active = sink
+
+            def __exit__(self, *exc):
+                GradSink.active = None
+                if exc[0] is not None:
+                    sink.jobs, sink.keep = [], []
+        return _Scope()
+
+    def locate(self, w):
+        """(first element, columns, row stride, elements) of the parameter, or the 2-D column slice of one, that `w` IS — None if
+        `w` is not (a view of) one of this sink's parameters in a layout the finishing launch addresses."""
+        if w is None:
+            return None
+        base = w._base if w._base is not None else w
+        hit = self.index.get(base.data_ptr())
+        if hit is None or hit[1] != base.numel():
+            return None
+        rel = (w.data_ptr() - base.data_ptr()) // 4
+        n = w.numel()
+        if n == 0 or rel < 0 or w.dtype != torch.float32:
+            return None
+        if w.is_contiguous():
+            return (hit[0] + rel, n, n, n) if rel + n <= hit[1] else None
+        if w.dim() == 2 and w.stride(1) == 1 and w.stride(0) >= w.shape[1] and rel + (w.shape[0] - 1) * w.stride(0) + w.shape[1] <= hit[1]:
+            return (hit[0] + rel, w.shape[1], w.stride(0), n)
+        return None
+
+    def push(self, loc, partials, nchunks):
+        """partials: a tensor holding [nchunks][loc's elements] float32 sums (kept alive until the flush)."""
+        self.jobs.append((loc[0], loc[1], loc[2], loc[3], partials.data_ptr(), int(nchunks)))
+        self.keep.append(partials)
+
+    def flush(self):
+        """The one finishing launch: afterwards every `.grad` view holds its parameter's gradient."""
+        self.plan.run(self.jobs, self.flat)
+        self.jobs, self.keep = [], []
+
+
+def _sunk(w):
+    sink = GradSink.active
+    loc = sink.locate(w) if sink is not None else None
+    return (sink, loc) if loc is not None else (None, None)
+
+
+def weight_grad(w, dz, x, x_scale=None, x_shift=None):
+    """dz^T x, the gradient of the (out, in) weight `w` (a parameter or a view of one, as the forward pass held it): the finished
+    tensor — or None once an active GradSink has taken the kernel's partial sums."""
+    sink, loc = _sunk(w)
+    if sink is None:
+        return ops.linear_wgrad(dz, x, x_scale=x_scale, x_shift=x_shift)
+    ws, nch = ops.linear_wgrad_partials(dz, x, x_scale, x_shift)
+    sink.push(loc, ws, nch)
+    return None
+
+
+def bias_grad(b, g2):
+    """The column sums of g2, the gradient of the bias `b`: finished, or None (GradSink)."""
+    sink, loc = _sunk(b)
+    if sink is None:
+        return ops.colsum(g2)
+    ws, nch = ops.colsum_partials(g2)
+    sink.push(loc, ws, nch)
+    return None
+
+
+def small_grad(p, g):
+    """A gradient `g` some launch already finished, of the parameter (or column slice) `p`: returned, or handed to the GradSink."""
+    if g is None:
+        return None
+    sink, loc = _sunk(p)
+    if sink is None or g.numel() != loc[3] or g.dtype != torch.float32:
+        return g
+    g = g.contiguous()
+    if g.data_ptr() % 16:
+        g = g.clone()
+    sink.push(loc, g, 1)
+    return None
+
+
 class _GatherRows(torch.autograd.Function):
     """rows (B,N,C), idx (B,E) -> (B,E,C); backward = the deterministic row scatter-add."""
 
@@ -250,7 +378,7 @@ class _AddRelTerm(torch.autograd.Function):
         rel, wx = ctx.saved_tensors
         g = g.contiguous()
         d_rel = ops.linear(g, packed(ctx.wx, True), 3) if ctx.needs_input_grad[1] else None
-        d_wx = ops.linear_wgrad(g, rel.contiguous()) if ctx.needs_input_grad[2] else None
+        d_wx = weight_grad(ctx.wx, g, rel.contiguous()) if ctx.needs_input_grad[2] else None
         return g, d_rel, d_wx
 
 
@@ -260,10 +388,22 @@ class _SplitCols(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, w, k):
+        ctx.set_materialize_grads(False)
+        ctx.w, ctx.k = w, int(k)
         return w[:, :k], w[:, k:]
 
     @staticmethod
     def backward(ctx, ga, gb):
+        w, k = ctx.w, ctx.k
+        # under a GradSink each half goes straight to its columns of the parameter's gradient (the halves' consumers may have
+        # sent theirs already: None)
+        ga, gb = small_grad(w[:, :k], ga), small_grad(w[:, k:], gb)
+        if ga is None and gb is None:
+            return None, None
+        if ga is None:
+            ga = gb.new_zeros((w.shape[0], k))
+        if gb is None:
+            gb = ga.new_zeros((w.shape[0], w.shape[1] - k))
         return torch.cat((ga, gb), dim=1), None
 
 
@@ -297,7 +437,7 @@ class _SharedMlpPool(torch.autograd.Function):
         elif front is not None:
             x, rel, z0_part = ops.sa_z0_rows(f0.contiguous(), f1.contiguous(), f2, f3.contiguous() if f3 is not None else None, f4.detach(),
                                              front[1], front[2], want_stats=True)
-            ctx.sa_points, ctx.has_term = f0.shape[1], f3 is not None
+            ctx.sa_points, ctx.has_term, ctx.f4 = f0.shape[1], f3 is not None, f4
             front_saved = (f2, rel)
         cur, cur_a, cur_b = x.contiguous(), None, None
         for l in range(L):
@@ -333,6 +473,7 @@ class _SharedMlpPool(torch.autograd.Function):
         pooled, arg = ops.pool_select(extrema, cur_a, cur_b) if extrema is not None else ops.pool_rows(cur, ns, cur_a, cur_b)
         ctx.save_for_backward(arg, *saved, *[p.detach() for p in params], *front_saved)
         ctx.weights = tuple(params[3 * l] for l in range(L))     # the parameter objects themselves: keys of the pack cache
+        ctx.param_objs = tuple(params)                           # ... and of a GradSink
         ctx.L, ctx.ns, ctx.preact, ctx.sync = L, int(ns), bool(preact), tuple(sync)
         ctx.mark_non_differentiable(*stats)
         return (pooled,) + tuple(stats)
@@ -373,7 +514,7 @@ class _SharedMlpPool(torch.autograd.Function):
                 g, part, dz = fused
                 grads[3 * l + 1], grads[3 * l + 2] = dgamma, dbeta
                 has_t = in_a.numel() > 0
-                grads[3 * l] = ops.linear_wgrad(dz, x_in, x_scale=in_a if has_t else None, x_shift=in_b if has_t else None).view_as(W)
+                grads[3 * l] = weight_grad(w2, dz, x_in, in_a if has_t else None, in_b if has_t else None)
                 continue
             if ctx.sync[l] is not None:
                 # torch's SyncBatchNorm: dgamma / dbeta are the rank's LOCAL sums (DDP averages parameter gradients); dz
@@ -433,13 +574,13 @@ class _SharedMlpPool(torch.autograd.Function):
                     dzc = dz.contiguous()
                     if ctx.has_term and ctx.needs_input_grad[11]:
                         front_grads[3] = ops.scatter_rows_det(dzc.view(B, M * ns_, -1), idx.view(B, M * ns_), ctx.sa_points)
-                    front_grads[4] = ops.linear_wgrad(dzc, rel)
+                    front_grads[4] = weight_grad(ctx.f4, dzc, rel)
                     g = None
                 break
             Wp = ctx.weights[l]
             w2 = Wp.reshape(Wp.shape[0], -1)
             has_t = in_a.numel() > 0
-            grads[3 * l] = ops.linear_wgrad(dz, x_in, x_scale=in_a if has_t else None, x_shift=in_b if has_t else None).view_as(W)
+            grads[3 * l] = weight_grad(w2, dz, x_in, in_a if has_t else None, in_b if has_t else None)
             part = None
             if l > 0:
                 # the gradient w.r.t. the activated input of layer l = the gradient BatchNorm l - 1 receives: its backward sums
@@ -453,6 +594,11 @@ class _SharedMlpPool(torch.autograd.Function):
                 g, _ = conv_rows(dz, w2, transpose=True)                                # w.r.t. the (not normalised) input rows
             else:
                 g = None
+        for l in range(L):
+            if grads[3 * l] is not None:
+                grads[3 * l] = grads[3 * l].view_as(params[3 * l])
+            grads[3 * l + 1] = small_grad(ctx.param_objs[3 * l + 1], grads[3 * l + 1])
+            grads[3 * l + 2] = small_grad(ctx.param_objs[3 * l + 2], grads[3 * l + 2])
         return (g, None, None, None, None, None, None, None) + tuple(front_grads) + tuple(grads)
 
 
@@ -666,6 +812,7 @@ class _RowsLinear(torch.autograd.Function):
         ctx.save_for_backward(x2, W)                         # W too: autograd's version check then catches an in-place update
         ctx.W = W                                            # between forward and backward (backward re-packs the weight).
         #                                                      ctx.W = the object as passed (a parameter or a view of one): key of the pack cache
+        ctx.b = b
         ctx.shape = x.shape
         r2 = residual.reshape(-1, W.shape[0]).contiguous() if residual is not None else None
         y = lin_rows(x2, W, b.detach() if b is not None else None, residual=r2)
@@ -676,8 +823,8 @@ class _RowsLinear(torch.autograd.Function):
         x2, _ = ctx.saved_tensors
         g2 = g.reshape(-1, g.shape[-1]).contiguous()
         dx = lin_rows(g2, ctx.W, transpose=True).view(ctx.shape) if ctx.needs_input_grad[0] else None
-        dW = ops.linear_wgrad(g2, x2) if ctx.needs_input_grad[1] else None
-        db = ops.colsum(g2) if ctx.needs_input_grad[2] else None
+        dW = weight_grad(ctx.W, g2, x2) if ctx.needs_input_grad[1] else None
+        db = bias_grad(ctx.b, g2) if ctx.needs_input_grad[2] else None
         return dx, dW, db, (g if ctx.needs_input_grad[3] else None)
 
 
@@ -699,7 +846,7 @@ class _RowsMlp2(torch.autograd.Function):
         h = lin_rows(x2, W1, b1.detach(), relu=True)
         y = lin_rows(h, W2, b2.detach())
         ctx.save_for_backward(x2, h, W1, W2)                 # the weights too: see _RowsLinear
-        ctx.Ws = (W1, W2)
+        ctx.Ws, ctx.bs = (W1, W2), (b1, b2)
         ctx.shape = x.shape
         return y.view(*x.shape[:-1], W2.shape[0])
 
@@ -709,16 +856,16 @@ class _RowsMlp2(torch.autograd.Function):
         W1, W2 = ctx.Ws
         dy2 = dy.reshape(-1, dy.shape[-1]).contiguous()
         rows, D1 = h.shape
-        dW2 = ops.linear_wgrad(dy2, h)
-        db2 = ops.colsum(dy2)
+        dW2 = weight_grad(W2, dy2, h)
+        db2 = bias_grad(ctx.bs[1], dy2)
         if ops.rows_gemm_supported(rows, W2.shape[0], D1, dy2.stride(0), D1, x=dy2):
             dz1, db1 = ops.rows_gemm_masked(dy2, packed(W2, True), D1, h, want_colsum=True)
         else:
             dz1 = lin_rows(dy2, W2, transpose=True) * (h > 0)
             db1 = dz1.sum(0)
-        dW1 = ops.linear_wgrad(dz1, x2)
+        dW1 = weight_grad(W1, dz1, x2)
         dx = lin_rows(dz1, W1, transpose=True).view(ctx.shape) if ctx.needs_input_grad[0] else None
-        return dx, dW1, db1, dW2, db2
+        return dx, dW1, small_grad(ctx.bs[0], db1), dW2, db2
 
 
 def rows_mlp2(seq, x):

@@ -1,6 +1,11 @@
 """Data-parallel training step of the full tracker (BASELINE.json configs[3]): one process per GPU, the batch
-sharded across ranks, ONE gradient all-reduce per step (4 903 113 fp32 values = 19.6 MB, one DDP bucket) over
-RCCL/xGMI, overlapped with the backward pass by DistributedDataParallel.
+sharded across ranks, ONE gradient all-reduce per step (4 903 113 fp32 values = 19.6 MB) over RCCL/xGMI.
+
+On a HIP device the gradients of a step live in ONE flat buffer (train_ops.GradSink: every `.grad` is a view of it, filled by
+one finishing launch after the backward pass) and the all-reduce is one collective over that buffer — what
+DistributedDataParallel does with its single 25-MB bucket (all 19.6 MB become ready with the LAST gradient of the backward
+pass, so there is nothing for it to overlap), without the bucket copies and the per-parameter hooks. `reducer="ddp"` (and
+every CPU run: the gloo tests) wraps the model in DistributedDataParallel instead.
 
 What it stands in for in the reference: tools/train_tracking.py:158-159 (the DistributedDataParallel wrap — dead
 code there because :63 forces dist_train=False, so the reference's `--launcher pytorch` runs N unsynchronised
@@ -41,12 +46,22 @@ class DataParallelTrainer(object):
         loss = trainer.step(batch)          # forward, backward (all-reduce inside), clip, Adam
     """
 
-    def __init__(self, model, device, lr=1e-3, betas=(0.5, 0.999), eps=1e-6, clip=10.0, bucket_cap_mb=25, sync_bn=False, force_ddp=False):
-        """force_ddp: wrap in DistributedDataParallel whenever a process group is initialised, a ONE-rank group included (the
-        bucket all-reduce then runs on the device with one participant: how a one-GPU box exercises the multi-GPU code)."""
+    def __init__(self, model, device, lr=1e-3, betas=(0.5, 0.999), eps=1e-6, clip=10.0, bucket_cap_mb=25, sync_bn=False, force_ddp=False,
+                 reducer=None):
+        """force_ddp: reduce the gradients over the process group whenever one is initialised, a ONE-rank group included (the
+        all-reduce then runs on the device with one participant: how a one-GPU box exercises the multi-GPU code).
+        reducer: "flat" (HIP devices, the default there) = train_ops.GradSink + one all-reduce over its buffer; "ddp" =
+        DistributedDataParallel (the default, and the only choice, off the HIP device)."""
         self.device = torch.device(device)
         self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
-        self.ddp = self.world > 1 or (force_ddp and dist.is_available() and dist.is_initialized())
+        collective = self.world > 1 or (force_ddp and dist.is_available() and dist.is_initialized())
+        if reducer is None:
+            reducer = "flat" if self.device.type == 'cuda' else "ddp"
+        if reducer not in ("flat", "ddp") or (reducer == "flat" and self.device.type != 'cuda'):
+            raise ValueError("reducer: 'flat' (HIP device) or 'ddp'")
+        self.reducer = reducer
+        self.collective = collective
+        self.ddp = collective and reducer == "ddp"
         if sync_bn and self.world > 1:
             # tools/train_tracking.py:133-134 (--sync_bn). The SharedMLP stages keep running on the hand-written row
             # kernels: their statistics are exchanged as 2C + 1 float64 sums per layer (ptt_amd/train_ops.py)
@@ -62,13 +77,27 @@ class DataParallelTrainer(object):
         # torch.optim.Adam with clip_grad_norm_ folded into step(): two launches on a HIP device, the stock path elsewhere
         self.optimizer = ClipAdam(self.model.parameters(), lr=lr, betas=betas, eps=eps)
         self.clip = clip
+        self.sink = None
+        if reducer == "flat":
+            from .train_ops import GradSink
+            self.sink = GradSink(list(self.model.parameters()), self.device)
 
     def forward_backward(self, batch):
-        """loss.mean() and its gradients (averaged over ranks by DDP); no optimiser step."""
+        """loss.mean() and its gradients (averaged over ranks); no optimiser step."""
         ret, _, _ = self.model(dict(batch))
         loss = ret['loss'] if ret['loss'].dim() == 0 else ret['loss'].mean()
-        self.optimizer.zero_grad(set_to_none=True)
-        loss.backward()
+        if self.sink is None:
+            self.optimizer.zero_grad(set_to_none=True)
+            loss.backward()
+            return loss
+        with self.sink.collecting():
+            loss.backward()
+        self.sink.flush()
+        if self.collective:
+            # the mean over ranks, as DistributedDataParallel forms it: one all-reduce of the whole gradient
+            dist.all_reduce(self.sink.flat)
+            if self.world > 1:
+                self.sink.flat.mul_(1.0 / self.world)
         return loss
 
     def step(self, batch):
@@ -77,15 +106,30 @@ class DataParallelTrainer(object):
         self.tracker.update_global_step()
         return loss
 
+    def no_sync(self):
+        """Steps inside this scope keep their gradients local (DistributedDataParallel.no_sync(), or the flat reducer's
+        all-reduce skipped): what bench.py times to see how much of the all-reduce a step does not hide."""
+        if self.ddp:
+            return self.model.no_sync()
+        trainer = self
+
+        class _Scope(object):
+            def __enter__(self):
+                self.was, trainer.collective = trainer.collective, False
+
+            def __exit__(self, *exc):
+                trainer.collective = self.was
+        return _Scope()
+
     def grad_bytes_allreduced(self):
         """Bytes of gradient one step hands to the bucket all-reduce (0 without DDP): every parameter that requires a gradient."""
-        if not self.ddp:
+        if not self.collective:
             return 0
         return sum(p.numel() * p.element_size() for p in self.model.parameters() if p.requires_grad)
 
     def ranks_seen(self):
         """All-reduce of ones: how many ranks actually take part in the collective."""
-        if not self.ddp:
+        if not self.collective:
             return 1
         one = torch.ones(1, device=self.device)
         dist.all_reduce(one)

@@ -73,7 +73,7 @@ def _torchrun_one_rank(script, *flags):
 
 def test_the_rccl_branches_of_the_training_line_run_at_world_size_one():
     """What an 8-GPU launch runs, on this one-GPU box: init_process_group("nccl", device_id=...), the ranks-seen all-reduce,
-    DistributedDataParallel around the tracker on the row kernels (one 19.6 MB bucket all-reduced per step on the device), and the
+    the tracker on the row kernels with its flat gradient buffer all-reduced once per step on the device (19.6 MB), and the
     no_sync() exposure measurement (tools/train_tracking.py:158-159, ptt/utils/common_utils.py:275-289)."""
     d = _torchrun_one_rank("bench.py", "--gpus", "1", "--workload", "train", "--steps", "2", "--warmup", "1", "--sustain", "0",
                            "--no-cpu-baseline", "--force-collective")
@@ -85,9 +85,12 @@ def test_the_rccl_branches_of_the_training_line_run_at_world_size_one():
 
 
 def test_ddp_on_one_rccl_rank_is_bit_identical_to_the_unwrapped_trainer():
+    """Both reducers — the flat gradient buffer's one all-reduce (default) and DistributedDataParallel — on one RCCL rank: bit-identical
+    to the same trainer without a collective; the two reducers' gradients agree to fp32 rounding (different summation trees)."""
     d = _torchrun_one_rank("scripts/rccl_one_rank_check.py")
-    assert d["backend"] == "nccl" and d["world"] == 1 and d["ranks_seen"] == 1 and d["ddp"] and d["unwrapped_is_plain"]
+    assert d["backend"] == "nccl" and d["world"] == 1 and d["ranks_seen"] == 1 and d["flat"] and d["ddp"] and d["unwrapped_is_plain"]
     assert d["grad_keys_equal"] and d["grads_bit_equal"] and d["params_bit_equal"] and d["loss_equal"], d
+    assert d["flat_vs_ddp_max_rel"] < 1e-5, d["flat_vs_ddp_max_rel"]
     assert d["grad_bytes_allreduced_per_step"] == d["expected_grad_bytes"] == 4903113 * 4
 
 

@@ -311,7 +311,7 @@ def test_ctypes_structures_match_the_c_header(tmp_path):
              ("ptt_attn_desc", _lib.AttnDesc), ("ptt_sa_layer", _lib.SaLayer), ("ptt_crop_job", _lib.CropJob),
              ("ptt_regularize_job", _lib.RegularizeJob), ("ptt_pack_job", _lib.PackJob), ("ptt_bn_train_tail", _lib.BnTrainTail),
              ("ptt_track_loss_desc", _lib.TrackLossDesc), ("ptt_adam_tensor", _lib.AdamTensor), ("ptt_adam_hyper", _lib.AdamHyper),
-             ("ptt_bn_bwd_input", _lib.BnBwdInput)]
+             ("ptt_bn_bwd_input", _lib.BnBwdInput), ("ptt_grad_job", _lib.GradJob), ("ptt_grad_segment", _lib.GradSegment)]
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "ptt_hip.h"', 'int main(void) {']
     for cname, st in pairs:
         lines.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))

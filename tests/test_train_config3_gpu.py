@@ -5,7 +5,8 @@
    model too (fixture G10 names those: biases in front of a softmax over neighbours), and two runs from the same seed
    leave bit-identical parameters (fixed-order BatchNorm sums, deterministic scatter-adds, fixed-order weight gradients).
 2. Two ranks (gloo, both on cuda:0 — RCCL refuses two ranks on one device; the driver's SCALE run covers RCCL): the full
-   tracker inside DistributedDataParallel ON THE HAND-WRITTEN ROW KERNELS (train_ops.usable / pt_block_usable asserted
+   tracker with its gradient all-reduce (the flat gradient buffer's one collective, and DistributedDataParallel) ON THE
+   HAND-WRITTEN ROW KERNELS (train_ops.usable / pt_block_usable asserted
    true on both ranks — on the CPU/gloo test they are bypassed), different batches per rank: every gradient equals the
    mean of two single-process GPU runs, both replicas hold identical parameters after clip + Adam; once more with
    --sync_bn (SyncBatchNorm statistics exchanged by the row kernels' float64 sums).
@@ -91,7 +92,7 @@ def test_config3_full_batch_step_is_finite_complete_and_bit_reproducible(dev):
     assert not differing, ("parameters differ between two identical runs", differing[:8])
 
 
-def _rank_main(rank, world, port, outdir, sync_bn):
+def _rank_main(rank, world, port, outdir, sync_bn, reducer):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
@@ -99,9 +100,12 @@ def _rank_main(rank, world, port, outdir, sync_bn):
     torch.cuda.set_device(dev)
     from ptt_amd.train_step import DataParallelTrainer, synthetic_train_batch
     seen, restore = _count_paths()
-    trainer = DataParallelTrainer(_build(dev), dev, sync_bn=sync_bn)
-    assert trainer.world == world and trainer.ranks_seen() == world
-    assert isinstance(trainer.model, torch.nn.parallel.DistributedDataParallel)
+    trainer = DataParallelTrainer(_build(dev), dev, sync_bn=sync_bn, reducer=reducer)
+    assert trainer.world == world and trainer.ranks_seen() == world and trainer.collective
+    if reducer == "ddp":
+        assert isinstance(trainer.model, torch.nn.parallel.DistributedDataParallel) and trainer.sink is None
+    else:
+        assert trainer.sink is not None and not trainer.ddp
     if sync_bn:
         assert any(isinstance(m, torch.nn.SyncBatchNorm) for m in trainer.tracker.modules())
     batch = synthetic_train_batch(500 + rank, 2, dev)
@@ -119,27 +123,29 @@ def _rank_main(rank, world, port, outdir, sync_bn):
     dist.destroy_process_group()
 
 
-def _two_ranks(sync_bn):
+def _two_ranks(sync_bn, reducer="flat"):
     import torch.multiprocessing as mp
-    port = 29800 + (os.getpid() % 150) + (50 if sync_bn else 0)
+    port = 29800 + (os.getpid() % 150) + (50 if sync_bn else 0) + (200 if reducer == "ddp" else 0)
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_rank_main, args=(2, port, d, sync_bn), nprocs=2, join=True)
+        mp.spawn(_rank_main, args=(2, port, d, sync_bn, reducer), nprocs=2, join=True)
         return [dict(np.load(os.path.join(d, "rank%d.npz" % k))) for k in range(2)]
 
 
-def _single(dev, batch_seed):
+def _single(dev, batch_seed, reducer="flat"):
     from ptt_amd.train_step import DataParallelTrainer, synthetic_train_batch
-    trainer = DataParallelTrainer(_build(dev), dev)
+    trainer = DataParallelTrainer(_build(dev), dev, reducer=reducer)
     trainer.forward_backward(synthetic_train_batch(batch_seed, 2, dev))
     return {k: p.grad.detach().cpu().numpy() for k, p in trainer.tracker.named_parameters() if p.grad is not None}
 
 
-def test_config3_two_rank_ddp_on_the_row_kernels(dev):
-    r = _two_ranks(sync_bn=False)
+@pytest.mark.parametrize("reducer", ["flat", "ddp"])
+def test_config3_two_rank_ddp_on_the_row_kernels(dev, reducer):
+    """reducer: the flat gradient buffer with its one all-reduce (the trainer's default on a HIP device), and DistributedDataParallel."""
+    r = _two_ranks(sync_bn=False, reducer=reducer)
     for k in (0, 1):
         mlp_t, mlp_f, pt_t, pt_f = (int(v) for v in r[k]["seen"])
         assert mlp_t > 0 and mlp_f == 0 and pt_t > 0 and pt_f == 0, (k, r[k]["seen"])       # the hand-written path ran
-    g0, g1 = _single(dev, 500), _single(dev, 501)
+    g0, g1 = _single(dev, 500, reducer), _single(dev, 501, reducer)
     gmax = max(float(np.abs(v).max()) for v in g0.values())
     worst = 0.0
     for k in g0:
