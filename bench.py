@@ -753,7 +753,7 @@ def run_train(args, torch, dev, dist, world, rank, ranks_seen, sync_all, B, NS, 
     torch.manual_seed(1)                                    # tools/train_tracking.py:73-79
     model = build_network(ptt_model_cfg(), 1, StubDataset(training=True)).to(dev).train()
     collective = dist is not None                          # world > 1, or --force-collective at world 1
-    trainer = DataParallelTrainer(model, dev, force_ddp=collective)
+    trainer = DataParallelTrainer(model, dev, force_ddp=collective, reducer=os.environ.get("PTT_TRAIN_REDUCER") or None)   # dev A/B: flat | ddp
     batch = synthetic_train_batch(100 + rank, B, dev, NS, NT, K_s=W["K_s"], K_t=W["K_t"])
     last = {}
 

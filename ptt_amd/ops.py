@@ -1811,15 +1811,20 @@ class AdamTable(object):
         self.norm = torch.zeros((1,), dtype=torch.float32, device=self.device)
         self.keep = (list(params), list(exp_avgs), list(exp_avg_sqs))
         self.uploaded = torch.cuda.Event()
+        self.grad_ptrs = None
 
     def step(self, grads, beta1, beta2, eps, step_size, bias2_sqrt, weight_decay=0.0, max_norm=0.0, write_clipped=True):
-        self.uploaded.synchronize()                            # the previous step's upload has left the pinned table
-        for r, g, p in zip(self.rows, grads, self.keep[0]):
+        for g, p in zip(grads, self.keep[0]):
             if g.dtype != torch.float32 or not g.is_contiguous() or g.numel() != p.numel() or g.device != self.device:
                 raise ValueError("AdamTable.step: contiguous float32 gradients of the parameters' sizes expected")
-            r.grad = g.data_ptr()
-        self.table.copy_(self.host, non_blocking=True)
-        self.uploaded.record()
+        ptrs = [g.data_ptr() for g in grads]
+        if ptrs != self.grad_ptrs:                             # gradients that live in one place (train_ops.GradSink's views): one upload ever
+            self.uploaded.synchronize()                        # the previous step's upload has left the pinned table
+            for r, ptr in zip(self.rows, ptrs):
+                r.grad = ptr
+            self.table.copy_(self.host, non_blocking=True)
+            self.uploaded.record()
+            self.grad_ptrs = ptrs
         h = _lib.AdamHyper(float(beta1), float(beta2), 1.0 - float(beta1), 1.0 - float(beta2), float(eps), float(step_size), float(bias2_sqrt), float(weight_decay), float(max_norm),
                            1 if write_clipped else 0)
         with torch.cuda.device(self.device):

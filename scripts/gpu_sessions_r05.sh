@@ -52,6 +52,14 @@ h)  # ptt_rows_gemm_bnbwd_fused_f32: the dz it writes out (store hazard), the th
         PTT_FUSED_BN_BWD=$m timeout 300 python bench.py --workload train --steps 20 --warmup 5 --sustain 2 --no-cpu-baseline 2> $O/train_f$m.err | tee -a $O/train_modes.jsonl | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('fused $m', d['ms_per_step'], d['sustained'])"
     done
     ;;
+k)  # the gradient sink (one finishing launch per step): its tests, the training tests, the step with / without it
+    timeout 900 python -m pytest tests/test_grad_sink_gpu.py -x -q -m gpu -s > $O/pytest_sink.log 2>&1; grep -E "flat gradient|passed|failed|Error|error" $O/pytest_sink.log | tail -12 | cut -c1-300
+    timeout 1500 python -m pytest tests/test_train_config3_gpu.py tests/test_train_gpu.py tests/test_step_ops_gpu.py tests/test_syncbn_gpu.py tests/test_bench_gpu.py -q -m gpu -s > $O/pytest_train.log 2>&1
+    grep -E "^FAILED|passed|failed|worst gradient" $O/pytest_train.log | tail -12 | cut -c1-300
+    for m in flat ddp flat; do
+        PTT_TRAIN_REDUCER=$m timeout 300 python bench.py --workload train --steps 20 --warmup 5 --sustain 2 --no-cpu-baseline 2> $O/train_$m.err | tee -a $O/train_modes.jsonl | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('reducer $m', d['ms_per_step'], d['sustained'])"
+    done
+    ;;
 g)  # weight-gradient tile shapes (needs a build with PTT_GEMM_FLAGS=-DPTT_GEMM_DEV)
     WG_FIRSTS=0,1,2,3 timeout 600 python scripts/wgrad_bench.py 2>&1 | grep -v amdgpu.ids | tee $O/wgrad_bench.log
     ;;
