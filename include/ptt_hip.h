@@ -849,7 +849,8 @@ int ptt_cos_bwd_rows_f32(const float* A, const float* unit, const float* nrm, co
 /* Layer 0 of a hoisted SA level, backward, in one pass in row order over the gradient G (R, C) of its ACTIVATED output (training):
  * the BatchNorm + ReLU backward is applied row by row from G, the stored z0 and the sums of `partial` (ptt_rows_gemm_bnbwd_f32's),
  * dwx (C,3) = dz0^T rel_rows is accumulated on the way, and dz0 is written only if dz_out != NULL (a level with point features:
- * its row scatter reads it; dz_out may alias G). Also dgamma / dbeta of that BatchNorm. */
+ * its row scatter reads it; dz_out may alias G). Also dgamma / dbeta of that BatchNorm. dwx NULL: the partial sums of dwx,
+ * [workspace bytes / (12 C)][C][3], stay in the workspace for ptt_grad_finish_f32. */
 size_t ptt_sa_z0_bnbwd_workspace(long long R, int C);
 int ptt_sa_z0_bnbwd_f32(const double* partial, int chunks, const float* G, const float* Z0, const float* rel_rows, const float* mean,
                         const float* invstd, const float* gamma, const float* act_scale, const float* act_shift, long long R, int C,

@@ -1028,8 +1028,17 @@ __global__ __launch_bounds__(256) void grad_finish_kernel(const ptt_grad_segment
             int c = g - kbase % G;
             if (c < 0) c += G;
             if (sg.vec) {
+                const float* pe = jb.partial + e;
+                const size_t step = (size_t)G * sg.n;
+                for (; c + 3 * G < jb.nchunks; c += 4 * G) {     // four loads in flight, summed in chunk order
+                    const float* p0 = pe + (size_t)c * sg.n;
+                    const f32x4t v0 = *reinterpret_cast<const f32x4t*>(p0), v1 = *reinterpret_cast<const f32x4t*>(p0 + step),
+                                 v2 = *reinterpret_cast<const f32x4t*>(p0 + 2 * step), v3 = *reinterpret_cast<const f32x4t*>(p0 + 3 * step);
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) s[x] = (((s[x] + v0[x]) + v1[x]) + v2[x]) + v3[x];
+                }
                 for (; c < jb.nchunks; c += G) {
-                    const f32x4t v = *reinterpret_cast<const f32x4t*>(jb.partial + (size_t)c * sg.n + e);
+                    const f32x4t v = *reinterpret_cast<const f32x4t*>(pe + (size_t)c * sg.n);
 #pragma unroll
                     for (int x = 0; x < 4; ++x) s[x] += v[x];
                 }
@@ -2041,7 +2050,7 @@ extern "C" int ptt_sa_z0_bnbwd_f32(const double* partial, int chunks, const floa
                                    void* ws, size_t ws_bytes, ptt_stream_t stream) {
     if (R <= 0 || R > 0x7fffffffLL || C <= 0 || (C & 3) || C > 1024 || chunks <= 0)
         return fail(PTT_EINVAL, "ptt_sa_z0_bnbwd_f32: R=%lld C=%d chunks=%d (C %% 4 == 0, C <= 1024)", R, C, chunks);
-    if (!partial || !G || !Z0 || !rel_rows || !mean || !invstd || !gamma || !act_scale || !act_shift || !dwx || !dgamma || !dbeta ||
+    if (!partial || !G || !Z0 || !rel_rows || !mean || !invstd || !gamma || !act_scale || !act_shift || !dgamma || !dbeta ||
         !vec4_ok(G, C, C) || !vec4_ok(Z0, C, C) || (dz_out && !vec4_ok(dz_out, C, C)) || !vec4_ok(mean, 4, 4) || !vec4_ok(invstd, 4, 4) ||
         !vec4_ok(gamma, 4, 4) || !vec4_ok(dgamma, 4, 4) || !vec4_ok(dbeta, 4, 4) || !vec4_ok(act_scale, 4, 4) || !vec4_ok(act_shift, 4, 4))
         return fail(PTT_EINVAL, "ptt_sa_z0_bnbwd_f32: null or misaligned pointer");
@@ -2051,7 +2060,7 @@ extern "C" int ptt_sa_z0_bnbwd_f32(const double* partial, int chunks, const floa
     const int rows = sa_z0_bnbwd_rows(R), nwg = (int)((R + rows - 1) / rows);
     hipLaunchKernelGGL(sa_z0_bnbwd_kernel, dim3(nwg), dim3(256), 0, s, G, Z0, rel_rows, mean, invstd, gamma, dbeta, dgamma, act_scale, act_shift,
                        1.0f / (float)R, R, C, rows, dz_out, static_cast<float*>(ws));
-    launch_wgrad_finish(static_cast<const float*>(ws), nwg, (size_t)C * 3, 0, dwx, s);
+    if (dwx) launch_wgrad_finish(static_cast<const float*>(ws), nwg, (size_t)C * 3, 0, dwx, s);     // else: the caller sums the partials
     return check_launch("sa_z0_bnbwd_kernel");
 }
 

@@ -1312,7 +1312,7 @@ class GradFinishPlan(object):
     @staticmethod
     def _outputs_per_group(total_chunks):
         # a function of the chunk count only: the summation tree of a destination is fixed by its job list
-        return 4 if total_chunks > 1024 else 8 if total_chunks > 256 else 32 if total_chunks > 8 else 64 if total_chunks > 2 else 256
+        return 4 if total_chunks > 1024 else 8 if total_chunks > 256 else 16 if total_chunks > 64 else 32 if total_chunks > 8 else 64 if total_chunks > 2 else 256
 
     def _build(self, sig):
         by_dst, order = {}, []
@@ -1476,21 +1476,24 @@ def sa_z0_rows(xyz, new_xyz, idx, term, wx, radius, normalize_xyz, want_stats=Fa
     return (z0, rel, None) if want_stats else (z0, rel)
 
 
-def sa_z0_bnbwd(part, g, z0, rel, mean, invstd, gamma, act_scale, act_shift, want_dz):
+def sa_z0_bnbwd(part, g, z0, rel, mean, invstd, gamma, act_scale, act_shift, want_dz, dwx_partials=False):
     """Layer 0 of a hoisted SA level, backward, from the gradient g (R, C) of its ACTIVATED output and the BatchNorm-backward partial
     sums rows_gemm_bnbwd took with it: -> (dz0 (written over g) | None, d_wx (C,3), dgamma, dbeta) in one pass in row order over g and
     z0 — the apply pass and the K = 3 weight gradient folded together; dz0 is written only when want_dz (a level with point features:
-    its row scatter reads it) — ptt_sa_z0_bnbwd_f32."""
+    its row scatter reads it) — ptt_sa_z0_bnbwd_f32. dwx_partials: d_wx is returned as (workspace holding its [nchunks][C][3] partial
+    sums, nchunks) for GradFinishPlan instead of the finished tensor."""
     _rows(g, "g"); _rows(z0, "z0")
     R, C = z0.shape
     dev = g.device
-    d_wx = torch.empty((C, 3), dtype=torch.float32, device=dev)
+    d_wx = torch.empty((C, 3), dtype=torch.float32, device=dev) if not dwx_partials else None
     dgamma, dbeta = (torch.empty((C,), dtype=torch.float32, device=dev) for _ in range(2))
     ws = _ws(_lib.lib().ptt_sa_z0_bnbwd_workspace(R, C), dev)
     with torch.cuda.device(dev):
         _lib.check(_lib.lib().ptt_sa_z0_bnbwd_f32(_ptr(part), part.shape[0], _ptr(g), _ptr(z0), _ptr(rel), _ptr(mean), _ptr(invstd), _ptr(gamma),
                                                   _ptr(act_scale), _ptr(act_shift), R, C, _ptr(g) if want_dz else None, _ptr(d_wx), _ptr(dgamma),
                                                   _ptr(dbeta), _ptr(ws), ws.numel() * 8, _stream()), "ptt_sa_z0_bnbwd_f32")
+    if dwx_partials:
+        d_wx = (ws, _lib.lib().ptt_sa_z0_bnbwd_workspace(R, C) // (12 * C))
     return (g if want_dz else None), d_wx, dgamma, dbeta
 
 

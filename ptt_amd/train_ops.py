@@ -550,7 +550,11 @@ class _SharedMlpPool(torch.autograd.Function):
                 # row scatter of a level with point features
                 idx, rel = front
                 want_term = ctx.has_term and ctx.needs_input_grad[11]
-                dz, front_grads[4], dgamma, dbeta = ops.sa_z0_bnbwd(part, g, z, rel, mean, invstd, gamma, a, b, want_term)
+                sink, loc = _sunk(ctx.f4)
+                dz, front_grads[4], dgamma, dbeta = ops.sa_z0_bnbwd(part, g, z, rel, mean, invstd, gamma, a, b, want_term, dwx_partials=sink is not None)
+                if sink is not None:
+                    sink.push(loc, *front_grads[4])
+                    front_grads[4] = None
                 if want_term:
                     B, M, ns_ = idx.shape
                     front_grads[3] = ops.scatter_rows_det(dz.view(B, M * ns_, -1), idx.view(B, M * ns_), ctx.sa_points)
