@@ -882,6 +882,21 @@ int ptt_colsum_partials_f32(const float* X, int R, int C, int ldx, void* workspa
 int ptt_grad_finish_f32(const ptt_grad_segment* segments_device, const ptt_grad_job* jobs_device, const int32_t* blocks_device,
                         int n_blocks, float* flat, ptt_stream_t stream);
 
+/* The backward pass of a Point-Transformer block's attention core (variants.py:158-163 under autograd) with three passes folded away:
+ *   ptt_rows_gemm_rsum16_f32     plain = X @ W^T, out = plain + residual and, per group of 16 consecutive rows (a point's 16
+ *                                neighbours), gsum[g, :] = the column sums of plain over the group — one epilogue. With X = the gradient
+ *                                of fc_gamma's hidden layer and residual = the aggregation's gradient of (v + pos_enc): plain is the
+ *                                gradient of the pair input, out the gradient of pos_enc (its two consumers' sum, which autograd would
+ *                                form with a pass of its own) and gsum the gradient of q (a reduction pass).
+ *                                ptt_rows_gemm_rsum16_supported: K % 128 == 0, N % 128 == 0, rows % 16 == 0.
+ *   ptt_scatter_rows_csr_sub_f32 ptt_scatter_rows_csr_f32 with out = minuend - (the sums), minuend NULL = 0: the gradient of k is
+ *                                MINUS the scatter of the pair input's gradient (a negation pass). */
+int ptt_rows_gemm_rsum16_supported(int rows, int K, int N, int ldx);
+int ptt_rows_gemm_rsum16_f32(const float* X, int rows, int K, int ldx, const float* Wpacked, int N, const float* residual, int ldr,
+                             float* out, int ldo, float* plain, int ldp, float* gsum, int ldg, ptt_stream_t stream);
+int ptt_scatter_rows_csr_sub_f32(const float* g, const int32_t* order, const int32_t* start, int B, int N, int E, int C,
+                                 const float* minuend, float* out, ptt_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

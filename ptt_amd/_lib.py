@@ -43,6 +43,7 @@ EXPORTS = [
     "ptt_row_jobs_f32", "ptt_point_jobs_f32", "ptt_fps_ball_knn_f32", "ptt_crop_compact_host_f32", "ptt_crop_regularize_f32", "ptt_colsum_workspace", "ptt_colsum_f32", "ptt_rows_gemm_pool_supported", "ptt_rows_gemm_pool_f32", "ptt_pool_select_f32", "ptt_sa_z0_rows_stat_chunks", "ptt_sa_z0_rows_stats_f32",
     "ptt_track_losses_f32", "ptt_track_losses_bwd_f32", "ptt_adam_chunk_elems", "ptt_adam_clip_step_f32",
     "ptt_linear_wgrad_partials_f32", "ptt_linear_wgrad2_partials_f32", "ptt_colsum_partials_f32", "ptt_grad_finish_f32",
+    "ptt_rows_gemm_rsum16_supported", "ptt_rows_gemm_rsum16_f32", "ptt_scatter_rows_csr_sub_f32",
     "ptt_unit_rows_f32", "ptt_cos_bwd_rows_f32", "ptt_track_select_update", "ptt_sa_z0_bnbwd_workspace", "ptt_sa_z0_bnbwd_f32",
 ]
 PTT_MAX_SEGMENTS = 4
@@ -252,6 +253,9 @@ def _declare(lib):
         "ptt_linear_wgrad2_partials_f32": [vp, i, vp, i, i, i, i, vp, c_size_t, vp, vp, vp, vp],
         "ptt_colsum_partials_f32": [vp, i, i, i, vp, c_size_t, vp, vp],
         "ptt_grad_finish_f32": [vp, vp, vp, i, vp, vp],
+        "ptt_rows_gemm_rsum16_supported": [i, i, i, i],
+        "ptt_rows_gemm_rsum16_f32": [vp, i, i, i, vp, i, vp, i, vp, i, vp, i, vp, i, vp],
+        "ptt_scatter_rows_csr_sub_f32": [vp, vp, vp, i, i, i, i, vp, vp, vp],
         "ptt_rows_gemm_bnbwd_f32": [vp, i, i, i, vp, i, vp, i, vp, vp, vp, vp, vp, i, vp, c_size_t, vp],
         "ptt_bn_bwd_from_partials_f32": [vp, i, vp, i, vp, i, vp, vp, vp, i, i, vp, i, vp, vp, vp, vp, vp],
         "ptt_bn_bwd_consts_f32": [vp, i, vp, vp, vp, i, i, vp, vp, vp, vp, vp, vp],

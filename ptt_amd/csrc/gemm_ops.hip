@@ -91,6 +91,9 @@ struct RowsGemmParams {
     // written out once (by the workgroups of column group 0) for the weight gradient of the same layer.
     const float* tz; int ldtz; const float* tk1; const float* tc0; const float* tc1; const float* tmu;
     const float* tg; int ldtg; const int* targ; float* a_out; int lda_out;
+    // GS instantiations (with `residual`): the product is ALSO written without the residual (plain), and summed per group of 16
+    // consecutive rows and column (gsum)
+    float* gsum; float* plain; int ldgs, ldpl;
 };
 
 // WR x WC waves (WR * WC = 4): wave (wr, wc) owns row tiles wr*RT .. wr*RT+RT-1 of the workgroup's 32*RT*WR rows and the
@@ -101,8 +104,10 @@ struct RowsGemmParams {
 #define PTT_RG_PD 3          // weight fragments requested this many K-blocks ahead
 #endif
 // BNB: the statistics are the BatchNorm backward sums of the producing layer (p.bz ...), not those of the output
-template <int WR, int RT, int CT, int KC, bool STATS, bool ACT, int EXP = 0, bool BNB = false, int POOL = 0, int AIN = 0>
+// GS 16: the launch also sums its outputs (after the residual) over groups of 16 consecutive rows (ptt_rows_gemm_rsum16_f32)
+template <int WR, int RT, int CT, int KC, bool STATS, bool ACT, int EXP = 0, bool BNB = false, int POOL = 0, int AIN = 0, int GS = 0>
 __global__ __launch_bounds__(256, 2) void rows_gemm_kernel(RowsGemmParams p) {
+    static_assert(GS == 0 || (GS == 16 && !STATS && !ACT && !BNB && POOL == 0 && AIN == 0), "group sums: a plain GEMM with a residual");
     static_assert(!BNB || (STATS && !ACT), "the backward-sums epilogue is a statistics epilogue of a plain input gradient");
     static_assert(AIN == 0 || AIN == 2 || AIN == 16 || AIN == 32 || AIN == 64, "A-operand form");
     static_assert(AIN == 0 || (!ACT && POOL == 0), "the BatchNorm-backward A operand excludes the deferred-activation one");
@@ -277,6 +282,7 @@ __global__ __launch_bounds__(256, 2) void rows_gemm_kernel(RowsGemmParams p) {
                 }
                 float pv_max[2] = {-__builtin_inff(), -__builtin_inff()}, pv_min[2] = {__builtin_inff(), __builtin_inff()};
                 int pi_max[2] = {0, 0}, pi_min[2] = {0, 0};
+                float gs[2] = {0.f, 0.f};
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int dr = rt * 32 + (r & 3) + 8 * (r >> 2);
@@ -299,10 +305,22 @@ __global__ __launch_bounds__(256, 2) void rows_gemm_kernel(RowsGemmParams p) {
                         if (!FULL) nrows += in ? 1 : 0;
                     }
                     y = fmaxf(y, rfloor);
+                    if (GS == 16 && MODE == 1) {                // a lane's registers 0-7 / 8-15: the tile's two 16-row groups
+                        gs[r >> 3] += in ? y : 0.f;
+                        if (in) p.plain[(size_t)(row_w + 4 * half + dr) * p.ldpl + cn] = y;
+                    }
                     if (MODE == 1) y += rv[r];
                     if (!(EXP & 1) || r == 15)
                         if (in) g_store1(y, ro, obase + dr * (p.ldo * 4), 0);
                     acc[rt][u][r] = 0.f;
+                }
+                if constexpr (GS == 16 && MODE == 1) {
+#pragma unroll
+                    for (int gq = 0; gq < 2; ++gq) {            // the other half-wave holds the group's other eight rows
+                        const float tot = g_add_halves(gs[gq]);
+                        const int row_g = row_w + rt * 32 + gq * 16;
+                        if (half == 0 && row_g < p.rows) p.gsum[(size_t)(row_g >> 4) * p.ldgs + cn] = tot;
+                    }
                 }
                 if constexpr (POOL > 0 && MODE == 0) {
                     // the other half-wave holds the group's other rows; a 64-row group spans two row tiles of this wave
@@ -619,10 +637,33 @@ extern "C" int ptt_rows_gemm_stat_chunks(int rows, int K, int N) {
 
 struct BnBwdArgs { const float* z; int ldz; const float* mean; const float* invstd; const float* a; const float* b; };
 struct PoolArgs { float* pmax; float* pmin; int32_t* amax; int32_t* amin; int ns; };
+struct GroupSumArgs { float* gsum; int ldgs; float* plain; int ldpl; };
 static int rows_gemm_launch(const float* X, int rows, int K, int ldx, const float* in_scale, const float* in_shift,
                             const float* Wpacked, int N, const float* bias, int relu, const float* residual, int ldr,
                             const float* mask, int ldm, float* out, int ldo, double* stats, size_t stats_elems, ptt_stream_t stream,
-                            const BnBwdArgs* bn = nullptr, const PoolArgs* pool = nullptr, const ptt_bn_bwd_input* ain = nullptr);
+                            const BnBwdArgs* bn = nullptr, const PoolArgs* pool = nullptr, const ptt_bn_bwd_input* ain = nullptr,
+                            const GroupSumArgs* gs = nullptr);
+
+extern "C" int ptt_rows_gemm_rsum16_supported(int rows, int K, int N, int ldx) {
+    if (!ptt_rows_gemm_supported(rows, K, N, ldx, N) || rows % 16) return 0;
+    const RowsGemmGeom g = rows_gemm_geom(rows, K, N);
+    return (g.WR == 1 && g.RT == 2 && g.KC == 128) ? 1 : 0;
+}
+
+// plain = X @ W^T, out = plain + residual, gsum = the column sums of plain per group of 16 consecutive rows, from one epilogue: the
+// input gradient dt of the pair layer of a Point-Transformer block, the gradient of pos_enc (dt + the aggregation's, which rides in
+// as the residual) and the query gradient (dt summed over a point's 16 neighbours) — ptt_amd/train_ops.py: _AttnCore.
+extern "C" int ptt_rows_gemm_rsum16_f32(const float* X, int rows, int K, int ldx, const float* Wpacked, int N, const float* residual,
+                                        int ldr, float* out, int ldo, float* plain, int ldp, float* gsum, int ldg,
+                                        ptt_stream_t stream) {
+    if (!residual || !plain || !gsum || ldp < N || ldg < N) return fail(PTT_EINVAL, "ptt_rows_gemm_rsum16_f32: null pointer or ldp / ldg < N");
+    if ((long long)rows * ldp >= (1LL << 31)) return fail(PTT_EUNSUPPORTED, "ptt_rows_gemm_rsum16_f32: rows * ldp >= 2^31");
+    if (!ptt_rows_gemm_rsum16_supported(rows, K, N, ldx))
+        return fail(PTT_EUNSUPPORTED, "ptt_rows_gemm_rsum16_f32: rows=%d K=%d N=%d (whole groups of 16 rows, K %% 128 == 0, N %% 128 == 0)", rows, K, N);
+    const GroupSumArgs gs{gsum, ldg, plain, ldp};
+    return rows_gemm_launch(X, rows, K, ldx, nullptr, nullptr, Wpacked, N, nullptr, 0, residual, ldr, nullptr, 0, out, ldo, nullptr, 0, stream,
+                            nullptr, nullptr, nullptr, &gs);
+}
 
 extern "C" int ptt_rows_gemm_bnbwd_fused_supported(int rows, int K, int N, int ns) {
     if (!ptt_rows_gemm_supported(rows, K, N, K, N) || (ns != 0 && ns != 16 && ns != 32 && ns != 64) || (ns > 0 && rows % ns)) return 0;
@@ -701,7 +742,7 @@ extern "C" int ptt_rows_gemm_masked_f32(const float* X, int rows, int K, int ldx
 static int rows_gemm_launch(const float* X, int rows, int K, int ldx, const float* in_scale, const float* in_shift,
                             const float* Wpacked, int N, const float* bias, int relu, const float* residual, int ldr,
                             const float* mask, int ldm, float* out, int ldo, double* stats, size_t stats_elems, ptt_stream_t stream,
-                            const BnBwdArgs* bn, const PoolArgs* pool, const ptt_bn_bwd_input* ain) {
+                            const BnBwdArgs* bn, const PoolArgs* pool, const ptt_bn_bwd_input* ain, const GroupSumArgs* gs) {
     if (rows < 0 || K <= 0 || N <= 0 || ldx < K || ldo < N || (residual && ldr < N))
         return fail(PTT_EINVAL, "ptt_rows_gemm_f32: rows=%d K=%d N=%d ldx=%d ldo=%d ldr=%d", rows, K, N, ldx, ldo, ldr);
     if (rows == 0) return PTT_OK;
@@ -738,10 +779,23 @@ static int rows_gemm_launch(const float* X, int rows, int K, int ldx, const floa
         p.tz = ain->z; p.ldtz = ain->ldz; p.tk1 = ain->k1; p.tc0 = ain->c0; p.tc1 = ain->c1; p.tmu = ain->mean; p.in_a = ain->act_a; p.in_b = ain->act_b;
         p.tg = ain->g; p.ldtg = ain->ldg; p.targ = ain->arg; p.a_out = ain->dz_out; p.lda_out = ain->ldd;
     }
+    p.gsum = gs ? gs->gsum : nullptr; p.plain = gs ? gs->plain : nullptr; p.ldgs = gs ? gs->ldgs : 0; p.ldpl = gs ? gs->ldpl : 0;
     const int lds = 2 * g.TR * (g.KC + 4) * (int)sizeof(float);
     const dim3 grid(g.G * g.ncg);
     hipStream_t s = as_stream(stream);
     int rc = PTT_OK;
+    if (gs) {
+        if (!residual || bias || relu || mask || stats || bn || pool || ain || in_scale)
+            return fail(PTT_EINVAL, "ptt_rows_gemm_rsum16_f32: a plain GEMM with a residual");
+#define PTT_RG_GS(CT_)                                                                                                  \
+        if (g.WR == 1 && g.RT == 2 && g.CT == CT_ && g.KC == 128) {                                                     \
+            if ((rc = set_lds_limit(reinterpret_cast<const void*>(rows_gemm_kernel<1, 2, CT_, 128, false, false, 0, false, 0, 0, 16>), lds))) return rc; \
+            hipLaunchKernelGGL((rows_gemm_kernel<1, 2, CT_, 128, false, false, 0, false, 0, 0, 16>), grid, dim3(256), lds, s, p); \
+        }
+        PTT_RG_GS(2) PTT_RG_GS(1)
+#undef PTT_RG_GS
+        return check_launch("rows_gemm_kernel(rsum16)");
+    }
 #ifdef PTT_GEMM_DEV
     if (const char* e = getenv("PTT_RG_EXP")) {
         const int x = atoi(e);

@@ -1149,9 +1149,10 @@ __global__ __launch_bounds__(256) void sa_z0_rows_kernel(const float* __restrict
 
 // Its backward, deterministic: out[b, n, :] = sum of g[b, e, :] over the entries e with idx[b, e] == n, in ASCENDING e
 // (order / start = the CSR scatter_csr_kernel builds). Thread = (point n, channel quad): coalesced row reads.
+// negate: out = minuend - sum (minuend (B, N, C), or 0 if it is null) instead of the sum.
 __global__ __launch_bounds__(256) void scatter_rows_det_kernel(const float* __restrict__ g, const int32_t* __restrict__ order,
                                                                const int32_t* __restrict__ start, int N, int E, int C,
-                                                               float* __restrict__ out) {
+                                                               float* __restrict__ out, const float* __restrict__ minuend, int negate) {
     const int Cq = C >> 2, span = Cq < 256 ? Cq : 256, RG = 256 / span;
     const int q0 = threadIdx.x % span, rg = threadIdx.x / span;
     if (rg >= RG) return;
@@ -1176,6 +1177,12 @@ __global__ __launch_bounds__(256) void scatter_rows_det_kernel(const float* __re
             for (; k < k1; ++k) {
                 const f32x4t v = *reinterpret_cast<const f32x4t*>(gb + (size_t)ob[k] * C + 4 * q);
                 acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
+            }
+            if (negate) {
+                f32x4t m = {0.f, 0.f, 0.f, 0.f};
+                if (minuend) m = *reinterpret_cast<const f32x4t*>(minuend + ((size_t)b * N + n) * C + 4 * q);
+#pragma unroll
+                for (int x = 0; x < 4; ++x) acc[x] = m[x] - acc[x];
             }
             *reinterpret_cast<f32x4t*>(out + ((size_t)b * N + n) * C + 4 * q) = acc;
         }
@@ -1719,17 +1726,25 @@ extern "C" int ptt_sa_z0_rows_stats_f32(const float* xyz, const float* new_xyz, 
     return sa_z0_rows_launch(xyz, new_xyz, idx, term, wx, ldw, B, N, M, ns, C, radius, normalize_xyz, z0, rel_rows, stats_partial, stream);
 }
 
-extern "C" int ptt_scatter_rows_csr_f32(const float* g, const int32_t* order, const int32_t* start, int B, int N, int E, int C,
-                                        float* out, ptt_stream_t stream) {
+static int scatter_rows_run(const float* g, const int32_t* order, const int32_t* start, int B, int N, int E, int C, float* out,
+                            const float* minuend, int negate, ptt_stream_t stream) {
     if (B < 0 || N <= 0 || E < 0 || C <= 0 || (C & 3)) return fail(PTT_EINVAL, "ptt_scatter_rows_csr_f32: B=%d N=%d E=%d C=%d", B, N, E, C);
     if (B == 0) return PTT_OK;
-    if (!g || !order || !start || !out || ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(out)) & 15))
+    if (!g || !order || !start || !out || ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(minuend)) & 15))
         return fail(PTT_EINVAL, "ptt_scatter_rows_csr_f32: null or unaligned pointer");
     const int Cq = C >> 2, RG = 256 / (Cq < 256 ? Cq : 256);
     int gx = (N + RG - 1) / RG;
     if (gx > 4096) gx = 4096;
-    hipLaunchKernelGGL(scatter_rows_det_kernel, dim3(gx, B), dim3(256), 0, as_stream(stream), g, order, start, N, E, C, out);
+    hipLaunchKernelGGL(scatter_rows_det_kernel, dim3(gx, B), dim3(256), 0, as_stream(stream), g, order, start, N, E, C, out, minuend, negate);
     return check_launch("scatter_rows_det_kernel");
+}
+extern "C" int ptt_scatter_rows_csr_f32(const float* g, const int32_t* order, const int32_t* start, int B, int N, int E, int C,
+                                        float* out, ptt_stream_t stream) {
+    return scatter_rows_run(g, order, start, B, N, E, C, out, nullptr, 0, stream);
+}
+extern "C" int ptt_scatter_rows_csr_sub_f32(const float* g, const int32_t* order, const int32_t* start, int B, int N, int E, int C,
+                                            const float* minuend, float* out, ptt_stream_t stream) {
+    return scatter_rows_run(g, order, start, B, N, E, C, out, minuend, 1, stream);
 }
 
 static int pt_train_check(const char* what, int B, int N, int k, int D, const void* p0, const void* p1, const void* p2, const void* p3) {

@@ -173,9 +173,14 @@ class TransformerBlock(nn.Module):
             pos_enc = train_ops.rows_mlp2(self.fc_delta, rel)                          # (B,N,k,D)
             # the backward scatters of k and v run over the same neighbour indices: their (bin, entry) order is formed once
             order, start = ops.scatter_csr(knn_idx.view(knn_idx.shape[0], -1), knn_idx.shape[1])
-            t = train_ops._PairInput.apply(q, kf, knn_idx, pos_enc, order, start)
-            a = train_ops.rows_mlp2(self.fc_gamma, t)
-            res, attn = train_ops._AttnAggregate.apply(a, vf, knn_idx, pos_enc, 1.0 / np.sqrt(self.d_model), order, start)
+            if train_ops.ATTN_CORE:
+                # pair input, fc_gamma, softmax and aggregate as one autograd function (its backward folds three passes over the
+                # (B,N,k,D) tensors into GEMM / scatter epilogues: train_ops._AttnCore)
+                res, attn = train_ops.attn_core(self.fc_gamma, q, kf, vf, knn_idx, pos_enc, 1.0 / np.sqrt(self.d_model), order, start)
+            else:
+                t = train_ops._PairInput.apply(q, kf, knn_idx, pos_enc, order, start)
+                a = train_ops.rows_mlp2(self.fc_gamma, t)
+                res, attn = train_ops._AttnAggregate.apply(a, vf, knn_idx, pos_enc, 1.0 / np.sqrt(self.d_model), order, start)
             res = train_ops.rows_linear(self.fc2, res, residual=features)
             return res, attn
 

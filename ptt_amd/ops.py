@@ -1509,18 +1509,48 @@ def scatter_csr(idx, N):
     return order, start
 
 
-def scatter_rows_det(g, idx, N, csr=None):
+def scatter_rows_det(g, idx, N, csr=None, minuend=None, negate=False):
     """The adjoint of gather_rows in a fixed summation order: g (B,E,C), idx (B,E) -> (B,N,C). csr: scatter_csr(idx, N) if the
-    caller already has it."""
+    caller already has it. minuend (B,N,C) / negate: the result is minuend - (the sums), resp. their negative —
+    ptt_scatter_rows_csr_sub_f32."""
     _chk(g, "g", torch.float32, 3)
     _chk(idx, "idx", torch.int32, 2)
     B, E, C = g.shape
     order, start = csr if csr is not None else scatter_csr(idx, N)
     out = torch.empty((B, int(N), C), dtype=torch.float32, device=g.device)
     with torch.cuda.device(g.device):
-        _lib.check(_lib.lib().ptt_scatter_rows_csr_f32(_ptr(g), _ptr(order), _ptr(start), B, int(N), E, C, _ptr(out), _stream()),
-                   "ptt_scatter_rows_csr_f32")
+        if minuend is None and not negate:
+            _lib.check(_lib.lib().ptt_scatter_rows_csr_f32(_ptr(g), _ptr(order), _ptr(start), B, int(N), E, C, _ptr(out), _stream()),
+                       "ptt_scatter_rows_csr_f32")
+        else:
+            if minuend is not None:
+                _chk(minuend, "minuend", torch.float32, 3)
+                if tuple(minuend.shape) != (B, int(N), C):
+                    raise ValueError("minuend: (B,N,C) expected")
+            _lib.check(_lib.lib().ptt_scatter_rows_csr_sub_f32(_ptr(g), _ptr(order), _ptr(start), B, int(N), E, C, _ptr(minuend), _ptr(out),
+                                                               _stream()), "ptt_scatter_rows_csr_sub_f32")
     return out
+
+
+def rows_gemm_rsum16_supported(x, K, N):
+    return bool(x.dim() == 2 and x.stride(1) == 1 and x.data_ptr() % 16 == 0
+                and _lib.lib().ptt_rows_gemm_rsum16_supported(x.shape[0], int(K), int(N), x.stride(0)))
+
+
+def rows_gemm_rsum16(x, wpacked, N, residual):
+    """-> (plain = x @ W^T (rows, N), out = plain + residual, gsum (rows / 16, N) = the sums of plain over groups of 16 consecutive
+    rows) from one launch — ptt_rows_gemm_rsum16_f32."""
+    _rows(x, "x"); _rows(residual, "residual")
+    rows, K = x.shape
+    if tuple(residual.shape) != (rows, int(N)):
+        raise ValueError("rows_gemm_rsum16: residual (rows, N) expected")
+    out, plain = (torch.empty((rows, int(N)), dtype=torch.float32, device=x.device) for _ in range(2))
+    gsum = torch.empty((rows // 16, int(N)), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device), _timed('ptt_linear_f32'):
+        _lib.check(_lib.lib().ptt_rows_gemm_rsum16_f32(_ptr(x), rows, K, x.stride(0), _ptr(wpacked), int(N), _ptr(residual), residual.stride(0),
+                                                       _ptr(out), int(N), _ptr(plain), int(N), _ptr(gsum), int(N), _stream()),
+                   "ptt_rows_gemm_rsum16_f32")
+    return plain, out, gsum
 
 
 # --------------------------------------------------------------------------- Point-Transformer block, training mode

@@ -788,6 +788,72 @@ class _AttnAggregate(torch.autograd.Function):
         return da, dvf, None, dvp, None, None, None
 
 
+ATTN_CORE = os.environ.get("PTT_ATTN_CORE", "1") != "0"      # dev A/B: 0 = _PairInput / rows_mlp2 / _AttnAggregate as three functions
+
+
+class _AttnCore(torch.autograd.Function):
+    """The attention core of a Point-Transformer block (variants.py:158-163) as ONE function:
+        t = q_i - kf[knn_ij] + pos_ij;  a = fc_gamma(t);  attn = softmax_j(a / sqrt(d));  res = sum_j attn * (vf[knn_ij] + pos_ij)
+    Forward: the launches of _PairInput, _RowsMlp2 and _AttnAggregate. Backward: theirs too, except that three passes over
+    (B, N, k, D) tensors ride in the epilogue of the GEMM that forms dt, the gradient of t (ptt_rows_gemm_rsum16_f32):
+      * pos_enc receives two gradients (through t, and through the aggregate: dvp), which autograd would add with a pass of its own
+        — dvp is that GEMM's residual, the sum dt + dvp its second output;
+      * dq = sum_j dt_ij, a reduction pass — the sums over a point's 16 rows come out of the same epilogue;
+      * dkf = -scatter_knn(dt): the negation is the scatter's own (ptt_scatter_rows_csr_sub_f32).
+    The values are those of the three-function form (dt itself is still written: forming dq / dkf from dt + dvp instead would lose
+    them to cancellation, dvp being ~1000 x larger). Per block and step 11 -> 8 launches, the two largest ATen launches gone."""
+
+    @staticmethod
+    def forward(ctx, q, kf, vf, knn, pos, W1, b1, W2, b2, scale, order, start):
+        ctx.set_materialize_grads(False)
+        q, kf, vf, pos = q.contiguous(), kf.contiguous(), vf.contiguous(), pos.contiguous()
+        t = ops.pt_pair_input(q, kf, knn, pos)
+        x2 = t.view(-1, t.shape[-1])
+        h = lin_rows(x2, W1, b1.detach(), relu=True)
+        a = lin_rows(h, W2, b2.detach()).view(*t.shape[:-1], W2.shape[0])
+        attn, res = ops.pt_attn_train_fwd(a, vf, knn, pos, scale)
+        ctx.save_for_backward(x2, h, attn, vf, knn, pos, order, start, W1, W2)      # the weights too: see _RowsLinear
+        ctx.Ws, ctx.bs, ctx.scale = (W1, W2), (b1, b2), float(scale)
+        ctx.mark_non_differentiable(attn)
+        return res, attn
+
+    @staticmethod
+    def backward(ctx, dres, _dattn):
+        x2, h, attn, vf, knn, pos, order, start = ctx.saved_tensors[:8]
+        W1, W2 = ctx.Ws
+        B, N, k, D = attn.shape
+        csr = (order, start)
+        dres = dres.contiguous()
+        da, dvp = ops.pt_attn_train_bwd(attn, vf, knn, pos, dres, ctx.scale)
+        dvf = ops.scatter_rows_det(dvp.view(B, N * k, D), knn.view(B, N * k), N, csr)
+        dy2 = da.view(-1, D)
+        rows, D1 = h.shape
+        dW2 = weight_grad(W2, dy2, h)
+        db2 = bias_grad(ctx.bs[1], dy2)
+        if ops.rows_gemm_supported(rows, W2.shape[0], D1, dy2.stride(0), D1, x=dy2):
+            dz1, db1 = ops.rows_gemm_masked(dy2, packed(W2, True), D1, h, want_colsum=True)
+        else:
+            dz1 = lin_rows(dy2, W2, transpose=True) * (h > 0)
+            db1 = dz1.sum(0)
+        dW1 = weight_grad(W1, dz1, x2)
+        Din = W1.shape[1]
+        if ops.rows_gemm_rsum16_supported(dz1, D1, Din) and k == 16 and Din == D:
+            dt, dpos, dq = ops.rows_gemm_rsum16(dz1, packed(W1, True), Din, dvp.view(-1, D))
+            dkf = ops.scatter_rows_det(dt.view(B, N * k, D), knn.view(B, N * k), N, csr, negate=True)
+            dq, dpos = dq.view(B, N, D), dpos.view(B, N, k, D)
+        else:
+            dt = lin_rows(dz1, W1, transpose=True).view(B, N, k, D)
+            dq = dt.sum(dim=2)
+            dkf = ops.scatter_rows_det(dt.view(B, N * k, D), knn.view(B, N * k), N, csr).neg_()
+            dpos = dt + dvp
+        return dq, dkf, dvf, None, dpos, dW1, small_grad(ctx.bs[0], db1), dW2, db2, None, None, None
+
+
+def attn_core(fc_gamma, q, kf, vf, knn, pos, scale, order, start):
+    """-> (res (B,N,D), attn (B,N,k,D)) for fc_gamma = nn.Sequential(Linear, ReLU, Linear) through _AttnCore."""
+    return _AttnCore.apply(q, kf, vf, knn, pos, fc_gamma[0].weight, fc_gamma[0].bias, fc_gamma[2].weight, fc_gamma[2].bias, scale, order, start)
+
+
 def pt_block_usable(block, xyz, features):
     return (block.training and xyz.is_cuda and features.dtype == torch.float32 and block.k == 16 and block.d_model % 4 == 0
             and xyz.shape[1] * block.k <= 16384)

@@ -60,6 +60,14 @@ k)  # the gradient sink (one finishing launch per step): its tests, the training
         PTT_TRAIN_REDUCER=$m timeout 300 python bench.py --workload train --steps 20 --warmup 5 --sustain 2 --no-cpu-baseline 2> $O/train_$m.err | tee -a $O/train_modes.jsonl | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('reducer $m', d['ms_per_step'], d['sustained'])"
     done
     ;;
+m)  # the fused attention core (_AttnCore): its tests, the training tests, the step with / without it
+    timeout 900 python -m pytest tests/test_attn_core_gpu.py -x -q -m gpu -s > $O/pytest_core.log 2>&1; grep -E "fused attention|passed|failed|Error|error" $O/pytest_core.log | tail -12 | cut -c1-300
+    timeout 1500 python -m pytest tests/test_train_config3_gpu.py tests/test_train_gpu.py tests/test_step_ops_gpu.py tests/test_grad_sink_gpu.py -q -m gpu -s > $O/pytest_train.log 2>&1
+    grep -E "^FAILED|passed|failed|G10 on|G15 \(|G14:" $O/pytest_train.log | tail -12 | cut -c1-300
+    for m in 1 0 1; do
+        PTT_ATTN_CORE=$m timeout 300 python bench.py --workload train --steps 20 --warmup 5 --sustain 2 --no-cpu-baseline 2> $O/train_core$m.err | tee -a $O/train_modes.jsonl | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('attention core $m', d['ms_per_step'], d['sustained'])"
+    done
+    ;;
 g)  # weight-gradient tile shapes (needs a build with PTT_GEMM_FLAGS=-DPTT_GEMM_DEV)
     WG_FIRSTS=0,1,2,3 timeout 600 python scripts/wgrad_bench.py 2>&1 | grep -v amdgpu.ids | tee $O/wgrad_bench.log
     ;;
