@@ -598,7 +598,10 @@ static RowsGemmGeom rows_gemm_geom(int rows, int K, int N) {
         // 256 columns per workgroup (two accumulator tiles per row tile: each staged row feeds twice the MFMAs) — unless the launch is
         // too small to give every CU its two workgroups that way (the 6144-row layers of the transformer blocks and the heads are
         // 96 row tiles: 96 or 192 workgroups on 256 CUs): then 128 columns per workgroup, twice the workgroups. Measured on the
-        // training step (round 5): always 256 columns 20.18 ms, 128 below one workgroup per CU 19.78, below two 19.70, below four 19.79
+        // training step (round 5): always 256 columns 20.18 ms, 128 below one workgroup per CU 19.78, below two 19.70, below four 19.79.
+        // (32-row tiles for launches that still leave CUs without a workgroup — 6144 rows x 256 columns is 192 workgroups: 19.34 against
+        // 19.46 ms when every such launch takes them, but the statistics epilogues then change their partial-sum layout with the
+        // launch size; for the plain launches alone 19.40 against 19.43: not kept)
         const int tiles64 = (rows + 63) / 64;
         g.WR = 1; g.RT = 2; g.KC = 128;
         g.CT = (N % 256 == 0 && (long long)tiles64 * (N / 256) >= 2 * cu_count()) ? 2 : 1;
