@@ -540,20 +540,29 @@ __global__ __launch_bounds__(512, 1) void wgrad2_kernel(const float* __restrict_
         fetch(rs0 + RS);                                        // past the end: clamped rows, zeroed when staged
         const float* A = As + buf * (RS * LDA) + half * LDA + wn * (32 * TN) + col;
         const float* B = Bs + buf * (RS * LDB) + half * LDB + wk * (32 * TK) + col;
+        // the operand fragments of step j + 1 are requested BEFORE the MFMAs of step j (two register sets): left to itself hipcc
+        // placed each step's LDS reads right in front of its MFMAs, behind an s_waitcnt — the matrix pipe drained for an LDS round
+        // trip every four MFMAs (profiles/r05p_pmc_train_gemm: 0.83 busy, 21 % of the wave cycles waiting)
+        float av[2][TN], bv[2][TK];
+        auto frag = [&](int j, int s) {
+#pragma unroll
+            for (int a = 0; a < TN; ++a) av[s][a] = A[2 * j * LDA + a * 32];
+#pragma unroll
+            for (int b = 0; b < TK; ++b) bv[s][b] = B[2 * j * LDB + b * 32];
+        };
+        frag(0, 0);
 #pragma unroll
         for (int j = 0; j < RS / 2; ++j) {
-            float av[TN], bv[TK];
-#pragma unroll
-            for (int a = 0; a < TN; ++a) av[a] = A[2 * j * LDA + a * 32];
-#pragma unroll
-            for (int b = 0; b < TK; ++b) bv[b] = B[2 * j * LDB + b * 32];
+            if (j + 1 < RS / 2) frag(j + 1, (j + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int a = 0; a < TN; ++a)
 #pragma unroll
-                for (int b = 0; b < TK; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+                for (int b = 0; b < TK; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j & 1][a], bv[j & 1][b], acc[a][b], 0, 0, 0);
             // the next sub-chunk goes to the OTHER buffer (free since the barrier that ended the previous iteration), one
             // piece behind each of the last MFMA steps: its global loads were issued RS/2 - NP steps ago
             if (j >= RS / 2 - NP) stage_piece(buf ^ 1, j - (RS / 2 - NP));
+            __builtin_amdgcn_sched_barrier(0);
         }
         g_lds_barrier();
         buf ^= 1;
