@@ -812,14 +812,22 @@ __global__ __launch_bounds__(256, 2) void linear_wgrad_kernel(const float* __res
         }
         const float* A = As(buf) + (half + sidx * (WG_KC / NS)) * WG_LD + wo + col;
         const float* B = Bs(buf) + (half + sidx * (WG_KC / NS)) * WG_LD + wi + col;
+        // the fragments of step j + 1 are requested before the MFMAs of step j (two register sets; see wgrad2_kernel, gemm_ops.hip)
+        float fa[2][2], fb[2][2];
+        fa[0][0] = A[0]; fa[0][1] = A[32]; fb[0][0] = B[0]; fb[0][1] = B[32];
 #pragma unroll
         for (int j = 0; j < WG_KC / 2 / NS; ++j) {
-            const float a0 = A[2 * j * WG_LD], a1 = A[2 * j * WG_LD + 32];
-            const float b0 = B[2 * j * WG_LD], b1 = B[2 * j * WG_LD + 32];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            const int s = j & 1;
+            if (j + 1 < WG_KC / 2 / NS) {
+                fa[s ^ 1][0] = A[2 * (j + 1) * WG_LD]; fa[s ^ 1][1] = A[2 * (j + 1) * WG_LD + 32];
+                fb[s ^ 1][0] = B[2 * (j + 1) * WG_LD]; fb[s ^ 1][1] = B[2 * (j + 1) * WG_LD + 32];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s][0], fb[s][0], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s][0], fb[s][1], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s][1], fb[s][0], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s][1], fb[s][1], acc[1][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (more) {
             wg_stage(As(buf ^ 1), t, sa);
