@@ -301,7 +301,9 @@ def test_hoisted_sa_level_training_equals_the_reference_op_sequence(dev, B, N, M
     (y2 * up).sum().backward()
     seen = {}
 
-    def close(p, q, name, tol=1.5e-5):                    # measured: 7.3e-6 at worst
+    def close(p, q, name, tol=3e-5):                      # measured: 6.8e-6 alone (six runs, the same digits every time); 1.7e-5 once inside
+        #                                                   the whole suite, in a weight gradient: the STOCK side picks its convolution-
+        #                                                   backward algorithm by what the process ran before (this side's kernels do not)
         err = float((p - q).abs().max()) / (float(q.abs().max()) + 1e-12)
         seen[name] = err
         assert err < tol, (name, err)
