@@ -493,24 +493,35 @@ __global__ __launch_bounds__(512, 1) void wgrad2_kernel(const float* __restrict_
         for (int b = 0; b < TK; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-    g32x4 sa[SA], sb[SB];
-    int va = 0, vb = 0;
+    // Rows in flight: sub-chunk k + 2 is requested at the top of iteration k into (na, nb) and handed over to (sa, sb) at the END of
+    // that iteration — a whole sub-chunk (16 MFMA steps, ~7 us) to arrive — from where iteration k + 1 stages it. With one register
+    // set (request at the top of the iteration that stages the rows from its 8th step on) the launch ran 1.6x slower on operands
+    // that come from HBM than on operands the producing GEMM left in the Infinity Cache: it was waiting for its rows.
+    g32x4 sa[SA], sb[SB], na[SA], nb[SB];
+    int va = 0, vb = 0, nva = 0, nvb = 0;
     auto fetch = [&](int rs0) {
-        va = 0; vb = 0;
+        nva = 0; nvb = 0;
 #pragma unroll
         for (int i = 0; i < SA; ++i) {
             const int row = rs0 + ra + i * RSA;
             const int rc = row < r_end ? row : r_end - 1;
-            if (row < r_end) va |= 1 << i;
-            sa[i] = g_load4(rz, (rc * ldz + o0 + 4 * qa) * 4, 0);
+            if (row < r_end) nva |= 1 << i;
+            na[i] = g_load4(rz, (rc * ldz + o0 + 4 * qa) * 4, 0);
         }
 #pragma unroll
         for (int i = 0; i < SB; ++i) {
             const int row = rs0 + rb + i * RSB;
             const int rc = row < r_end ? row : r_end - 1;
-            if (row < r_end) vb |= 1 << i;
-            sb[i] = g_load4(rxx, (rc * ldx + i0 + 4 * qb) * 4, 0);
+            if (row < r_end) nvb |= 1 << i;
+            nb[i] = g_load4(rxx, (rc * ldx + i0 + 4 * qb) * 4, 0);
         }
+    };
+    auto hand_over = [&]() {
+#pragma unroll
+        for (int i = 0; i < SA; ++i) sa[i] = na[i];
+#pragma unroll
+        for (int i = 0; i < SB; ++i) sb[i] = nb[i];
+        va = nva; vb = nvb;
     };
     // staging piece i < SA + SB of the fetched sub-chunk: one float4 of dZ (i < SA) or of X (deferred activation applied)
     auto stage_piece = [&](int buf, int i) {
@@ -532,12 +543,15 @@ __global__ __launch_bounds__(512, 1) void wgrad2_kernel(const float* __restrict_
     constexpr int NP = SA + SB;                                 // pieces per sub-chunk (4 .. 8), one behind each of the last j-steps
     static_assert(NP <= RS / 2, "one staging piece per MFMA step");
     fetch(r_begin);
+    hand_over();
+    fetch(r_begin + RS);                                        // past the end: clamped rows, zeroed when staged
 #pragma unroll
     for (int i = 0; i < NP; ++i) stage_piece(0, i);
+    hand_over();
     __syncthreads();
     int buf = 0;
     for (int rs0 = r_begin; rs0 < r_end; rs0 += RS) {
-        fetch(rs0 + RS);                                        // past the end: clamped rows, zeroed when staged
+        fetch(rs0 + 2 * RS);
         const float* A = As + buf * (RS * LDA) + half * LDA + wn * (32 * TN) + col;
         const float* B = Bs + buf * (RS * LDB) + half * LDB + wk * (32 * TK) + col;
         // the operand fragments of step j + 1 are requested BEFORE the MFMAs of step j (two register sets): left to itself hipcc
@@ -564,6 +578,7 @@ __global__ __launch_bounds__(512, 1) void wgrad2_kernel(const float* __restrict_
             if (j >= RS / 2 - NP) stage_piece(buf ^ 1, j - (RS / 2 - NP));
             __builtin_amdgcn_sched_barrier(0);
         }
+        hand_over();
         g_lds_barrier();
         buf ^= 1;
     }
