@@ -459,7 +459,9 @@ __global__ __launch_bounds__(256, 2) void rows_gemm_kernel(RowsGemmParams p) {
 // 128 x 64 = 8 accumulator tiles), each operand row is read once, 32-row sub-chunks double-buffered in LDS (one
 // barrier each). Partials per row chunk go to the workspace and are summed in chunk order by wgrad_finish_kernel.
 // ------------------------------------------------------------------------------------------
-template <int TN, int TK>   // wave tile (32 TN) x (32 TK); waves 2 (N) x 4 (K); block BN = 64 TN, BK = 128 TK
+// EXP (timing experiments of a -DPTT_GEMM_DEV build only, wrong results): 1 no staging writes in the loop, 2 no row requests in the
+// loop, 4 no barriers, 8 the fragments of step 0 for every step, 16 no partial stores
+template <int TN, int TK, int EXP = 0>   // wave tile (32 TN) x (32 TK); waves 2 (N) x 4 (K); block BN = 64 TN, BK = 128 TK
 __global__ __launch_bounds__(512, 1) void wgrad2_kernel(const float* __restrict__ dZ, int ldz, const float* __restrict__ X, int ldx,
                                                        int R, int Cout, int Cin, int nbk, int chunk_rows,
                                                        float* __restrict__ partial, const float* __restrict__ xa,
@@ -551,7 +553,7 @@ __global__ __launch_bounds__(512, 1) void wgrad2_kernel(const float* __restrict_
     __syncthreads();
     int buf = 0;
     for (int rs0 = r_begin; rs0 < r_end; rs0 += RS) {
-        fetch(rs0 + 2 * RS);
+        if (!(EXP & 2)) fetch(rs0 + 2 * RS);
         const float* A = As + buf * (RS * LDA) + half * LDA + wn * (32 * TN) + col;
         const float* B = Bs + buf * (RS * LDB) + half * LDB + wk * (32 * TK) + col;
         // the operand fragments of step j + 1 are requested BEFORE the MFMAs of step j (two register sets): left to itself hipcc
@@ -567,7 +569,7 @@ __global__ __launch_bounds__(512, 1) void wgrad2_kernel(const float* __restrict_
         frag(0, 0);
 #pragma unroll
         for (int j = 0; j < RS / 2; ++j) {
-            if (j + 1 < RS / 2) frag(j + 1, (j + 1) & 1);
+            if (j + 1 < RS / 2) frag((EXP & 8) ? 0 : j + 1, (j + 1) & 1);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int a = 0; a < TN; ++a)
@@ -575,11 +577,11 @@ __global__ __launch_bounds__(512, 1) void wgrad2_kernel(const float* __restrict_
                 for (int b = 0; b < TK; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j & 1][a], bv[j & 1][b], acc[a][b], 0, 0, 0);
             // the next sub-chunk goes to the OTHER buffer (free since the barrier that ended the previous iteration), one
             // piece behind each of the last MFMA steps: its global loads were issued RS/2 - NP steps ago
-            if (j >= RS / 2 - NP) stage_piece(buf ^ 1, j - (RS / 2 - NP));
+            if (!(EXP & 1) && j >= RS / 2 - NP) stage_piece(buf ^ 1, j - (RS / 2 - NP));
             __builtin_amdgcn_sched_barrier(0);
         }
-        hand_over();
-        g_lds_barrier();
+        if (!(EXP & 2)) hand_over();
+        if (!(EXP & 4)) g_lds_barrier();
         buf ^= 1;
     }
     // C/D layout: column (input channel) = lane & 31, row (output channel) = (reg & 3) + 8 (reg >> 2) + 4 half
@@ -592,7 +594,7 @@ __global__ __launch_bounds__(512, 1) void wgrad2_kernel(const float* __restrict_
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = o0 + wn * (32 * TN) + a * 32 + g_tile_row(r, half);
-                P[(size_t)co * Cin + ci] = acc[a][b][r];
+                if (!(EXP & 16) || r == 15) P[(size_t)co * Cin + ci] = acc[a][b][r];
             }
         }
 }
@@ -955,6 +957,22 @@ static int linear_wgrad2_run(const float* dZ, int ldz, const float* X, int ldx, 
         hipLaunchKernelGGL((wgrad2_kernel<TN_, TK_>), grid, dim3(512), lds, s, dZ, ldz, X, ldx, R, Cout, Cin, g.nbk, g.chunk_rows, \
                            static_cast<float*>(ws), x_scale, x_shift);                                                  \
     }
+#ifdef PTT_GEMM_DEV
+    if (const char* e = getenv("PTT_WG2_EXP")) {
+        const int x = atoi(e);
+#define PTT_WG2_EXP_CASE(X)                                                                                             \
+        if (x == X && g.TN == 4 && g.TK == 2) {                                                                         \
+            if ((rc = set_lds_limit(reinterpret_cast<const void*>(wgrad2_kernel<4, 2, X>), lds))) return rc;            \
+            hipLaunchKernelGGL((wgrad2_kernel<4, 2, X>), grid, dim3(512), lds, s, dZ, ldz, X_, ldx, R, Cout, Cin, g.nbk, g.chunk_rows, \
+                               static_cast<float*>(ws), x_scale, x_shift);                                              \
+            return check_launch("wgrad2_kernel(exp)");                                                                  \
+        }
+        const float* X_ = X;
+        PTT_WG2_EXP_CASE(1) PTT_WG2_EXP_CASE(2) PTT_WG2_EXP_CASE(3) PTT_WG2_EXP_CASE(4) PTT_WG2_EXP_CASE(7) PTT_WG2_EXP_CASE(8)
+        PTT_WG2_EXP_CASE(15) PTT_WG2_EXP_CASE(16) PTT_WG2_EXP_CASE(31)
+#undef PTT_WG2_EXP_CASE
+    }
+#endif
     PTT_WG2_CASE(4, 2) PTT_WG2_CASE(4, 1) PTT_WG2_CASE(2, 2) PTT_WG2_CASE(2, 1)
 #undef PTT_WG2_CASE
     if (dW) launch_wgrad_finish(static_cast<const float*>(ws), g.nchunks, (size_t)Cout * Cin, accumulate, dW, s);
