@@ -10,7 +10,8 @@ dev = torch.device("cuda:0")
 torch.manual_seed(1)
 model = build_network(ptt_model_cfg(), 1, StubDataset(training=True)).to(dev).train()
 tr = DataParallelTrainer(model, dev)
-batch = synthetic_train_batch(100, 48, dev)
+B = int(os.environ.get("PROBE_B", "48"))
+batch = synthetic_train_batch(100, B, dev)
 for _ in range(5):
     tr.step(batch)
 torch.cuda.synchronize()
