@@ -347,8 +347,10 @@ def linear(x, wpacked, cout, scale=None, shift=None, relu=False, residual=None, 
         if r2.stride(1) != 1:
             r2 = r2.contiguous()
     # above 8192 rows the persistent row GEMM is the faster launch where it takes the shape (12288 x 128 -> 128: 7.3 vs
-    # 9.2 us, 12288 x 256 -> 128: 11.0 vs 13.5; profiles/r03p_linear_infer_bench.log); below, the short-launch linear kernel
-    if (scale is None and rows > 8192 and x2.data_ptr() % 16 == 0 and o2.is_contiguous()
+    # 9.2 us, 12288 x 256 -> 128: 11.0 vs 13.5; profiles/r03p_linear_infer_bench.log); below, the short-launch linear kernel —
+    # except 256-column layers of 6144+ rows (fc2 and cov_final of 48 frames), which the row GEMM's 128-column workgroups of
+    # round 5 take faster: 6144 x 512 -> 256 18.7 vs 25.2 us, 6144 x 256 -> 256 11.1 vs 14.3 (1536 or 128 columns, 3072 rows: slower)
+    if (scale is None and (rows > 8192 or (rows >= 6144 and int(cout) == 256)) and x2.data_ptr() % 16 == 0 and o2.is_contiguous()
             and _lib.lib().ptt_rows_gemm_supported(rows, K, int(cout), x2.stride(0), int(cout))):
         with torch.cuda.device(x.device), _timed('ptt_linear_f32'):
             _lib.check(_lib.lib().ptt_rows_gemm_f32(_ptr(x2), rows, K, x2.stride(0), None, None, _ptr(wpacked), int(cout), _ptr(shift),
