@@ -1,7 +1,6 @@
 """The attention core of a Point-Transformer block in training mode as one autograd function (train_ops._AttnCore:
 ptt_rows_gemm_rsum16_f32, ptt_scatter_rows_csr_sub_f32) against the three-function form it replaces and against the reference's
 own op sequence (variants.py:149-165) in stock torch."""
-import numpy as np
 import pytest
 import torch
 

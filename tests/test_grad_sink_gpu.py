@@ -2,7 +2,6 @@
 ptt_grad_finish_f32 / ptt_linear_wgrad*_partials_f32 / ptt_colsum_partials_f32) against the per-weight finished form the
 functions return without a sink — what loss.backward() leaves in every .grad in the reference
 (tools/train_utils/train_utils.py:47-49)."""
-import numpy as np
 import pytest
 import torch
 
