@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PTT_ABI_VERSION 20
+#define PTT_ABI_VERSION 21
 
 enum {
     PTT_OK = 0,
@@ -834,6 +834,13 @@ int ptt_adam_chunk_elems(void);
 int ptt_adam_clip_step_f32(const ptt_adam_tensor* tensors_device, const int32_t* chunk_tensor_device, const int64_t* chunk_first_device,
                            int n_chunks, const ptt_adam_hyper* hyper, double* partial, size_t partial_elems, float* norm_out,
                            ptt_stream_t stream);
+/* The same two launches with the hyper-parameters read from DEVICE memory when the update launch runs: the form a captured
+ * training step (hipGraph) replays, the host writing step_size / bias2_sqrt (and a scheduler's lr) of the step into hyper_device
+ * before each replay. clip != 0: the norm pass is launched and hyper_device->max_norm (> 0) clips; clip == 0: hyper_device->max_norm
+ * must be <= 0. Arithmetic identical to ptt_adam_clip_step_f32. */
+int ptt_adam_clip_step_dev_f32(const ptt_adam_tensor* tensors_device, const int32_t* chunk_tensor_device, const int64_t* chunk_first_device,
+                               int n_chunks, const ptt_adam_hyper* hyper_device, int clip, double* partial, size_t partial_elems,
+                               float* norm_out, ptt_stream_t stream);
 /* The two element-wise ends of CosineSimAug's cosine map in training (p2b_xcoor.py:35-42 via nn.CosineSimilarity); the map
  * itself is a batched product of unit rows.
  *   ptt_unit_rows_f32     x addressed as x[b * sb + j * sn + c * sc] (any layout) -> unit (B,n,C) rows x / max(|x|, eps) and

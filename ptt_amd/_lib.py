@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libptt_hip.so")
 
 PTT_SA_MAX_LAYERS = 4
-ABI_VERSION = 20            # PTT_ABI_VERSION of include/ptt_hip.h these structures mirror
+ABI_VERSION = 21            # PTT_ABI_VERSION of include/ptt_hip.h these structures mirror
 
 # every symbol include/ptt_hip.h declares (tests check the library exports all of them)
 EXPORTS = [
@@ -41,7 +41,7 @@ EXPORTS = [
     "ptt_bn_stats_train_f32", "ptt_bn_finish_partials_train_f32", "ptt_pack_weights_f32",
     "ptt_sa_z0_rows_f32",
     "ptt_row_jobs_f32", "ptt_point_jobs_f32", "ptt_fps_ball_knn_f32", "ptt_crop_compact_host_f32", "ptt_crop_regularize_f32", "ptt_colsum_workspace", "ptt_colsum_f32", "ptt_rows_gemm_pool_supported", "ptt_rows_gemm_pool_f32", "ptt_pool_select_f32", "ptt_sa_z0_rows_stat_chunks", "ptt_sa_z0_rows_stats_f32",
-    "ptt_track_losses_f32", "ptt_track_losses_bwd_f32", "ptt_adam_chunk_elems", "ptt_adam_clip_step_f32",
+    "ptt_track_losses_f32", "ptt_track_losses_bwd_f32", "ptt_adam_chunk_elems", "ptt_adam_clip_step_f32", "ptt_adam_clip_step_dev_f32",
     "ptt_linear_wgrad_partials_f32", "ptt_linear_wgrad2_partials_f32", "ptt_colsum_partials_f32", "ptt_grad_finish_f32",
     "ptt_rows_gemm_rsum16_supported", "ptt_rows_gemm_rsum16_f32", "ptt_scatter_rows_csr_sub_f32",
     "ptt_unit_rows_f32", "ptt_cos_bwd_rows_f32", "ptt_track_select_update", "ptt_sa_z0_bnbwd_workspace", "ptt_sa_z0_bnbwd_f32",
@@ -214,6 +214,7 @@ def _declare(lib):
         "ptt_track_losses_f32": [vp, vp, vp, vp],
         "ptt_track_losses_bwd_f32": [vp, vp, vp, vp, vp, vp, vp],
         "ptt_adam_clip_step_f32": [vp, vp, vp, i, vp, vp, c_size_t, vp, vp],
+        "ptt_adam_clip_step_dev_f32": [vp, vp, vp, i, vp, i, vp, c_size_t, vp, vp],
         "ptt_unit_rows_f32": [vp, c_longlong, c_longlong, c_longlong, i, i, i, f, vp, vp, vp],
         "ptt_cos_bwd_rows_f32": [vp, vp, vp, vp, vp, c_longlong, c_longlong, c_longlong, i, i, i, i, vp, c_longlong, c_longlong, c_longlong, vp],
         "ptt_track_select_update": [vp, i, vp, vp, i, i, vp, vp, vp],

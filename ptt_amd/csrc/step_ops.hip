@@ -162,10 +162,15 @@ __global__ __launch_bounds__(256) void grad_sqsum_kernel(const ptt_adam_tensor* 
     if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// DEV: the hyper-parameters are read from device memory when the launch RUNS (a captured launch replays with the values of the
+// step it is replayed for); the arithmetic is the same either way.
+template <bool DEV>
 __global__ __launch_bounds__(256) void adam_update_kernel(const ptt_adam_tensor* __restrict__ tensors, const int32_t* __restrict__ tensor_of,
                                                           const int64_t* __restrict__ first, const double* __restrict__ partial, int n_partial,
-                                                          ptt_adam_hyper h, float* __restrict__ norm_out) {
+                                                          ptt_adam_hyper h_value, const ptt_adam_hyper* __restrict__ h_device,
+                                                          float* __restrict__ norm_out) {
 #pragma clang fp contract(off)
+    const ptt_adam_hyper h = DEV ? *h_device : h_value;
     __shared__ double red[4];
     __shared__ float clip_s;
     float clip = 1.f;
@@ -283,8 +288,25 @@ extern "C" int ptt_adam_clip_step_f32(const ptt_adam_tensor* tensors_device, con
         hipLaunchKernelGGL(grad_sqsum_kernel, dim3(n_chunks), dim3(256), 0, s, tensors_device, chunk_tensor_device, chunk_first_device, partial);
         if (int rc = check_launch("grad_sqsum_kernel")) return rc;
     }
-    hipLaunchKernelGGL(adam_update_kernel, dim3(n_chunks), dim3(256), 0, s, tensors_device, chunk_tensor_device, chunk_first_device, partial,
-                       n_chunks, *hyper, norm_out);
+    hipLaunchKernelGGL(adam_update_kernel<false>, dim3(n_chunks), dim3(256), 0, s, tensors_device, chunk_tensor_device, chunk_first_device,
+                       partial, n_chunks, *hyper, (const ptt_adam_hyper*)nullptr, norm_out);
+    return check_launch("adam_update_kernel");
+}
+
+extern "C" int ptt_adam_clip_step_dev_f32(const ptt_adam_tensor* tensors_device, const int32_t* chunk_tensor_device,
+                                          const int64_t* chunk_first_device, int n_chunks, const ptt_adam_hyper* hyper_device, int clip,
+                                          double* partial, size_t partial_elems, float* norm_out, ptt_stream_t stream) {
+    if (n_chunks < 0 || !hyper_device) return fail(PTT_EINVAL, "ptt_adam_clip_step_dev_f32: n_chunks=%d", n_chunks);
+    if (n_chunks == 0) return PTT_OK;
+    if (!tensors_device || !chunk_tensor_device || !chunk_first_device) return fail(PTT_EINVAL, "ptt_adam_clip_step_dev_f32: null table");
+    hipStream_t s = as_stream(stream);
+    if (clip) {
+        if (!partial || partial_elems < (size_t)n_chunks) return fail(PTT_EWORKSPACE, "ptt_adam_clip_step_dev_f32: %d partial sums needed", n_chunks);
+        hipLaunchKernelGGL(grad_sqsum_kernel, dim3(n_chunks), dim3(256), 0, s, tensors_device, chunk_tensor_device, chunk_first_device, partial);
+        if (int rc = check_launch("grad_sqsum_kernel")) return rc;
+    }
+    hipLaunchKernelGGL(adam_update_kernel<true>, dim3(n_chunks), dim3(256), 0, s, tensors_device, chunk_tensor_device, chunk_first_device,
+                       partial, n_chunks, ptt_adam_hyper{}, hyper_device, norm_out);
     return check_launch("adam_update_kernel");
 }
 

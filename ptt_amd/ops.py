@@ -1300,6 +1300,21 @@ def colsum_partials(x):
     return ws, nch.value
 
 
+_capture_uploads = []       # (device table, host contents) of launches recorded into a hipGraph, pending finish_capture_uploads()
+
+
+def finish_capture_uploads():
+    """After a stream capture ended: upload the device tables its launches read (their contents were only known while the
+    capture ran, and no host-to-device copy is recorded into the graph). Whoever captures a training step calls this before
+    the first replay; returns the tables (the caller keeps them alive with the graph)."""
+    done = []
+    while _capture_uploads:
+        table, host = _capture_uploads.pop(0)
+        table.copy_(host)
+        done.append(table)
+    return done
+
+
 class GradFinishPlan(object):
     """ptt_grad_finish_f32 over the contributions one backward pass left behind: `jobs` = [(dst, cols, ld, n, data_ptr, nchunks)] in the
     order they were issued (dst = first element inside the flat buffer; the n elements form rows of `cols` with row stride `ld`).
@@ -1309,7 +1324,15 @@ class GradFinishPlan(object):
     def __init__(self, device):
         self.device = torch.device(device)
         self.signature = None
+        self.capture_table = None
         self.uploaded = torch.cuda.Event()
+
+    def prepare_capture(self):
+        """Before a stream capture that will record run(): the job table of that capture (device + host side), allocated while
+        allocations are still ordinary ones."""
+        if self.signature is None:
+            raise RuntimeError("GradFinishPlan: a step must have run eagerly before it is captured")
+        self.capture_table = (torch.empty_like(self.table), torch.zeros(tuple(self.host.shape), dtype=torch.uint8))
 
     @staticmethod
     def _outputs_per_group(total_chunks):
@@ -1360,16 +1383,32 @@ class GradFinishPlan(object):
                 if n <= 0 or c <= 0 or n % c or l < c or nch <= 0 or d < 0 or d + (n // c - 1) * l + c > total:
                     raise ValueError("GradFinishPlan: job (dst %d, cols %d, ld %d, n %d, chunks %d) outside the %d-element buffer" % (d, c, l, n, nch, total))
             self._build(sig)
-        self.uploaded.synchronize()                            # the previous call's upload has left the pinned table
-        for r, k, vec in zip(self.rows, self.job_order, self.vec_jobs):
+        capturing = torch.cuda.is_current_stream_capturing()
+        if capturing:
+            # a launch recorded into a hipGraph: the partial sums live at the addresses of the graph's memory pool for as long as the
+            # graph does, so the table is written ONCE — into a table of the capture's own (a later eager run of this plan must not
+            # overwrite it), uploaded after the capture ends (finish_capture_uploads: no copy is recorded into the graph)
+            if sig != self.signature:
+                raise RuntimeError("GradFinishPlan: a step must have run eagerly before it is captured (the segment tables are built then)")
+            if self.capture_table is None:
+                raise RuntimeError("GradFinishPlan: prepare_capture() must be called before the stream starts capturing")
+            table, host = self.capture_table
+            self.capture_table = None
+            rows = (_lib.GradJob * len(self.job_order)).from_address(host.data_ptr())
+            _capture_uploads.append((table, host))
+        else:
+            self.uploaded.synchronize()                        # the previous call's upload has left the pinned table
+            rows, table = self.rows, self.table
+        for r, k, vec in zip(rows, self.job_order, self.vec_jobs):
             ptr = int(jobs[k][4])
             if vec and ptr % 16:
                 raise ValueError("GradFinishPlan: partial sums of a float4 segment must be 16-byte aligned")
             r.partial, r.nchunks = ptr, sig[k][4]
-        self.table.copy_(self.host, non_blocking=True)
-        self.uploaded.record()
+        if not capturing:
+            self.table.copy_(self.host, non_blocking=True)
+            self.uploaded.record()
         with torch.cuda.device(self.device):
-            _lib.check(_lib.lib().ptt_grad_finish_f32(_ptr(self.segs), _ptr(self.table), _ptr(self.blocks), self.n_blocks, _ptr(flat), _stream()),
+            _lib.check(_lib.lib().ptt_grad_finish_f32(_ptr(self.segs), _ptr(table), _ptr(self.blocks), self.n_blocks, _ptr(flat), _stream()),
                        "ptt_grad_finish_f32")
 
 
@@ -1860,13 +1899,56 @@ class AdamTable(object):
             self.table.copy_(self.host, non_blocking=True)
             self.uploaded.record()
             self.grad_ptrs = ptrs
-        h = _lib.AdamHyper(float(beta1), float(beta2), 1.0 - float(beta1), 1.0 - float(beta2), float(eps), float(step_size), float(bias2_sqrt), float(weight_decay), float(max_norm),
-                           1 if write_clipped else 0)
+        h = self.hyper(beta1, beta2, eps, step_size, bias2_sqrt, weight_decay, max_norm, write_clipped)
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().ptt_adam_clip_step_f32(_ptr(self.table), _ptr(self.which), _ptr(self.first), self.n_chunks, ctypes.byref(h),
                                                          _ptr(self.partial), self.partial.numel(), _ptr(self.norm), _stream()),
                        "ptt_adam_clip_step_f32")
         return self.norm
+
+    @staticmethod
+    def hyper(beta1, beta2, eps, step_size, bias2_sqrt, weight_decay=0.0, max_norm=0.0, write_clipped=True):
+        return _lib.AdamHyper(float(beta1), float(beta2), 1.0 - float(beta1), 1.0 - float(beta2), float(eps), float(step_size), float(bias2_sqrt),
+                              float(weight_decay), float(max_norm), 1 if write_clipped else 0)
+
+    def check_grads_in_place(self, grads):
+        """The table as uploaded addresses exactly these gradients (True once a step() saw them and they have not moved)."""
+        return self.grad_ptrs is not None and [g.data_ptr() for g in grads] == self.grad_ptrs
+
+    def step_device_hyper(self, hyper_device, clip):
+        """The two launches of step() with the hyper-parameters read from `hyper_device` (AdamHyperRing.dev) when they RUN: what
+        a captured training step records. The gradients are the ones the last step() uploaded (check_grads_in_place)."""
+        if self.grad_ptrs is None:
+            raise RuntimeError("AdamTable.step_device_hyper: step() must have run once (the gradient addresses are uploaded then)")
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().ptt_adam_clip_step_dev_f32(_ptr(self.table), _ptr(self.which), _ptr(self.first), self.n_chunks, _ptr(hyper_device),
+                                                             1 if clip else 0, _ptr(self.partial), self.partial.numel(), _ptr(self.norm), _stream()),
+                       "ptt_adam_clip_step_dev_f32")
+        return self.norm
+
+
+class AdamHyperRing(object):
+    """ptt_adam_hyper of the step about to be replayed, handed to the device: a ring of pinned host slots (the host may run
+    `slots` steps ahead of the device; the slot's previous upload is waited for before it is rewritten) copied into ONE device
+    struct on the stream the step runs on."""
+
+    def __init__(self, device, slots=64):
+        n = ctypes.sizeof(_lib.AdamHyper)
+        self.host = torch.zeros((slots, n), dtype=torch.uint8).pin_memory()
+        self.dev = torch.zeros((n,), dtype=torch.uint8, device=device)
+        self.events = [None] * slots
+        self.k = 0
+
+    def upload(self, h):
+        s = self.k % len(self.events)
+        if self.events[s] is not None:
+            self.events[s].synchronize()
+        ctypes.memmove(self.host[s].data_ptr(), ctypes.byref(h), ctypes.sizeof(_lib.AdamHyper))
+        self.dev.copy_(self.host[s], non_blocking=True)
+        ev = self.events[s] or torch.cuda.Event()
+        ev.record()
+        self.events[s] = ev
+        self.k += 1
 
 
 def unit_rows_eps(x, eps):

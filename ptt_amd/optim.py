@@ -28,6 +28,8 @@ class ClipAdam(torch.optim.Adam):
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad, foreach=True)
         self._tables = {}                 # group index -> (ids of the parameters in the table, ops.AdamTable)
         self.last_norm = None             # the total gradient norm of the last clipped step: a (1,) device tensor
+        self._ring = None                 # ops.AdamHyperRing of the captured form of the step
+        self._graph = None                # (group, params, table, step counters) pinned by prepare_graph_step()
 
     def _fusable(self, group, params):
         return (not group['amsgrad'] and not group.get('maximize', False) and not group.get('capturable', False)
@@ -83,6 +85,55 @@ class ClipAdam(torch.optim.Adam):
             _bump_versions(params)
         return loss
 
+    # ------------------------------------------------------------------ the step in two halves, for a captured training step
+    def _graph_table(self):
+        """(group, params, AdamTable) when the whole optimizer is ONE table that has already stepped eagerly (state, table and
+        gradient addresses exist) — the precondition of the captured form; None otherwise."""
+        if len(self.param_groups) != 1:
+            return None
+        group = self.param_groups[0]
+        params = [p for p in group['params'] if p.grad is not None]
+        cached = self._tables.get(0)
+        if not params or cached is None or not self._fusable(group, params):
+            return None
+        if cached[0] != tuple((id(p), p.data_ptr()) for p in params) or not cached[1].check_grads_in_place([p.grad for p in params]):
+            return None
+        return group, params, cached[1]
+
+    def prepare_graph_step(self):
+        """Before a capture: checks the one-table state and pins it (the per-step halves below do no checking of their own — they
+        run once per replay). False when the optimizer cannot take the captured form (it then steps eagerly)."""
+        hit = self._graph_table()
+        if hit is None:
+            self._graph = None
+            return False
+        group, params, table = hit
+        if self._ring is None:
+            self._ring = ops.AdamHyperRing(table.device)
+        self._graph = (group, params, table, [self.state[p]['step'] for p in params])
+        return True
+
+    def begin_graph_step(self, max_norm=None):
+        """Host half of a captured step, BEFORE the replay: the step counters advance and this step's hyper-parameters (the lr of
+        the moment, the bias corrections) go to the device struct the recorded launches read."""
+        group, params, table, steps = self._graph
+        torch._foreach_add_(steps, 1)
+        t = float(steps[0])
+        beta1, beta2 = group['betas']
+        self._ring.upload(table.hyper(beta1, beta2, group['eps'], float(group['lr']) / (1.0 - beta1 ** t), math.sqrt(1.0 - beta2 ** t),
+                                      group['weight_decay'], max_norm if max_norm is not None else 0.0))
+
+    def record_graph_step(self, max_norm=None):
+        """Device half: the two launches, reading the device struct (called while the stream is capturing)."""
+        table = self._graph[2]
+        norm = table.step_device_hyper(self._ring.dev, clip=max_norm is not None)
+        if max_norm is not None:
+            self.last_norm = norm
+
+    def end_graph_step(self):
+        """Host half AFTER the replay was queued: the parameters changed under autograd's feet."""
+        _bump_versions(self._graph[1])
+
     def _stock_group(self, group):
         saved = self.param_groups
         try:
@@ -93,4 +144,5 @@ class ClipAdam(torch.optim.Adam):
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
+        self._graph = None
         self._tables = {}                 # the moments are new tensors

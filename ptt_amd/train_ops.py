@@ -149,6 +149,66 @@ _pack_plans = {}       # device -> _PackPlan
 PACK_PLAN = True       # False: every weight packed by its own launch (development comparisons)
 
 
+_pack_capture = None    # the PackCapture of the training step being recorded into a hipGraph, else None
+
+
+class PackCapture(object):
+    """What `packed` answers while a training step is RECORDED into a hipGraph. The recorded step must depend on nothing the
+    eager code can change afterwards, and must leave nothing in the shared caches that only a replay fills in: so the capture gets
+    a job table of its own (built eagerly, before the stream starts capturing, from the views of `params` the device's plan has
+    seen) and a cache of its own. The first request records ONE ptt_pack_weights_f32 launch over that table — every replay re-packs
+    the weights of the moment — and later requests inside the capture are answered from it. Whoever owns the graph keeps this
+    object (table and arena) alive with it.
+
+        pc = PackCapture(model.parameters(), device)       # eager
+        with pc, torch.cuda.graph(g): ...                  # packed() goes through pc"""
+
+    def __init__(self, params, device):
+        ids = set(id(p) for p in params)
+        self.device = torch.device(device)
+        self.plan = _PackPlan()
+        shared = _pack_plans.get(self.device)
+        for ekey, (ref, elems) in (list(shared.entries.items()) if shared is not None else []):
+            if ekey[0] in ids and ref() is not None:
+                self.plan.entries[ekey] = [ref, elems]
+        self.plan._build(self.device)
+        self.cache, self.arena = {}, None
+
+    def __enter__(self):
+        global _pack_capture
+        if _pack_capture is not None:
+            raise RuntimeError("PackCapture: another capture is active")
+        _pack_capture = self
+        return self
+
+    def __exit__(self, *exc):
+        global _pack_capture
+        _pack_capture = None
+
+    def get(self, W, transpose):
+        base = W._base if W._base is not None else W
+        ekey = (id(base), W.data_ptr() - base.data_ptr(), tuple(W.shape), tuple(W.stride()), bool(transpose))
+        hit = self.cache.get(ekey)
+        if hit is not None:
+            return hit
+        if self.arena is None and self.plan.table is not None:
+            table, keys, _, total = self.plan.table
+            self.arena = ops.pack_weights(table, len(keys), torch.empty((total,), dtype=torch.float32, device=self.device))
+            off = 0
+            for k in keys:
+                elems = self.plan.entries[k][1]
+                self.cache[k] = self.arena[off:off + elems]
+                off += elems
+            hit = self.cache.get(ekey)
+            if hit is not None:
+                return hit
+        w = W.detach()                                           # a view the eager steps never asked for: its own launch
+        cout, k = (w.shape[1], w.shape[0]) if transpose else w.shape
+        so, sk = (w.stride(1), w.stride(0)) if transpose else (w.stride(0), w.stride(1))
+        hit = self.cache[ekey] = ops.pack_weight_strided(w, cout, k, so, sk, 1, 0)[0]
+        return hit
+
+
 def packed(W, transpose=False):
     """ops.pack_weight(W) (or of W^T) cached per weight VERSION on the PARAMETER the view belongs to: within one training step
     a weight is packed for its forward GEMM and, transposed, for its input gradient, and the search / template branches share
@@ -158,6 +218,8 @@ def packed(W, transpose=False):
     A miss on a view seen before re-packs every registered weight of the device in one launch (_PackPlan).
     What the key cannot see: an update made through `.data` (p.data.copy_(ema), fastai-style master copies) changes neither the
     version nor the address — call invalidate_packed() after such an update."""
+    if _pack_capture is not None:
+        return _pack_capture.get(W, transpose)
     base = W._base if W._base is not None else W
     slot = _pack_slot(base)
     off = (W.data_ptr() - base.data_ptr())

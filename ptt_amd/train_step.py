@@ -13,9 +13,20 @@ replicas) and tools/train_utils/train_utils.py:47-51 (model_func -> loss.backwar
 optimizer.step()), with the optimiser of tools/cfgs/kitti_models/ptt.yaml:129-133 (Adam, lr 1e-3, betas 0.5/0.999,
 eps 1e-6; ptt/optimization/__init__.py:12-14).
 
+On a HIP device with the flat reducer the step is CAPTURED after `graph_warmup` eager steps and replayed as hipGraphs from then
+on (`graph=None`, the default; `graph=False` keeps every step eager): forward + backward + the gradient-finishing launch as one
+graph, clip + Adam as a second, the all-reduce issued eagerly between the two (no collective is ever captured: the first run
+with more than one RCCL rank is the driver's, and a captured collective is the one thing that could not be tried here). Without
+a collective the two are ONE graph. Queuing a step then costs the host two replays instead of ~415 launches through Python and
+autograd (12.4 ms -> well under a millisecond), so that eight ranks no longer need eight busy cores and small per-GPU batches
+become device-bound. The replayed step is bit-identical to the eager one (tests/test_train_graph_gpu.py).
+
 The same class runs on `gloo` + CPU tensors in the tests (world_size 2) — there the HIP index ops are replaced by
 the tests' oracle, because the product ops refuse CPU tensors.
 """
+import os
+import warnings
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -39,6 +50,37 @@ def synthetic_train_batch(seed, B, device, NS=1024, NT=512, K_s=200, K_t=100):
     return {'search_points': to(s), 'template_points': to(t), 'batch_size': B, 'cls_label': to(cls), 'reg_label': to(reg)}
 
 
+class _CapturedStep(object):
+    """The hipGraphs of one training step for one batch shape, with the static tensors they read and write."""
+
+    def __init__(self, batch):
+        self.static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
+        self.signature = self._signature(batch)
+        self.first, self.second = torch.cuda.CUDAGraph(), None
+        self.loss, self.tables, self.optimizer_state, self.packs = None, None, None, None
+        self.loaded = {}                  # key -> (data_ptr, version) of the caller's tensor the static copy holds
+
+    @staticmethod
+    def _signature(batch):
+        return tuple(sorted((k, tuple(v.shape), str(v.dtype), str(v.device)) if torch.is_tensor(v) else (k, v) for k, v in batch.items()))
+
+    def accepts(self, batch):
+        return self._signature(batch) == self.signature
+
+    def valid(self, trainer):
+        return trainer.optimizer._graph is not None and trainer.optimizer._graph is self.optimizer_state
+
+    def load(self, batch):
+        """The batch into the static tensors the graphs read; a tensor that is the very one loaded last time, unmodified since
+        (same storage, same version counter), is not copied again."""
+        for k, v in batch.items():
+            if torch.is_tensor(v):
+                tag = (v.data_ptr(), v._version)
+                if self.loaded.get(k) != tag:
+                    self.static[k].copy_(v, non_blocking=True)
+                    self.loaded[k] = tag
+
+
 class DataParallelTrainer(object):
     """model (+ DDP when a process group with more than one rank is initialised) + Adam + gradient clipping.
 
@@ -47,8 +89,11 @@ class DataParallelTrainer(object):
     """
 
     def __init__(self, model, device, lr=1e-3, betas=(0.5, 0.999), eps=1e-6, clip=10.0, bucket_cap_mb=25, sync_bn=False, force_ddp=False,
-                 reducer=None):
-        """force_ddp: reduce the gradients over the process group whenever one is initialised, a ONE-rank group included (the
+                 reducer=None, graph=None, graph_warmup=3):
+        """graph: None = replay the step as hipGraphs where that is possible (HIP device, flat reducer, no SyncBatchNorm exchange;
+        anything else steps eagerly), True = the same but raise where it is not possible, False = always eager. graph_warmup:
+        eager steps before the capture (the plans, tables and workspaces of a step are built by them).
+        force_ddp: reduce the gradients over the process group whenever one is initialised, a ONE-rank group included (the
         all-reduce then runs on the device with one participant: how a one-GPU box exercises the multi-GPU code).
         reducer: "flat" (HIP devices, the default there) = train_ops.GradSink + one all-reduce over its buffer; "ddp" =
         DistributedDataParallel (the default, and the only choice, off the HIP device)."""
@@ -60,7 +105,8 @@ class DataParallelTrainer(object):
         if reducer not in ("flat", "ddp") or (reducer == "flat" and self.device.type != 'cuda'):
             raise ValueError("reducer: 'flat' (HIP device) or 'ddp'")
         self.reducer = reducer
-        self.collective = collective
+        self.collective = collective          # no_sync() switches this off for a scope
+        self._collective_cfg = collective     # what the trainer was built with (what a capture records)
         self.ddp = collective and reducer == "ddp"
         if sync_bn and self.world > 1:
             # tools/train_tracking.py:133-134 (--sync_bn). The SharedMLP stages keep running on the hand-written row
@@ -81,30 +127,135 @@ class DataParallelTrainer(object):
         if reducer == "flat":
             from .train_ops import GradSink
             self.sink = GradSink(list(self.model.parameters()), self.device)
+            if self.world > 1:
+                self.sync_replicas()
+        can_graph = reducer == "flat" and not (sync_bn and self.world > 1)
+        if graph and not can_graph:
+            raise ValueError("graph=True needs the flat reducer on a HIP device and no SyncBatchNorm exchange inside the step")
+        self.graph_mode = can_graph and graph is not False and os.environ.get("PTT_TRAIN_GRAPH", "1") != "0"
+        self.graph_warmup = max(1, int(graph_warmup))
+        self.eager_steps = 0
+        self.captured = None              # _CapturedStep once the step has been captured
+        self.graph_steps = 0
 
-    def forward_backward(self, batch):
-        """loss.mean() and its gradients (averaged over ranks); no optimiser step."""
+    def sync_replicas(self, buffers_only=False):
+        """Every parameter and buffer (BatchNorm running statistics, num_batches_tracked) takes rank 0's value — what
+        DistributedDataParallel does at construction, and for the buffers before every forward pass. The flat reducer calls it once
+        at construction, so that ranks which built their models under different seeds still train ONE model; afterwards the
+        parameters stay equal by construction (same averaged gradients, same update), while the running statistics are PER RANK
+        (each rank's own shard of the batches, as in the reference's unsynchronised `--launcher pytorch` replicas): call
+        sync_replicas(buffers_only=True) before evaluating or checkpointing from a rank other than 0 if that matters."""
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return
+        with torch.no_grad():
+            tensors = ([] if buffers_only else [p.data for p in self.tracker.parameters()]) + [b.data for b in self.tracker.buffers()]
+            by_type = {}
+            for t in tensors:
+                by_type.setdefault(t.dtype, []).append(t)
+            for ts in by_type.values():                       # one broadcast per dtype over a flattened copy
+                flat = torch.cat([t.reshape(-1) for t in ts])
+                dist.broadcast(flat, src=0)
+                off = 0
+                for t in ts:
+                    t.copy_(flat[off:off + t.numel()].view_as(t))
+                    off += t.numel()
+        if not buffers_only:
+            from . import train_ops
+            train_ops.invalidate_packed()                     # written through .data: the version counters did not move
+
+    def _local_forward_backward(self, batch):
+        """This rank's loss and gradients, finished into the sink's flat buffer (flat reducer only)."""
         ret, _, _ = self.model(dict(batch))
         loss = ret['loss'] if ret['loss'].dim() == 0 else ret['loss'].mean()
-        if self.sink is None:
-            self.optimizer.zero_grad(set_to_none=True)
-            loss.backward()
-            return loss
         with self.sink.collecting():
             loss.backward()
         self.sink.flush()
+        return loss
+
+    def _reduce(self):
+        # the mean over ranks, as DistributedDataParallel forms it: one all-reduce of the whole gradient
+        dist.all_reduce(self.sink.flat)
+
+    def forward_backward(self, batch):
+        """loss.mean() and its gradients (averaged over ranks); no optimiser step."""
+        if self.sink is None:
+            ret, _, _ = self.model(dict(batch))
+            loss = ret['loss'] if ret['loss'].dim() == 0 else ret['loss'].mean()
+            self.optimizer.zero_grad(set_to_none=True)
+            loss.backward()
+            return loss
+        loss = self._local_forward_backward(batch)
         if self.collective:
-            # the mean over ranks, as DistributedDataParallel forms it: one all-reduce of the whole gradient
-            dist.all_reduce(self.sink.flat)
+            self._reduce()
             if self.world > 1:
                 self.sink.flat.mul_(1.0 / self.world)
         return loss
 
     def step(self, batch):
+        """One training step; returns the loss (a 0-dim device tensor — in graph mode the SAME tensor every step, holding the
+        latest step's value once the device gets there)."""
+        if self.graph_mode:
+            if self.captured is not None and not self.captured.valid(self):
+                self.captured = None                          # e.g. optimizer.load_state_dict(): new moment tensors
+            if self.captured is None and self.eager_steps >= self.graph_warmup:
+                self._capture(batch)
+            if self.captured is not None and self.captured.accepts(batch):
+                return self._replay(batch)
         loss = self.forward_backward(batch)
         self.optimizer.step(max_norm=self.clip if self.clip else None)
         self.tracker.update_global_step()
+        self.eager_steps += 1
         return loss
+
+    # ------------------------------------------------------------------------------------------------ the captured step
+    def _capture(self, batch):
+        """Records the step for batches shaped like `batch` (other shapes keep stepping eagerly). Nothing is executed here: the
+        caller replays. A capture that fails turns graph mode off (with a warning) and the trainer continues eagerly."""
+        from . import ops, train_ops
+        if not self.optimizer.prepare_graph_step():
+            self.graph_mode = False
+            warnings.warn("DataParallelTrainer: the optimizer is not in the one-table state a captured step needs; stepping eagerly")
+            return
+        clip = self.clip if self.clip else None
+        cap = _CapturedStep(batch)
+        try:
+            # what the recorded launches read besides tensors of the step itself is built NOW, eagerly, and belongs to the capture:
+            # the finishing launch's job table and the weight-packing launch's table (nothing the eager code touches afterwards)
+            self.sink.plan.prepare_capture()
+            cap.packs = train_ops.PackCapture(list(self.model.parameters()), self.device)
+            torch.cuda.synchronize(self.device)
+            with cap.packs, torch.cuda.graph(cap.first):
+                cap.loss = self._local_forward_backward(cap.static)
+                if not self._collective_cfg:
+                    self.optimizer.record_graph_step(clip)
+            if self._collective_cfg:
+                cap.second = torch.cuda.CUDAGraph()
+                with cap.packs, torch.cuda.graph(cap.second, pool=cap.first.pool()):
+                    if self.world > 1:
+                        self.sink.flat.mul_(1.0 / self.world)
+                    self.optimizer.record_graph_step(clip)
+            cap.tables = ops.finish_capture_uploads()
+        except Exception as e:                                # noqa: BLE001 — whatever the runtime refuses, the eager step still works
+            ops.finish_capture_uploads()
+            self.graph_mode = False
+            warnings.warn("DataParallelTrainer: capturing the training step failed (%s: %s); stepping eagerly" % (type(e).__name__, e))
+            return
+        cap.optimizer_state = self.optimizer._graph
+        self.captured = cap
+
+    def _replay(self, batch):
+        cap = self.captured
+        cap.load(batch)
+        self.optimizer.begin_graph_step(self.clip if self.clip else None)
+        cap.first.replay()
+        if cap.second is not None:
+            if self.collective:                               # False inside no_sync(): a timing scope — the 1 / world scaling stays
+                self._reduce()
+            cap.second.replay()
+        self.optimizer.end_graph_step()
+        self.tracker.update_global_step()
+        self.graph_steps += 1
+        return cap.loss
 
     def no_sync(self):
         """Steps inside this scope keep their gradients local (DistributedDataParallel.no_sync(), or the flat reducer's
