@@ -135,7 +135,7 @@ def spawn_ranks(n):
         return launch(argv, False)[0]
     rc, line = launch(argv, True)
     # the DDP step of configs[3] on the same n ranks; a failure here must not take the headline line down
-    rc2, train = launch(["--gpus", str(n), "--workload", "train", "--steps", "5", "--warmup", "2", "--sustain", "0",
+    rc2, train = launch(["--gpus", str(n), "--workload", "train", "--steps", "10", "--warmup", "5", "--sustain", "0",
                          "--no-cpu-baseline", "--no-workloads"], True)
     if line is not None:
         if train is not None and rc2 == 0:
@@ -159,7 +159,7 @@ def pair_alg_bytes(B, N, k=16, D=512):
     return B * N * (3 * D * 4 + k * 16 + D * 4) + 3 * D * D * 4 + 6 * D * 4
 
 
-def hot_path_flops_per_frame(NPS, NPT, n_seeds):
+def hot_path_flops_per_frame(NPS, NPT, n_seeds, executed=False):
     """Algorithmic FLOPs of one frame of the hot path as the reference executes it (3.65 GFLOP of grouped
     MLPs + 5.24 GFLOP of transformer blocks at the shipped cfg): every SharedMLP layer on every (centre, neighbour)
     row, fc1 / q,k,v / fc2 per point and the three 512 x 512 layers per (point, neighbour) pair."""
@@ -170,6 +170,14 @@ def hot_path_flops_per_frame(NPS, NPT, n_seeds):
     mac += sa(64, 16, [259, 256, 256, 256])                                    # vote aggregation
     for N in (n_seeds, 64):                                                     # the two TransformerBlocks
         mac += N * (256 * 512 + 3 * 512 * 512 + 512 * 256) + N * 16 * (3 * 512 + 3 * 512 * 512)
+    if executed:
+        # what the kernels execute: layer 0 of every SA level that has features (SA1, SA2 of both branches, vote aggregation) is
+        # evaluated per POINT of the level below (C x Cout per point) plus the 3 relative coordinates per (centre, neighbour) row,
+        # instead of (3 + C) x Cout per row
+        def hoist(points, M, ns, cin, cout):
+            return M * ns * cin * cout - (points * (cin - 3) * cout + M * ns * 3 * cout)
+        mac -= sum(hoist(P[0], P[1], 32, specs[1][0], specs[1][1]) + hoist(P[1], P[2], 32, specs[2][0], specs[2][1]) for P in (NPS, NPT))
+        mac -= hoist(n_seeds, 64, 16, 259, 256)
     return 2.0 * mac
 
 
@@ -312,6 +320,9 @@ def main():
               file=sys.stderr)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # one process per GPU: each rank gets its own share of the host's cores (NUMA-local when sysfs tells), whoever launched it
+    from ptt_amd import affinity
+    bound = affinity.bind_rank(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     dist = None
     ranks_seen = 1
     if world > 1 or args.force_collective:
@@ -332,6 +343,8 @@ def main():
     env = dict(torch=torch, ops=ops, synth=synth, dev=dev, dist=dist, world=world, rank=rank, ranks_seen=ranks_seen, sync_all=sync_all,
                hp=(FrameHotPath, GraphedHotPath, InterleavedHotPath, PipelinedHotPath, TrackerThroughput, kitti_model_cfg, randomize_))
     out = run_workload(args, env)
+    out["cpu_affinity"] = ({"cores_per_rank": len(bound["cores"]), "rank0_cores": bound["cores"][:16], "numa_node": bound["numa_node"],
+                            "allowed": bound["allowed"]} if bound else {"bound": False, "allowed": len(os.sched_getaffinity(0))})
     # BASELINE.json configs[2], [4], [3] beside the headline: the default `python bench.py` line carries a short run of each
     # (value, ms_per_step, dominant-kernel roofline), so that one driver invocation observes every GPU config
     if (args.workload == "car" and world == 1 and not args.no_workloads and not args.serial and not args.no_graph
@@ -356,7 +369,7 @@ PROSE_KEYS = ("how", "split", "note", "traffic_note", "per_frame", "launch", "ti
 LINE_ORDER = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
               "data", "config", "roofline", "cpu_baseline", "speedup_vs_cpu_baseline", "rccl_ranks_seen", "latency_b1", "workloads",
               "sustained", "full_model", "whole_step", "index_ops", "loss", "grad_bytes_allreduced_per_step", "allreduce",
-              "kernel_ms_per_step")
+              "host_issue_ms_per_step", "small_batch", "cpu_affinity", "kernel_ms_per_step")
 LINE_LIMIT = 6144            # the driver keeps a tail of its child's stdout: the ONE line must fit it whole
 
 
@@ -407,9 +420,13 @@ def side_record(sub, name, process=None, wall_s=None):
             "grad_bytes_allreduced_per_step", "allreduce")
     rec = {k: sub[k] for k in keep if sub.get(k) is not None}
     r = sub.get("roofline") or {}
-    rec["roofline"] = {k: r.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms") if k in r}
+    rec["roofline"] = {k: r.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "alg_bytes", "traffic_over_alg_bytes") if k in r}
     if (sub.get("whole_step") or {}).get("frac_of_mfma_peak") is not None:
         rec["whole_step_frac_of_mfma_peak"] = sub["whole_step"]["frac_of_mfma_peak"]
+        rec["whole_step_frac_of_mfma_peak_executed"] = sub["whole_step"].get("frac_of_mfma_peak_executed")
+    for k in ("host_issue_ms_per_step", "small_batch", "cpu_affinity"):
+        if sub.get(k) is not None:
+            rec[k] = sub[k]
     rec["config"] = {"workload": sub["config"]["workload"], "name": name, "ref": WORKLOADS[name]["ref"]}
     if sub["config"].get("sharding") and name == "train":
         rec["config"]["sharding"] = sub["config"]["sharding"]
@@ -561,11 +578,16 @@ def run_infer(args, torch, ops, dev, dist, world, rank, ranks_seen, sync_all, B,
     # the whole step against the matrix roof: reference-algorithm FLOPs of B frames / step time. The hoisted layer 0 of
     # SA1 / SA2 / vote aggregation executes fewer FLOPs than the reference's per-row form, so this is an effective rate
     step_flops = B * hot_path_flops_per_frame(ps, pt, n_seeds)
+    exec_flops = B * hot_path_flops_per_frame(ps, pt, n_seeds, executed=True)
     whole_step = {"alg_gflop_per_frame": round(step_flops / B / 1e9, 3),
                   "achieved_tflops": round(step_flops * world / (elapsed / args.steps) / 1e12 / world, 2),
                   "frac_of_mfma_peak": round(step_flops / (elapsed / args.steps) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
-                  "note": "per GPU; reference-algorithm FLOPs (SURVEY.md 8d) over the timed step, index ops and launch gaps "
-                          "included; layer-0 hoisting executes ~10 % fewer FLOPs than counted"}
+                  "executed_gflop_per_frame": round(exec_flops / B / 1e9, 3),
+                  "frac_of_mfma_peak_executed": round(exec_flops / (elapsed / args.steps) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                  "note": "per GPU, index ops and launch gaps included. frac_of_mfma_peak divides the REFERENCE algorithm's FLOPs "
+                          "(SURVEY.md 8d) by the step time: an effective rate, not a hardware fraction; frac_of_mfma_peak_executed "
+                          "divides what the kernels execute (layer 0 of SA1 / SA2 / vote aggregation evaluated per point): "
+                          "what the hardware did"}
 
     solo = rank == 0 and world == 1
     note("%s: headline done (%.3f ms per step)" % (args.workload, ms_per_step))
@@ -731,6 +753,27 @@ def launches_per_frame(torch, dev, tracker, runner):
         return {"error": "%s: %s" % (type(e).__name__, e)}
 
 
+def train_alg_bytes(B, npoints_s=(512, 256, 128), npoints_t=(256, 128, 64), n_params=4903113):
+    """A denominator for the training step's HBM traffic: the bytes a step moves if every dense layer's output (the saved
+    activation) is written once and read once in the forward pass, read once more in the backward pass, and its gradient is
+    written once and read once (5 x 4 bytes per output element of every layer of SURVEY.md 8a's layer list + N1 + the heads),
+    plus the parameters: read by the forward and by the backward pass, gradient written, Adam's read of p, g, m, v and write of
+    p, m, v (10 x 4 bytes per parameter). Index tensors and coordinates are negligible beside it. Not a lower bound (a kernel that
+    fuses two layers moves less) — the figure `traffic` is to be read against."""
+    def sa(M, ns, couts, points=0):
+        return M * ns * sum(couts) + points * couts[0] + M * couts[-1]          # rows of the three layers, hoisted point term, pooled
+    def block(N, D=512, k=16):                                                  # TransformerBlock: per point + per (point, neighbour)
+        return N * (D + 3 * D + D + 256) + N * k * 6 * D                        # fc1, q|k|v, aggregate, fc2; delta0, delta, t, gamma0, gamma, attn
+    e = 0
+    for P, first in ((npoints_s, 0), (npoints_t, 0)):
+        e += sa(P[0], 32, (64, 64, 128)) + sa(P[1], 32, (128, 128, 256), P[0]) + sa(P[2], 32, (128, 128, 256), P[1]) + P[2] * 256
+    ns_, nt_ = npoints_s[2], npoints_t[2]
+    e += ns_ * nt_ * (1 + 3 * 256) + ns_ * 256 * 3                              # CosineSimAug: cosine map, SharedMLP over the map, pool + two Conv1d
+    e += block(ns_) + ns_ * (256 + 256 + 1 + 256 + 256 + 259)                   # centroid head
+    e += sa(64, 16, (256, 256, 256), ns_) + block(64) + 64 * (256 + 256 + 5)    # box head
+    return B * e * 4 * 5 + n_params * 4 * 10
+
+
 def train_roofline(achieved, flops, B, NS, NT):
     """The training step has no single dominant kernel: the roofline object is the whole step against the fp32-MFMA peak;
     `traffic` = HBM-side bytes of one step (every launch) from the committed PMC passes of scripts/pmc_train_step.sh, taken at the
@@ -738,10 +781,12 @@ def train_roofline(achieved, flops, B, NS, NT):
     r = {"kernel": "whole training step (no single dominant kernel)", "bound": "mfma", "achieved": round(achieved, 2),
          "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
          "alg_flops_per_step": flops, "timing": "wall clock of the timed steps (3 x 12.3 GFLOP per frame dense fp32)"}
+    r["alg_bytes"] = train_alg_bytes(B)
     if (B, NS, NT) == (48, 1024, 512):
         tr, src = committed_traffic("whole training step", "train_step")
         if tr is not None:
             r["traffic"], r["traffic_source"] = tr, src
+            r["traffic_over_alg_bytes"] = round(tr / r["alg_bytes"], 3)
     return r
 
 
@@ -760,6 +805,9 @@ def run_train(args, torch, dev, dist, world, rank, ranks_seen, sync_all, B, NS, 
     def step():
         last["loss"] = trainer.step(batch)
 
+    # the trainer captures the step after its first eager steps: the warm-up must reach the first REPLAY, so that the timed
+    # region holds replays only (the line reports the warm-up actually run)
+    args.warmup = max(args.warmup, trainer.graph_warmup + 2) if trainer.graph_mode else args.warmup
     for _ in range(args.warmup):
         step()
     elapsed = reduce_max(torch, dist, dev, timed_loop(step, args.steps, sync_all))
@@ -770,6 +818,31 @@ def run_train(args, torch, dev, dist, world, rank, ranks_seen, sync_all, B, NS, 
         sustained = {"steps": n_sus, "seconds": round(dt, 3), "value": round(B * world * n_sus / dt, 2),
                      "ms_per_step": round(dt / n_sus * 1e3, 4)}
     value = B * world * args.steps / elapsed
+    graphed = trainer.captured is not None
+
+    def host_issue(fn, n=20):
+        """Host time to QUEUE a step (n steps issued back to back, no synchronisation in between), per step."""
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        dt = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        return round(dt / n * 1e3, 4)
+    issue_ms = host_issue(step)
+    small = None
+    if world == 1 and not collective and B > 8 and (NS, NT) == (W["ns"], W["nt"]):
+        # 8 frames per GPU: the step the HOST used to bound (12.4 ms of Python / autograd per step whatever the batch)
+        torch.manual_seed(1)
+        m8 = build_network(ptt_model_cfg(), 1, StubDataset(training=True)).to(dev).train()
+        t8 = DataParallelTrainer(m8, dev)
+        b8 = synthetic_train_batch(100, 8, dev, NS, NT, K_s=W["K_s"], K_t=W["K_t"])
+        for _ in range(t8.graph_warmup + 2):
+            t8.step(b8)
+        dt8 = timed_loop(lambda: t8.step(b8), 50, sync_all)
+        small = {"frames_per_step": 8, "ms_per_step": round(dt8 / 50 * 1e3, 4), "value": round(8 * 50 / dt8, 2),
+                 "host_issue_ms_per_step": host_issue(lambda: t8.step(b8)), "launch": "hipGraph replay" if t8.captured is not None else "eager"}
+        del t8, m8
     allreduce = None
     if collective:
         # what the gradient all-reduce costs the step: the same steps with DDP's synchronisation switched off
@@ -798,8 +871,12 @@ def run_train(args, torch, dev, dist, world, rank, ranks_seen, sync_all, B, NS, 
                    "sample_detail": "%s; train mode (batch-statistics BatchNorm), Adam lr 1e-3 betas .5/.999 eps 1e-6, clip 10" % W["text"],
                    "name": "train", "frames_per_gpu_per_step": B, "search_points": NS, "template_points": NT,
                    "sharding": "batch across ranks, one gradient all-reduce per step over RCCL (%s)" % trainer.reducer if collective else "single rank, no collective",
-                   "launch": "eager"},
+                   "launch": ("hipGraph replay: forward + backward + gradient finish, %s" % (
+                       "the all-reduce issued between it and a second graph (clip + Adam)" if collective else "clip + Adam in the same graph")
+                       if graphed else "eager")},
         "rccl_ranks_seen": ranks_seen,
+        "host_issue_ms_per_step": issue_ms,
+        "small_batch": small,
         "roofline": train_roofline(achieved, flops, B, NS, NT),
         "cpu_baseline": None,
         "sustained": sustained,

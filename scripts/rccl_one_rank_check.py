@@ -32,10 +32,10 @@ def main():
     one = torch.ones(1, device=dev)
     dist.all_reduce(one)                                               # RCCL communicator creation + one collective
 
-    def run(force_ddp, steps, reducer="flat"):
+    def run(force_ddp, steps, reducer="flat", graph=None):
         torch.manual_seed(1)
         model = build_network(ptt_model_cfg(), 1, StubDataset(training=True)).to(dev).train()
-        trainer = DataParallelTrainer(model, dev, force_ddp=force_ddp, reducer=reducer)
+        trainer = DataParallelTrainer(model, dev, force_ddp=force_ddp, reducer=reducer, graph=graph)
         batch = synthetic_train_batch(100, 8, dev)
         trainer.forward_backward(batch)
         grads = {k: p.grad.detach().clone() for k, p in trainer.tracker.named_parameters() if p.grad is not None}
@@ -54,6 +54,10 @@ def main():
     t3, g3, p3, l3 = run(True, 2, "ddp")
     with t3.no_sync():
         t3.step(synthetic_train_batch(100, 8, dev))
+    # the CAPTURED step (two hipGraphs around the eager all-reduce) on the one-rank group against the eager, unwrapped trainer:
+    # seven steps = three eager ones, the capture, four replays
+    t4, _, p4, l4 = run(False, 7, graph=False)
+    t5, _, p5, l5 = run(True, 7, graph=True)
     gmax = max(float(v.abs().max()) for v in g0.values())
     flat_vs_ddp = max(float((g0[k] - g2[k]).abs().max()) / max(float(g2[k].abs().max()), 1e-3 * gmax) for k in g0)
     out = {"world": world, "ranks_seen": int(one.item()), "flat": t1.sink is not None and bool(t1.collective) and not t1.ddp,
@@ -63,6 +67,8 @@ def main():
            "params_bit_equal": all(torch.equal(p0[k], p1[k]) for k in p0) and all(torch.equal(p2[k], p3[k]) for k in p2),
            "flat_vs_ddp_max_rel": flat_vs_ddp,
            "n_grads": len(g1), "grad_bytes_allreduced_per_step": t1.grad_bytes_allreduced(), "expected_grad_bytes": GRAD_ELEMS * 4,
+           "graph_captured": t5.captured is not None and t5.captured.second is not None and t5.graph_steps == 4 and t4.captured is None,
+           "graph_params_bit_equal": all(torch.equal(p4[k], p5[k]) for k in p4) and l4 == l5,
            "loss_equal": l0 == l1 and l2 == l3, "loss": l1, "env": env_seen, "backend": dist.get_backend()}
     torch.cuda.synchronize()
     dist.destroy_process_group()

@@ -50,8 +50,12 @@ def test_headline_line_and_its_cpu_baseline():
 
 def test_training_line():
     d = _run("--workload", "train", "--steps", "2", "--warmup", "1", "--sustain", "0", "--no-cpu-baseline")
-    _contract(d, 2, 1)
+    _contract(d, 2, 5)                        # the warm-up is raised to reach the first replay of the captured step
     assert "forward + backward" in d["metric"] and d["ms_per_step"] < 100.0
+    assert d["config"]["launch"].startswith("hipGraph replay") and d["host_issue_ms_per_step"] < 2.0
+    assert d["small_batch"]["frames_per_step"] == 8 and d["small_batch"]["launch"] == "hipGraph replay" and d["small_batch"]["ms_per_step"] < 12.0
+    r = d["roofline"]
+    assert r["alg_bytes"] > 3e10 and (r["traffic"] is None or r["traffic"] > r["alg_bytes"])
 
 
 def _torchrun_one_rank(script, *flags):
@@ -77,7 +81,8 @@ def test_the_rccl_branches_of_the_training_line_run_at_world_size_one():
     no_sync() exposure measurement (tools/train_tracking.py:158-159, ptt/utils/common_utils.py:275-289)."""
     d = _torchrun_one_rank("bench.py", "--gpus", "1", "--workload", "train", "--steps", "2", "--warmup", "1", "--sustain", "0",
                            "--no-cpu-baseline", "--force-collective")
-    _contract(d, 2, 1)
+    _contract(d, 2, 5)
+    assert "second graph" in d["config"]["launch"]
     assert d["rccl_ranks_seen"] == 1 and d["grad_bytes_allreduced_per_step"] == 4903113 * 4
     a = d["allreduce"]
     assert a["ms_per_step_without_allreduce"] > 0 and abs(a["exposed_ms_per_step"]) < d["ms_per_step"]
@@ -90,6 +95,7 @@ def test_ddp_on_one_rccl_rank_is_bit_identical_to_the_unwrapped_trainer():
     d = _torchrun_one_rank("scripts/rccl_one_rank_check.py")
     assert d["backend"] == "nccl" and d["world"] == 1 and d["ranks_seen"] == 1 and d["flat"] and d["ddp"] and d["unwrapped_is_plain"]
     assert d["grad_keys_equal"] and d["grads_bit_equal"] and d["params_bit_equal"] and d["loss_equal"], d
+    assert d["graph_captured"] and d["graph_params_bit_equal"], d            # the captured step: two graphs around the eager all-reduce
     assert d["flat_vs_ddp_max_rel"] < 1e-5, d["flat_vs_ddp_max_rel"]
     assert d["grad_bytes_allreduced_per_step"] == d["expected_grad_bytes"] == 4903113 * 4
 
@@ -109,4 +115,8 @@ def test_the_default_line_fits_the_drivers_tail_and_carries_every_workload():
         w = d["workloads"][name]
         assert "error" not in w and w["value"] > 0 and 0 < w["roofline"]["frac"] < 1, (name, w)
     assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1
+    ws = d["whole_step"]                                                                 # what the hardware did, beside the effective rate
+    assert 0 < ws["frac_of_mfma_peak_executed"] < ws["frac_of_mfma_peak"] < 1 and ws["executed_gflop_per_frame"] < ws["alg_gflop_per_frame"]
+    t = d["workloads"]["train"]
+    assert t["roofline"]["alg_bytes"] > 3e10 and t["host_issue_ms_per_step"] < 2.0 and t["small_batch"]["ms_per_step"] > 0
     assert any(l.startswith("[bench detail] {") for l in p.stderr.splitlines())          # the prose went to stderr
