@@ -19,9 +19,15 @@
  *   FPS         PINNED by the reference's own numpy farthest-point sampling,
  *               ptt/utils/common_utils.py:78-112 (fps_downsample): fixture tests/golden/G11 holds its
  *               outputs on float32 clouds with duplicated points and exact distance ties (start index 0);
- *               oracle_fps equals them bit for bit (tests/test_oracle_cpu.py::test_G11_...). Not covered by
- *               that pin: the skip of points with |p|^2 <= 1e-3 (upstream CUDA behaviour; G11 is origin-free).
- *   ball query  PARITY UNPINNED (no reference-held source or vector).
+ *               oracle_fps equals them bit for bit (tests/test_oracle_cpu.py::test_G11_...). The skip of points with
+ *               |p|^2 <= 1e-3 (upstream CUDA behaviour) is pinned as far as the reference can: with such points in the cloud
+ *               oracle_fps selects what fps_downsample selects on the cloud WITHOUT them (fixture G17, 15 cases); that upstream
+ *               skips exactly that ball is restated from its published source, not reference-held.
+ *   ball query  the HIT SET is PINNED: for every centre of the nine (M, N, r, nsample) calls of fixture G17 (car / pedestrian /
+ *               all-zero clouds, 7808 centres) slots 0 .. min(count, nsample) - 1 are the points the reference's own fp32
+ *               square_distance (model_utils/layer_utils.py:12-26) places strictly inside r^2, ascending
+ *               (tests/test_oracle_cpu.py::test_G17_...). PARITY UNPINNED for the FILL RULE ONLY (remaining slots = the
+ *               first hit; no hit => zeros): upstream's documented behaviour, no reference-held source or vector.
  *   kNN, gather, group   pinned: tests/golden/make_golden.py checks them against the imported reference
  *               (torch argsort / the reference's own QueryAndGroup glue run on these ops).
  *

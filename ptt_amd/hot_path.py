@@ -93,11 +93,11 @@ class FrameHotPath(nn.Module):
         d = self._backbone(search_points, template_points, inds)
         seeds = d['search_seeds']
         fused = self.centroid_transformer(xyz=seeds, features=d['search_feats'].transpose(1, 2).contiguous(),
-                                          knn=d.pop('search_seeds_knn', None))[0]
+                                          knn=d.pop('search_seeds_knn', None), want_attn=False)[0]
         votes, votes_feats = self.bridge(seeds, fused)
         centres, prop_feats, _ = self.vote_aggregation(xyz=votes, features=votes_feats, npoint=self.npoints_box)
         box_feats = self.box_transformer(xyz=centres, features=prop_feats.transpose(1, 2).contiguous(),
-                                         knn=self.vote_aggregation.centres_knn)[0]
+                                         knn=self.vote_aggregation.centres_knn, want_attn=False)[0]
         d['centroid_feats'] = fused
         d['pred_box_center'] = centres
         d['box_feats'] = box_feats

@@ -10,10 +10,13 @@ so its checkpoints load unchanged.
 
 Eval mode on a HIP device runs four kernels: kNN, the q|k|v projection with fc1 folded in, the fused pair
 kernel (fc_delta[2], fc_gamma[0], fc_gamma[2] on fp32 MFMA + softmax + weighted sum, with every
-(B,N,k,d_model) intermediate kept in LDS/registers) and fc2+residual. The reference returns
-`(res, attn)`; both heads keep only `[0]` (centroids_voting_head.py:76, box_voting_head.py:86), so
-the (B,N,k,d_model) attention tensor is written to HBM only when `materialize_attn` is True —
-otherwise the second return value is None.
+(B,N,k,d_model) intermediate kept in LDS/registers) and fc2+residual.
+
+Return contract = the reference's (variants.py:165): `forward(xyz, features) -> (res, attn)` with attn the (B,N,k,d_model)
+attention tensor — ALWAYS, unless the CALLER opts out with `want_attn=False` (second value None; the tensor is then never
+written to HBM: 100 MB per 48 frames of 128 points). Who opts out: this build's own callers, which keep `[0]` only exactly as
+the reference's heads do (centroids_voting_head.py:76, box_voting_head.py:86) — ptt_amd's CentroidVotingHead / BoxVotingHead
+and hot_path.FrameHotPath. Anyone else calling the block as the reference does gets what the reference returns.
 """
 import numpy as np
 import torch
@@ -51,7 +54,6 @@ class TransformerBlock(nn.Module):
         self.k = k
         self.d_model = d_model
         self.d_points = d_points
-        self.materialize_attn = False
         self._cache = None
 
     # ---------------------------------------------------------------- fused-path parameters
@@ -99,9 +101,11 @@ class TransformerBlock(nn.Module):
         return P
 
     # xyz: b x n x 3, features: b x n x f
-    def forward(self, xyz, features, knn=None):
-        """`knn` (an extension of the reference signature, used on the fused path only): (knn_idx (B,N,k) int32, rel (B,N,k,3))
-        of `xyz` already formed by the caller — the backbone computes the seeds' neighbours beside its ball queries."""
+    def forward(self, xyz, features, knn=None, want_attn=True):
+        """-> (res (B,N,d_points), attn (B,N,k,d_model)), as the reference (variants.py:149-165). Extensions of its signature:
+        `knn` (used on the fused path only): (knn_idx (B,N,k) int32, rel (B,N,k,3)) of `xyz` already formed by the caller — the
+        backbone computes the seeds' neighbours beside its ball queries; `want_attn=False`: the caller keeps `[0]` only, attn is
+        None and never leaves the chip."""
         if self._fusable(xyz, features):
             P = self._params()
             D = self.d_model
@@ -110,7 +114,7 @@ class TransformerBlock(nn.Module):
                 knn_idx, rel = knn
             else:
                 knn_idx, rel = ops.knn(xyz, self.k, want_rel=True)
-            if xyz.shape[0] * xyz.shape[1] <= PER_LAYER_MAX_POINTS and not self.materialize_attn:
+            if xyz.shape[0] * xyz.shape[1] <= PER_LAYER_MAX_POINTS and not want_attn:
                 # a handful of frames (one tracklet frame: 128 / 64 points): the fused pair kernel's one workgroup per two
                 # points is a 64-workgroup launch of three chained 512 x 512 GEMMs (106 us on 64 of the 256 CUs). Per layer,
                 # each GEMM over the (point, neighbour) rows fills the chip, and the element-wise steps between them ride in
@@ -138,21 +142,21 @@ class TransformerBlock(nn.Module):
                 return out, None
             qkv = ops.linear(features, P['qkv'], 3 * D, None, P['qkv_b'])
             if xyz.shape[0] * xyz.shape[1] <= PER_LAYER_MAX_POINTS:
-                # the same per-layer form with the (B,N,k,D) attention tensor written out (materialize_attn)
+                # the same per-layer form with the (B,N,k,D) attention tensor written out
                 pairs = rel.view(-1, 3)
                 h = ops.linear(pairs, P['wd1_lin'], D, None, P['bd1'], relu=True)
                 pos = ops.linear(h, P['wd2'], D, None, P['bd2']).view(xyz.shape[0], xyz.shape[1], self.k, D)
                 t = ops.pt_pair_input_qkv(qkv, knn_idx, pos, D)
                 g = ops.linear(t.view(-1, D), P['wg1'], D, None, P['bg1'], relu=True)
                 a = ops.linear(g, P['wg2'], D, None, P['bg2']).view_as(t)
-                res, attn = ops.pt_attn_fwd_qkv(a, qkv, knn_idx, pos, D, 1.0 / np.sqrt(D), self.materialize_attn)
+                res, attn = ops.pt_attn_fwd_qkv(a, qkv, knn_idx, pos, D, 1.0 / np.sqrt(D), want_attn)
             else:
                 # many points per cloud: the workgroups take them along a space-filling curve, so that those running together
                 # gather k | v rows of the same neighbourhood out of L2 (FPS order = far apart: ~10x the compulsory HBM reads
                 # at 2048 points); the k | v rows of a 128-point cloud fit L2 whole
                 order = ops.spatial_order(xyz) if SPATIAL_ORDER_MIN_POINTS <= xyz.shape[1] <= 8192 else None
                 res, attn = ops.pt_attn_pair(xyz, knn_idx, qkv, P['wd1'], P['wd2'], P['bd2'], P['wg1'],
-                                             P['bg1'], P['wg2'], P['bg2'], D, self.materialize_attn, rel=rel, order=order)
+                                             P['bg1'], P['wg2'], P['bg2'], D, want_attn, rel=rel, order=order)
             res = ops.linear(res, P['fc2'], self.d_points, None, P['fc2_b'], False, features)
             return res, attn
 
@@ -253,8 +257,9 @@ class TransformerBlockSTD(nn.Module):
         self._cache = (key, P)
         return P
 
-    def forward(self, xyz, features, knn=None):
-        # `knn`: the callers hand every block the neighbour table formed beside their sampling; full attention has no use for it
+    def forward(self, xyz, features, knn=None, want_attn=True):
+        # `knn`: the callers hand every block the neighbour table formed beside their sampling; full attention has no use for it.
+        # `want_attn`: accepted for the callers' sake; the (B,N,N) attention matrix exists either way and is always returned
         if self._fusable(xyz, features):
             P, D = self._params(), self.d_model
             B, N, _ = xyz.shape

@@ -94,7 +94,7 @@ class BoxVotingHead(VotingHeadTemplate):
             # the layout the caller wants
             rows = feats.transpose(1, 2)                                                         # (B,M,C)
             if hasattr(self, 'transformer_block'):
-                rows = self.transformer_block(xyz=centres, features=rows.contiguous(), knn=self.vote_aggregation.centres_knn)[0]
+                rows = self.transformer_block(xyz=centres, features=rows.contiguous(), knn=self.vote_aggregation.centres_knn, want_attn=False)[0]
             if not self.training and self._one_frame(rows):
                 # a handful of frames: one ptt_row_jobs_f32 launch per refine convolution, the last one adding the proposal
                 # centres to its first three columns (reference :91) and writing pred_box_data directly
@@ -127,7 +127,7 @@ class BoxVotingHead(VotingHeadTemplate):
                 self._train_labels(batch_dict, centres)
             return batch_dict
         if hasattr(self, 'transformer_block'):
-            fused = self.transformer_block(xyz=centres, features=feats.transpose(1, 2).contiguous())[0]
+            fused = self.transformer_block(xyz=centres, features=feats.transpose(1, 2).contiguous(), want_attn=False)[0]
             feats = fused.transpose(1, 2).contiguous()
 
         offsets = self.refine_layer(feats)                                                       # (B,5,M)

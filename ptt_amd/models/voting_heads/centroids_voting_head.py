@@ -75,7 +75,7 @@ class CentroidVotingHead(VotingHeadTemplate):
         seeds = batch_dict['search_seeds']                                        # (B,N,3)
         rows = batch_dict['cosine_feats'].transpose(1, 2)                         # (B,N,C)
         if hasattr(self, 'transformer_block'):
-            rows = self.transformer_block(xyz=seeds, features=rows.contiguous())[0]
+            rows = self.transformer_block(xyz=seeds, features=rows.contiguous(), want_attn=False)[0]
         with_xyz = torch.cat((seeds, rows), dim=2)                                # (B,N,3+C)
         cls_in = with_xyz if getattr(self.model_cfg, 'CLS_USE_SEARCH_XYZ', False) else rows
         cls_out = self._stack(self.cla_layer, cls_in).squeeze(-1)                 # (B,N)
@@ -104,7 +104,7 @@ class CentroidVotingHead(VotingHeadTemplate):
         knn = batch_dict.pop('search_seeds_knn', None)                            # formed by the backbone beside its ball queries
         rows = batch_dict['cosine_feats'].transpose(1, 2).contiguous()            # (B,N,C): a view of point-major storage
         if hasattr(self, 'transformer_block'):
-            rows = self.transformer_block(xyz=seeds, features=rows, knn=knn)[0]
+            rows = self.transformer_block(xyz=seeds, features=rows, knn=knn, want_attn=False)[0]
         B, N, C = rows.shape
         dev = rows.device
         cls_xyz = getattr(self.model_cfg, 'CLS_USE_SEARCH_XYZ', False)
@@ -160,7 +160,7 @@ class CentroidVotingHead(VotingHeadTemplate):
 
         if hasattr(self, 'transformer_block'):
             fused = self.transformer_block(xyz=batch_dict['search_seeds'],
-                                           features=feats.transpose(1, 2).contiguous())[0]
+                                           features=feats.transpose(1, 2).contiguous(), want_attn=False)[0]
             feats = fused.transpose(1, 2).contiguous()
 
         if getattr(self.model_cfg, 'CLS_USE_SEARCH_XYZ', False):

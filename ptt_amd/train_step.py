@@ -137,6 +137,7 @@ class DataParallelTrainer(object):
         self.eager_steps = 0
         self.captured = None              # _CapturedStep once the step has been captured
         self.graph_steps = 0
+        self._capture_misses = 0
 
     def sync_replicas(self, buffers_only=False):
         """Every parameter and buffer (BatchNorm running statistics, num_batches_tracked) takes rank 0's value — what
@@ -213,9 +214,13 @@ class DataParallelTrainer(object):
         caller replays. A capture that fails turns graph mode off (with a warning) and the trainer continues eagerly."""
         from . import ops, train_ops
         if not self.optimizer.prepare_graph_step():
-            self.graph_mode = False
-            warnings.warn("DataParallelTrainer: the optimizer is not in the one-table state a captured step needs; stepping eagerly")
+            # e.g. right after optimizer.load_state_dict(): the next eager step rebuilds the optimizer's table, then this succeeds
+            self._capture_misses += 1
+            if self._capture_misses > 3:
+                self.graph_mode = False
+                warnings.warn("DataParallelTrainer: the optimizer is not in the one-table state a captured step needs; stepping eagerly")
             return
+        self._capture_misses = 0
         clip = self.clip if self.clip else None
         cap = _CapturedStep(batch)
         try:

@@ -327,3 +327,37 @@ def test_ctypes_structures_match_the_c_header(tmp_path):
         assert int(got[cname]) == ctypes.sizeof(st), (cname, got[cname], ctypes.sizeof(st))
         for fname, *_ in st._fields_:
             assert int(got["%s.%s" % (cname, fname)]) == getattr(st, fname).offset, (cname, fname)
+
+
+def _g17_check_ball(idx, cnt, first, tag):
+    """idx (B,M,ns) against fixture G17: slots 0 .. min(count, ns) - 1 = the reference's ascending in-ball list; the remaining slots
+    hold the first hit (zeros when the ball is empty) — upstream's fill rule, the part only this build's restatement states."""
+    ns = idx.shape[-1]
+    c = np.minimum(cnt, ns)
+    slot = np.arange(ns)[None, None, :]
+    pinned = slot < c[:, :, None]
+    assert np.array_equal(idx[pinned], first[pinned]), tag
+    fill = np.where(cnt[:, :, None] > 0, first[:, :, :1], 0)
+    assert np.array_equal(idx[~pinned], np.broadcast_to(fill, idx.shape)[~pinned]), tag + " (fill rule)"
+    return int(pinned.sum())
+
+
+def test_G17_oracle_ball_query_hits_are_the_references_square_distance_hits():
+    """The one reference-held statement about ball query: which points lie inside the ball under the reference's own fp32
+    square_distance (layer_utils.py:12-26), in ascending order — for the nine (M, N, r, nsample) calls of fixture G17."""
+    g = _g("G17_ball_hits_origin_fps.npz")
+    pinned = 0
+    for name in [str(n) for n in g["ball_cases"]]:
+        xyz, sel = g[name + "_xyz"], g[name + "_sel"]
+        r, ns = float(g[name + "_rn"][0]), int(g[name + "_rn"][1])
+        centres = np.take_along_axis(xyz, sel[:, :, None].astype(np.int64), 1)
+        pinned += _g17_check_ball(O.ball_query(centres, xyz, r, ns), g[name + "_count"], g[name + "_first"], name)
+    assert pinned > 50000
+
+
+def test_G17_oracle_fps_with_origin_ball_points_is_the_references_fps_on_the_kept_points():
+    g = _g("G17_ball_hits_origin_fps.npz")
+    for ci, m in g["fps_cases"]:
+        pts = g["fps_cloud_%d" % ci]
+        np.testing.assert_array_equal(O.fps(pts[None], int(m))[0], g["fps_idx_%d_%d" % (ci, m)], err_msg="cloud %d npoint %d" % (ci, m))
+    assert len(g["fps_cases"]) == 15
