@@ -11,6 +11,7 @@
 // BatchNorm+ReLU of the producing layer applied in registers on the way), weight fragments stream from L2 two K-blocks
 // ahead and across unit boundaries, ONE workgroup barrier per unit (LDS traffic only: global loads stay in flight across
 // it). Same operand layouts as mfma_ops.hip: packed weights [K/8][N/32][64 lanes][4], LDS row stride == 4 (mod 8) floats.
+#include <atomic>
 #include <math.h>
 #include <stdlib.h>
 #include <type_traits>
@@ -602,14 +603,19 @@ __global__ __launch_bounds__(512, 1) void wgrad2_kernel(const float* __restrict_
 // the fixed-order sum over row chunks (train_ops.hip)
 void launch_wgrad_finish(const float* partial, int nchunks, size_t n, int accumulate, float* dW, hipStream_t s);
 
+// Compute units of the CURRENT device, cached per device ordinal (a process may drive several device models; the launch shape —
+// and with it the K-summation order of a 256-column layer — follows the device the launch goes to: results are bit-reproducible per
+// device model).
 static int cu_count() {
-    static int n = 0;
+    constexpr int MAX_DEV = 64;
+    static std::atomic<int> cached[MAX_DEV];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return 256;
+    int n = cached[dev].load(std::memory_order_relaxed);
     if (n == 0) {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
-            n = v;
-        else
-            n = 256;
+        int v = 0;
+        n = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+        cached[dev].store(n, std::memory_order_relaxed);
     }
     return n;
 }

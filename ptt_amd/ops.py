@@ -1361,6 +1361,13 @@ class GradFinishPlan(object):
             units = n // 4 if vec else n
             for u in range(0, units, out):
                 blocks += [si, u]
+        # two segments may not touch the same elements: the launch adds into flat[] without atomics, one workgroup per slice of
+        # a segment (e.g. a weight used whole in one branch and through a column slice in another: not a layout this plan takes)
+        spans = sorted((dst, dst + (n // cols - 1) * ld + cols, cols, ld) for dst, cols, ld, n in order)
+        for (a0, a1, ac, al), (b0, b1, bc, bl) in zip(spans, spans[1:]):
+            if b0 < a1 and not (al == bl and (b0 - a0) % al >= ac and (b0 - a0) % al + bc <= al):
+                raise ValueError("GradFinishPlan: two gradient destinations overlap inside the flat buffer "
+                                 "(elements %d..%d and %d..%d): the same parameter was handed over both whole and as a slice" % (a0, a1, b0, b1))
         self.vec_jobs = [bool(segs[si].vec) for si, key in enumerate(order) for _ in by_dst[key]]
         self.n_blocks = len(blocks) // 2
         self.segs = torch.frombuffer(bytearray(bytes(segs)), dtype=torch.uint8).to(self.device)

@@ -287,6 +287,10 @@ class GradSink(object):
     gradient, no autograd add for the weights the search and template branches share, no concatenation of column-slice
     gradients (~120 launches of a 530-launch step). The sum per parameter runs in the order the contributions were issued — a
     step stays bit-reproducible. Without an active sink every function returns finished gradient tensors as before.
+    A parameter that received no gradient in a step holds ZEROS afterwards (its view of the zeroed buffer), not None — what
+    DistributedDataParallel leaves as well, and unlike zero_grad(set_to_none=True): an optimizer sees it (Adam's moments decay, a
+    weight decay would apply). Every parameter of the shipped tracker receives a gradient every step. One backward pass at a time
+    is collected per process (`active` is process-wide: the autograd engine's worker thread must see it).
 
         sink = GradSink(model.parameters(), device)        # sets p.grad = views of sink.flat
         with sink.collecting():                            # sink.flat was zeroed: gradients autograd forms itself add in place
@@ -302,6 +306,8 @@ class GradSink(object):
         for p in self.params:
             if not (p.is_cuda and p.device == self.device and p.dtype == torch.float32 and p.is_contiguous()):
                 raise ValueError("GradSink: contiguous float32 parameters on %s expected" % self.device)
+            if p.data_ptr() in self.index:
+                raise ValueError("GradSink: two parameters share storage (tied weights): their gradients cannot be told apart by address")
             self.index[p.data_ptr()] = (off, p.numel())
             off += (p.numel() + 3) // 4 * 4                      # every parameter starts on a 16-byte boundary
         self.flat = torch.zeros((max(off, 4),), dtype=torch.float32, device=self.device)

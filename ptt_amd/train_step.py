@@ -50,6 +50,28 @@ def synthetic_train_batch(seed, B, device, NS=1024, NT=512, K_s=200, K_t=100):
     return {'search_points': to(s), 'template_points': to(t), 'batch_size': B, 'cls_label': to(cls), 'reg_label': to(reg)}
 
 
+def broadcast_module_state(module, buffers_only=False, src=0):
+    """Parameters (unless buffers_only) and buffers of `module` on every rank := rank `src`'s, one broadcast per dtype over a
+    flattened copy. No-op without a process group of more than one rank."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    with torch.no_grad():
+        tensors = ([] if buffers_only else [p.data for p in module.parameters()]) + [b.data for b in module.buffers()]
+        by_type = {}
+        for t in tensors:
+            by_type.setdefault(t.dtype, []).append(t)
+        for ts in by_type.values():
+            flat = torch.cat([t.reshape(-1) for t in ts])
+            dist.broadcast(flat, src=src)
+            off = 0
+            for t in ts:
+                t.copy_(flat[off:off + t.numel()].view_as(t))
+                off += t.numel()
+    if not buffers_only:
+        from . import train_ops
+        train_ops.invalidate_packed()                     # written through .data: the version counters did not move
+
+
 class _CapturedStep(object):
     """The hipGraphs of one training step for one batch shape, with the static tensors they read and write."""
 
@@ -146,23 +168,7 @@ class DataParallelTrainer(object):
         parameters stay equal by construction (same averaged gradients, same update), while the running statistics are PER RANK
         (each rank's own shard of the batches, as in the reference's unsynchronised `--launcher pytorch` replicas): call
         sync_replicas(buffers_only=True) before evaluating or checkpointing from a rank other than 0 if that matters."""
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-            return
-        with torch.no_grad():
-            tensors = ([] if buffers_only else [p.data for p in self.tracker.parameters()]) + [b.data for b in self.tracker.buffers()]
-            by_type = {}
-            for t in tensors:
-                by_type.setdefault(t.dtype, []).append(t)
-            for ts in by_type.values():                       # one broadcast per dtype over a flattened copy
-                flat = torch.cat([t.reshape(-1) for t in ts])
-                dist.broadcast(flat, src=0)
-                off = 0
-                for t in ts:
-                    t.copy_(flat[off:off + t.numel()].view_as(t))
-                    off += t.numel()
-        if not buffers_only:
-            from . import train_ops
-            train_ops.invalidate_packed()                     # written through .data: the version counters did not move
+        broadcast_module_state(self.tracker, buffers_only)
 
     def _local_forward_backward(self, batch):
         """This rank's loss and gradients, finished into the sink's flat buffer (flat reducer only)."""

@@ -111,3 +111,51 @@ def test_two_rank_gloo_ddp_gradients_are_the_mean_of_the_ranks(monkeypatch):
     for k in got[0][2]:
         assert np.array_equal(got[0][2][k], got[1][2][k]), k
     assert np.isfinite(got[0][0]) and np.isfinite(got[1][0])
+
+
+def _sync_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ptt_amd.train_step import broadcast_module_state
+    torch.manual_seed(1000 + rank)                          # ranks that did NOT seed alike
+    m = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.BatchNorm1d(5), torch.nn.Linear(5, 3))
+    m.train()
+    m(torch.randn(16, 7))                                   # running statistics and the batch counter move, differently per rank
+    for _ in range(rank):
+        m(torch.randn(16, 7))
+    before = {k: v.numpy().copy() for k, v in m.state_dict().items()}
+    broadcast_module_state(m, buffers_only=True)
+    mid = {k: v.numpy().copy() for k, v in m.state_dict().items()}
+    broadcast_module_state(m)
+    after = {k: v.numpy().copy() for k, v in m.state_dict().items()}
+    q.put((rank, before, mid, after))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_replicas_built_under_different_seeds_take_rank_zeros_parameters_and_buffers():
+    """What the flat reducer does at construction in place of DistributedDataParallel's initial broadcast (train_step.
+    DataParallelTrainer.sync_replicas): two gloo ranks seed differently; afterwards every parameter and buffer (the int64 batch
+    counter included) is rank 0's."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sync_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(2):
+        rank, before, mid, after = q.get(timeout=300)
+        got[rank] = (before, mid, after)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    b0, b1 = got[0][0], got[1][0]
+    assert not np.array_equal(b0["0.weight"], b1["0.weight"]) and b0["1.num_batches_tracked"] != b1["1.num_batches_tracked"]
+    # buffers_only: the statistics are rank 0's, the parameters still each rank's own
+    assert np.array_equal(got[1][1]["1.running_mean"], b0["1.running_mean"]) and got[1][1]["1.num_batches_tracked"] == b0["1.num_batches_tracked"]
+    assert np.array_equal(got[1][1]["0.weight"], b1["0.weight"])
+    for k in b0:                                            # everything: rank 0 unchanged, rank 1 == rank 0
+        assert np.array_equal(got[0][2][k], b0[k]) and np.array_equal(got[1][2][k], b0[k]), k

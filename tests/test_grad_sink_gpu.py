@@ -50,6 +50,15 @@ def test_grad_finish_sums_every_job_of_a_destination_in_a_fixed_order(dev):
     assert torch.equal(outs[0][~touched], flat0[~touched])
     with pytest.raises(ValueError):
         plan.run([(total - 2, 4, 4, 4, keep[0].data_ptr(), 1)], flat0.clone())
+    # a weight handed over whole AND as a column slice: two workgroups would add into the same elements without atomics
+    with pytest.raises(ValueError, match="overlap"):
+        plan.run([(0, 64 * 67, 64 * 67, 64 * 67, keep[0].data_ptr(), 1), (0, 3, 67, 64 * 3, keep[2].data_ptr(), 1)], flat0.clone())
+    # column slices of one weight that tile its rows side by side are fine ([:, :3] and [:, 3:67] of a 64 x 67 weight)
+    a, b = torch.randn(2, 64 * 3, generator=g).to(dev), torch.randn(1, 64 * 64, generator=g).to(dev)
+    flat = torch.zeros(64 * 67 + 4, device=dev)
+    plan.run([(0, 3, 67, 64 * 3, a.data_ptr(), 2), (3, 64, 67, 64 * 64, b.data_ptr(), 1)], flat)
+    w = flat[:64 * 67].view(64, 67)
+    assert torch.allclose(w[:, :3], (a[0] + a[1]).view(64, 3)) and torch.equal(w[:, 3:], b.view(64, 64))
 
 
 def test_partial_sums_entries_match_the_finished_kernels(dev):
