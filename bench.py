@@ -430,6 +430,7 @@ def side_record(sub, name, process=None, wall_s=None):
     rec["config"] = {"workload": sub["config"]["workload"], "name": name, "ref": WORKLOADS[name]["ref"]}
     if sub["config"].get("sharding") and name == "train":
         rec["config"]["sharding"] = sub["config"]["sharding"]
+        rec["config"]["graphs_per_step"] = sub["config"].get("graphs_per_step")
     if process:
         rec["process"] = process
     if wall_s is not None:
@@ -841,7 +842,7 @@ def run_train(args, torch, dev, dist, world, rank, ranks_seen, sync_all, B, NS, 
             t8.step(b8)
         dt8 = timed_loop(lambda: t8.step(b8), 50, sync_all)
         small = {"frames_per_step": 8, "ms_per_step": round(dt8 / 50 * 1e3, 4), "value": round(8 * 50 / dt8, 2),
-                 "host_issue_ms_per_step": host_issue(lambda: t8.step(b8)), "launch": "hipGraph replay" if t8.captured is not None else "eager"}
+                 "host_issue_ms_per_step": host_issue(lambda: t8.step(b8)), "graphs_per_step": 1 if t8.captured is not None else 0}
         del t8, m8
     allreduce = None
     if collective:
@@ -873,7 +874,8 @@ def run_train(args, torch, dev, dist, world, rank, ranks_seen, sync_all, B, NS, 
                    "sharding": "batch across ranks, one gradient all-reduce per step over RCCL (%s)" % trainer.reducer if collective else "single rank, no collective",
                    "launch": ("hipGraph replay: forward + backward + gradient finish, %s" % (
                        "the all-reduce issued between it and a second graph (clip + Adam)" if collective else "clip + Adam in the same graph")
-                       if graphed else "eager")},
+                       if graphed else "eager"),
+                   "graphs_per_step": (2 if trainer.captured.second is not None else 1) if graphed else 0},
         "rccl_ranks_seen": ranks_seen,
         "host_issue_ms_per_step": issue_ms,
         "small_batch": small,

@@ -1309,9 +1309,9 @@ def finish_capture_uploads():
     the first replay; returns the tables (the caller keeps them alive with the graph)."""
     done = []
     while _capture_uploads:
-        table, host = _capture_uploads.pop(0)
+        table, host, keep = _capture_uploads.pop(0)
         table.copy_(host)
-        done.append(table)
+        done.append((table, keep))
     return done
 
 
@@ -1402,7 +1402,9 @@ class GradFinishPlan(object):
             table, host = self.capture_table
             self.capture_table = None
             rows = (_lib.GradJob * len(self.job_order)).from_address(host.data_ptr())
-            _capture_uploads.append((table, host))
+            # the segment / workgroup tables the recorded launch reads stay alive with the capture: a later eager step of another
+            # shape REPLACES this plan's tables (never rewrites them)
+            _capture_uploads.append((table, host, (self.segs, self.blocks)))
         else:
             self.uploaded.synchronize()                        # the previous call's upload has left the pinned table
             rows, table = self.rows, self.table
