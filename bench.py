@@ -90,6 +90,8 @@ def parse_args():
     ap.add_argument("--no-workloads", action="store_true",
                     help="default car run at N = 1: do not append the short ped / stress / train runs (`workloads` object)")
     ap.add_argument("--workloads", default="ped,stress,train", help="which short side runs the default car line carries")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="train: only the warm-up and the timed steps (no host-issue measurement, no 8-frame run): the form to put under a profiler")
     ap.add_argument("--force-collective", action="store_true",
                     help="take the multi-rank branches (RCCL process group, ranks-seen all-reduce, DistributedDataParallel, the "
                          "no_sync() exposure measurement) at ANY world size, 1 included: how a one-GPU box runs the code an 8-GPU launch runs")
@@ -830,9 +832,9 @@ def run_train(args, torch, dev, dist, world, rank, ranks_seen, sync_all, B, NS, 
         dt = time.perf_counter() - t0
         torch.cuda.synchronize()
         return round(dt / n * 1e3, 4)
-    issue_ms = host_issue(step)
+    issue_ms = None if args.no_extras else host_issue(step)
     small = None
-    if world == 1 and not collective and B > 8 and (NS, NT) == (W["ns"], W["nt"]):
+    if world == 1 and not collective and B > 8 and (NS, NT) == (W["ns"], W["nt"]) and not args.no_extras:
         # 8 frames per GPU: the step the HOST used to bound (12.4 ms of Python / autograd per step whatever the batch)
         torch.manual_seed(1)
         m8 = build_network(ptt_model_cfg(), 1, StubDataset(training=True)).to(dev).train()
