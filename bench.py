@@ -90,6 +90,9 @@ def parse_args():
     ap.add_argument("--no-workloads", action="store_true",
                     help="default car run at N = 1: do not append the short ped / stress / train runs (`workloads` object)")
     ap.add_argument("--workloads", default="ped,stress,train", help="which short side runs the default car line carries")
+    ap.add_argument("--no-train-launch", action="store_true",
+                    help="N > 1 car line: do not follow it with the training launch (set by bench.py itself when it spawned the ranks: it "
+                         "runs that launch from the parent)")
     ap.add_argument("--no-extras", action="store_true",
                     help="train: only the warm-up and the timed steps (no host-issue measurement, no 8-frame run): the form to put under a profiler")
     ap.add_argument("--force-collective", action="store_true",
@@ -106,6 +109,43 @@ def _free_port():
     return p
 
 
+LAUNCHER_ENV = ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "GROUP_WORLD_SIZE", "ROLE_RANK", "ROLE_WORLD_SIZE",
+                "ROLE_NAME", "MASTER_ADDR", "MASTER_PORT", "OMP_NUM_THREADS")
+
+
+def launch_ranks(n, extra, capture):
+    """`python -m torch.distributed.run --nproc-per-node n bench.py extra...` in an environment without a launcher's variables
+    -> (exit code, the JSON line of its rank 0 | None)."""
+    env = {k: v for k, v in os.environ.items() if k not in LAUNCHER_ENV and not k.startswith("TORCHELASTIC_")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this host driver (RCCL needs it)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + extra
+    print("[bench] spawn: %d ranks: bench.py %s" % (n, " ".join(extra)), file=sys.stderr, flush=True)
+    if not capture:
+        return subprocess.call(cmd, env=env), None
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+    lines = [l for l in p.stdout.decode(errors="replace").splitlines() if l.startswith("{")]
+    try:
+        return p.returncode, (json.loads(lines[-1]) if lines else None)
+    except ValueError:
+        return p.returncode, None
+
+
+def train_launch(n):
+    """The DDP step of configs[3] on n ranks of their own -> the `workloads.train` record (an `error` record if the launch fails:
+    it must not take the headline line down)."""
+    flags = ["--gpus", str(n), "--workload", "train", "--steps", "10", "--warmup", "5", "--sustain", "0", "--no-cpu-baseline", "--no-workloads"]
+    rc, train = launch_ranks(n, flags + (["--force-collective"] if n == 1 else []), True)
+    if train is not None and rc == 0:
+        return side_record(train, "train")
+    return {"error": "the train launch on %d ranks exited with code %d" % (n, rc)}
+
+
+def wants_train_launch(args):
+    return (args.workload == "car" and not args.no_workloads and "train" in args.workloads.split(",") and args.batch is None
+            and args.ns is None and args.nt is None and not args.serial and not args.no_graph)
+
+
 def spawn_ranks(n):
     """WORLD_SIZE unset and --gpus n > 1: run this very command line as n ranks under torch.distributed.run — and, for the
     default car line, run the n ranks a SECOND time on `--workload train` (BASELINE.json configs[3]: the DDP step whose
@@ -113,38 +153,14 @@ def spawn_ranks(n):
     scripts/train_ddp.sh:9) and carry that line as `workloads.train` of the one JSON line printed: the car workload
     shards frames with no data-path collective, so without the second launch the one command a driver runs at N > 1 would
     never meet RCCL beyond a barrier."""
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this host driver (RCCL needs it)
-
-    def launch(extra, capture):
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
-               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + extra
-        print("[bench] spawn: %d ranks: bench.py %s" % (n, " ".join(extra)), file=sys.stderr, flush=True)
-        if not capture:
-            return subprocess.call(cmd, env=env), None
-        p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
-        lines = [l for l in p.stdout.decode(errors="replace").splitlines() if l.startswith("{")]
-        try:
-            return p.returncode, (json.loads(lines[-1]) if lines else None)
-        except ValueError:
-            return p.returncode, None
-
     argv = sys.argv[1:]
     args = parse_args()
-    with_train = (args.workload == "car" and not args.no_workloads and "train" in args.workloads.split(",") and args.batch is None
-                  and args.ns is None and args.nt is None and not args.serial and not args.no_graph)
-    if not with_train:
-        return launch(argv, False)[0]
-    rc, line = launch(argv, True)
-    # the DDP step of configs[3] on the same n ranks; a failure here must not take the headline line down
-    rc2, train = launch(["--gpus", str(n), "--workload", "train", "--steps", "10", "--warmup", "5", "--sustain", "0",
-                         "--no-cpu-baseline", "--no-workloads"], True)
+    if not wants_train_launch(args):
+        return launch_ranks(n, argv, False)[0]
+    rc, line = launch_ranks(n, argv + ["--no-train-launch"], True)
+    train = train_launch(n)                               # whatever became of the headline launch
     if line is not None:
-        if train is not None and rc2 == 0:
-            rec = side_record(train, "train")
-        else:
-            rec = {"error": "the train launch on %d ranks exited with code %d" % (n, rc2)}
-        line.setdefault("workloads", {})["train"] = rec
+        line.setdefault("workloads", {})["train"] = train
         print(json.dumps(compact_line(line)), flush=True)
     return rc
 
@@ -345,6 +361,10 @@ def main():
     env = dict(torch=torch, ops=ops, synth=synth, dev=dev, dist=dist, world=world, rank=rank, ranks_seen=ranks_seen, sync_all=sync_all,
                hp=(FrameHotPath, GraphedHotPath, InterleavedHotPath, PipelinedHotPath, TrackerThroughput, kitti_model_cfg, randomize_))
     out = run_workload(args, env)
+    from ptt_amd import graph_policy
+    # parallel branches inside this process's captured graphs (ptt_amd/graph_policy.py): a headline taken with serialised graphs says so
+    out["graph_policy"] = {"mode": graph_policy.graph_mode(), "forked_captures": graph_policy.forked_captures, "budget": graph_policy.FORK_BUDGET,
+                           "serialised": graph_policy.graph_mode() == "safe" or (graph_policy.graph_mode() == "auto" and graph_policy._warned)}
     out["cpu_affinity"] = ({"cores_per_rank": len(bound["cores"]), "rank0_cores": bound["cores"][:16], "numa_node": bound["numa_node"],
                             "allowed": bound["allowed"]} if bound else {"bound": False, "allowed": len(os.sched_getaffinity(0))})
     # BASELINE.json configs[2], [4], [3] beside the headline: the default `python bench.py` line carries a short run of each
@@ -358,11 +378,24 @@ def main():
             note("workload %s" % name)
             out["workloads"][name] = side_workload(name, steps, warm)
     note("done")
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    # N > 1 started by a launcher (`python -m torch.distributed.run ... bench.py --gpus N`, what a driver runs): the car workload
+    # shards frames with no data-path collective, so this command would never meet RCCL beyond a barrier. Once every rank is
+    # through, rank 0 runs the n ranks a second time — on `--workload train`, BASELINE.json configs[3], whose gradient all-reduce
+    # over RCCL / xGMI is the only collective of the whole path (tools/train_tracking.py:158-159, scripts/train_ddp.sh:9) — and
+    # carries that line as workloads.train. In ranks of their own: the graphs and pools of the car run stay out of its way.
+    follow = (world > 1 or os.environ.get("PTT_BENCH_TRAIN_AFTER") == "1") and "WORLD_SIZE" in os.environ and wants_train_launch(args) \
+        and not args.no_train_launch
     if rank == 0:
+        if follow:
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+            out.setdefault("workloads", {})["train"] = train_launch(world)
         print("[bench detail] " + json.dumps(out), file=sys.stderr, flush=True)     # every key, with its prose
         print(json.dumps(compact_line(out)), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
 
 
 # keys that hold prose (how a number was taken): DESIGN.md section 6 says it once; the stdout line carries numbers and names
@@ -371,7 +404,7 @@ PROSE_KEYS = ("how", "split", "note", "traffic_note", "per_frame", "launch", "ti
 LINE_ORDER = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
               "data", "config", "roofline", "cpu_baseline", "speedup_vs_cpu_baseline", "rccl_ranks_seen", "latency_b1", "workloads",
               "sustained", "full_model", "whole_step", "index_ops", "loss", "grad_bytes_allreduced_per_step", "allreduce",
-              "host_issue_ms_per_step", "small_batch", "cpu_affinity", "kernel_ms_per_step")
+              "host_issue_ms_per_step", "small_batch", "cpu_affinity", "graph_policy", "kernel_ms_per_step")
 LINE_LIMIT = 6144            # the driver keeps a tail of its child's stdout: the ONE line must fit it whole
 
 

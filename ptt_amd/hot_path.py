@@ -14,6 +14,8 @@ view of point-major rows).
 import torch
 import torch.nn as nn
 
+from . import graph_policy
+from .graph_policy import graph_mode, set_graph_mode          # noqa: F401 — the switch lives here for callers (graph_policy.py)
 from .models.backbones_3d.pointnet2.pointnet2_modules import PointnetSAModuleVotes
 from .models.backbones_3d.pointnet2_backbone import PointNet2BackboneLight
 from .models.transformer_block import build_transformer
@@ -143,7 +145,7 @@ class GraphedHotPath(object):
             torch.cuda.current_stream().wait_stream(s)
             torch.cuda.synchronize()
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
+            with graph_policy.capture_scope(), torch.cuda.graph(self.graph):
                 self.out = model(self.search, self.template)
 
     def __call__(self, search_points=None, template_points=None):
@@ -183,13 +185,13 @@ class PipelinedHotPath(object):
             torch.cuda.current_stream().wait_stream(s)
             torch.cuda.synchronize()
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
+            with graph_policy.capture_scope(), torch.cuda.graph(self.graph):
                 main = torch.cuda.current_stream()
-                self.side.wait_stream(main)
-                with torch.cuda.stream(self.side):
+                side = graph_policy.branch(main, self.side)                # (the policy may keep the stage in line: graph_policy.py)
+                with torch.cuda.stream(side):
                     inds_nxt = model.sample(*self.nxt)                     # stage A of batch n+1
                 self.out = model(self.cur[0], self.cur[1], self.inds_cur)  # stage B of batch n
-                main.wait_stream(self.side)
+                graph_policy.join(main, side)
                 # rotate: what was "next" becomes "current" for the following replay
                 for dst, src in zip(self.inds_cur, inds_nxt):
                     dst.copy_(src)

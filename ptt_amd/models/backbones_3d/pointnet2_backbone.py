@@ -12,7 +12,7 @@ from typing import List
 import torch
 import torch.nn as nn
 
-from ... import ops, train_ops
+from ... import graph_policy, ops, train_ops
 from .pointnet2 import pointnet2_modules
 
 
@@ -144,14 +144,15 @@ class PointNet2BackboneLight(nn.Module):
         else:
             if self._side_stream is None or self._side_stream.device != search_points.device:
                 self._side_stream = torch.cuda.Stream(device=search_points.device)
-            main, side = torch.cuda.current_stream(search_points.device), self._side_stream
-            side.wait_stream(main)
+            main = torch.cuda.current_stream(search_points.device)
+            side = graph_policy.branch(main, self._side_stream)       # inside a capture the policy may keep the branch in line
             with torch.cuda.stream(side):
                 t_seeds, t_feats, t_inds = self.branch_forward(template_points, sa.NPOINTS_TEMPLATE, i_t)
             r = self.branch_forward(search_points, sa.NPOINTS_SEARCH, i_s, want_knn=self.seed_knn)
-            main.wait_stream(side)
-            for t in (t_seeds, t_feats, t_inds, template_points):
-                t.record_stream(main)
+            graph_policy.join(main, side)
+            if side is not main:
+                for t in (t_seeds, t_feats, t_inds, template_points):
+                    t.record_stream(main)
         s_seeds, s_feats, s_inds = r[:3]
         s_knn = r[3] if len(r) > 3 else None
         out = {'search_seeds': s_seeds, 'search_feats': s_feats, 'search_inds': s_inds,

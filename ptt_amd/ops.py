@@ -96,6 +96,15 @@ def publish_params(device):
         torch.cuda.current_stream(device).synchronize()
 
 
+def require_finite(*tensors):
+    """Raises ValueError if any of the device tensors holds a NaN or an infinity (one reduction per tensor and ONE host
+    synchronisation: a guard for the boundary of a pipeline, not something the hot path calls per frame). Non-finite coordinates
+    are outside the contract of this library ("Non-finite input")."""
+    bad = [k for k, t in enumerate(tensors) if t is not None and t.is_floating_point() and not bool(torch.isfinite(t).all())]
+    if bad:
+        raise ValueError("non-finite values in tensor(s) %s" % ", ".join("#%d %s" % (k, tuple(tensors[k].shape)) for k in bad))
+
+
 def _chk(t, name, dtype, ndim=None):
     if not isinstance(t, torch.Tensor):
         raise TypeError("%s must be a torch.Tensor" % name)

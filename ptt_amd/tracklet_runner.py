@@ -26,7 +26,7 @@ is implemented.
 import numpy as np
 import torch
 
-from . import ops
+from . import graph_policy, ops
 from .hot_path import GraphedHotPath, TrackerThroughput
 
 
@@ -325,7 +325,7 @@ class TrackletRunner(object):
                 cur.wait_stream(side)
                 torch.cuda.synchronize(self.device)
                 self._frame = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self._frame):
+                with graph_policy.capture_scope(), torch.cuda.graph(self._frame):
                     self._frame_body()
                     self.readback_host.copy_(self.readback, non_blocking=True)
             finally:

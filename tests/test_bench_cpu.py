@@ -41,6 +41,31 @@ def test_gpus_2_spawns_two_ranks_itself():
     assert p.stderr.count("bench.py needs a HIP device") >= 2, p.stderr[-2000:]
 
 
+def test_launched_ranks_get_an_environment_without_the_outer_launchers_variables(monkeypatch):
+    """bench.py started BY a launcher (python -m torch.distributed.run ... bench.py --gpus N) follows the car line with a launch of
+    its own for the training step: the inner torch.distributed.run must not inherit the outer one's rendezvous."""
+    sys.path.insert(0, ROOT)
+    import bench
+    seen = {}
+
+    class P(object):
+        returncode, stdout = 0, b'{"value": 1.0, "config": {"workload": "w", "sharding": "s", "graphs_per_step": 2}, "roofline": {"frac": 0.5}}\n'
+
+    def run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return P()
+    for k, v in (("WORLD_SIZE", "8"), ("RANK", "0"), ("LOCAL_RANK", "0"), ("MASTER_PORT", "29400"), ("TORCHELASTIC_RUN_ID", "x"), ("OMP_NUM_THREADS", "1")):
+        monkeypatch.setenv(k, v)
+    monkeypatch.setattr(bench.subprocess, "run", run)
+    rec = bench.train_launch(8)
+    assert rec["value"] == 1.0 and rec["config"]["graphs_per_step"] == 2
+    assert not any(k in seen["env"] for k in bench.LAUNCHER_ENV) and "TORCHELASTIC_RUN_ID" not in seen["env"]
+    assert seen["cmd"][1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in seen["cmd"] and "train" in seen["cmd"]
+    assert "--force-collective" not in seen["cmd"]
+    bench.train_launch(1)
+    assert "--force-collective" in seen["cmd"]                      # one rank: the collective branches are taken anyway
+
+
 def test_gpus_2_with_another_workload_is_one_launch():
     """Only the default car line carries the train launch: `--workload train --gpus 2` itself is a single launch."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}

@@ -89,6 +89,18 @@ def test_the_rccl_branches_of_the_training_line_run_at_world_size_one():
     assert "RCCL" in d["config"]["sharding"]
 
 
+def test_a_launcher_started_car_line_is_followed_by_the_training_launch(monkeypatch):
+    """`python -m torch.distributed.run ... bench.py --gpus N` (how a driver starts N > 1): after the car workload rank 0 launches the
+    ranks again on the training step and carries its line as workloads.train — here forced at one rank (PTT_BENCH_TRAIN_AFTER)."""
+    monkeypatch.setenv("PTT_BENCH_TRAIN_AFTER", "1")
+    d = _torchrun_one_rank("bench.py", "--gpus", "1", "--steps", "3", "--warmup", "1", "--sustain", "0", "--no-cpu-baseline", "--no-full-model",
+                           "--no-latency", "--workloads", "train")
+    _contract(d, 3, 1)
+    t = d["workloads"]["train"]
+    assert "error" not in t and t["rccl_ranks_seen"] == 1 and t["config"]["graphs_per_step"] == 2 and t["value"] > 0
+    assert t["grad_bytes_allreduced_per_step"] == 4903113 * 4
+
+
 def test_ddp_on_one_rccl_rank_is_bit_identical_to_the_unwrapped_trainer():
     """Both reducers — the flat gradient buffer's one all-reduce (default) and DistributedDataParallel — on one RCCL rank: bit-identical
     to the same trainer without a collective; the two reducers' gradients agree to fp32 rounding (different summation trees)."""

@@ -273,3 +273,28 @@ def test_full_tracker_eval_fused_equals_reference_op_sequence(dev, variant):
                 else:
                     np.testing.assert_array_equal(after[k].cpu().numpy(), plain[k].cpu().numpy(), err_msg=k)
     assert {'search_feats', 'search_inds', 'cosine_feats', 'pred_centroids_votes', 'pred_box_data'} <= checked
+
+
+def test_a_frame_with_non_finite_points_stays_alone_with_its_garbage(dev):
+    """Non-finite coordinates are outside the contract ("Non-finite input": the reference's torch layers propagate a
+    NaN to every output of THAT frame; this build's ReLU / max-pool instructions return the non-NaN operand, so the frame's outputs may
+    be finite and meaningless). What IS guaranteed and tested: frames are independent — every other frame of the batch comes out bit
+    for bit as without the poisoned frame — nothing crashes or hangs, and ops.require_finite names the problem at the boundary."""
+    cfg = kitti_model_cfg()
+    model = randomize_(FrameHotPath(cfg), seed=3).to(dev).eval()
+    s, t = synth.frames(33, 4, 1024, 512)
+    s_bad, t_bad = s.copy(), t.copy()
+    s_bad[2, 5] = np.nan
+    s_bad[2, 700, 1] = np.inf
+    t_bad[2, 9, 2] = np.nan
+    with torch.no_grad():
+        good = model(torch.from_numpy(s).to(dev), torch.from_numpy(t).to(dev))
+        good = {k: v.clone() for k, v in good.items() if torch.is_tensor(v)}
+        bad = model(torch.from_numpy(s_bad).to(dev), torch.from_numpy(t_bad).to(dev))
+    torch.cuda.synchronize()
+    others = [0, 1, 3]
+    for k, v in good.items():
+        assert torch.equal(v[others], bad[k][others]), k
+    with pytest.raises(ValueError, match="non-finite"):
+        ops.require_finite(torch.from_numpy(s_bad).to(dev), torch.from_numpy(t).to(dev))
+    ops.require_finite(torch.from_numpy(s).to(dev), torch.from_numpy(t).to(dev))

@@ -175,6 +175,52 @@ def test_every_baseline_workload_in_one_process_seven_rounds():
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1500, env=env, cwd=root)
     assert p.returncode == 0 and "bench car,ped,stress x7: PASSED" in p.stdout, p.stdout[-3000:]
     assert p.stdout.count(" ok, ") == 21
+    assert "further captures are serialised" not in p.stdout           # 8 queues: the policy keeps forking
+
+
+def test_every_baseline_workload_in_one_process_under_the_default_environment():
+    """The same 21 workloads with NOTHING exported: ptt_amd.graph_policy (mode "auto") lets the first 16 captures of the process fork
+    and serialises the later ones — linear graphs cannot meet the runtime bug — saying so once (RuntimeWarning). The library's
+    default is "may warn", not "may segfault"."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("GPU_MAX_HW_QUEUES", "PTT_GRAPH_MODE", "PTT_GRAPH_FORK_BUDGET")}
+    env["PROBE_ROUNDS"] = "7"
+    p = subprocess.run([sys.executable, os.path.join(root, "scripts", "probes", "graph_sequence_probe.py"), "bench", "car,ped,stress"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1500, env=env, cwd=root)
+    assert p.returncode == 0 and "bench car,ped,stress x7: PASSED" in p.stdout, p.stdout[-3000:]
+    assert p.stdout.count(" ok, ") == 21
+    assert p.stdout.count("further captures are serialised") == 1, p.stdout[-2000:]
+
+
+def test_graph_policy_modes(dev):
+    """graph_policy: "safe" records no fork (a linear graph) and gives the same numbers as the forked capture; the budget of mode
+    "auto" counts forked CAPTURES (a capture with two forks counts once)."""
+    from ptt_amd import graph_policy, synth
+    from ptt_amd.hot_path import FrameHotPath, GraphedHotPath, PipelinedHotPath, kitti_model_cfg, randomize_, set_graph_mode
+    model = randomize_(FrameHotPath(kitti_model_cfg()), seed=0).to(dev).eval()
+    s, t = (torch.from_numpy(a).to(dev) for a in synth.frames(7, 4, 1024, 512))
+    prev = set_graph_mode("fast")
+    try:
+        n0 = graph_policy.forked_captures
+        fast = PipelinedHotPath(model, s, t)                       # two forks (next batch's sampling, template branch): ONE forked capture
+        assert graph_policy.forked_captures == n0 + 1
+        set_graph_mode("safe")
+        safe = PipelinedHotPath(model, s, t)
+        g = GraphedHotPath(model, s, t)
+        assert graph_policy.forked_captures == n0 + 1              # nothing forked
+        for _ in range(2):
+            a, b = fast(), safe()
+        c = g()
+        torch.cuda.synchronize()
+        ka = sorted(k for k in a if torch.is_tensor(a[k]))
+        assert ka and all(torch.equal(a[k], b[k]) and torch.equal(a[k], c[k]) for k in ka)
+        with pytest.raises(ValueError):
+            set_graph_mode("quick")
+    finally:
+        set_graph_mode(prev)
 
 
 @pytest.mark.parametrize("R,K,N,ns", [(131072, 64, 64, 0), (196608, 128, 64, 32), (98304, 256, 128, 32), (49152, 256, 256, 16), (100000, 128, 128, 0)])
