@@ -20,6 +20,14 @@ __device__ __forceinline__ float sqdist3(float ax, float ay, float az, float bx,
     return (dx * dx + dy * dy) + dz * dz;
 }
 
+// kNN candidate distance: a NON-FINITE one (NaN / infinite coordinates: outside the contract, INTEGRATION.md "Non-finite input")
+// becomes FLT_MAX — still a selectable candidate, after every finite one, lowest index first — so that a round always finds a
+// winner and no index leaves the cloud (a retired candidate is marked NaN: never selectable again). Finite input: unchanged.
+__device__ __forceinline__ float knn_dist(float ax, float ay, float az, float bx, float by, float bz) {
+    const float d = sqdist3(ax, ay, az, bx, by, bz);
+    return d < __builtin_inff() ? d : 3.402823466e+38f;
+}
+
 // ------------------------------------------------------------------------------------------
 // FPS. One workgroup per cloud, T threads, P points per thread held in registers together
 // with their running min-distance; nothing but the chosen index leaves the CU per iteration.
@@ -567,7 +575,7 @@ __global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ xyz,
 #pragma unroll
     for (int i = 0; i < P; ++i) {
         const int c = lane + i * 64;
-        d[i] = (c < N) ? sqdist3(qx, qy, qz, pts[3 * c + 0], pts[3 * c + 1], pts[3 * c + 2]) : __builtin_inff();
+        d[i] = (c < N) ? knn_dist(qx, qy, qz, pts[3 * c + 0], pts[3 * c + 1], pts[3 * c + 2]) : __builtin_inff();
     }
     for (int r = 0; r < k; ++r) {
         float best = __builtin_inff();
@@ -659,7 +667,7 @@ __global__ __launch_bounds__(256) void point_jobs_kernel(PointJobs P) {
         const int k = lane + i * 64;
         const int pi = k < J.Npts ? (ps ? ps[k] : k) : 0;
         px[i] = raw[3 * pi + 0]; py[i] = raw[3 * pi + 1]; pz[i] = raw[3 * pi + 2];
-        d[i] = k < J.Npts ? sqdist3(cx, cy, cz, px[i], py[i], pz[i]) : __builtin_inff();
+        d[i] = k < J.Npts ? knn_dist(cx, cy, cz, px[i], py[i], pz[i]) : __builtin_inff();
     }
     int32_t* __restrict__ out = J.idx_out + (size_t)c * J.ns;
     for (int r = 0; r < J.ns; ++r) {
@@ -783,7 +791,7 @@ __global__ __launch_bounds__(256) void fps_ball_knn_kernel(FbkParams p) {
         const int kk = lane + i * 64;
         const int pi = kk < p.M ? sel[kk] : 0;
         qx[i] = cl[3 * pi + 0]; qy[i] = cl[3 * pi + 1]; qz[i] = cl[3 * pi + 2];
-        d[i] = kk < p.M ? sqdist3(cx, cy, cz, qx[i], qy[i], qz[i]) : __builtin_inff();
+        d[i] = kk < p.M ? knn_dist(cx, cy, cz, qx[i], qy[i], qz[i]) : __builtin_inff();
     }
     int32_t* __restrict__ ko = p.knn + c * p.k;
     for (int r = 0; r < p.k; ++r) {

@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from oracle import frame_ref
-from ptt_amd import synth
+from ptt_amd import ops, synth
 from ptt_amd.hot_path import FrameHotPath, kitti_model_cfg, randomize_
 
 pytestmark = pytest.mark.gpu
