@@ -12,16 +12,18 @@ speed (the template branch beside the search branch, the next batch's sampling b
                   that names the way out. A process that exported GPU_MAX_HW_QUEUES >= 8 before the runtime started (INTEGRATION.md,
                   "Known limits") is always "fast": with 8 queues the sequence was replayed 7 x without a crash.
 
-FORK_BUDGET = 16: the headline car run of bench.py (three pipelined graphs, the full tracker, the B = 1 graphs and the tracklet
-loops) instantiates 12; the crash was first seen at the 17th forked capture of a process. PTT_GRAPH_MODE / PTT_GRAPH_FORK_BUDGET
-override the defaults from the environment."""
+FORK_BUDGET = 10: what the headline car run of bench.py instantiates (three pipelined graphs, the full tracker, the B = 1 graphs and
+the tracklet loops) — every number of bench.py is taken with forked graphs — while the crash was met at the 14th forked capture of a
+process (car 10 + ped 3 + the stress graph; scripts/probes/graph_sequence_probe.py prints the count). What serialising costs: car /
+ped ~2 %, the stress frames (16384-point clouds: the next batch's FPS no longer hides beside the dense stage) 1335 -> 800 frames/s.
+PTT_GRAPH_MODE / PTT_GRAPH_FORK_BUDGET override the defaults from the environment."""
 import os
 import warnings
 
 import torch
 
 _mode = os.environ.get("PTT_GRAPH_MODE", "auto")
-FORK_BUDGET = int(os.environ.get("PTT_GRAPH_FORK_BUDGET", "16"))
+FORK_BUDGET = int(os.environ.get("PTT_GRAPH_FORK_BUDGET", "10"))
 forked_captures = 0          # captures of this process in which at least one fork was recorded
 _warned = False
 _capture_forked = None       # None outside a capture_scope(); inside: whether a fork was recorded so far

@@ -69,8 +69,10 @@ def bench_mode(order, rounds):
             print("[probe] bench round %d: %s" % (rnd, name), flush=True)
             out = bench.run_workload(args, env)
             torch.cuda.synchronize()
-            print("[probe] bench round %d: %s ok, %.1f frames/s, reserved %.2f GB" % (rnd, name, out["value"], torch.cuda.memory_reserved() / 2**30),
-                  flush=True)
+            from ptt_amd import graph_policy
+            print("[probe] bench round %d: %s ok, %.1f frames/s, reserved %.2f GB, forked captures so far %d%s" % (
+                rnd, name, out["value"], torch.cuda.memory_reserved() / 2**30, graph_policy.forked_captures,
+                " (serialising)" if graph_policy._warned else ""), flush=True)
             if os.environ.get("PROBE_EMPTY_CACHE"):
                 del out
                 gc.collect()

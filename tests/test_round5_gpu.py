@@ -179,7 +179,7 @@ def test_every_baseline_workload_in_one_process_seven_rounds():
 
 
 def test_every_baseline_workload_in_one_process_under_the_default_environment():
-    """The same 21 workloads with NOTHING exported: ptt_amd.graph_policy (mode "auto") lets the first 16 captures of the process fork
+    """The same 21 workloads with NOTHING exported: ptt_amd.graph_policy (mode "auto") lets the first 10 forked captures of the process fork
     and serialises the later ones — linear graphs cannot meet the runtime bug — saying so once (RuntimeWarning). The library's
     default is "may warn", not "may segfault"."""
     import os
