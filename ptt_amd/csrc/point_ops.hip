@@ -53,23 +53,12 @@ __device__ __forceinline__ float lane_bcast(float v, int src_lane) {
 // 12 N bytes of LDS beside the index buffer: clouds up to ~4096 points; larger ones keep the coordinates in the selects.
 typedef float fps_f2 __attribute__((ext_vector_type(2)));
 
-// Dev builds only (-DPTT_DEV): shader-cycle stamps at the segment boundaries of EIGHT iterations (256 .. 263) of cloud 0, read back
-// with ptt_dev_fps_stamps — what scripts/fps_iteration_breakdown.py prints ("One FPS iteration"). A stamped
-// iteration waits for its LDS reads before the last stamp (the next iteration's first instruction would have waited there anyway).
-#ifdef PTT_DEV
-__device__ int g_fps_stamps[8 * 8];
-#define FPS_STAMP_BEGIN() const bool fps_st = (blockIdx.x == 0) && j >= 256 && j < 264; int fps_c[8] = {0, 0, 0, 0, 0, 0, 0, 0}
-#define FPS_STAMP(k) do { if (fps_st) fps_c[k] = (int)__builtin_amdgcn_s_getreg(29 | (0 << 6) | (19 << 11)); } while (0)
-#define FPS_STAMP_WAIT() do { if (fps_st) __builtin_amdgcn_s_waitcnt(0xc07f); } while (0)        /* lgkmcnt(0) */
-#define FPS_STAMP_END() do { if (fps_st && t == 0) { for (int q_ = 0; q_ < 8; ++q_) g_fps_stamps[(j - 256) * 8 + q_] = fps_c[q_]; } } while (0)
-#else
-#define FPS_STAMP_BEGIN() do { } while (0)
-#define FPS_STAMP(k) do { } while (0)
-#define FPS_STAMP_WAIT() do { } while (0)
-#define FPS_STAMP_END() do { } while (0)
-#endif
+// Dev builds only (-DPTT_DEV): ABL removes links of the iteration's dependency chain (the RESULTS are then wrong; the time per
+// iteration is what is read: scripts/fps_iteration_breakdown.py, DESIGN.md section 4 "One FPS iteration"). Bits: 1 the wave maximum
+// (DPP chain), 2 ballot + find-first, 4 the exchange between the waves (slot write, barrier, fold), 8 the winner's coordinates read
+// back from LDS, 16 the barrier alone (slots still written and read), 32 the scan over the thread's points. ABL = 0 is the kernel.
 
-template <int T, int P, bool LX>
+template <int T, int P, bool LX, int ABL = 0>
 __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, int N, int npoint,
                                                int32_t* __restrict__ idx_out) {
     constexpr int W = T / 64;
@@ -110,14 +99,12 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
     if (LX) __syncthreads();
 
     for (int j = 1; j < npoint; ++j) {
-        FPS_STAMP_BEGIN();
-        FPS_STAMP(0);
         float best = -1.0f, bx = 0.f, by = 0.f, bz = 0.f;
         int besti = 0;
         if constexpr ((P % 2) == 0) {
             const fps_f2 lxv = {lx, lx}, lyv = {ly, ly}, lzv = {lz, lz};
 #pragma unroll
-            for (int i = 0; i < P; i += 2) {
+            for (int i = 0; i < ((ABL & 32) ? 2 : P); i += 2) {
                 const fps_f2 dx = fps_f2{px[i], px[i + 1]} - lxv, dy = fps_f2{py[i], py[i + 1]} - lyv,
                              dz = fps_f2{pz[i], pz[i + 1]} - lzv;
                 const fps_f2 d = (dx * dx + dy * dy) + dz * dz;
@@ -151,17 +138,22 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
                 }
             }
         }
-        FPS_STAMP(1);                                              // the scan over this thread's P points
-        const float wmax = wave_max_f32_fused(best);
-        FPS_STAMP(2);                                              // the wave maximum (DPP)
-        const unsigned long long winners = __ballot(best == wmax);
-        const int src = __ffsll((long long)winners) - 1;          // lowest lane among the maxima
-        FPS_STAMP(3);                                              // ballot + find-first
+        float wmax;
+        if constexpr (ABL & 1) wmax = __builtin_amdgcn_readfirstlane(best); else wmax = wave_max_f32_fused(best);
+        int src;
+        if constexpr (ABL & 2) {
+            src = (int)(__builtin_bit_cast(unsigned, wmax) & 63u);   // still a function of the maximum
+        } else {
+            const unsigned long long winners = __ballot(best == wmax);
+            src = __ffsll((long long)winners) - 1;                // lowest lane among the maxima
+            if constexpr (ABL & 1) src &= 63;
+        }
         if constexpr (W == 1) {
             int widx = __builtin_amdgcn_readlane(besti, src);
             if (wmax < 0.f) widx = 0;            // no selectable point left: index 0 (upstream's besti init)
-            FPS_STAMP(4);                                          // the winner's index out of its lane
-            if constexpr (LX) {
+            if constexpr ((ABL & 8) != 0) {
+                lx = (float)widx * 1e-3f; ly = lx; lz = lx;
+            } else if constexpr (LX) {
                 lx = xyz_lds[3 * widx + 0]; ly = xyz_lds[3 * widx + 1]; lz = xyz_lds[3 * widx + 2];
             } else if (wmax < 0.f) {
                 lx = pts[0]; ly = pts[1]; lz = pts[2];
@@ -169,9 +161,12 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
                 lx = lane_bcast(bx, src); ly = lane_bcast(by, src); lz = lane_bcast(bz, src);
             }
             if (lane == 0) sel_lds[j] = widx;
-            FPS_STAMP_WAIT();
-            FPS_STAMP(7);                                          // the winner's coordinates back from LDS
-            FPS_STAMP_END();
+        } else if constexpr ((ABL & 4) != 0) {   // no exchange between the waves: every wave follows its own maximum
+            int gi = __builtin_amdgcn_readlane(besti, src);
+            if (wmax < 0.f) gi = 0;
+            if constexpr ((ABL & 8) != 0) { lx = (float)gi * 1e-3f; ly = lx; lz = lx; }
+            else { lx = xyz_lds[3 * gi + 0]; ly = xyz_lds[3 * gi + 1]; lz = xyz_lds[3 * gi + 2]; }
+            if (lane == 0 && wv == 0) sel_lds[j] = gi;
         } else {
             const int par = j & 1;
             if (lane == src) {                   // the winning lane publishes its own candidate
@@ -183,9 +178,7 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
                     slots[par][wv][4] = bz;
                 }
             }
-            FPS_STAMP(4);                                          // the winning lane's slot written
-            __syncthreads();
-            FPS_STAMP(5);                                          // the workgroup barrier
+            if constexpr ((ABL & 16) == 0) __syncthreads();
             float gd, gx = 0.f, gy = 0.f, gz = 0.f;
             int gi;
             if constexpr (W <= 4) {
@@ -226,36 +219,35 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
                 }
             }
             if (gd < 0.f) gi = 0;
-            FPS_STAMP_WAIT();
-            FPS_STAMP(6);                                          // the W slots read and folded
-            if constexpr (LX) {
+            if constexpr ((ABL & 16) != 0) gi &= 1023;           // (racy slots: keep the index inside the cloud)
+            if constexpr ((ABL & 8) != 0) {
+                lx = (float)gi * 1e-3f; ly = lx; lz = lx;
+            } else if constexpr (LX) {
                 lx = xyz_lds[3 * gi + 0]; ly = xyz_lds[3 * gi + 1]; lz = xyz_lds[3 * gi + 2];
             } else {
                 if (gd < 0.f) { gx = pts[0]; gy = pts[1]; gz = pts[2]; }
                 lx = gx; ly = gy; lz = gz;
             }
             if (t == 0) sel_lds[j] = gi;
-            FPS_STAMP_WAIT();
-            FPS_STAMP(7);                                          // the winner's coordinates back from LDS
-            FPS_STAMP_END();
         }
     }
     __syncthreads();
     for (int j = t; j < npoint; j += T) out[j] = sel_lds[j];
 }
 
-#ifdef PTT_DEV
-}  // namespace ptt
-extern "C" int ptt_dev_fps_stamps(int* out64) {              // dev builds only: not part of include/ptt_hip.h
-    return hipMemcpyFromSymbol(out64, HIP_SYMBOL(ptt::g_fps_stamps), sizeof(int) * 64) == hipSuccess ? 0 : -1;
-}
-namespace ptt {
-#endif
-
 template <int T, int P>
 static int launch_fps(const float* xyz, int B, int N, int npoint, int32_t* idx, hipStream_t s) {
     const size_t sel_bytes = (size_t)((npoint + 3) & ~3) * sizeof(int);
     if (sel_bytes + (size_t)N * 12 + 1024 <= 65536 && !dev_switches().fps_plain) {   // fits the default 64 KB with the slots
+#ifdef PTT_DEV
+        if (const char* e = getenv("PTT_FPS_ABL")) {              // timing ablations (wrong results): see the kernel's header
+            const int abl = atoi(e);
+#define PTT_FPS_ABL_CASE(A) if (abl == A) { hipLaunchKernelGGL((fps_kernel<T, P, true, A>), dim3(B), dim3(T), sel_bytes + (size_t)N * 12, s, xyz, N, npoint, idx); return check_launch("fps_kernel(abl)"); }
+            PTT_FPS_ABL_CASE(1) PTT_FPS_ABL_CASE(2) PTT_FPS_ABL_CASE(3) PTT_FPS_ABL_CASE(4) PTT_FPS_ABL_CASE(8) PTT_FPS_ABL_CASE(12) PTT_FPS_ABL_CASE(15)
+            PTT_FPS_ABL_CASE(16) PTT_FPS_ABL_CASE(32) PTT_FPS_ABL_CASE(47) PTT_FPS_ABL_CASE(7) PTT_FPS_ABL_CASE(24) PTT_FPS_ABL_CASE(40)
+#undef PTT_FPS_ABL_CASE
+        }
+#endif
         hipLaunchKernelGGL((fps_kernel<T, P, true>), dim3(B), dim3(T), sel_bytes + (size_t)N * 12, s, xyz, N, npoint, idx);
         return check_launch("fps_kernel");
     }
