@@ -398,7 +398,7 @@ def main():
         print(json.dumps(compact_line(out)), flush=True)
 
 
-# keys that hold prose (how a number was taken): DESIGN.md section 6 says it once; the stdout line carries numbers and names
+# keys that hold prose (how a number was taken): DESIGN.md section 7 says it once; the stdout line carries numbers and names
 PROSE_KEYS = ("how", "split", "note", "traffic_note", "per_frame", "launch", "timing", "process", "per_launch_shape", "sample_detail",
               "sharding_detail")
 LINE_ORDER = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",

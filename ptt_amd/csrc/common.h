@@ -14,7 +14,7 @@ int check_launch(const char* what);
 
 static inline hipStream_t as_stream(ptt_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
-// Developer A/B switches (DESIGN.md §4 "Developer switches"). A release build of the library has none: the
+// Developer A/B switches (docs/experiments.md "Developer switches"). A release build of the library has none: the
 // structure holds the measured-best defaults as constants, no entry point calls getenv, and the per-phase cycle
 // stamps of the chained kernels are compiled out. A build with -DPTT_DEV (PTT_HIP_FLAGS="-DPTT_DEV" python -m
 // ptt_amd.build --force) reads the PTT_* environment variables (per call, so sweep scripts can flip them between

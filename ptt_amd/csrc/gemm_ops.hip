@@ -605,7 +605,7 @@ void launch_wgrad_finish(const float* partial, int nchunks, size_t n, int accumu
 
 // Compute units of the CURRENT device, cached per device ordinal (a process may drive several device models; the launch shape —
 // and with it the K-summation order of a 256-column layer — follows the device the launch goes to: results are bit-reproducible per
-// device model).
+// device model, DESIGN.md section 2 "Batch dependence").
 static int cu_count() {
     constexpr int MAX_DEV = 64;
     static std::atomic<int> cached[MAX_DEV];

@@ -5,7 +5,7 @@ Restates, in array form, the few operations the reference performs through `pyqu
 `kitti_tracking_utils.Box` (ptt/datasets/kitti/kitti_tracking_utils.py:68-160, 186-216): unit quaternions (w, x, y, z),
 Hamilton product, inverse, rotation matrix, matrix -> quaternion (the branch-by-largest-diagonal method pyquaternion
 documents), box corners, and `get_box_by_offset`. pyquaternion itself is not installed in this image; its published
-algorithms are what is restated (DESIGN.md §N4).
+algorithms are what is restated (SURVEY.md §8f N4).
 """
 import numpy as np
 

@@ -1,7 +1,7 @@
 """Parallel branches inside captured hipGraphs: allowed or serialised — a process-wide policy.
 
 Why: on ROCm 7.2 `hipGraphLaunch` segfaults when two parallel branches of ONE instantiated graph were mapped to the same hardware
-queue (pure-PyTorch reproduction in scripts/probes/graph_queue_repro.py). With the runtime's default of 4
+queue (DESIGN.md section 5 "Forked graphs per process", docs/experiments.md; pure-PyTorch reproduction in scripts/probes/graph_queue_repro.py). With the runtime's default of 4
 queues that takes a process which has instantiated a few dozen forked graphs (the car -> ped -> stress sequence in one process);
 a graph WITHOUT parallel branches never crashes. The drivers of ptt_amd.hot_path and the backbone fork inside their captures for
 speed (the template branch beside the search branch, the next batch's sampling beside the dense stage), so:

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Repro hunt: car -> ped -> stress hipGraph drivers in ONE process ("was seen to crash inside hipGraphLaunch").
+"""Repro hunt: car -> ped -> stress hipGraph drivers in ONE process (docs/experiments.md: "was seen to crash inside hipGraphLaunch").
 
     python scripts/probes/graph_sequence_probe.py MODE [ORDER]
       MODE   drop   : build a workload's model + graph driver, replay, delete it (gc), next workload   (what a loop over workloads does)

@@ -163,7 +163,7 @@ def test_every_baseline_workload_in_one_process_seven_rounds():
     process per run): bench.run_workload for car (with its full-tracker, B = 1 latency and tracklet-loop graphs), ped and stress,
     seven rounds = 21 workloads. With the runtime's default of 4 hardware queues the third workload crashes inside hipGraphLaunch:
     ROCm 7.2 segfaults when two parallel branches of an instantiated graph are given the same hardware queue
-    (scripts/probes/graph_queue_repro.py reproduces it with PyTorch alone under GPU_MAX_HW_QUEUES=1). The
+    (scripts/probes/graph_queue_repro.py reproduces it with PyTorch alone under GPU_MAX_HW_QUEUES=1; DESIGN.md section 5, docs/experiments.md). The
     documented way to hold every workload in one process is GPU_MAX_HW_QUEUES=8, which this run sets (it costs replay speed —
     one tracklet frame 0.65 -> 0.80 ms — so it is not the default; bench.py keeps its side workloads in processes of their own)."""
     import os
