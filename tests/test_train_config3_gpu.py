@@ -181,3 +181,58 @@ def test_config3_two_rank_ddp_with_sync_bn_on_the_row_kernels(dev):
             assert np.array_equal(r[0][k], r[1][k]), k
     assert changed > 50, changed          # statistics over both ranks' rows: not the per-rank-statistics gradients
     assert np.isfinite(r[0]["loss"]) and np.isfinite(r[1]["loss"])
+
+
+def _graph_rank_main(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    from ptt_amd.config import StubDataset, ptt_model_cfg
+    from ptt_amd.models import build_network
+    from ptt_amd.train_step import DataParallelTrainer, synthetic_train_batch
+
+    def make(graph):
+        torch.manual_seed(1000 + rank)                      # ranks that did NOT seed alike: the trainer broadcasts rank 0's state
+        model = build_network(ptt_model_cfg(), 1, StubDataset(training=True)).to(dev).train()
+        return DataParallelTrainer(model, dev, graph=graph)
+    out = {}
+    batches = [synthetic_train_batch(700 + 10 * k + rank, 2, dev) for k in range(3)]
+    for name, graph in (("eager", False), ("graph", True)):
+        tr = make(graph)
+        assert tr.collective and tr.world == world
+        for k in range(7):
+            loss = tr.step(batches[k % 3])
+        torch.cuda.synchronize()
+        out[name + ".loss"] = np.float64(float(loss.detach()))
+        out[name + ".graph_steps"] = np.int64(tr.graph_steps)
+        out[name + ".two_graphs"] = np.int64(tr.captured is not None and tr.captured.second is not None)
+        for k, v in tr.tracker.state_dict().items():
+            out[name + ".s." + k] = v.detach().cpu().numpy()
+    np.savez(os.path.join(outdir, "rank%d.npz" % rank), **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_config3_two_rank_captured_step_equals_the_eager_step(dev):
+    """The captured training step with a REAL exchange: two ranks (gloo, sharing cuda:0), differently seeded models (the flat reducer
+    broadcasts rank 0's parameters and buffers at construction), different batches per rank, seven steps = three eager, the capture, four
+    replays of [forward + backward + finish] | all-reduce | [x 1 / world, clip + Adam]. Parameters after the last step: bit-identical
+    to the same run with graph=False, and identical on both ranks (the BatchNorm running statistics are per rank by design)."""
+    import torch.multiprocessing as mp
+    port = 30300 + (os.getpid() % 150)
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_graph_rank_main, args=(2, port, d), nprocs=2, join=True)
+        r = [dict(np.load(os.path.join(d, "rank%d.npz" % k))) for k in range(2)]
+    for k in (0, 1):
+        assert int(r[k]["graph.graph_steps"]) == 4 and int(r[k]["graph.two_graphs"]) == 1 and int(r[k]["eager.graph_steps"]) == 0
+        assert np.isfinite(r[k]["graph.loss"]) and r[k]["graph.loss"] == r[k]["eager.loss"]
+        for key in r[k]:
+            if key.startswith("graph.s."):
+                assert np.array_equal(r[k][key], r[k]["eager.s." + key[len("graph.s."):]]), (k, key)
+    params = [key for key in r[0] if key.startswith("graph.s.") and "running_" not in key and "num_batches" not in key]
+    assert len(params) > 100
+    for key in params:
+        assert np.array_equal(r[0][key], r[1][key]), key
+    assert r[0]["graph.loss"] != r[1]["graph.loss"]                           # the ranks saw different batches
