@@ -235,13 +235,16 @@ class DataParallelTrainer(object):
             self.sink.plan.prepare_capture()
             cap.packs = train_ops.PackCapture(list(self.model.parameters()), self.device)
             torch.cuda.synchronize(self.device)
-            with cap.packs, torch.cuda.graph(cap.first):
+            # capture_error_mode "thread_local": calls other threads make while this one records (RCCL's watchdog polling its events,
+            # a data loader pinning memory) neither fail nor invalidate the capture; the autograd thread's launches are recorded all the
+            # same — capturing is a property of the stream
+            with cap.packs, torch.cuda.graph(cap.first, capture_error_mode="thread_local"):
                 cap.loss = self._local_forward_backward(cap.static)
                 if not self._collective_cfg:
                     self.optimizer.record_graph_step(clip)
             if self._collective_cfg:
                 cap.second = torch.cuda.CUDAGraph()
-                with cap.packs, torch.cuda.graph(cap.second, pool=cap.first.pool()):
+                with cap.packs, torch.cuda.graph(cap.second, pool=cap.first.pool(), capture_error_mode="thread_local"):
                     if self.world > 1:
                         self.sink.flat.mul_(1.0 / self.world)
                     self.optimizer.record_graph_step(clip)
