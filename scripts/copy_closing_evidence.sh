@@ -1,6 +1,6 @@
 #!/bin/bash
 # Copies the merged output of a closing GPU session (gpurun_out/r<NN><S>, scripts/gpu_sessions_r<NN>.sh z / p) into profiles/r<NN><S>_*.
-#   bash scripts/copy_closing_evidence.sh z [05]
+#   bash scripts/copy_closing_evidence.sh z [06]
 set -e
 S=${1:-z}
 R=${2:-05}

@@ -1,6 +1,7 @@
 #!/bin/bash
 # HBM-side traffic of ONE training step (BASELINE.json configs[3]): rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in two separate
-# counter-only runs of `bench.py --workload train` (no trace domains in the same run), every dispatch summed, divided by the
+# counter-only runs of `bench.py --workload train --no-extras` with PTT_TRAIN_GRAPH=0 (the eager step: the same launches the captured
+# step replays, and the step count of the run is exactly steps + warm-up), every dispatch summed, divided by the
 # steps the run executed -> <out>/pmc_summary.json in the form bench.committed_traffic() reads ("whole training step").
 #   bash scripts/pmc_train_step.sh gpurun_out/r05p/pmc_train_step
 set -u
@@ -11,7 +12,7 @@ REPO=$(pwd)
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf /tmp/pmc_ts_$c
-    timeout 900 rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_ts_$c -- python "$REPO/bench.py" --workload train --steps $STEPS --warmup $WARM \
+    PTT_TRAIN_GRAPH=0 timeout 900 rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_ts_$c -- python "$REPO/bench.py" --workload train --steps $STEPS --warmup $WARM --no-extras \
         --sustain 0 --no-cpu-baseline > /tmp/pmc_ts_$c.log 2>&1
     f=$(find /tmp/pmc_ts_$c -name "*counter_collection.csv" | head -1)
     [ -n "$f" ] && cp "$f" "$REPO/$OUT/pmc_$c.csv" || tail -5 /tmp/pmc_ts_$c.log > "$REPO/$OUT/pmc_$c.err"

@@ -3,7 +3,7 @@
 # (name, grid, workgroup, duration) — the neighbours of an ATen launch name its call site, which torch.profiler's stacks do not
 # for the backward thread — and (2) the launches grouped by (kernel, grid) with count and average duration.
 O=${1:-$GRAFT_REPO_ROOT/gpurun_out/timeline}; mkdir -p $O
-cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/kt && timeout 900 rocprofv3 --kernel-trace --output-format csv -d /tmp/kt -- python $GRAFT_REPO_ROOT/bench.py --workload train --steps 3 --warmup 2 --no-cpu-baseline --sustain 0 > $O/bench_line.json 2> $O/bench_err.log
+cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/kt && timeout 900 rocprofv3 --kernel-trace --output-format csv -d /tmp/kt -- python $GRAFT_REPO_ROOT/bench.py --workload train --steps 3 --warmup 2 --no-cpu-baseline --sustain 0 --no-extras > $O/bench_line.json 2> $O/bench_err.log
 f=$(find /tmp/kt -name "*kernel_trace.csv" | head -1)
 python - "$f" "$O" <<'PY'
 import csv, sys, collections, re
