@@ -105,3 +105,16 @@ def test_graph_mode_refuses_what_it_cannot_capture(dev):
     with pytest.raises(ValueError):
         _trainer(dev, True, reducer="ddp")
     assert _trainer(dev, None, reducer="ddp").graph_mode is False
+
+
+def test_replayed_step_without_clipping_equals_the_eager_step(dev):
+    """clip = 0 (GRAD_NORM_CLIP unset): no norm pass is recorded, the update launch reads max_norm = 0 from the device struct."""
+    from ptt_amd.train_step import synthetic_train_batch
+    eager, graphed = _trainer(dev, False, clip=0), _trainer(dev, True, clip=0)
+    b = synthetic_train_batch(100, 4, dev)
+    for k in range(6):
+        le, lg = eager.step(b).detach().clone(), graphed.step(b).detach().clone()
+    torch.cuda.synchronize()
+    assert graphed.graph_steps == 3 and torch.equal(le, lg)
+    bad = [k for (k, p), q in zip(eager.tracker.state_dict().items(), graphed.tracker.state_dict().values()) if not torch.equal(p, q)]
+    assert not bad and torch.equal(eager.sink.flat, graphed.sink.flat), bad[:4]
