@@ -33,6 +33,7 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with, besides th
 import argparse
 import json
 import os
+import signal
 import socket
 import subprocess
 import sys
@@ -109,11 +110,29 @@ def _free_port():
     return p
 
 
+TRAIN_LAUNCH_TIMEOUT_S = int(os.environ.get("PTT_BENCH_TRAIN_TIMEOUT", "420"))     # the follow-up training launch at N > 1
 LAUNCHER_ENV = ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "GROUP_WORLD_SIZE", "ROLE_RANK", "ROLE_WORLD_SIZE",
                 "ROLE_NAME", "MASTER_ADDR", "MASTER_PORT", "OMP_NUM_THREADS")
 
 
-def launch_ranks(n, extra, capture):
+def run_captured(cmd, env, timeout):
+    """cmd in a process group of its own -> (exit code, stdout bytes). Past `timeout` seconds the whole group is killed (a launcher and
+    the ranks it started: a collective that never returns must not take the caller's own line with it) and the exit code is -9."""
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, start_new_session=True)
+    try:
+        out, _ = proc.communicate(timeout=timeout)
+        return proc.returncode, out
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)          # proc.pid is the id of the group this call created
+        except OSError:
+            proc.kill()
+        out, _ = proc.communicate()
+        print("[bench] launch killed after %d s: %s" % (timeout, " ".join(cmd[-8:])), file=sys.stderr, flush=True)
+        return -9, out
+
+
+def launch_ranks(n, extra, capture, timeout=None):
     """`python -m torch.distributed.run --nproc-per-node n bench.py extra...` in an environment without a launcher's variables
     -> (exit code, the JSON line of its rank 0 | None)."""
     env = {k: v for k, v in os.environ.items() if k not in LAUNCHER_ENV and not k.startswith("TORCHELASTIC_")}
@@ -123,19 +142,20 @@ def launch_ranks(n, extra, capture):
     print("[bench] spawn: %d ranks: bench.py %s" % (n, " ".join(extra)), file=sys.stderr, flush=True)
     if not capture:
         return subprocess.call(cmd, env=env), None
-    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
-    lines = [l for l in p.stdout.decode(errors="replace").splitlines() if l.startswith("{")]
+    rc, out = run_captured(cmd, env, timeout)
+    lines = [l for l in out.decode(errors="replace").splitlines() if l.startswith("{")]
     try:
-        return p.returncode, (json.loads(lines[-1]) if lines else None)
+        return rc, (json.loads(lines[-1]) if lines else None)
     except ValueError:
-        return p.returncode, None
+        return rc, None
 
 
 def train_launch(n):
     """The DDP step of configs[3] on n ranks of their own -> the `workloads.train` record (an `error` record if the launch fails:
     it must not take the headline line down)."""
     flags = ["--gpus", str(n), "--workload", "train", "--steps", "10", "--warmup", "5", "--sustain", "0", "--no-cpu-baseline", "--no-workloads"]
-    rc, train = launch_ranks(n, flags + (["--force-collective"] if n == 1 else []), True)
+    # bounded: this is the first place a run with several RCCL ranks can hang, and the caller still has its own line to print
+    rc, train = launch_ranks(n, flags + (["--force-collective"] if n == 1 else []), True, timeout=TRAIN_LAUNCH_TIMEOUT_S)
     if train is not None and rc == 0:
         return side_record(train, "train")
     return {"error": "the train launch on %d ranks exited with code %d" % (n, rc)}

@@ -48,17 +48,14 @@ def test_launched_ranks_get_an_environment_without_the_outer_launchers_variables
     import bench
     seen = {}
 
-    class P(object):
-        returncode, stdout = 0, b'{"value": 1.0, "config": {"workload": "w", "sharding": "s", "graphs_per_step": 2}, "roofline": {"frac": 0.5}}\n'
-
-    def run(cmd, env=None, **kw):
-        seen["cmd"], seen["env"] = cmd, env
-        return P()
+    def run(cmd, env, timeout):
+        seen["cmd"], seen["env"], seen["timeout"] = cmd, env, timeout
+        return 0, b'{"value": 1.0, "config": {"workload": "w", "sharding": "s", "graphs_per_step": 2}, "roofline": {"frac": 0.5}}\n'
     for k, v in (("WORLD_SIZE", "8"), ("RANK", "0"), ("LOCAL_RANK", "0"), ("MASTER_PORT", "29400"), ("TORCHELASTIC_RUN_ID", "x"), ("OMP_NUM_THREADS", "1")):
         monkeypatch.setenv(k, v)
-    monkeypatch.setattr(bench.subprocess, "run", run)
+    monkeypatch.setattr(bench, "run_captured", run)
     rec = bench.train_launch(8)
-    assert rec["value"] == 1.0 and rec["config"]["graphs_per_step"] == 2
+    assert rec["value"] == 1.0 and rec["config"]["graphs_per_step"] == 2 and seen["timeout"] == bench.TRAIN_LAUNCH_TIMEOUT_S
     assert not any(k in seen["env"] for k in bench.LAUNCHER_ENV) and "TORCHELASTIC_RUN_ID" not in seen["env"]
     assert seen["cmd"][1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in seen["cmd"] and "train" in seen["cmd"]
     assert "--force-collective" not in seen["cmd"]
@@ -132,3 +129,18 @@ def test_the_stdout_line_is_compact_ordered_and_bounded():
     out["kernel_ms_per_step"] = {"k%d" % i: 1.0 for i in range(2000)}
     small = bench.compact_line(out)
     assert len(json.dumps(small)) <= bench.LINE_LIMIT and "kernel_ms_per_step" not in small and "latency_b1" in small
+
+
+def test_a_captured_launch_that_never_returns_is_killed_with_its_whole_process_group():
+    """run_captured: the command runs in a process group of its own; past the timeout the group (a launcher AND what it started) is
+    killed and the caller gets exit code -9 with whatever was printed."""
+    sys.path.insert(0, ROOT)
+    import time
+    import bench
+    code = ("import subprocess, sys, time; print('{\"started\": 1}', flush=True); "
+            "subprocess.Popen([sys.executable, '-c', 'import time; time.sleep(600)']); time.sleep(600)")
+    t0 = time.time()
+    rc, out = bench.run_captured([sys.executable, "-c", code], dict(os.environ), 3)
+    assert rc == -9 and b"started" in out and time.time() - t0 < 30
+    rc, out = bench.run_captured([sys.executable, "-c", "print('{}')"], dict(os.environ), 30)
+    assert rc == 0 and out.strip() == b"{}"
